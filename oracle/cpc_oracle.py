@@ -1,0 +1,330 @@
+"""CPU oracle for the CPC-audio train step.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU restatement (torch functional ops on CPU tensors,
+float32 or float64) of the reference algorithm of
+vincentherrmann/constrastive-predictive-coding-audio for ONE path: the
+ContrastiveEstimationTrainer train / validate step.  It is the checker for the HIP
+path; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product package never imports anything from ``oracle/``.
+
+Pinning: every function here is checked in ``tests/test_oracle_golden.py`` against
+golden vectors produced by importing the reference itself in the development
+container (``tests/golden/generate_golden.py``; the reference's own tests hold no
+numeric vectors — SURVEY.md section 8c).  Each function cites the reference
+file:line it follows (paths relative to the reference repository root).
+
+Parameters are passed as a flat ``dict`` keyed by the reference's state_dict names
+(``encoder.layers.N.weight`` ...), so a reference checkpoint can be fed directly.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+DEFAULT_STRIDES = (5, 4, 2, 2, 2)
+DEFAULT_KERNELS = (10, 8, 4, 4, 4)
+
+
+# --------------------------------------------------------------------------- encoder
+def encoder_geometry(strides: Sequence[int], kernel_sizes: Sequence[int]) -> Tuple[int, int]:
+    """(downsampling_factor, receptive_field) — audio_model.py:19-25."""
+    ds = 1
+    for s in strides:
+        ds *= int(s)
+    rf = int(kernel_sizes[0])
+    hop = 1
+    for i in range(1, len(strides)):
+        hop *= int(strides[i - 1])
+        rf += (int(kernel_sizes[i]) - 1) * hop
+    return ds, rf
+
+
+def encoder_layer_lengths(length: int, strides: Sequence[int], kernel_sizes: Sequence[int]) -> List[int]:
+    """Output length of every conv layer (no padding, dilation 1) — audio_model.py:28-34."""
+    out = []
+    cur = int(length)
+    for s, k in zip(strides, kernel_sizes):
+        cur = (cur - int(k)) // int(s) + 1
+        out.append(cur)
+    return out
+
+
+def encoder_forward(x: torch.Tensor, params: Params, strides: Sequence[int] = DEFAULT_STRIDES,
+                    prefix: str = "encoder.", return_all: bool = False):
+    """relu(conv) on every layer but the last, bare conv on the last — audio_model.py:36-44.
+
+    x: (B, 1, L).  Returns (B, C, T) (and the per-layer activations if return_all).
+    """
+    acts = []
+    n = len(strides)
+    for l in range(n):
+        w = params[f"{prefix}layers.{l}.weight"]
+        b = params.get(f"{prefix}layers.{l}.bias")
+        x = F.conv1d(x, w, b, stride=int(strides[l]))
+        if l < n - 1:
+            x = torch.relu(x)
+        acts.append(x)
+    return (x, acts) if return_all else x
+
+
+# ------------------------------------------------------------------------------- GRU
+def gru_cell(x: torch.Tensor, h: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
+    """One torch.nn.GRUCell step written out (gate order r, z, n) — audio_model.py:58-60,72."""
+    gi = x @ w_ih.t()
+    gh = h @ w_hh.t()
+    if b_ih is not None:
+        gi = gi + b_ih
+        gh = gh + b_hh
+    hs = h.shape[1]
+    r = torch.sigmoid(gi[:, :hs] + gh[:, :hs])
+    u = torch.sigmoid(gi[:, hs:2 * hs] + gh[:, hs:2 * hs])
+    n = torch.tanh(gi[:, 2 * hs:] + r * gh[:, 2 * hs:])
+    return (1.0 - u) * n + u * h
+
+
+def gru_forward(z: torch.Tensor, params: Params, prefix: str = "autoregressive_model.gruCell.",
+                return_trace: bool = False):
+    """AudioGRUModel.forward with reset_hidden=True — audio_model.py:66-77.
+
+    z: (B, input_size, steps); hidden starts at zero; returns the last hidden (B, H).
+    """
+    w_ih = params[prefix + "weight_ih"]
+    w_hh = params[prefix + "weight_hh"]
+    b_ih = params.get(prefix + "bias_ih")
+    b_hh = params.get(prefix + "bias_hh")
+    h = torch.zeros(z.shape[0], w_hh.shape[1], dtype=z.dtype)
+    trace = []
+    for t in range(z.shape[2]):
+        h = gru_cell(z[:, :, t], h, w_ih, w_hh, b_ih, b_hh)
+        trace.append(h)
+    return (h, trace) if return_trace else h
+
+
+# ------------------------------------------------------------------------- CPC model
+def item_length(receptive_field: int, downsampling: int, visible_steps: int, prediction_steps: int) -> int:
+    """audio_model.py:187-191."""
+    return receptive_field + (visible_steps + prediction_steps) * downsampling
+
+
+def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_steps: int,
+                strides: Sequence[int] = DEFAULT_STRIDES):
+    """AudioPredictiveCodingModel.forward with AudioEncoder + AudioGRUModel — audio_model.py:193-211.
+
+    Returns (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)); targets are NOT detached.
+    """
+    enc = encoder_forward(x, params, strides)
+    K, V = prediction_steps, visible_steps
+    targets = enc[:, :, -K:]
+    z = enc[:, :, -(V + K):-K]
+    c = gru_forward(z, params)
+    w_p = params["prediction_model.weight"]
+    predicted = (c @ w_p.t()).view(-1, K, enc.shape[1])
+    return predicted, targets, z, c
+
+
+# ------------------------------------------------------------------- score functions
+def linear_scores(predicted_z: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """scores[b,k,b',k'] = sum_e predicted_z[b,k,e] * targets[b',e,k'] — contrastive_estimation_training.py:19-22."""
+    return torch.einsum("bke,cel->bkcl", predicted_z, targets)
+
+
+def softplus_scores(predicted_z: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """softplus of the linear scores — contrastive_estimation_training.py:12-16."""
+    return F.softplus(linear_scores(predicted_z, targets))
+
+
+def difference_scores(predicted_z: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """1 / squared distance — contrastive_estimation_training.py:25-33 (small shapes only)."""
+    diff = predicted_z[:, :, :, None, None] - targets.permute(1, 0, 2)[None, None]
+    return 1.0 / (diff ** 2).sum(dim=2)
+
+
+SCORE_FUNCTIONS = {"linear": linear_scores, "softplus": softplus_scores, "difference": difference_scores}
+
+
+# ------------------------------------------------------------------------------ loss
+def _loss_terms(scores4: torch.Tensor, all_timesteps: bool):
+    """The (scores, noise_scoring, valid_scores) triple of contrastive_estimation_training.py:108-119.
+
+    Keeps the reference's raw ``view(-1, batch, steps)`` reinterpretation in the default
+    branch (:117) so that the per-step numbers ``validate`` reports (:237-241) match too.
+    """
+    B, K = scores4.shape[0], scores4.shape[1]
+    if all_timesteps:
+        noise = torch.logsumexp(scores4.reshape(-1, B, K), dim=0)
+        valid = torch.diagonal(torch.diagonal(scores4, dim1=0, dim2=2), dim1=0, dim2=1)
+        return scores4, noise, valid
+    s = torch.diagonal(scores4, dim1=1, dim2=3).permute(0, 2, 1).contiguous()  # (b, k, b')
+    noise = torch.logsumexp(s.view(-1, B, K), dim=0)
+    valid = torch.diagonal(s, dim1=0, dim2=2).permute(1, 0)
+    return s, noise, valid
+
+
+def info_nce_loss(scores4: torch.Tensor, all_timesteps: bool = False, regularization: float = 1.0):
+    """Train-mode loss incl. the regulariser — contrastive_estimation_training.py:106-122,141.
+
+    Returns (loss, max_score) where max_score is what the logger records (:166).
+    """
+    s, noise, valid = _loss_terms(scores4, all_timesteps)
+    loss = torch.mean(-torch.mean(valid - noise, dim=1))
+    loss = loss + regularization * torch.mean(torch.mean(s, dim=1) ** 2)
+    return loss, s.max()
+
+
+def validation_terms(scores4: torch.Tensor, all_timesteps: bool = False):
+    """Per-step losses and accuracies of one validation batch — contrastive_estimation_training.py:227-247."""
+    B, K = scores4.shape[0], scores4.shape[1]
+    s, noise, valid = _loss_terms(scores4, all_timesteps)
+    prediction_losses = -torch.mean(valid - noise, dim=0)
+    n = B * K if all_timesteps else B
+    template = torch.arange(n)
+    template = template.view(B, K) if all_timesteps else template.unsqueeze(1).repeat(1, K)
+    max_score = torch.argmax(s.reshape(B, K, -1), dim=2)
+    accuracy = torch.sum(torch.eq(template, max_score), dim=0).to(scores4.dtype) / n
+    return prediction_losses, accuracy, s.mean()
+
+
+# ------------------------------------------------------------------------------ Adam
+def adam_update(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (no weight decay / amsgrad), as built at
+    contrastive_estimation_training.py:83.  In place on p, m, v; ``step`` counts from 1."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+class OracleTrainer:
+    """Holds parameters + Adam state and runs the reference train step on CPU.
+
+    Follows the loop body of contrastive_estimation_training.py:97-169 for the
+    AudioEncoder + AudioGRUModel model (no preprocessing, no gradient penalty).
+    """
+
+    def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
+                 strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
+                 all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4):
+        self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.V, self.K = visible_steps, prediction_steps
+        self.strides = tuple(strides)
+        self.score = SCORE_FUNCTIONS[score]
+        self.all_timesteps = all_timesteps
+        self.regularization = regularization
+        self.lr = lr
+        self.t = 0
+
+    def loss_and_grads(self, batch: torch.Tensor):
+        """batch (B, L) -> (loss, max_score, grads dict); does not update parameters."""
+        for p in self.params.values():
+            p.grad = None
+        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides)
+        loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
+        loss.backward()
+        return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}
+
+    def step(self, batch: torch.Tensor):
+        loss, smax, grads = self.loss_and_grads(batch)
+        self.t += 1
+        with torch.no_grad():
+            for k, p in self.params.items():
+                adam_update(p, grads[k], self.m[k], self.v[k], self.t, self.lr)
+        return float(loss), float(smax)
+
+
+# --------------------------------------------------------------------------- sampler
+def file_batch_sampler(index_count_per_file: Sequence[int], batch_size: int, file_batch_size: int = 1,
+                       drop_last: bool = True, seed: Optional[int] = None) -> List[List[int]]:
+    """The batch index lists FileBatchSampler.__iter__ yields — audio_dataset.py:202-263.
+
+    Uses Python's ``random`` exactly as the reference does (same call order), so the same
+    seed / global RNG state gives the same lists.  Note ``len()`` of the reference sampler
+    is the number of FILE batches (sum of per-file counts), which is also the index range
+    shuffled when file_batch_size == 1 (:236).
+    """
+    if drop_last:
+        per_file = [n // file_batch_size for n in index_count_per_file]
+    else:
+        per_file = [-(-n // file_batch_size) for n in index_count_per_file]
+    total = int(sum(per_file))
+
+    def chunks(seq, n):
+        out = []
+        for i in range(0, len(seq), n):
+            if drop_last and i + n > len(seq):
+                break
+            out.append(seq[i:i + n])
+        return out
+
+    if file_batch_size == 1:
+        order = list(range(total))
+        if seed is not None:
+            random.seed(seed)
+        random.shuffle(order)
+        return chunks(order, batch_size)
+
+    files, start = [], 0
+    for n in index_count_per_file:
+        files.append(list(range(start, start + n)))
+        start += n
+    for i, f in enumerate(files):
+        if seed is not None:
+            random.seed(seed + i)
+        random.shuffle(f)
+    groups = []
+    for f in files:
+        groups.extend(chunks(f, file_batch_size))
+    if seed is not None:
+        random.seed(seed)
+    random.shuffle(groups)
+    per_batch = batch_size // file_batch_size
+    if per_batch > 1:
+        merged = []
+        for i in range(0, len(groups), per_batch):
+            if drop_last and i + per_batch > len(groups):
+                break
+            merged.append([x for g in groups[i:i + per_batch] for x in g])
+        return merged
+    return groups
+
+
+def deterministic_order(n: int, seed: int = 0) -> List[int]:
+    """DeterministicSampler.__iter__ — contrastive_estimation_training.py:373-378."""
+    order = list(range(n))
+    random.seed(seed)
+    random.shuffle(order)
+    return order
+
+
+# ------------------------------------------------------------------- parameter setup
+def init_params(channels: Sequence[int] = (512,) * 5, kernel_sizes: Sequence[int] = DEFAULT_KERNELS,
+                ar_size: int = 256, prediction_steps: int = 12, seed: int = 0,
+                dtype=torch.float32) -> Params:
+    """Builds a parameter dict with torch's default initialisers in the reference's
+    construction order (AudioEncoder, AudioGRUModel, then the predictor Linear —
+    audio_model.py:26-34, :59-61, :174), so that ``torch.manual_seed(seed)`` gives the
+    same values as constructing the reference modules in that order."""
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    out: Params = {}
+    cin = 1
+    for l, (c, k) in enumerate(zip(channels, kernel_sizes)):
+        conv = nn.Conv1d(cin, c, k)
+        out[f"encoder.layers.{l}.weight"] = conv.weight.detach().to(dtype)
+        out[f"encoder.layers.{l}.bias"] = conv.bias.detach().to(dtype)
+        cin = c
+    cell = nn.GRUCell(cin, ar_size)
+    for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        out["autoregressive_model.gruCell." + name] = getattr(cell, name).detach().to(dtype)
+    lin = nn.Linear(ar_size, cin * prediction_steps, bias=False)
+    out["prediction_model.weight"] = lin.weight.detach().to(dtype)
+    return out

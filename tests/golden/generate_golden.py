@@ -1,0 +1,335 @@
+"""Generates the golden fixtures under tests/golden/ by importing the REFERENCE itself.
+
+Run ONLY in the development container (the reference lives at /root/reference, read-only,
+and never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/generate_golden.py
+
+The three audio-I/O packages the reference imports but never uses on this path
+(librosa, torchaudio, mutagen) are absent from the image and are replaced by empty stub
+modules.  Only inputs and outputs are stored — no reference source.
+
+Fixtures written (all float32 unless noted):
+  small_model.npz       params, batch, forward 4-tuple, scores (3 score fns), losses for every
+                        (score fn, all_timesteps, regularisation) combination, grads, Adam steps
+  encoder_ref_test.npz  the reference's own encoder test case [7,1,4800] -> [7,32,28] plus the
+                        receptive-field impulse probe (tests/test_audioEncoder.py:19-48)
+  gru.npz               GRUCell sequence B7 I32 H64 13 steps with hidden trace and grads
+  validate.npz          ContrastiveEstimationTrainer.validate() outputs on a fixed set
+  samplers.json         FileBatchSampler / DeterministicSampler index lists (integers)
+  cfg1_trajectory.json  BASELINE config 1 (B=8, L=20480, 512 ch) loss for 5 train steps
+"""
+import io
+import json
+import os
+import random
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+for name in ("librosa", "torchaudio", "mutagen", "mutagen.mp3"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["mutagen.mp3"].MP3 = object
+sys.path.insert(0, REF)
+
+import audio_model as ref_model  # noqa: E402
+import contrastive_estimation_training as ref_train  # noqa: E402
+from audio_dataset import FileBatchSampler  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+class TensorDataset:
+    """Implements the dataset protocol the trainer uses and records accesses."""
+
+    def __init__(self, data, counts=None):
+        self.data = data
+        self.counts = counts or [data.shape[0]]
+        self.accessed = []
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, i):
+        self.accessed.append(int(i))
+        return self.data[i]
+
+    def get_example_count_per_file(self):
+        return list(self.counts)
+
+
+class Meter:
+    def __init__(self):
+        self.values = []
+
+    def update(self, v):
+        self.values.append(float(v))
+
+
+class Logger:
+    def __init__(self):
+        self.loss_meter = Meter()
+        self.score_meter = Meter()
+
+    def log(self, step):
+        pass
+
+
+def build_model(channels, ar_size, K, V, seed, scale=None):
+    torch.manual_seed(seed)
+    enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4],
+                                  'channel_count': [channels] * 5, 'bias': True})
+    ar = ref_model.AudioGRUModel(input_size=channels, hidden_size=ar_size)
+    model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=channels, ar_size=ar_size,
+                                                 visible_steps=V, prediction_steps=K)
+    if scale is not None:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+    return model
+
+
+def np_state(model):
+    return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+# ------------------------------------------------------------------ small model
+def gen_small_model():
+    C, H, K, V, B = 64, 64, 4, 12, 6
+    L = 465 + (V + K) * 160 + 37 + 160      # one spare frame + ragged tail: exercises the -(V+K) slicing
+    # scale the weights so that the scores are NOT degenerate (~0) at init
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 6.0
+    out = {}
+    model = build_model(C, H, K, V, seed=11, scale=scale)
+    state0 = np_state(model)
+    for k, v in state0.items():
+        out["param/" + k] = v
+    g = torch.Generator().manual_seed(5)
+    n_items = 24
+    data = torch.randn(n_items, L, generator=g) * 0.5
+    out["data"] = data.numpy()
+    batch = data[:B]
+    out["batch"] = batch.numpy()
+    with torch.no_grad():
+        pz, tg, z, c = model(batch.unsqueeze(1))
+        out["fwd/predicted_z"], out["fwd/targets"] = pz.numpy(), tg.numpy().copy()
+        out["fwd/z"], out["fwd/c"] = z.numpy().copy(), c.numpy()
+        x = batch.unsqueeze(1)
+        for l, layer in enumerate(model.encoder.layers):
+            x = layer(x)
+            if l < 4:
+                x = torch.relu(x)
+            out[f"fwd/enc{l}"] = x.numpy().copy()
+        out["scores/linear"] = ref_train.linear_score_function(pz, tg).numpy()
+        out["scores/softplus"] = ref_train.softplus_score_function(pz, tg).numpy()
+        out["scores/difference"] = ref_train.difference_score_function(pz, tg).numpy()
+
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "runs": []}
+    fns = {"linear": ref_train.linear_score_function, "softplus": ref_train.softplus_score_function}
+    run_id = 0
+    for fn_name, fn in fns.items():
+        for all_t in (False, True):
+            for reg in (1.0, 0.01):
+                for steps, lr in ((1, 1e-3), (5, 1e-4)):
+                    full = (fn_name, all_t, reg) in (("softplus", False, 1.0), ("linear", True, 0.01))
+                    if steps == 5 and not full:
+                        continue
+                    model = build_model(C, H, K, V, seed=11, scale=scale)
+                    ds = TensorDataset(data)
+                    logger = Logger()
+                    with quiet():
+                        tr = ref_train.ContrastiveEstimationTrainer(
+                            model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                            score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H)
+                        random.seed(77)
+                        tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+                    tag = f"run{run_id}"
+                    meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg,
+                                         "steps": steps, "lr": lr, "python_seed": 77,
+                                         "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                                         "loss": logger.loss_meter.values, "max_score": logger.score_meter.values})
+                    # full tensors for two combinations, a representative subset for the rest (fixture size)
+                    subset = ("prediction_model.weight", "encoder.layers.4.bias", "encoder.layers.0.weight",
+                              "autoregressive_model.gruCell.bias_hh")
+                    if steps == 1:
+                        for n, p in model.named_parameters():
+                            if full or n in subset:
+                                out[f"{tag}/grad/{n}"] = p.grad.numpy().copy()
+                    if full:
+                        for k, v in np_state(model).items():
+                            out[f"{tag}/param_after/{k}"] = v
+                    run_id += 1
+    np.savez_compressed(os.path.join(OUT, "small_model.npz"), **out)
+    with open(os.path.join(OUT, "small_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("small_model: losses", [(r["score"], r["all_timesteps"], r["reg"], r["loss"][:2]) for r in meta["runs"]])
+
+
+# ------------------------------------------------------------------ encoder reference test
+def gen_encoder_ref_test():
+    out = {}
+    torch.manual_seed(3)
+    enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4],
+                                  'channel_count': [32] * 5, 'bias': False})
+    assert enc.downsampling_factor == 160 and enc.receptive_field == 465
+    x = torch.randn(7, 1, 4800)
+    with torch.no_grad():
+        y = enc(x)
+    assert list(y.shape) == [7, 32, 28]
+    for k, v in enc.state_dict().items():
+        out["param/encoder." + k] = v.numpy().copy()
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    # receptive-field probe, all weights 0.1 (tests/test_audioEncoder.py:27-48)
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.zero_()
+            p += 0.1
+        for name, idx in (("inside", 464), ("outside", 465)):
+            t = torch.zeros(7, 1, 2000)
+            t[:, :, idx] += 1.0
+            out[f"probe_{name}"] = enc(t).numpy()
+    assert out["probe_inside"][0, 0, 0] != 0 and out["probe_outside"][0, 0, 0] == 0
+    np.savez_compressed(os.path.join(OUT, "encoder_ref_test.npz"), **out)
+    print("encoder_ref_test ok", y.abs().mean().item())
+
+
+# ------------------------------------------------------------------ GRU
+def gen_gru():
+    out = {}
+    torch.manual_seed(9)
+    gru = ref_model.AudioGRUModel(input_size=32, hidden_size=64)
+    z = torch.randn(7, 32, 13, requires_grad=True)
+    h = gru(z)
+    # hidden trace by stepping the cell (same module) without touching the forward above
+    with torch.no_grad():
+        hid = None
+        trace = []
+        for t in range(13):
+            hid = gru.gruCell(z[:, :, t], hid)
+            trace.append(hid.numpy().copy())
+    w = torch.randn(7, 64)
+    (h * w).sum().backward()
+    for k, v in gru.state_dict().items():
+        out["param/autoregressive_model." + k] = v.numpy().copy()
+        out["grad/autoregressive_model." + k] = dict(gru.named_parameters())[k].grad.numpy().copy()
+    out["z"], out["h"], out["trace"] = z.detach().numpy(), h.detach().numpy(), np.stack(trace, 1)
+    out["dh"], out["dz"] = w.numpy(), z.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "gru.npz"), **out)
+    print("gru ok")
+
+
+# ------------------------------------------------------------------ validate()
+def gen_validate():
+    C, H, K, V, B = 64, 64, 4, 12, 8
+    L = 465 + (V + K) * 160
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 6.0
+    g = torch.Generator().manual_seed(21)
+    counts = [9, 17, 8]
+    data = torch.randn(sum(counts), L, generator=g) * 0.5
+    out = {"data": data.numpy()}
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "counts": counts, "runs": []}
+    model = build_model(C, H, K, V, seed=12, scale=scale)
+    for k, v in np_state(model).items():
+        out["param/" + k] = v
+    i = 0
+    for fn_name, fn in (("softplus", ref_train.softplus_score_function), ("linear", ref_train.linear_score_function)):
+        for all_t in (False, True):
+            ds = TensorDataset(data, counts)
+            with quiet():
+                tr = ref_train.ContrastiveEstimationTrainer(
+                    model=model, dataset=None, validation_set=ds, device=None, score_over_all_timesteps=all_t,
+                    score_function=fn, prediction_steps=K, ar_size=H)
+                with torch.no_grad():
+                    losses, acc, score, mi = tr.validate(batch_size=B, num_workers=0, max_steps=None)
+            out[f"v{i}/losses"], out[f"v{i}/accuracy"], out[f"v{i}/mi"] = losses.numpy(), acc.numpy(), mi.numpy()
+            meta["runs"].append({"tag": f"v{i}", "score": fn_name, "all_timesteps": all_t, "mean_score": float(score),
+                                 "accessed": ds.accessed})
+            i += 1
+    np.savez_compressed(os.path.join(OUT, "validate.npz"), **out)
+    with open(os.path.join(OUT, "validate.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("validate ok", [r["mean_score"] for r in meta["runs"]])
+
+
+# ------------------------------------------------------------------ samplers
+def gen_samplers():
+    cases = []
+    with quiet():
+        for counts, bs, fbs, seed, drop in [([10], 4, 1, 0, True), ([6, 5], 4, 2, 0, True), ([9, 17, 8], 8, 8, 0, True),
+                                            ([9, 17, 8], 8, 4, 1, True), ([30, 12, 7], 6, 1, 1, True),
+                                            ([30, 12, 7], 6, 3, 5, False), ([64], 8, 1, 0, True),
+                                            ([5, 5, 5], 4, 2, 3, False), ([3], 4, 1, 2, True), ([3], 4, 1, 2, False)]:
+            s = FileBatchSampler(counts, batch_size=bs, file_batch_size=fbs, drop_last=drop, seed=seed)
+            cases.append({"counts": counts, "batch_size": bs, "file_batch_size": fbs, "seed": seed,
+                          "drop_last": drop, "len": int(len(s)), "batches": [list(map(int, b)) for b in iter(s)]})
+        # seed=None: uses the global Python RNG state
+        random.seed(123)
+        s = FileBatchSampler([20, 4], batch_size=5, file_batch_size=1, drop_last=True, seed=None)
+        cases.append({"counts": [20, 4], "batch_size": 5, "file_batch_size": 1, "seed": None, "global_seed": 123,
+                      "drop_last": True, "len": int(len(s)), "batches": [list(map(int, b)) for b in iter(s)]})
+    det = {"n": 17, "seed": 0, "order": list(iter(ref_train.DeterministicSampler(list(range(17)), seed=0)))}
+    assert cases[0]["batches"] == [[7, 8, 1, 5], [3, 4, 2, 0]]
+    with open(os.path.join(OUT, "samplers.json"), "w") as f:
+        json.dump({"file_batch_sampler": cases, "deterministic_sampler": det}, f, indent=1)
+    print("samplers ok")
+
+
+# ------------------------------------------------------------------ BASELINE config 1 trajectory
+def gen_cfg1():
+    B, L, K, V = 8, 20480, 12, 100
+    res = {"B": B, "L": L, "K": K, "V": V, "channels": 512, "ar_size": 256, "model_seed": 0, "data_seed": 0,
+           "n_items": 64, "lr": 1e-4, "runs": []}
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(64, L, generator=g)
+    for fn_name, fn, reg in (("softplus", ref_train.softplus_score_function, 1.0),
+                             ("linear", ref_train.linear_score_function, 0.01)):
+        model = build_model(512, 256, K, V, seed=0)
+        assert model.parameter_count() == 7414784
+        ds = TensorDataset(data)
+        logger = Logger()
+        with quiet():
+            tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None,
+                                                        regularization=reg, score_function=fn,
+                                                        prediction_steps=K, ar_size=256)
+            random.seed(0)
+            tr.train(batch_size=B, epochs=1, lr=1e-4, num_workers=0, max_steps=5)
+        with torch.no_grad():
+            pz, tg, z, c = model(data[:B].unsqueeze(1))
+        res["runs"].append({"score": fn_name, "reg": reg, "python_seed": 0, "loss": logger.loss_meter.values,
+                            "max_score": logger.score_meter.values,
+                            "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(5)],
+                            "after5": {"c_abs_mean": float(c.abs().mean()), "z_abs_mean": float(z.abs().mean()),
+                                       "pz_abs_mean": float(pz.abs().mean()),
+                                       "c_slice": c[0, :8].tolist(), "z_slice": z[0, :8, 0].tolist()}})
+        print("cfg1", fn_name, logger.loss_meter.values)
+    with open(os.path.join(OUT, "cfg1_trajectory.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1"]
+    if "small" in which:
+        gen_small_model()
+    if "encoder" in which:
+        gen_encoder_ref_test()
+    if "gru" in which:
+        gen_gru()
+    if "validate" in which:
+        gen_validate()
+    if "samplers" in which:
+        gen_samplers()
+    if "cfg1" in which:
+        gen_cfg1()
