@@ -1,0 +1,139 @@
+"""ctypes binding of libcpc_hip.so (the C ABI declared in include/cpc_hip.h).
+
+The product path has NO fallback: if the library is missing or a launch is refused, this module raises.
+Tensors are passed as raw device pointers; everything is launched on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR = 1, 2, 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("Bt", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_longlong), ("ldb", C.c_longlong), ("ldc", C.c_longlong),
+                ("a_rpi", C.c_int), ("a_item", C.c_longlong),
+                ("b_rpi", C.c_int), ("b_item", C.c_longlong),
+                ("c_rpi", C.c_int), ("c_item", C.c_longlong), ("c_valid", C.c_int),
+                ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
+                ("flags", C.c_int), ("dtype", C.c_int)]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("I", C.c_int), ("J", C.c_int),
+                ("lda", C.c_longlong), ("ldb", C.c_longlong), ("ldc", C.c_longlong),
+                ("a_rpi", C.c_int), ("a_item", C.c_longlong),
+                ("b_rpi", C.c_int), ("b_item", C.c_longlong),
+                ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
+                ("nsplit", C.c_int), ("m_chunk", C.c_int), ("slab_stride", C.c_longlong),
+                ("flags", C.c_int), ("dtype", C.c_int)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_SIGNATURES = {
+    "cpc_abi_version": ([], _I),
+    "cpc_gemm_nt": ([C.POINTER(GemmNTArgs), _P], _I),
+    "cpc_gemm_tn": ([C.POINTER(GemmTNArgs), _P], _I),
+    "cpc_reduce_slabs": ([_P, _P, _I, _I, _I, _L, _I, _L, _L, _L, _P], _I),
+    "cpc_colsum": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
+    "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _P], _I),
+    "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
+    "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
+    "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_gru_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_nce_workspace_floats": ([_I, _I], _L),
+    "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P], _I),
+    "cpc_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P], _I),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Loads libcpc_hip.so (once).  Raises HipLibraryMissing — never falls back to another implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C {os.path.join(_HERE, 'csrc')}`); there is no CPU fallback for the CPC hot path")
+        handle = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if handle.cpc_abi_version() != 1:
+            raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipCallError(f"{what} failed with code {rc} ({'EINVAL: unsupported shape/argument' if rc == -22 else 'launch error'})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported storage dtype {dt}")
+
+
+def ptr(t, offset_elems: int = 0):
+    """Raw device address of a tensor's first element (+ offset in elements); None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP path needs device tensors"
+    return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+# ----------------------------------------------------------------------------- thin call wrappers
+def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None, a_rpi=0, a_item=0, b_rpi=0, b_item=0,
+            c_rpi=0, c_item=0, c_valid=0, a_batch=0, b_batch=0, c_batch=0, batch=1, flags=0):
+    """A, Bt, Cout, bias, mask are ctypes void pointers (see ptr())."""
+    args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
+                      c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
+    _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt")
+
+
+def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_rpi=0, b_item=0, a_batch=0, b_batch=0,
+            c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0):
+    args = GemmTNArgs(A, B, Cout, M, I, J, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, a_batch, b_batch, c_batch, batch,
+                      nsplit, m_chunk, slab_stride, flags, dtype)
+    _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")
+
+
+def call(name, *args):
+    """Generic call of an exported function; appends the current stream and checks the status."""
+    fn = getattr(lib(), name)
+    _check(fn(*args, stream_ptr()), name)

@@ -1,0 +1,209 @@
+// Encoder layer 1 (C_in = 1): the genuinely HBM-bound piece of the conv stack.
+//   fwd : y[b][t][co] = relu(bias[co] + sum_j x[b][t*s + j] * w[co][j])      x f32 [B][Lx], y T channels-last
+//   bwd : dw[co][j] = sum_{b,t} dy[b][t][co] * x[b][t*s + j],  db[co] = sum dy   (dy already relu-masked)
+// A lane owns 8 consecutive output channels (one 16-byte bf16 store per position); the raw waveform window of the
+// workgroup's positions is staged once in LDS and broadcast-read; weights live in registers.
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+
+namespace {
+
+constexpr int C1_MAXK = 16;      // max kernel size of layer 1 handled (reference default: 10)
+constexpr int C1_POS = 64;       // output positions per workgroup pass
+
+template <typename T>
+__device__ __forceinline__ void store8(T* dst, const float* v);
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *(bf16x8*)dst = o;
+}
+template <>
+__device__ __forceinline__ void store8<float>(float* dst, const float* v) {
+    *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+template <typename T>
+__device__ __forceinline__ void load8(const T* src, float* v);
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* src, float* v) {
+    bf16x8 i = *(const bf16x8*)src;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)i[e];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* src, float* v) {
+    f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// grid: (ceil(L_alloc / C1_POS), B).  Threads: lanes_per_row = C/8 lanes cover one output row; 256/lanes_per_row rows
+// are produced per pass.
+template <typename T, int KW>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int C,
+                                                        int stride, int kw_rt, long long ldx, int L_valid, int L_alloc) {
+    const int kw = KW > 0 ? KW : kw_rt;
+    __shared__ float xs[C1_POS * 8 + C1_MAXK + 8];     // stride <= 8 supported
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * C1_POS;
+    const int tid = threadIdx.x;
+    const int lpr = C / 8;
+    const int cg = tid % lpr, rl = tid / lpr, nrl = 256 / lpr;
+
+    // stage the input window of positions [t0, t0 + C1_POS): samples [t0*stride, (t0+C1_POS-1)*stride + kw)
+    const int npos = min(C1_POS, L_valid - t0);          // valid positions in this block (may be <= 0)
+    const int nsamp = npos > 0 ? (npos - 1) * stride + kw : 0;
+    const float* xb = x + (long long)b * ldx + (long long)t0 * stride;
+    for (int i = tid; i < nsamp; i += 256) xs[i] = xb[i];
+
+    float wr[(KW > 0 ? KW : C1_MAXK)][8];
+    float br[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) br[e] = bias ? bias[cg * 8 + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < (KW > 0 ? KW : C1_MAXK); ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[j][e] = j < kw ? w[(cg * 8 + e) * kw + j] : 0.f;
+    __syncthreads();
+
+    T* yb = y + ((long long)b * L_alloc + t0) * C + cg * 8;
+    const int nrows = min(C1_POS, L_alloc - t0);
+    for (int r = rl; r < nrows; r += nrl) {
+        float v[8];
+        if (r < npos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = br[e];
+#pragma unroll
+            for (int j = 0; j < (KW > 0 ? KW : C1_MAXK); ++j) {
+                const float xv = j < kw ? xs[r * stride + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(xv, wr[j][e], v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;      // pad rows are written as zeros
+        }
+        store8<T>(yb + (long long)r * C, v);
+    }
+}
+
+// grid: (nblk_t, B): block handles positions [bx*tpb, (bx+1)*tpb) of item b and writes a partial slab
+// slabs[(b*nblk_t + bx)][(kw+1)][C]  (row kw = bias grad).
+template <typename T, int KW>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                        float* __restrict__ slabs, int C, int stride, int kw_rt,
+                                                        long long ldx, int L_valid, int L_alloc, int tpb) {
+    const int kw = KW > 0 ? KW : kw_rt;
+    constexpr int KA = (KW > 0 ? KW : C1_MAXK);
+    __shared__ float xs[C1_POS * 8 + C1_MAXK + 8];
+    __shared__ float red[256 * 8];                     // cross-row-lane reduction scratch
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lpr = C / 8;
+    const int cg = tid % lpr, rl = tid / lpr, nrl = 256 / lpr;
+    const int t_begin = blockIdx.x * tpb;
+    const int t_end = min(L_valid, t_begin + tpb);
+
+    float acc[KA + 1][8];
+#pragma unroll
+    for (int j = 0; j <= KA; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+
+    for (int t0 = t_begin; t0 < t_end; t0 += C1_POS) {
+        const int npos = min(C1_POS, t_end - t0);
+        const int nsamp = (npos - 1) * stride + kw;
+        const float* xb = x + (long long)b * ldx + (long long)t0 * stride;
+        __syncthreads();
+        for (int i = tid; i < nsamp; i += 256) xs[i] = xb[i];
+        __syncthreads();
+        const T* dyb = dy + ((long long)b * L_alloc + t0) * C + cg * 8;
+        for (int r = rl; r < npos; r += nrl) {
+            float g[8];
+            load8<T>(dyb + (long long)r * C, g);
+#pragma unroll
+            for (int j = 0; j < KA; ++j) {
+                const float xv = j < kw ? xs[r * stride + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(xv, g[e], acc[j][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[KA][e] += g[e];
+        }
+    }
+    // reduce over the row lanes through LDS (one accumulator row at a time), then write the slab
+    float* slab = slabs + ((long long)b * gridDim.x + blockIdx.x) * (long long)(kw + 1) * C;
+#pragma unroll
+    for (int j = 0; j <= KA; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[j][e];
+        __syncthreads();
+        const int out_row = j < KA ? j : kw;       // accumulator row KA is the bias gradient -> slab row kw
+        if (rl == 0 && (j == KA || j < kw)) {
+            float s8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s8[e] = acc[j][e];
+            for (int r = 1; r < nrl; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s8[e] += red[(tid + r * lpr) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) slab[(long long)out_row * C + cg * 8 + e] = s8[e];
+        }
+    }
+}
+
+}  // namespace
+
+static bool c1_ok(int C, int stride, int kw) {
+    if (C < 8 || C % 8) return false;
+    const int lpr = C / 8;
+    if (lpr > 256 || (256 % lpr)) return false;
+    if (stride < 1 || stride > 8 || kw < 1 || kw > C1_MAXK) return false;
+    return true;
+}
+
+int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
+                     long long ldx, int L_valid, int L_alloc, int dtype, hipStream_t stream) {
+    if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid) return CPC_EINVAL;
+    dim3 grid((L_alloc + C1_POS - 1) / C1_POS, B);
+#define LAUNCH(T, KWT) \
+    hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc)
+    if (dtype == CPC_DTYPE_BF16) {
+        if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);
+    } else if (dtype == CPC_DTYPE_F32) {
+        if (kw == 10) LAUNCH(float, 10); else LAUNCH(float, 0);
+    } else {
+        return CPC_EINVAL;
+    }
+#undef LAUNCH
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+// slabs: [B * nblk_t][(kw+1)][C] f32.  Reduce with reduce_slabs (I = kw+1, J = C).
+int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
+                     int L_valid, int L_alloc, int nblk_t, int dtype, hipStream_t stream) {
+    if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid || nblk_t <= 0) return CPC_EINVAL;
+    int tpb = (L_valid + nblk_t - 1) / nblk_t;
+    tpb = (tpb + C1_POS - 1) / C1_POS * C1_POS;
+    dim3 grid(nblk_t, B);
+#define LAUNCH(T, KWT) \
+    hipLaunchKernelGGL((conv1_bwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, (const T*)dy, slabs, C, stride, kw, ldx, L_valid, L_alloc, tpb)
+    if (dtype == CPC_DTYPE_BF16) {
+        if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);
+    } else if (dtype == CPC_DTYPE_F32) {
+        if (kw == 10) LAUNCH(float, 10); else LAUNCH(float, 0);
+    } else {
+        return CPC_EINVAL;
+    }
+#undef LAUNCH
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

@@ -1,0 +1,159 @@
+// extern "C" boundary of libcpc_hip.so: argument checking + translation of the domain-level calls (conv / GRU / NCE /
+// Adam) onto the kernel launchers.  See include/cpc_hip.h for the contract.
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+#include "../../include/cpc_hip.h"
+
+static_assert(CPC_GEMM_RELU == GEMM_RELU && CPC_GEMM_OUT_F32 == GEMM_OUT_F32 && CPC_GEMM_TN_NO_TR == GEMM_TN_NO_TR, "flag mismatch");
+static_assert(CPC_F32 == CPC_DTYPE_F32 && CPC_BF16 == CPC_DTYPE_BF16, "dtype mismatch");
+
+static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
+
+extern "C" {
+
+int cpc_abi_version(void) { return 1; }
+
+int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
+    if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
+    GemmNT p;
+    p.A = a->A; p.Bt = a->Bt; p.C = a->C; p.bias = a->bias; p.mask = a->mask;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+    p.a_rpi = a->a_rpi; p.a_item = a->a_item;
+    p.b_rpi = a->b_rpi; p.b_item = a->b_item;
+    p.c_rpi = a->c_rpi; p.c_item = a->c_item; p.c_valid = a->c_valid;
+    p.a_batch = a->a_batch; p.b_batch = a->b_batch; p.c_batch = a->c_batch;
+    p.flags = a->flags;
+    if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
+    if (a->mask && (p.flags & GEMM_OUT_F32) && a->dtype != CPC_DTYPE_F32) return CPC_EINVAL;
+    return launch_gemm_nt(p, a->dtype, a->batch > 0 ? a->batch : 1, (hipStream_t)stream);
+}
+
+int cpc_gemm_tn(const cpc_gemm_tn_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return CPC_EINVAL;
+    GemmTN p;
+    p.A = a->A; p.B = a->B; p.C = a->C;
+    p.M = a->M; p.I = a->I; p.J = a->J;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+    p.a_rpi = a->a_rpi; p.a_item = a->a_item;
+    p.b_rpi = a->b_rpi; p.b_item = a->b_item;
+    p.a_batch = a->a_batch; p.b_batch = a->b_batch; p.c_batch = a->c_batch;
+    const int nsplit = a->nsplit > 0 ? a->nsplit : 1;
+    p.m_chunk = nsplit > 1 ? a->m_chunk : a->M;
+    p.slab_stride = a->slab_stride;
+    p.flags = a->flags;
+    if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
+    const int blk = a->dtype == CPC_DTYPE_BF16 ? 64 : 32;
+    if (nsplit > 1 && (p.m_chunk % blk)) return CPC_EINVAL;
+    return launch_gemm_tn(p, a->dtype, nsplit, a->batch > 0 ? a->batch : 1, (hipStream_t)stream);
+}
+
+int cpc_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv, long long s_j,
+                     long long s_hi, long long s_lo, void* stream) {
+    if (!slabs || !out) return CPC_EINVAL;
+    return launch_reduce_slabs(slabs, out, I, J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo, (hipStream_t)stream);
+}
+
+int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nblocks, int dtype, void* stream) {
+    if (!X || !slabs) return CPC_EINVAL;
+    return launch_colsum(X, slabs, M, N, ldx, dtype, nblocks, (hipStream_t)stream);
+}
+
+int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw, long long ldx,
+                  int L_valid, int L_alloc, int dtype, void* stream) {
+    if (!x || !w || !y) return CPC_EINVAL;
+    if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
+    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, dtype, (hipStream_t)stream);
+}
+
+int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx, int L_valid,
+                  int L_alloc, int nblk_t, int dtype, void* stream) {
+    if (!x || !dy || !slabs) return CPC_EINVAL;
+    if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
+    return launch_conv1_bwd(x, dy, slabs, B, C, stride, kw, ldx, L_valid, L_alloc, nblk_t, dtype, (hipStream_t)stream);
+}
+
+int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw, int stride,
+                 int Lout_alloc, int Lout_valid, int relu, int dtype, void* stream) {
+    if (!x || !w_fwd || !y || B <= 0 || Lout_alloc <= 0 || Lout_valid > Lout_alloc) return CPC_EINVAL;
+    GemmNT p = {};
+    p.A = x; p.Bt = w_fwd; p.C = y; p.bias = bias; p.mask = nullptr;
+    p.M = B * Lout_alloc; p.N = Cout; p.K = kw * Cin;
+    p.lda = (long long)stride * Cin; p.ldb = p.K; p.ldc = Cout;
+    p.c_rpi = Lout_alloc; p.c_item = (long long)Lout_alloc * Cout; p.c_valid = Lout_valid;
+    p.flags = (relu ? GEMM_RELU : 0) | (dtype == CPC_DTYPE_F32 ? GEMM_OUT_F32 : 0);
+    return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
+                   int stride, int Lout_alloc, int Lin_valid, int dtype, void* stream) {
+    if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0) return CPC_EINVAL;
+    (void)Lin_valid;   // positions >= Lin_valid receive zeros because the pad rows of dy are zero
+    const int D = (kw + stride - 1) / stride;
+    GemmNT p = {};
+    p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);   // D-1 zero guard rows precede the buffer
+    p.Bt = w_dgrad; p.C = dx; p.bias = nullptr; p.mask = x_act;
+    p.M = B * Lout_alloc; p.N = stride * Cin; p.K = D * Cout;
+    p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
+    p.flags = dtype == CPC_DTYPE_F32 ? GEMM_OUT_F32 : 0;
+    return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride, int Lout_alloc,
+                   int nsplit, int dtype, void* stream) {
+    if (!x || !dy || !slabs || B <= 0 || Lout_alloc <= 0 || nsplit <= 0) return CPC_EINVAL;
+    GemmTN p = {};
+    p.A = x; p.B = dy; p.C = slabs;
+    p.M = B * Lout_alloc; p.I = kw * Cin; p.J = Cout;
+    p.lda = (long long)stride * Cin; p.ldb = Cout; p.ldc = Cout;
+    const int blk = dtype == CPC_DTYPE_BF16 ? 64 : 32;
+    int chunk = (p.M + nsplit - 1) / nsplit;
+    chunk = (chunk + blk - 1) / blk * blk;
+    p.m_chunk = chunk;
+    p.slab_stride = (long long)p.I * p.J;
+    p.flags = GEMM_OUT_F32;
+    return launch_gemm_tn(p, dtype, nsplit, 1, (hipStream_t)stream);
+}
+
+int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype, void* stream) {
+    if (!w || !w_fwd) return CPC_EINVAL;
+    return launch_conv_w_prep(w, w_fwd, w_dgrad, Cout, Cin, kw, stride, dtype, (hipStream_t)stream);
+}
+
+int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
+    if (!src || !dst) return CPC_EINVAL;
+    return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);
+}
+
+int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, void* stream) {
+    if (!src || !dst) return CPC_EINVAL;
+    return launch_prep_frag(src, dst, R, Kd, ld, transpose, dtype, (hipStream_t)stream);
+}
+
+int cpc_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B, int V,
+                int H, int dtype, void* stream) {
+    if (!Gi || !Wfrag || !Hall || !gates || !c_out) return CPC_EINVAL;
+    return launch_gru_fwd(Gi, Wfrag, bhh, Hall, gates, c_out, B, V, H, dtype, (hipStream_t)stream);
+}
+
+int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B, int V,
+                int H, int dtype, void* stream) {
+    if (!dc || !Hall || !gates || !WTfrag || !dGi || !dGh) return CPC_EINVAL;
+    return launch_gru_bwd(dc, Hall, gates, WTfrag, dGi, dGh, B, V, H, dtype, (hipStream_t)stream);
+}
+
+long long cpc_nce_workspace_floats(int B, int K) { return nce_workspace_floats(B, K); }
+
+int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus,
+                 float regularization, int dtype, void* stream) {
+    if (!S || !dS || !dST || !out || !workspace) return CPC_EINVAL;
+    return launch_nce(S, dS, dST, out, workspace, B, K, softplus, regularization, dtype, (hipStream_t)stream);
+}
+
+int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+             float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return CPC_EINVAL;
+    return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal launcher interface between the kernel translation units and the C ABI (cpc_abi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// gemm flags
+#define GEMM_RELU 1        // NT: relu in the epilogue
+#define GEMM_OUT_F32 2     // output stored as f32 regardless of the storage dtype
+#define GEMM_TN_NO_TR 4    // TN/bf16: use scalar LDS reads instead of ds_read_b64_tr_b16 (debug / A-B check)
+
+struct GemmNT {
+    const void* A;        // [M][K], row m at row_off(m, a_rpi, a_item, lda); rows may overlap (strided-conv view)
+    const void* Bt;       // [N][K]
+    void* C;              // [M][N]
+    const float* bias;    // [N] or null
+    const void* mask;     // same addressing/type as C's storage dtype; out = mask > 0 ? out : 0  (relu backward); or null
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int a_rpi; long long a_item;
+    int b_rpi; long long b_item;
+    int c_rpi; long long c_item; int c_valid;   // rows with (m % c_rpi) >= c_valid are written as zeros (c_rpi != 0)
+    long long a_batch, b_batch, c_batch;
+    int flags;
+};
+
+struct GemmTN {
+    const void* A;        // [M][I]
+    const void* B;        // [M][J]
+    void* C;              // [I][J]  (+ split * slab_stride)
+    int M, I, J;
+    long long lda, ldb, ldc;
+    int a_rpi; long long a_item;
+    int b_rpi; long long b_item;
+    long long a_batch, b_batch, c_batch;
+    int m_chunk;          // reduction rows per split
+    long long slab_stride;
+    int flags;
+};
+
+int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
+int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);
+int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
+                        long long s_j, long long s_hi, long long s_lo, hipStream_t stream);
+int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
+
+int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
+                     long long ldx, int L_valid, int L_alloc, int dtype, hipStream_t stream);
+int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
+                     int L_valid, int L_alloc, int nblk_t, int dtype, hipStream_t stream);
+int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
+                   int V, int H, int dtype, hipStream_t stream);
+int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
+                   int V, int H, int dtype, hipStream_t stream);
+int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
+long long nce_workspace_floats(int B, int K);
+int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus, float reg,
+               int dtype, hipStream_t stream);
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                float grad_scale, hipStream_t stream);
+int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,
+                       hipStream_t stream);
+int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, hipStream_t stream);

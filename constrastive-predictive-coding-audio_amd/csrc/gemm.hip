@@ -1,0 +1,410 @@
+// MFMA GEMM family for the CPC-audio hot path (gfx950 / CDNA4).
+//
+// All activations live channels-last ("NLC": [item][position][channel]).  In that layout a strided,
+// unpadded Conv1d IS a GEMM whose A operand has overlapping rows:
+//     out[(b,t), co] = sum_{(j,c)} X[(b,t)*s*C + (j,c)] * W2[co][(j,c)]          (forward,  "NT")
+//     dX[(b,q), (r,c)] = sum_{(d,co)} dY[(b,q-D+1)*C + (d,co)] * W3[(r,c)][(d,co)] (data grad, "NT")
+//     dW2[(j,c), co]  = sum_{(b,t)} X[(b,t)*s*C + (j,c)] * dY[(b,t), co]          (weight grad, "TN")
+// so no im2col buffer ever exists.  The same two kernels serve the GRU projections, the predictor and the
+// InfoNCE score contraction.
+//
+//   gemm_nt : C[m][n] = epi( sum_k A[m][k] * Bt[n][k] )       both operands K-contiguous
+//   gemm_tn : C[i][j] =      sum_m A[m][i] * B[m][j]           both operands reduction-strided
+//
+// Storage type T is bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact-f32 parity mode);
+// accumulation is always f32.  128x128 output tile per 256-thread workgroup (4 waves, 64x64 each).
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+
+// ---------------------------------------------------------------------------------------------------- NT
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+// LDS tile: 128 rows x 128 bytes (8 chunks of 16 B); chunk index XOR-swizzled with (row & 7) so that the
+// ds_read_b128 fragment reads (16 rows x same chunk) spread over all banks.
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BK = 8 * CH;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + 128 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: the blocks of one XCD (bid % 8) walk the N tiles of one M tile back to back, so the
+    // A panel of that M tile is fetched into that XCD's L2 once.
+    const int numM = (p.M + BM - 1) / BM, numN = (p.N + BN - 1) / BN;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mt = (slot / numN) * 8 + xcd, nt = slot % numN;
+    if (mt >= numM) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
+    const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
+
+    // Staging: 1024 chunks per operand tile, 4 per thread.  chunk c = tid + 256*i -> row = c >> 3, ch = c & 7.
+    const int ch = tid & 7;
+    long long a_off[4], b_off[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row, n = n0 + row;
+        a_ok[i] = m < p.M;
+        b_ok[i] = n < p.N;
+        a_off[i] = a_ok[i] ? row_off(m, p.a_rpi, p.a_item, p.lda) + ch * CH : 0;
+        b_off[i] = b_ok[i] ? row_off(n, p.b_rpi, p.b_item, p.ldb) + ch * CH : 0;
+    }
+    uint4 ra[4], rb[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto gload = [&](int k0) {
+        const bool kin = (k0 + ch * CH) < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (a_ok[i] && kin) ? *(const uint4*)(Ab + a_off[i] + k0) : zero4;
+            rb[i] = (b_ok[i] && kin) ? *(const uint4*)(Bb + b_off[i] + k0) : zero4;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *(uint4*)(ldsA + lds_off(row, ch)) = ra[i];
+            *(uint4*)(ldsB + lds_off(row, ch)) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4;
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();          // previous tile's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (t + 1 < nk) gload((t + 1) * BK);   // next tile's global loads fly under this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra_ = wm * 64 + i * 16 + frow;
+                const int rb_ = wn * 64 + i * 16 + frow;
+                fa[i] = *(const uint4*)(ldsA + lds_off(ra_, kk * 4 + fg));
+                fb[i] = *(const uint4*)(ldsB + lds_off(rb_, kk * 4 + fg));
+            }
+            // Transposed product D[n][m]: the Bt rows are the MFMA "A" operand, the A rows its "B" operand, so that
+            // a lane ends up holding 4 consecutive n for one m (vector stores along the contiguous output axis).
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
+        }
+    }
+
+    // Epilogue.  lane: m = m0 + wm*64 + i*16 + (lane&15);  n = n0 + wn*64 + j*16 + (lane>>4)*4 + {0..3}
+    TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch;
+    const T* Mb = (const T*)p.mask;
+    const bool relu = p.flags & GEMM_RELU;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        if (m >= p.M) continue;
+        const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
+        const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
+                v += bv;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (Mb) {
+                const f32x4 mk = load4(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
+            if (!row_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            store4(Cb + coff + n, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- TN
+// bf16: 64 reduction rows per stage, LDS rows of 128 columns + 16 pad (288 B) so that the 8 rows one half-wave
+// touches in a transposed read start 8 banks apart.
+// f32 : 32 reduction rows per stage, LDS rows of 128 columns + 16 pad (576 B).
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_t> { static constexpr int BKM = 64, ROWB = 288, CPR = 16; };   // chunks per row
+template <> struct TnCfg<float> { static constexpr int BKM = 32, ROWB = 576, CPR = 32; };
+
+// Fragment for the 16 columns starting at tile column cb, k-step ks.
+// bf16: ds_read_b64_tr_b16 hardware-transposed reads.  Within each 16-lane group the instruction reads a
+// 4-row x 16-column block: lane 4q+p supplies the address of row q, columns 4p..4p+3, and lane i receives
+// column i of the 4 rows.  Group g takes rows 4g..4g+3 (first read) and 16+4g..16+4g+3 (second read) of the
+// 32-row k-step: the same permutation of the reduction index for both operands.
+__device__ __forceinline__ uint4 tn_frag_bf16(const unsigned char* tile, int cb, int ks, int lane, bool use_tr) {
+    const int g = lane >> 4, idx = lane & 15;
+    if (use_tr) {
+        const int q = idx >> 2, pp = idx & 3;
+        const int r1 = ks * 32 + 4 * g + q;
+        const unsigned char* a1 = tile + r1 * 288 + (cb + 4 * pp) * 2;
+        const unsigned char* a2 = a1 + 16 * 288;
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a2);
+        uint2 lo = __builtin_bit_cast(uint2, v1), hi = __builtin_bit_cast(uint2, v2);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    // reference path (scalar LDS reads), same element order
+    unsigned int e[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int r = ks * 32 + (jj < 4 ? 4 * g + jj : 16 + 4 * g + (jj - 4));
+        e[jj] = *(const unsigned short*)(tile + r * 288 + (cb + idx) * 2);
+    }
+    return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BKM = TnCfg<T>::BKM, ROWB = TnCfg<T>::ROWB, CPR = TnCfg<T>::CPR;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BKM * ROWB];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + BKM * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int numJ = (p.J + 127) / 128;
+    const int it = blockIdx.x / numJ, jt = blockIdx.x % numJ;
+    const int i0 = it * 128, j0 = jt * 128;
+    const int split = blockIdx.y;
+    const int m_begin = split * p.m_chunk;
+    const int m_end = min(p.M, m_begin + p.m_chunk);
+
+    const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
+    const T* Bb = (const T*)p.B + (long long)blockIdx.z * p.b_batch;
+
+    // staging: BKM rows x CPR chunks = 1024 chunks per operand, 4 per thread
+    constexpr int RPP = 256 / CPR;           // rows covered per pass of 256 threads
+    const int ch = tid % CPR, r0 = tid / CPR;
+    const bool a_col_ok = (i0 + ch * CH) < p.I;
+    const bool b_col_ok = (j0 + ch * CH) < p.J;
+    uint4 ra[4], rb[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + r0 + RPP * i;
+            const bool ok = m < m_end;
+            ra[i] = (ok && a_col_ok) ? *(const uint4*)(Ab + row_off(m, p.a_rpi, p.a_item, p.lda) + i0 + ch * CH) : zero4;
+            rb[i] = (ok && b_col_ok) ? *(const uint4*)(Bb + row_off(m, p.b_rpi, p.b_item, p.ldb) + j0 + ch * CH) : zero4;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + RPP * i;
+            *(uint4*)(ldsA + row * ROWB + ch * 16) = ra[i];
+            *(uint4*)(ldsB + row * ROWB + ch * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool use_tr = !(p.flags & GEMM_TN_NO_TR);
+    const int fidx = lane & 15, fg = lane >> 4;
+    if (m_begin < m_end) gload(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += BKM) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (mb + BKM < m_end) gload(mb + BKM);
+        if constexpr (IS_BF16) {
+#pragma unroll
+            for (int ks = 0; ks < BKM / 32; ++ks) {
+                uint4 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = tn_frag_bf16(ldsA, wi * 64 + i * 16, ks, lane, use_tr);
+                    fb[i] = tn_frag_bf16(ldsB, wj * 64 + i * 16, ks, lane, use_tr);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mfma_chunk<bf16_t>(acc[i][j], fb[j], fa[i]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BKM / 4; ++ks) {
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = *(const float*)(ldsA + (ks * 4 + fg) * ROWB + (wi * 64 + i * 16 + fidx) * 4);
+                    fb[i] = *(const float*)(ldsB + (ks * 4 + fg) * ROWB + (wj * 64 + i * 16 + fidx) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // D[row=j][col=i]: lane holds i = i0 + wi*64 + it*16 + (lane&15), j = j0 + wj*64 + jt*16 + (lane>>4)*4 + {0..3}
+    TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ii = i0 + wi * 64 + i * 16 + fidx;
+        if (ii >= p.I) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j0 + wj * 64 + j * 16 + fg * 4;
+            if (jj >= p.J) continue;
+            store4(Cb + (long long)ii * p.ldc + jj, acc[i][j]);
+        }
+    }
+}
+
+// out[perm(i, j)] = (accumulate ? out : 0) + sum_z slab[z][i][j];   perm(i,j) = j*s_j + (i / cdiv)*s_hi + (i % cdiv)*s_lo
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                           int I, int J, int nslab, long long slab_stride,
+                                                           int cdiv, long long s_j, long long s_hi, long long s_lo) {
+    const long long total4 = (long long)I * J / 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const long long e = idx * 4;
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nslab; ++z) s += *(const f32x4*)(slabs + (long long)z * slab_stride + e);
+        const int i = (int)(e / J), j = (int)(e % J);
+        const long long base = (long long)(i / cdiv) * s_hi + (long long)(i % cdiv) * s_lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[base + (long long)(j + q) * s_j] = s[q];
+    }
+}
+
+// Column sums of a [M][N] T matrix into per-block partial slabs [gridDim.x][N] (f32); reduced by reduce_slabs.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ slabs, int M, int N,
+                                                     long long ldx, int rows_per_block) {
+    // A thread owns a group of 4 columns; when there are fewer than 256 groups several row lanes share a group
+    // and are combined through LDS.
+    __shared__ float red[256 * 4];
+    const int ncg = N / 4;
+    const int tid = threadIdx.x;
+    const int m_begin = blockIdx.x * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    for (int cg0 = 0; cg0 < ncg; cg0 += 256) {
+        const int lpr = min(ncg - cg0, 256);     // column groups handled in this pass
+        const int nrl = 256 / lpr;               // row lanes per column group
+        const int cg = cg0 + tid % lpr;
+        const int rl = tid / lpr;
+        const bool active = rl < nrl;
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (int m = m_begin + rl; m < m_end; m += nrl) s += load4(X + (long long)m * ldx + cg * 4);
+        *(f32x4*)(red + tid * 4) = s;
+        __syncthreads();
+        if (rl == 0) {
+            for (int r = 1; r < nrl; ++r) s += *(const f32x4*)(red + (tid + r * lpr) * 4);
+            *(f32x4*)(slabs + (long long)blockIdx.x * N + cg * 4) = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
+    const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if (p.K % ch || p.lda % ch || p.ldb % ch || p.N % 4 || p.ldc % 4) return CPC_EINVAL;
+    if (p.a_rpi && p.a_item % ch) return CPC_EINVAL;
+    if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
+    if (p.c_rpi && p.c_item % 4) return CPC_EINVAL;
+    const int numM = (p.M + BM - 1) / BM, numN = (p.N + BN - 1) / BN;
+    const long long blocks = (long long)((numM + 7) / 8) * 8 * numN;
+    if (blocks > 0x7fffffffLL) return CPC_EINVAL;
+    dim3 grid((unsigned)blocks, 1, batch);
+    const bool of32 = p.flags & GEMM_OUT_F32;
+    if (dtype == CPC_DTYPE_BF16) {
+        if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+    } else if (dtype == CPC_DTYPE_F32) {
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
+    } else {
+        return CPC_EINVAL;
+    }
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream) {
+    if (p.M <= 0 || p.I <= 0 || p.J <= 0 || batch <= 0 || nsplit <= 0) return CPC_EINVAL;
+    const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if (p.I % ch || p.J % ch || p.lda % ch || p.ldb % ch || p.ldc % 4) return CPC_EINVAL;
+    if (p.a_rpi && p.a_item % ch) return CPC_EINVAL;
+    if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
+    if (nsplit > 1 && (p.m_chunk <= 0 || (long long)p.m_chunk * nsplit < p.M)) return CPC_EINVAL;
+    if (nsplit > 1 && !(p.flags & GEMM_OUT_F32)) return CPC_EINVAL;   // slabs are f32
+    const int numI = (p.I + 127) / 128, numJ = (p.J + 127) / 128;
+    dim3 grid(numI * numJ, nsplit, batch);
+    const bool of32 = p.flags & GEMM_OUT_F32;
+    if (dtype == CPC_DTYPE_BF16) {
+        if (of32) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+    } else if (dtype == CPC_DTYPE_F32) {
+        hipLaunchKernelGGL((gemm_tn_kernel<float, float>), grid, dim3(256), 0, stream, p);
+    } else {
+        return CPC_EINVAL;
+    }
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
+                        long long s_j, long long s_hi, long long s_lo, hipStream_t stream) {
+    if (I <= 0 || J <= 0 || J % 4 || nslab <= 0 || cdiv <= 0) return CPC_EINVAL;
+    const long long total4 = (long long)I * J / 4;
+    const int blocks = (int)min((long long)2048, (total4 + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, slabs, out, I, J, nslab, slab_stride,
+                       cdiv, s_j, s_hi, s_lo);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || N % 4 || nblocks <= 0 || ldx % 4) return CPC_EINVAL;
+    const int rpb = (M + nblocks - 1) / nblocks;
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)X, slabs, M, N, ldx, rpb);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(nblocks), dim3(256), 0, stream, (const float*)X, slabs, M, N, ldx, rpb);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

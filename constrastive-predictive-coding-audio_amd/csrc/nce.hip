@@ -1,0 +1,172 @@
+// InfoNCE loss of ContrastiveEstimationTrainer.train (default branch: same-step scores only), forward + analytic
+// gradient with respect to the linear scores.
+//
+//   S[k][b][b'] = <predicted_z[b,k,:], targets[b',:,k]>      (computed by a batched gemm_nt, f32)
+//   sp = softplus(S) (softplus score) or S (linear score)
+//   loss = -mean_{b,k} sp[k][b][b] + mean_{k,b'} logsumexp_b sp[k][b][b'] + reg * mean_{b,b'} (mean_k sp[k][b][b'])^2
+//   dL/dS = dsp * (softplus ? sigmoid(S) : 1),
+//   dsp[k][b][b'] = (softmax_b(sp[k][:,b'])[b] - [b == b']) / (B K) + 2 reg / (B^2 K) * mean_k sp[k][b][b']
+//
+// The softmax runs over the PREDICTION axis b for every target b' (columns), as the reference does.
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float score_tf(float x, int softplus) {
+    if (!softplus) return x;
+    return x > 20.f ? x : log1pf(expf(x));       // torch.nn.functional.softplus, beta = 1, threshold = 20
+}
+__device__ __forceinline__ float score_grad(float x, int softplus) {
+    if (!softplus) return 1.f;
+    return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+}
+
+// One thread per (k, b') column: logsumexp over b.  grid = ceil(K*B / 256).  Writes lse[k][b'] and a per-block partial sum.
+__global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
+                                                      float* __restrict__ partial, int B, int K, int softplus) {
+    __shared__ float red[256];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float mine = 0.f;
+    if (idx < K * B) {
+        const int k = idx / B, bp = idx % B;
+        const float* col = S + (long long)k * B * B + bp;
+        float mx = -INFINITY;
+        for (int b = 0; b < B; ++b) mx = fmaxf(mx, score_tf(col[(long long)b * B], softplus));
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += expf(score_tf(col[(long long)b * B], softplus) - mx);
+        mine = mx + logf(sum);
+        lse[idx] = mine;
+    }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
+// Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T) and per-block partials {sum valid, sum m^2, max sp}.
+template <typename T>
+__global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
+                                                       T* __restrict__ dS, T* __restrict__ dST,
+                                                       float* __restrict__ partial, int B, int K, int softplus,
+                                                       float reg) {
+    __shared__ float tile[32][33];
+    __shared__ float red[3][256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
+    const int bp0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const float inv_bk = 1.f / ((float)B * (float)K);
+    const float reg_c = 2.f * reg / ((float)B * (float)B * (float)K);
+    float valid = 0.f, msq = 0.f, mx = -INFINITY;
+    float mean[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + ty + 8 * r, bp = bp0 + tx;
+        float m = 0.f;
+        if (b < B && bp < B) {
+            for (int k = 0; k < K; ++k) {
+                const float sp = score_tf(S[((long long)k * B + b) * B + bp], softplus);
+                m += sp;
+                mx = fmaxf(mx, sp);
+                if (b == bp) valid += sp;
+            }
+            m /= (float)K;
+            msq += m * m;
+        }
+        mean[r] = m;
+    }
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + ty + 8 * r, bp = bp0 + tx;
+            float g = 0.f;
+            if (b < B && bp < B) {
+                const float x = S[((long long)k * B + b) * B + bp];
+                const float sp = score_tf(x, softplus);
+                float dsp = expf(sp - lse[k * B + bp]) * inv_bk + reg_c * mean[r];
+                if (b == bp) dsp -= inv_bk;
+                g = dsp * score_grad(x, softplus);
+                dS[((long long)k * B + b) * B + bp] = from_f32<T>(g);
+            }
+            tile[ty + 8 * r][tx] = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bp = bp0 + ty + 8 * r, b = b0 + tx;
+            if (b < B && bp < B) dST[((long long)k * B + bp) * B + b] = from_f32<T>(tile[tx][ty + 8 * r]);
+        }
+    }
+    red[0][threadIdx.x] = valid;
+    red[1][threadIdx.x] = msq;
+    red[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+            red[2][threadIdx.x] = fmaxf(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        partial[blk * 3 + 0] = red[0][0];
+        partial[blk * 3 + 1] = red[1][0];
+        partial[blk * 3 + 2] = red[2][0];
+    }
+}
+
+// out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
+__global__ void nce_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
+                                    int ngrad, float* __restrict__ out, int B, int K, float reg) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
+    for (int i = 0; i < ncol; ++i) lse_sum += col_partial[i];
+    for (int i = 0; i < ngrad; ++i) {
+        valid += grad_partial[i * 3 + 0];
+        msq += grad_partial[i * 3 + 1];
+        mx = fmaxf(mx, grad_partial[i * 3 + 2]);
+    }
+    const float bk = (float)B * (float)K;
+    const float t_valid = -valid / bk, t_lse = lse_sum / bk, t_reg = reg * msq / ((float)B * (float)B);
+    out[0] = t_valid + t_lse + t_reg;
+    out[1] = mx;
+    out[2] = t_valid;
+    out[3] = t_lse;
+    out[4] = t_reg;
+}
+
+}  // namespace
+
+// workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
+long long nce_workspace_floats(int B, int K) {
+    const long long nb = (B + 31) / 32;
+    return (long long)K * B + ((long long)K * B + 255) / 256 + 3 * nb * nb;
+}
+
+int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus, float reg,
+               int dtype, hipStream_t stream) {
+    if (B <= 0 || K <= 0) return CPC_EINVAL;
+    float* lse = workspace;
+    const int ncol = (K * B + 255) / 256;
+    float* colp = lse + (long long)K * B;
+    float* gradp = colp + ncol;
+    const int nb = (B + 31) / 32;
+    hipLaunchKernelGGL(nce_col_kernel, dim3(ncol), dim3(256), 0, stream, S, lse, colp, B, K, softplus);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
+                           gradp, B, K, softplus, reg);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (float*)dS, (float*)dST, gradp,
+                           B, K, softplus, reg);
+    else
+        return CPC_EINVAL;
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

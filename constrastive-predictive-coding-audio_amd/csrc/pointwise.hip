@@ -1,0 +1,123 @@
+// Small streaming kernels of the train step: fused Adam over the flat parameter buffer, and the per-step re-layout of
+// the f32 master weights (kept in the reference's state_dict shapes) into the storage-dtype GEMM operand layouts.
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+
+namespace {
+
+// torch.optim.Adam (no weight decay, no amsgrad):  m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).   g is pre-multiplied by grad_scale (1 / world size for DP means).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float step_size, float b1, float b2,
+                                                   float eps, float inv_bc2_sqrt, float grad_scale) {
+    const long long n4 = n / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] * grad_scale;
+            mm[e] = mm[e] + (ge - mm[e]) * (1.f - b1);
+            vv[e] = vv[e] * b2 + (1.f - b2) * ge * ge;
+            const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+            pp[e] = pp[e] - step_size * (mm[e] / denom);
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    // tail
+    for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float ge = g[i] * grad_scale;
+        const float mm = m[i] + (ge - m[i]) * (1.f - b1);
+        const float vv = v[i] * b2 + (1.f - b2) * ge * ge;
+        m[i] = mm; v[i] = vv;
+        p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    }
+}
+
+// Conv weight W[co][c][tap] (f32, reference layout) ->
+//   fwd  [co][(j, c)]            : gemm_nt Bt operand of the forward conv       (K = kw * Cin)
+//   dgrd [(r, c)][(dd, co)]      : gemm_nt Bt operand of the data gradient      (K = D * Cout), tap = r + (D-1-dd)*stride,
+//                                  zero where tap >= kw.  D = ceil(kw / stride).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restrict__ W, T* __restrict__ fwd,
+                                                          T* __restrict__ dgrd, int Cout, int Cin, int kw, int stride, int D) {
+    const long long nf = (long long)Cout * kw * Cin;
+    const long long nd = (long long)stride * Cin * D * Cout;
+    const long long gstride = (long long)gridDim.x * 256;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nf; idx += gstride) {
+        const int c = (int)(idx % Cin);
+        const int j = (int)((idx / Cin) % kw);
+        const int co = (int)(idx / ((long long)Cin * kw));
+        fwd[idx] = from_f32<T>(W[((long long)co * Cin + c) * kw + j]);
+    }
+    if (dgrd) {
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nd; idx += gstride) {
+            const int co = (int)(idx % Cout);
+            const int dd = (int)((idx / Cout) % D);
+            const int c = (int)((idx / ((long long)Cout * D)) % Cin);
+            const int r = (int)(idx / ((long long)Cout * D * Cin));
+            const int tap = r + (D - 1 - dd) * stride;
+            const float v = tap < kw ? W[((long long)co * Cin + c) * kw + tap] : 0.f;
+            dgrd[idx] = from_f32<T>(v);
+        }
+    }
+}
+
+// dst[r][c] = (T) src[r * sr + c * sc]   (dst contiguous [R][C])
+template <typename T>
+__global__ __launch_bounds__(256) void cast2d_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C,
+                                                     long long sr, long long sc) {
+    const long long total = (long long)R * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long r = idx / C;
+        dst[idx] = from_f32<T>(src[r * sr + (long long)c * sc]);
+    }
+}
+
+}  // namespace
+
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                float grad_scale, hipStream_t stream) {
+    if (n <= 0 || step < 1) return CPC_EINVAL;
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const int blocks = (int)min((long long)2048, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, step_size, b1, b2, eps, inv_bc2_sqrt,
+                       grad_scale);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,
+                       hipStream_t stream) {
+    if (Cout <= 0 || Cin <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;
+    const int D = (kw + stride - 1) / stride;
+    const long long n = (long long)Cout * kw * Cin;
+    const int blocks = (int)min((long long)2048, (n + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((conv_w_prep_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, W, (bf16_t*)fwd, (bf16_t*)dgrd, Cout,
+                           Cin, kw, stride, D);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((conv_w_prep_kernel<float>), dim3(blocks), dim3(256), 0, stream, W, (float*)fwd, (float*)dgrd, Cout, Cin,
+                           kw, stride, D);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return CPC_EINVAL;
+    const long long n = (long long)R * C;
+    const int blocks = (int)min((long long)2048, (n + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((cast2d_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, R, C, sr, sc);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((cast2d_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, (float*)dst, R, C, sr, sc);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

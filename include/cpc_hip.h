@@ -1,0 +1,134 @@
+/* cpc_hip.h — C ABI of the MI355X-native CPC-audio train-step library (libcpc_hip.so).
+ *
+ * The reference (vincentherrmann/constrastive-predictive-coding-audio) is pure Python/PyTorch and has no FFI of its
+ * own; the seam this library sits behind is the ATen call each reference line makes.  Every entry point below names
+ * the reference statement(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every call is stream-ordered and asynchronous, never allocates, never synchronises, never throws;
+ *     returns 0 on success, -22 (EINVAL) for unsupported shapes/arguments, -5 (EIO) if the launch failed.
+ *   - dtype: CPC_F32 (0) = exact-f32 parity mode (v_mfma_f32_16x16x4_f32), CPC_BF16 (1) = bf16 storage with f32
+ *     accumulation (v_mfma_f32_16x16x32_bf16).  "T" below means that storage type.
+ *   - activations are channels-last: act[item][position][channel], positions padded per item to L_alloc rows
+ *     (pad rows hold zeros); see DESIGN.md "Data layout in HBM".
+ */
+#ifndef CPC_HIP_H
+#define CPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPC_F32 0
+#define CPC_BF16 1
+
+#define CPC_GEMM_RELU 1      /* NT epilogue: relu */
+#define CPC_GEMM_OUT_F32 2   /* store the result as f32 even when dtype is bf16 */
+#define CPC_GEMM_TN_NO_TR 4  /* TN/bf16 only: scalar LDS reads instead of ds_read_b64_tr_b16 (A/B check) */
+
+int cpc_abi_version(void);
+
+/* Row addressing used by both GEMMs: row m of an operand starts at element
+ *   rpi == 0 :  m * ld
+ *   rpi  > 0 :  (m / rpi) * item + (m % rpi) * ld        ("items" of rpi rows, e.g. a window of frames per clip)   */
+
+/* C[m][n] = epi( sum_k A[m][k] * Bt[n][k] ), epi = (+bias[n]) -> (relu) -> (mask[m][n] > 0 ? . : 0) -> (pad row -> 0).
+ * Replaces, in channels-last layout: F.conv1d forward of AudioEncoder layers 2..5 (audio_model.py:38-41, A rows
+ * overlap: lda = stride*C_in, K = kernel*C_in), their data gradient (autograd of the same lines), nn.GRUCell's
+ * input projection for all steps at once (audio_model.py:72), prediction_model (audio_model.py:208) and the
+ * tensordot of the score functions restricted to equal steps (contrastive_estimation_training.py:13-14, :20-21). */
+typedef struct cpc_gemm_nt_args {
+    const void* A;  const void* Bt;  void* C;
+    const float* bias;            /* [N] f32 or NULL */
+    const void* mask;             /* T, addressed like C, or NULL */
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int a_rpi; long long a_item;
+    int b_rpi; long long b_item;
+    int c_rpi; long long c_item; int c_valid;   /* rows with (m % c_rpi) >= c_valid are stored as zeros */
+    long long a_batch, b_batch, c_batch; int batch;
+    int flags; int dtype;
+} cpc_gemm_nt_args;
+int cpc_gemm_nt(const cpc_gemm_nt_args* args, void* stream);
+
+/* C[i][j] = sum_m A[m][i] * B[m][j]  (reduction over the row index of both operands), optionally split over m into
+ * nsplit f32 slabs C + s*slab_stride that cpc_reduce_slabs sums deterministically.
+ * Replaces the weight gradients autograd computes for conv1d / GRUCell / Linear (loss.backward(),
+ * contrastive_estimation_training.py:161) and the two score-gradient contractions. */
+typedef struct cpc_gemm_tn_args {
+    const void* A;  const void* B;  void* C;
+    int M, I, J;
+    long long lda, ldb, ldc;
+    int a_rpi; long long a_item;
+    int b_rpi; long long b_item;
+    long long a_batch, b_batch, c_batch; int batch;
+    int nsplit; int m_chunk; long long slab_stride;
+    int flags; int dtype;
+} cpc_gemm_tn_args;
+int cpc_gemm_tn(const cpc_gemm_tn_args* args, void* stream);
+
+/* out[j*s_j + (i / cdiv)*s_hi + (i % cdiv)*s_lo] = sum_z slabs[z*slab_stride + i*J + j]  (f32; fixed summation order). */
+int cpc_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
+                     long long s_j, long long s_hi, long long s_lo, void* stream);
+
+/* slabs[blk][n] = partial column sums of X[M][N] (T) — bias gradients; reduce with cpc_reduce_slabs(I=1). */
+int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nblocks, int dtype, void* stream);
+
+/* AudioEncoder layer 1 (C_in = 1): y[b][t][co] = relu(bias[co] + sum_j x[b][t*stride+j] * w[co][j])
+ * (audio_model.py:38-39 for l == 0).  x: f32 [B][ldx]; w: f32 [C][kw] (reference layout); y: T [B][L_alloc][C]. */
+int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
+                  long long ldx, int L_valid, int L_alloc, int dtype, void* stream);
+/* Weight/bias gradient of layer 1: slabs[B*nblk_t][(kw+1)][C] partials (row kw = bias); reduce with cpc_reduce_slabs. */
+int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
+                  int L_valid, int L_alloc, int nblk_t, int dtype, void* stream);
+
+/* Conv1d (layers >= 2) in channels-last layout, expressed through the GEMMs above.
+ *   fwd  : y[(b,t)][co] = relu?(bias + sum_{j,c} x[(b, t*stride + j)][c] * w[co][c][j])       audio_model.py:38-41
+ *   dgrad: dx[(b,p)][c]  = (x_act > 0 ?) sum_{t,co: t*stride + j = p} dy[(b,t)][co] * w[co][c][j]
+ *   wgrad: slabs of dw[(j,c)][co] = sum_{b,t} x[(b, t*stride+j)][c] * dy[(b,t)][co]
+ * w_fwd / w_dgrad are the operand layouts cpc_conv_w_prep produces.  Lout_alloc * stride == Lin_alloc is required. */
+int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw,
+                 int stride, int Lout_alloc, int Lout_valid, int relu, int dtype, void* stream);
+int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
+                   int stride, int Lout_alloc, int Lin_valid, int dtype, void* stream);
+int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride,
+                   int Lout_alloc, int nsplit, int dtype, void* stream);
+int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
+                    void* stream);
+
+/* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
+int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);
+/* MFMA fragment order of a [R][Kd] operand (transpose: logical[n][k] = src[k*ld + n]) for the GRU kernels. */
+int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, void* stream);
+
+/* AudioGRUModel.forward's python loop over nn.GRUCell (audio_model.py:66-77) as one persistent launch.
+ *   Gi    f32 [B][V][3H]  = x_t W_ih^T + b_ih for all steps (cpc_gemm_nt), gate order r, z, n
+ *   Wfrag T   cpc_prep_frag(weight_hh [3H][H]);  bhh f32 [3H]
+ *   Hall  T   [B][V+1][H] hidden states (Hall[:,0] = 0);  gates T [B][V][4][H] = r, z, n, (W_hn h + b_hn)
+ *   c_out f32 [B][H] last hidden state (what AudioGRUModel.forward returns). */
+int cpc_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
+                int V, int H, int dtype, void* stream);
+/* Backward through time: dc f32 [B][H] -> dGi, dGh T [B][V][3H] (gradients w.r.t. the two pre-activation terms).
+ * WTfrag = cpc_prep_frag(weight_hh, transpose=1) ([H][3H] logical). */
+int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
+                int V, int H, int dtype, void* stream);
+
+/* InfoNCE loss of ContrastiveEstimationTrainer.train, default branch score_over_all_timesteps=False
+ * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32), with the score
+ * function folded in (softplus != 0: softplus_score_function :12-16, else linear_score_function :19-22).
+ *   out[0] = loss (incl. regulariser), out[1] = max score (logger value, :166), out[2..4] = -mean valid, mean lse, reg
+ *   dS[k][b][b'], dST[k][b'][b] (T): d loss / d linear score.  workspace: cpc_nce_workspace_floats(B,K) f32. */
+long long cpc_nce_workspace_floats(int B, int K);
+int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus,
+                 float regularization, int dtype, void* stream);
+
+/* torch.optim.Adam.step with default betas/eps semantics over one flat f32 buffer
+ * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first. */
+int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+             int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPC_HIP_H */

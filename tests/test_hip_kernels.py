@@ -1,0 +1,360 @@
+"""GPU unit tests of every C-ABI entry point against plain PyTorch CPU references (float64 where cheap).
+
+Tolerances: f32 mode 2e-5 relative to the operand scale (exact-f32 MFMA, different summation order);
+bf16 mode 1e-2 (inputs rounded to 8 significant bits, f32 accumulation).
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cpc_audio_amd import _hip  # noqa: E402
+from oracle import cpc_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 3e-5 if dt == torch.float32 else 1.2e-2
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def dev(t, dt=None):
+    t = t.to(DEV)
+    return t.to(dt) if dt is not None else t
+
+
+def rounded(t, dt):
+    """The value the device sees after storage in dt (so that references use identical inputs)."""
+    return t.to(dt).double()
+
+
+# --------------------------------------------------------------------------------------- gemm_nt
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 72, 96), (256, 128, 128), (130, 260, 40), (17, 8, 8)])
+def test_gemm_nt_plain(dt, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    Bt = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = rounded(A, dt) @ rounded(Bt, dt).T
+    code = _hip.dtype_code(dt)
+    dA, dB, db = dev(A, dt), dev(Bt, dt), dev(bias)
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, N, K, K, K, N, code)
+    assert rel_err(out, ref) < tol(dt)
+    # bias + relu, f32 output
+    out32 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32)
+    _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out32), M, N, K, K, K, N, code, bias=_hip.ptr(db),
+                 flags=_hip.GEMM_RELU | _hip.GEMM_OUT_F32)
+    ref2 = torch.relu(ref + bias.double())
+    assert rel_err(out32, ref2) < tol(dt)
+    assert not torch.isnan(out32).any()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_addressing_mask_batch(dt):
+    """Overlapping rows (strided-conv view), item addressing on A and C, pad-row zeroing, relu mask, batch strides."""
+    g = torch.Generator().manual_seed(3)
+    code = _hip.dtype_code(dt)
+    # A: 3 items of 40 rows x 16 channels, conv k=8 (2 rows... here: K = 2*16 spans two consecutive rows), stride 1 row
+    items, rows, ch = 3, 40, 16
+    X = torch.randn(items * rows * ch + 64, generator=g)          # trailing guard
+    Bt = torch.randn(24, 2 * ch, generator=g)
+    dX, dB = dev(X, dt), dev(Bt, dt)
+    M = items * rows
+    valid = 37
+    out = torch.full((items, rows, 24), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_nt(_hip.ptr(dX), _hip.ptr(dB), _hip.ptr(out), M, 24, 2 * ch, ch, 2 * ch, 24, code,
+                 c_rpi=rows, c_item=rows * 24, c_valid=valid)
+    Xr = rounded(X, dt)
+    Arows = torch.stack([Xr[m * ch: m * ch + 2 * ch] for m in range(M)])
+    ref = (Arows @ rounded(Bt, dt).T).view(items, rows, 24)
+    ref[:, valid:, :] = 0
+    assert rel_err(out, ref) < tol(dt)
+    assert (out[:, valid:, :] == 0).all()
+    # relu-backward mask + item addressing on A (windows of 5 rows starting at row 7 of each item)
+    win, start = 5, 7
+    mask = torch.randn(items * win, 24, generator=g)
+    dM = dev(mask, dt)
+    out2 = torch.full((items * win, 24), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_nt(_hip.ptr(dX, start * ch), _hip.ptr(dB), _hip.ptr(out2), items * win, 24, 2 * ch, ch, 2 * ch, 24, code,
+                 a_rpi=win, a_item=rows * ch, mask=_hip.ptr(dM))
+    rows_idx = [i * rows + start + w for i in range(items) for w in range(win)]
+    ref2 = Arows[rows_idx] @ rounded(Bt, dt).T
+    ref2 = torch.where(rounded(mask, dt) > 0, ref2, torch.zeros_like(ref2))
+    assert rel_err(out2, ref2) < tol(dt)
+    # batched (the score contraction pattern): A_k = P[:, k, :], Bt_k = Tg[:, k, :]
+    Bn, Kn, E = 20, 3, 32
+    P = torch.randn(Bn, Kn, E, generator=g)
+    Tg = torch.randn(Bn, 7, E, generator=g)       # rows of 7 frames, use frames 4..6
+    dP, dT = dev(P, dt), dev(Tg, dt)
+    S = torch.full((Kn, Bn, Bn), float("nan"), device=DEV, dtype=torch.float32)
+    _hip.gemm_nt(_hip.ptr(dP), _hip.ptr(dT, 4 * E), _hip.ptr(S), Bn, Bn, E, Kn * E, 7 * E, Bn, code,
+                 a_batch=E, b_batch=E, c_batch=Bn * Bn, batch=Kn, flags=_hip.GEMM_OUT_F32)
+    refS = torch.einsum("bke,cke->kbc", rounded(P, dt), rounded(Tg, dt)[:, 4:7])
+    assert rel_err(S, refS) < tol(dt)
+
+
+# --------------------------------------------------------------------------------------- gemm_tn
+@pytest.mark.parametrize("dt,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, _hip.GEMM_TN_NO_TR)])
+@pytest.mark.parametrize("M,I,J", [(1000, 136, 72), (64, 128, 128), (129, 8, 264)])
+def test_gemm_tn(dt, flags, M, I, J):
+    g = torch.Generator().manual_seed(M + I)
+    A = torch.randn(M, I, generator=g)
+    B = torch.randn(M, J, generator=g)
+    code = _hip.dtype_code(dt)
+    dA, dB = dev(A, dt), dev(B, dt)
+    ref = rounded(A, dt).T @ rounded(B, dt)
+    out = torch.full((I, J), float("nan"), device=DEV, dtype=torch.float32)
+    _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, I, J, I, J, J, code, flags=flags | _hip.GEMM_OUT_F32)
+    assert rel_err(out, ref) < tol(dt)
+    # split over m into slabs + deterministic reduce with the conv-weight permutation (i = (j, c) -> out[co][c][j])
+    nsplit = 3
+    blk = 64 if dt == torch.bfloat16 else 32
+    chunk = -(-M // nsplit)
+    chunk = -(-chunk // blk) * blk
+    slabs = torch.full((nsplit, I, J), float("nan"), device=DEV, dtype=torch.float32)
+    _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(slabs), M, I, J, I, J, J, code, nsplit=nsplit, m_chunk=chunk,
+                 slab_stride=I * J, flags=flags | _hip.GEMM_OUT_F32)
+    assert rel_err(slabs.sum(0), ref) < tol(dt)
+    if I % 8 == 0:
+        cin, kw = I // 4, 4          # i = j*cin + c
+        outp = torch.full((J, cin, kw), float("nan"), device=DEV, dtype=torch.float32)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(slabs), _hip.ptr(outp), I, J, nsplit, I * J, cin, cin * kw, 1, kw)
+        refp = ref.view(kw, cin, J).permute(2, 1, 0)
+        assert rel_err(outp, refp) < tol(dt)
+    # direct storage-dtype output
+    outT = torch.full((I, J), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(outT), M, I, J, I, J, J, code, flags=flags)
+    assert rel_err(outT, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_colsum(dt):
+    g = torch.Generator().manual_seed(1)
+    for M, N in [(1000, 64), (333, 768), (50, 2048), (77, 8)]:
+        X = torch.randn(M, N, generator=g)
+        dX = dev(X, dt)
+        nb = 7
+        slabs = torch.full((nb, N), float("nan"), device=DEV)
+        _hip.call("cpc_colsum", _hip.ptr(dX), _hip.ptr(slabs), M, N, N, nb, _hip.dtype_code(dt))
+        ref = rounded(X, dt).sum(0)
+        assert rel_err(slabs.sum(0), ref) < 1e-5
+        out = torch.full((N,), float("nan"), device=DEV)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(slabs), _hip.ptr(out), 1, N, nb, N, 1, 1, 0, 0)
+        assert rel_err(out, ref) < 1e-5
+
+
+# --------------------------------------------------------------------------------------- conv layer 1
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,kw,stride", [(64, 10, 5), (512, 10, 5), (32, 7, 3)])
+def test_conv1_fwd_bwd(dt, C, kw, stride):
+    g = torch.Generator().manual_seed(C)
+    B, L = 3, 1234
+    x = torch.randn(B, L, generator=g)
+    w = torch.randn(C, 1, kw, generator=g) * 0.3
+    bias = torch.randn(C, generator=g) * 0.1
+    Lv = (L - kw) // stride + 1
+    La = Lv + 3
+    code = _hip.dtype_code(dt)
+    dx, dw, db = dev(x), dev(w), dev(bias)
+    y = torch.full((B, La, C), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(y), B, C, stride, kw, L, Lv, La, code)
+    xr = x.double().unsqueeze(1).requires_grad_(False)
+    wr = w.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    ref = torch.relu(F.conv1d(xr, wr, br, stride=stride))            # (B, C, Lv)
+    assert rel_err(y[:, :Lv].float().transpose(1, 2), ref) < (1e-5 if dt == torch.float32 else 6e-3)
+    assert (y[:, Lv:] == 0).all()
+    # backward: dy random (as if already relu-masked)
+    dy = torch.randn(B, La, C, generator=g)
+    dy[:, Lv:] = 0
+    ddy = dev(dy, dt)
+    nblk = 3
+    slabs = torch.full((B * nblk, kw + 1, C), float("nan"), device=DEV)
+    _hip.call("cpc_conv1_bwd", _hip.ptr(dx), _hip.ptr(ddy), _hip.ptr(slabs), B, C, stride, kw, L, Lv, La, nblk, code)
+    pre = F.conv1d(xr, wr, br, stride=stride)
+    (pre * rounded(dy, dt)[:, :Lv].transpose(1, 2)).sum().backward()
+    got = slabs.sum(0)
+    assert rel_err(got[:kw].T, wr.grad[:, 0, :]) < 2e-5
+    assert rel_err(got[kw], br.grad) < 2e-5
+
+
+# --------------------------------------------------------------------------------------- conv layers >= 2
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Cin,Cout,kw,stride", [(64, 64, 8, 4), (32, 64, 4, 2), (64, 32, 4, 2)])
+def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
+    g = torch.Generator().manual_seed(Cin + kw)
+    code = _hip.dtype_code(dt)
+    B = 3
+    Lin_valid = 67
+    Lout_valid = (Lin_valid - kw) // stride + 1
+    Lout_alloc = Lout_valid + 2
+    Lin_alloc = Lout_alloc * stride
+    assert Lin_alloc >= Lin_valid + 1
+    guard = 16 * max(Cin, Cout)
+    x = torch.relu(torch.randn(B, Lin_alloc, Cin, generator=g))
+    x[:, Lin_valid:] = 0
+    w = torch.randn(Cout, Cin, kw, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g) * 0.1
+
+    def padded(t):
+        buf = torch.zeros(guard + t.numel() + guard, device=DEV, dtype=dt)
+        buf[guard:guard + t.numel()] = t.reshape(-1).to(DEV).to(dt)
+        return buf
+
+    xbuf = padded(x)
+    dw_, db_ = dev(w), dev(bias)
+    wf = torch.empty(Cout * kw * Cin, device=DEV, dtype=dt)
+    D = -(-kw // stride)
+    wd = torch.empty(stride * Cin * D * Cout, device=DEV, dtype=dt)
+    _hip.call("cpc_conv_w_prep", _hip.ptr(dw_), _hip.ptr(wf), _hip.ptr(wd), Cout, Cin, kw, stride, code)
+    assert rel_err(wf.float().view(Cout, kw, Cin), rounded(w, dt).permute(0, 2, 1)) == 0
+    ybuf = torch.full((guard + B * Lout_alloc * Cout + guard,), float("nan"), device=DEV, dtype=dt)
+    for relu in (1, 0):
+        _hip.call("cpc_conv_fwd", _hip.ptr(xbuf, guard), _hip.ptr(wf), _hip.ptr(db_), _hip.ptr(ybuf, guard), B, Cin, Cout, kw,
+                  stride, Lout_alloc, Lout_valid, relu, code)
+        y = ybuf[guard:guard + B * Lout_alloc * Cout].view(B, Lout_alloc, Cout)
+        xr = rounded(x, dt)[:, :Lin_valid].transpose(1, 2)
+        ref = F.conv1d(xr, rounded(w, dt), bias.double(), stride=stride)
+        if relu:
+            ref = torch.relu(ref)
+        assert rel_err(y[:, :Lout_valid].float().transpose(1, 2), ref) < tol(dt)
+        assert (y[:, Lout_valid:] == 0).all()
+    # gradients
+    dy = torch.randn(B, Lout_alloc, Cout, generator=g)
+    dy[:, Lout_valid:] = 0
+    dybuf = padded(dy)
+    dxbuf = torch.full((guard + B * Lin_alloc * Cin + guard,), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(xbuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
+              kw, stride, Lout_alloc, Lin_valid, code)
+    xin = rounded(x, dt)[:, :Lin_valid].transpose(1, 2).clone().requires_grad_(True)
+    wr = rounded(w, dt).clone().requires_grad_(True)
+    out = F.conv1d(xin, wr, None, stride=stride)
+    (out * rounded(dy, dt)[:, :Lout_valid].transpose(1, 2)).sum().backward()
+    dx = dxbuf[guard:guard + B * Lin_alloc * Cin].view(B, Lin_alloc, Cin)
+    ref_dx = xin.grad.transpose(1, 2) * (rounded(x, dt)[:, :Lin_valid] > 0)
+    assert rel_err(dx[:, :Lin_valid], ref_dx) < tol(dt)
+    assert (dx[:, Lin_valid:] == 0).all()
+    nsplit = 2
+    slabs = torch.full((nsplit, kw * Cin, Cout), float("nan"), device=DEV)
+    _hip.call("cpc_conv_wgrad", _hip.ptr(xbuf, guard), _hip.ptr(dybuf, guard), _hip.ptr(slabs), B, Cin, Cout, kw, stride, Lout_alloc,
+              nsplit, code)
+    got = slabs.sum(0).view(kw, Cin, Cout).permute(2, 1, 0)
+    assert rel_err(got, wr.grad) < tol(dt)
+
+
+# --------------------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,V,H", [(7, 13, 64), (20, 5, 32), (16, 3, 256)])
+def test_gru_fwd_bwd(dt, B, V, H):
+    g = torch.Generator().manual_seed(B + H)
+    code = _hip.dtype_code(dt)
+    w_hh = torch.randn(3 * H, H, generator=g) / math.sqrt(H)
+    b_hh = torch.randn(3 * H, generator=g) * 0.1
+    Gi = torch.randn(B, V, 3 * H, generator=g)
+    dc = torch.randn(B, H, generator=g)
+    dW, db, dGi_in, ddc = dev(w_hh), dev(b_hh), dev(Gi), dev(dc)
+    wfrag = torch.empty(3 * H * H, device=DEV, dtype=dt)
+    wTfrag = torch.empty(3 * H * H, device=DEV, dtype=dt)
+    _hip.call("cpc_prep_frag", _hip.ptr(dW), _hip.ptr(wfrag), 3 * H, H, H, 0, code)
+    _hip.call("cpc_prep_frag", _hip.ptr(dW), _hip.ptr(wTfrag), H, 3 * H, H, 1, code)
+    Hall = torch.full((B, V + 1, H), float("nan"), device=DEV, dtype=dt)
+    gates = torch.full((B, V, 4, H), float("nan"), device=DEV, dtype=dt)
+    c = torch.full((B, H), float("nan"), device=DEV)
+    _hip.call("cpc_gru_fwd", _hip.ptr(dGi_in), _hip.ptr(wfrag), _hip.ptr(db), _hip.ptr(Hall), _hip.ptr(gates), _hip.ptr(c), B, V, H, code)
+    # reference (float64) with the weights as the device sees them
+    wr = rounded(w_hh, dt).requires_grad_(True)
+    br = b_hh.double().requires_grad_(True)
+    gir = Gi.double().requires_grad_(True)
+    h = torch.zeros(B, H, dtype=torch.float64)
+    hs = [h]
+    for t in range(V):
+        gh = h @ wr.T + br
+        r = torch.sigmoid(gir[:, t, :H] + gh[:, :H])
+        u = torch.sigmoid(gir[:, t, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gir[:, t, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - u) * n + u * h
+        hs.append(h)
+    t_f = 2e-5 if dt == torch.float32 else 2e-2
+    assert rel_err(c, h) < t_f
+    assert rel_err(Hall, torch.stack(hs, 1)) < t_f
+    (h * dc.double()).sum().backward()
+    dGi = torch.full((B, V, 3 * H), float("nan"), device=DEV, dtype=dt)
+    dGh = torch.full((B, V, 3 * H), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_gru_bwd", _hip.ptr(ddc), _hip.ptr(Hall), _hip.ptr(gates), _hip.ptr(wTfrag), _hip.ptr(dGi), _hip.ptr(dGh), B, V, H, code)
+    t_b = 5e-5 if dt == torch.float32 else 4e-2
+    assert rel_err(dGi, gir.grad) < t_b
+    # dGh: gradient wrt (h W_hh^T + b_hh): its column sums are the b_hh gradient
+    assert rel_err(dGh.double().sum((0, 1)), br.grad) < t_b
+    # dW_hh = sum_t dGh_t^T h_{t-1}
+    dWhh = torch.einsum("bvg,bvh->gh", dGh.double().cpu(), Hall[:, :V].double().cpu())
+    assert rel_err(dWhh, wr.grad) < t_b
+
+
+# --------------------------------------------------------------------------------------- InfoNCE
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("softplus", [0, 1])
+@pytest.mark.parametrize("B,K,reg", [(6, 4, 1.0), (40, 12, 0.01), (33, 3, 0.5)])
+def test_nce_loss(dt, softplus, B, K, reg):
+    g = torch.Generator().manual_seed(B * 3 + K)
+    S = torch.randn(K, B, B, generator=g) * 3.0
+    S[0, 0, 0] = 25.0                                  # exercises the softplus threshold branch
+    code = _hip.dtype_code(dt)
+    dS_in = dev(S)
+    dS = torch.full((K, B, B), float("nan"), device=DEV, dtype=dt)
+    dST = torch.full((K, B, B), float("nan"), device=DEV, dtype=dt)
+    out = torch.full((8,), float("nan"), device=DEV)
+    ws = torch.empty(_hip.lib().cpc_nce_workspace_floats(B, K), device=DEV)
+    _hip.call("cpc_nce_loss", _hip.ptr(dS_in), _hip.ptr(dS), _hip.ptr(dST), _hip.ptr(out), _hip.ptr(ws), B, K, softplus,
+              C.c_float(reg), code)
+    # oracle on the 4-D score tensor whose equal-step diagonal is S (other entries irrelevant in this branch)
+    lin = S.double().requires_grad_(True)
+    full = torch.zeros(B, K, B, K, dtype=torch.float64)
+    for k in range(K):
+        full[:, k, :, k] = lin[k]
+    sc = F.softplus(full) if softplus else full
+    loss, smax = O.info_nce_loss(sc, all_timesteps=False, regularization=reg)
+    loss.backward()
+    assert abs(out[0].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert abs(out[1].item() - smax.item()) < 1e-5 * max(1.0, abs(smax.item()))
+    t = 2e-5 if dt == torch.float32 else 1e-2
+    assert rel_err(dS, lin.grad) < t
+    assert rel_err(dST, lin.grad.transpose(1, 2)) < t
+
+
+# --------------------------------------------------------------------------------------- Adam
+def test_adam_matches_torch():
+    g = torch.Generator().manual_seed(0)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p = dev(p0.clone())
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        ref_p.grad = grad.clone()
+        opt.step()
+        dg = dev(grad * 2.0)
+        _hip.call("cpc_adam", _hip.ptr(p), _hip.ptr(dg), _hip.ptr(m), _hip.ptr(v), C.c_longlong(n), C.c_float(1e-3),
+                  C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), step, C.c_float(0.5))
+        assert (p.cpu() - ref_p.detach()).abs().max().item() < 2e-6
+
+
+def test_unsupported_shapes_fail_loudly():
+    a = torch.zeros(64, 12, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_hip.HipCallError):
+        _hip.gemm_nt(_hip.ptr(a), _hip.ptr(a), _hip.ptr(a), 64, 64, 12, 12, 12, 64, _hip.BF16)   # K % 8 != 0
