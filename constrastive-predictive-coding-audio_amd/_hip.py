@@ -61,7 +61,7 @@ _SIGNATURES = {
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),
-    "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P], _I),
+    "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P], _I),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

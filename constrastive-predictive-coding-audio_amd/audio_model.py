@@ -1,0 +1,350 @@
+"""Drop-in model surface: AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel (+ activation taps).
+
+Same constructor arguments, attributes, state_dict keys and forward return values as the reference's
+``audio_model.py`` (AudioEncoder :14-44, AudioGRUModel :47-77, AudioPredictiveCodingModel :164-219, ActivationRegister /
+ActivationWriter :222-284), but ``forward`` runs the hand-written HIP path (``engine.CPCEngine``) instead of ATen
+convolutions / GRUCell loops.  Parameters stay ``nn.Parameter``s in the reference's shapes (so checkpoints and
+``model.parameters()``-built optimizers keep working); on the device they are views into one flat f32 buffer.
+
+There is no CPU implementation here: calling ``forward`` with a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+encoder_default_dict = {'strides': [5, 4, 2, 2, 2],
+                        'kernel_sizes': [10, 8, 4, 4, 4],
+                        'channel_count': [512, 512, 512, 512, 512],
+                        'bias': True}
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+           torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+
+
+class _ConvParams(nn.Module):
+    """Holds ``weight`` (out, in, k) and optional ``bias`` with nn.Conv1d's default initialisation; no forward."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = (kernel_size,), (stride,)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size[0])
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _GRUCellParams(nn.Module):
+    """weight_ih / weight_hh / bias_ih / bias_hh with nn.GRUCell's names, shapes and initialisation; no forward."""
+
+    def __init__(self, input_size, hidden_size, bias=True):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.weight_ih = nn.Parameter(torch.empty(3 * hidden_size, input_size))
+        self.weight_hh = nn.Parameter(torch.empty(3 * hidden_size, hidden_size))
+        if bias:
+            self.bias_ih = nn.Parameter(torch.empty(3 * hidden_size))
+            self.bias_hh = nn.Parameter(torch.empty(3 * hidden_size))
+        else:
+            self.register_parameter("bias_ih", None)
+            self.register_parameter("bias_hh", None)
+        stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+
+class AudioEncoder(nn.Module):
+    """Strided 1-D conv stack, relu between layers, none after the last (reference audio_model.py:14-44)."""
+
+    def __init__(self, args_dict=encoder_default_dict):
+        super().__init__()
+        self.strides = list(args_dict['strides'])
+        self.kernel_sizes = list(args_dict['kernel_sizes'])
+        self.channel_count = list(args_dict['channel_count'])
+        self.num_layers = len(self.strides)
+        self.downsampling_factor = np.prod(self.strides)
+        self.receptive_field = self.kernel_sizes[0]
+        hop = 1
+        for i in range(1, self.num_layers):
+            hop *= self.strides[i - 1]
+            self.receptive_field += (self.kernel_sizes[i] - 1) * hop
+        self.layers = nn.ModuleList()
+        for l in range(self.num_layers):
+            self.layers.append(_ConvParams(1 if l == 0 else self.channel_count[l - 1], self.channel_count[l],
+                                           self.kernel_sizes[l], self.strides[l], bias=args_dict['bias']))
+
+    def forward(self, x):
+        """x (B, 1, L) on the GPU -> (B, C, T) float32.  Inference only when called stand-alone; gradients flow when the
+        encoder is used through AudioPredictiveCodingModel."""
+        owner = _standalone_owner(self)
+        return owner.encode(x)
+
+
+class AudioGRUModel(nn.Module):
+    """GRU context network; ``forward(input)`` takes (batch, input_size, steps) and returns the last hidden state
+    (reference audio_model.py:47-77).  Only ``reset_hidden=True`` (the reference default) is supported."""
+
+    def __init__(self, input_size, hidden_size, bias=True, reset_hidden=True):
+        super().__init__()
+        if not reset_hidden:
+            raise NotImplementedError("reset_hidden=False (state carried across calls) is not part of the HIP path")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.gruCell = _GRUCellParams(input_size, hidden_size, bias)
+        self.hidden = None
+        self.reset_hidden = reset_hidden
+
+    def forward(self, input):
+        raise NotImplementedError("AudioGRUModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+
+
+class AudioPredictiveCodingModel(nn.Module):
+    """encoder -> (targets, z) -> autoregressive context c -> W_k c predictions (reference audio_model.py:164-219).
+
+    ``compute_dtype``: "bf16" (default; bf16 storage, f32 accumulate — BASELINE config 2) or "fp32" (exact-f32 MFMA,
+    the parity mode)."""
+
+    def __init__(self, encoder, autoregressive_model, enc_size, ar_size, visible_steps=100, prediction_steps=12,
+                 activation_register=None, compute_dtype="bf16"):
+        super().__init__()
+        self.enc_size = enc_size
+        self.ar_size = ar_size
+        self.visible_steps = visible_steps
+        self.prediction_steps = prediction_steps
+        self.encoder = encoder
+        self.autoregressive_model = autoregressive_model
+        self.prediction_model = _LinearParams(ar_size, enc_size * prediction_steps)
+        self.activation_register = activation_register
+        self.input_activation_writer = ActivationWriter(register=self.activation_register, name='scalogram')
+        self.z_activation_writer = ActivationWriter(register=self.activation_register, name='z_code')
+        self.c_activation_writer = ActivationWriter(register=self.activation_register, name='c_code')
+        self.prediction_activation_writer = ActivationWriter(register=self.activation_register, name='prediction')
+        self.compute_dtype = _DTYPES[compute_dtype]
+        self._engines = {}
+        self._flat_param = None
+        self._flat_grad = None
+        self._param = {}
+        self._grad = {}
+        if not isinstance(encoder, AudioEncoder) or not isinstance(autoregressive_model, AudioGRUModel):
+            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel (SURVEY.md section 8 rows a1-a4)")
+
+    @property
+    def item_length(self):
+        item_length = self.encoder.receptive_field
+        item_length += (self.visible_steps + self.prediction_steps) * self.encoder.downsampling_factor
+        return item_length
+
+    def parameter_count(self):
+        return sum(int(np.prod(p.shape)) for p in self.parameters())
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flatten_parameters(self, device):
+        """Moves all parameters into ONE f32 buffer on ``device`` (each a 256-byte aligned view) and creates the
+        parallel flat gradient buffer the engine writes (``self._grad`` views; ``link_grads`` exposes them as
+        ``p.grad``).  Idempotent."""
+        device = torch.device(device)
+        named = list(self.named_parameters())
+        if self._flat_param is not None and self._flat_param.device == device and \
+                all(p.data_ptr() == self._param[n].data_ptr() for n, p in named):
+            return
+        offsets, total = {}, 0
+        for n, p in named:
+            offsets[n] = total
+            total += (p.numel() + 63) // 64 * 64
+        flat = torch.zeros(total, device=device, dtype=torch.float32)
+        grad = torch.zeros(total, device=device, dtype=torch.float32)
+        self._param, self._grad = {}, {}
+        with torch.no_grad():
+            for n, p in named:
+                view = flat[offsets[n]:offsets[n] + p.numel()].view(p.shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+                gview = grad[offsets[n]:offsets[n] + p.numel()].view(p.shape)
+                self._param[n], self._grad[n] = view, gview
+        self._flat_param, self._flat_grad = flat, grad
+        self._engines = {}
+
+    def link_grads(self):
+        """Makes every parameter's ``.grad`` the engine's gradient view (used by the fused trainer path, where autograd
+        is not involved; e.g. for the reference's grad_mean_var helper)."""
+        for n, p in self.named_parameters():
+            p.grad = self._grad[n]
+
+    def engine(self, batch_size, length, device=None):
+        from .engine import CPCEngine
+        if device is None:
+            device = next(self.parameters()).device
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the CPC hot path runs on the GPU only (no CPU fallback): call model.to('cuda') first")
+        key = (int(batch_size), int(length), self.compute_dtype, str(device))
+        eng = self._engines.get(key)
+        if eng is None or self._flat_param is None or any(
+                p.data_ptr() != self._param[n].data_ptr() for n, p in self.named_parameters()):
+            self._flatten_parameters(device)
+            eng = CPCEngine(self, batch_size, length, device, self.compute_dtype)
+            self._engines[key] = eng
+        return eng
+
+    def encode(self, x):
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError("expected input of shape (batch, 1, samples)")
+        eng = self.engine(x.shape[0], x.shape[2], x.device)
+        xin = x.detach()[:, 0, :].contiguous().float()
+        eng.prepare_weights()
+        eng.encoder_forward(xin)
+        return eng.view_top()[:, :eng.T, :].float().transpose(1, 2)
+
+    def forward(self, x):
+        """x (B, 1, L) -> (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)), autograd-connected to the
+        parameters (targets are not detached, as in the reference audio_model.py:197)."""
+        x = self.input_activation_writer(x)
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError("expected input of shape (batch, 1, samples)")
+        eng = self.engine(x.shape[0], x.shape[2], x.device)
+        params = [p for _, p in self.named_parameters()]
+        predicted_z, targets, z, c = _CPCForward.apply(eng, x, *params)
+        z = self.z_activation_writer(z)
+        c = self.c_activation_writer(c)
+        predicted_z = self.prediction_activation_writer(predicted_z)
+        return predicted_z, targets, z, c
+
+
+class _LinearParams(nn.Module):
+    """``weight`` (out, in) with nn.Linear's default initialisation, no bias; no forward."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class _CPCForward(torch.autograd.Function):
+    """Autograd bridge: forward = engine.forward, backward = engine.backward fed with the incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        xin = x.detach()[:, 0, :].contiguous().float()
+        eng.forward(xin)
+        ctx.eng, ctx.xin = eng, xin
+        ctx.set_materialize_grads(False)
+        pred, targets, z, c = eng.outputs()
+        return pred, targets, z, c
+
+    @staticmethod
+    def backward(ctx, d_pred, d_targets, d_z, d_c):
+        eng = ctx.eng
+        B, E, K, V, T = eng.B, eng.E, eng.K, eng.V, eng.T
+        dtop = eng.dact[-1].view(B, eng.geo.alloc[-1], E)
+        if d_pred is None:
+            eng.dpred.zero_()
+        else:
+            eng.dpred.view(B, K, E).copy_(d_pred)
+        if d_targets is None:
+            dtop[:, T - K:T, :].zero_()
+        else:
+            dtop[:, T - K:T, :].copy_(d_targets.transpose(1, 2))
+        eng.backward(ctx.xin, add_dc=d_c, add_dz=d_z)
+        grads = [eng.model._grad[n].clone() for n, _ in eng.model.named_parameters()]
+        return (None, None, *grads)
+
+
+def _standalone_owner(encoder):
+    """A stand-alone AudioEncoder call needs an engine; it is hosted by a private model wrapper cached on the encoder."""
+    owner = getattr(encoder, "_owner", None)
+    if owner is None:
+        c = encoder.channel_count[-1]
+        gru = AudioGRUModel(c, 32)
+        object.__setattr__(encoder, "_owner", None)
+        owner = AudioPredictiveCodingModel.__new__(AudioPredictiveCodingModel)
+        nn.Module.__init__(owner)
+        owner.enc_size, owner.ar_size = c, 32
+        owner.visible_steps, owner.prediction_steps = 0, 0
+        owner.encoder = encoder
+        owner.autoregressive_model = gru
+        owner.prediction_model = _LinearParams(32, c)
+        owner.compute_dtype = getattr(encoder, "compute_dtype", torch.float32)
+        owner._engines, owner._flat_param, owner._flat_grad, owner._param, owner._grad = {}, None, None, {}, {}
+        object.__setattr__(encoder, "_owner", owner)
+    dev = next(encoder.parameters()).device
+    if next(owner.autoregressive_model.parameters()).device != dev:
+        owner.autoregressive_model.to(dev)
+        owner.prediction_model.to(dev)
+    return owner
+
+
+class ActivationRegister:
+    """Collects tapped activations by name (reference audio_model.py:222-271)."""
+
+    def __init__(self, writing_condition=None, clone_activations=False, batch_filter=None, move_to_cpu=False, devices=None):
+        self.devices = devices
+        if devices is not None:
+            self.activations = {dev: OrderedDict() for dev in devices}
+        else:
+            self.activations = OrderedDict()
+        self.active = True
+        self.writing_condition = writing_condition
+        self.clone_activations = clone_activations
+        self.batch_filter = batch_filter
+        self.move_to_cpu = move_to_cpu
+
+    def write_activation(self, name, value):
+        if not self.active:
+            return
+        if self.writing_condition is not None and not self.writing_condition(value):
+            return
+        if self.batch_filter is not None:
+            value = value[self.batch_filter]
+        dev = value.device.index if self.devices is not None else None
+        if self.move_to_cpu:
+            value = value.cpu()
+        if self.clone_activations:
+            value = value.clone()
+        if self.devices is not None:
+            self.activations[dev][name] = value
+        else:
+            self.activations[name] = value
+
+    def get_activations(self):
+        if self.devices is None:
+            return self.activations
+        first = self.devices[0]
+        return {key: torch.cat([self.activations[dev][key].to(f"cuda:{first}") for dev in self.devices], dim=0)
+                for key in self.activations[first].keys()}
+
+
+class ActivationWriter(nn.Module):
+    def __init__(self, register, name):
+        super().__init__()
+        self.register = register
+        self.name = name
+
+    def forward(self, x):
+        if self.register is not None:
+            self.register.write_activation(self.name, x)
+        return x
+
+
+def load_to_cpu(path):
+    model = torch.load(path, map_location=lambda storage, loc: storage)
+    model.cpu()
+    return model
+
+
+def num_parameters(model):
+    return sum(int(np.prod(p.shape)) for p in model.parameters())
+
+
+def cuda0_writing_condition(x):
+    """Write only if x is on the CPU or the first GPU."""
+    return x.device.index == 0 if x.device.type == 'cuda' else True

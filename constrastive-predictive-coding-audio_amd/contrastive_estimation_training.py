@@ -1,0 +1,318 @@
+"""Drop-in trainer surface: score functions, ContrastiveEstimationTrainer, DeterministicSampler, grad_mean_var.
+
+Mirrors the reference's ``contrastive_estimation_training.py`` (score functions :12-33, trainer :36-269,
+DeterministicSampler :363-382, grad_mean_var :385-391).  ``train`` has two routes:
+
+* fused (the hot path): AudioEncoder + AudioGRUModel model, softplus/linear score, same-step scores
+  (``score_over_all_timesteps=False``), Adam.  Forward, InfoNCE loss, analytic backward and the Adam update all run as
+  HIP kernels (engine.CPCEngine); with torch.distributed initialised, one process per GPU, the flat gradient buffer is
+  all-reduced over RCCL before the update (per-GPU in-batch negatives).
+* generic: any other score function / ``score_over_all_timesteps=True``: the model forward and backward still run on
+  the HIP path (through the autograd bridge); the loss itself is assembled with torch ops on the GPU exactly as the
+  reference does (:106-122, :141).
+"""
+from __future__ import annotations
+
+import math
+import random
+import time
+
+import torch
+import torch.nn.functional as F
+import torch.optim
+import torch.utils.data
+
+from .audio_model import *          # noqa: F401,F403  (the reference re-exports the model names from here)
+from .audio_dataset import FileBatchSampler
+
+
+def softplus_score_function(predicted_z, targets):
+    """scores[b, k, b', k'] = softplus(sum_e predicted_z[b,k,e] * targets[b',e,k'])  (reference :12-16)."""
+    return F.softplus(torch.tensordot(predicted_z, targets, dims=([2], [1])))
+
+
+def linear_score_function(predicted_z, targets):
+    """scores[b, k, b', k'] = sum_e predicted_z[b,k,e] * targets[b',e,k']  (reference :19-22)."""
+    return torch.tensordot(predicted_z, targets, dims=([2], [1]))
+
+
+def difference_score_function(predicted_z, targets):
+    """1 / squared distance between every prediction and every target (reference :25-33); O(B^2 K^2 E) memory."""
+    diff = predicted_z.unsqueeze(3).unsqueeze(4) - targets.permute(1, 0, 2).unsqueeze(0).unsqueeze(1)
+    return 1 / torch.sum(diff ** 2, dim=2)
+
+
+def _loss_terms(scores, batch_size, prediction_steps, all_timesteps):
+    """(scores, noise_scoring, valid_scores) exactly as the reference forms them (:108-119), including the raw
+    ``view(-1, batch, steps)`` reinterpretation in the default branch."""
+    if all_timesteps:
+        noise = torch.logsumexp(scores.view(-1, batch_size, prediction_steps), dim=0)
+        valid = torch.diagonal(torch.diagonal(scores, dim1=0, dim2=2), dim1=0, dim2=1)
+        return scores, noise, valid
+    s = torch.diagonal(scores, dim1=1, dim2=3).permute([0, 2, 1]).contiguous()
+    noise = torch.logsumexp(s.view(-1, batch_size, prediction_steps), dim=0)
+    valid = torch.diagonal(s, dim1=0, dim2=2).permute([1, 0])
+    return s, noise, valid
+
+
+class ContrastiveEstimationTrainer:
+    def __init__(self, model, dataset, logger=None, device=None,
+                 regularization=1., validation_set=None, test_task_set=None, prediction_noise=0.01,
+                 optimizer=torch.optim.Adam,
+                 file_batch_size=1,
+                 score_over_all_timesteps=False,
+                 score_function=softplus_score_function,
+                 wasserstein_gradient_penalty=False,
+                 gradient_penalty_factor=10.,
+                 preprocessing=None,
+                 ar_size=256,
+                 prediction_steps=16):
+        self.model = model
+        self.ar_size = ar_size
+        self.prediction_steps = prediction_steps
+        self.dataset = dataset
+        self.logger = logger
+        self.device = device
+        self.regularization = regularization
+        self.validation_set = validation_set
+        self.test_task_set = test_task_set
+        self.training_step = 0
+        self.print_out_scores = False
+        self.prediction_noise = prediction_noise
+        self.optimizer = optimizer
+        self.file_batch_size = file_batch_size
+        self.score_over_all_timesteps = score_over_all_timesteps
+        self.score_function = score_function
+        self.wasserstein_gradient_penalty = wasserstein_gradient_penalty
+        self.gradient_penalty_factor = gradient_penalty_factor
+        self.preprocessing = preprocessing
+        # Not in the reference: how often loss / max-score are read back to the host (the reference reads them every
+        # step, :124 and :165-166).  Values are delivered to the logger in order, at most this many steps late.
+        self.host_sync_interval = 1
+        self.verbose = True
+        if wasserstein_gradient_penalty:
+            raise NotImplementedError("the Wasserstein gradient penalty (double backward through the encoder) is not "
+                                      "part of the HIP path yet (SURVEY.md section 8f, rank 3)")
+        if preprocessing is not None:
+            raise NotImplementedError("the CQT preprocessing variant is not part of the HIP path yet (SURVEY.md 8a, a7-a10)")
+        if self.verbose:
+            print("use score function", self.score_function)
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _device(self):
+        if self.device is not None:
+            return torch.device(self.device)
+        return next(self.model.parameters()).device
+
+    def _fused(self):
+        return (self.score_function in (softplus_score_function, linear_score_function)
+                and not self.score_over_all_timesteps and self.optimizer is torch.optim.Adam)
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _batches(self, dataset, sampler, device, num_workers, pin_memory, rank, world):
+        """Yields device batches (B, L).  A dataset exposing ``device_data`` (an (N, L) tensor already in HBM) is
+        indexed on the device; anything else goes through a torch DataLoader as in the reference (:87-91)."""
+        resident = getattr(dataset, "device_data", None)
+        if world > 1:
+            import torch.distributed as dist
+            lists = [list(b) for b in iter(sampler)] if rank == 0 else None
+            box = [lists]
+            dist.broadcast_object_list(box, src=0)
+            per = len(box[0][0]) // world if box[0] else 0
+            index_lists = [b[rank * per:(rank + 1) * per] for b in box[0]]
+        else:
+            index_lists = None
+        if resident is not None:
+            it = index_lists if index_lists is not None else iter(sampler)
+            for idx in it:
+                yield resident[torch.as_tensor(list(idx), device=resident.device)]
+            return
+        loader = torch.utils.data.DataLoader(dataset, batch_sampler=index_lists if index_lists is not None else sampler,
+                                             num_workers=num_workers, pin_memory=pin_memory)
+        for batch in iter(loader):
+            yield batch.to(device=device, non_blocking=True)
+
+    # ------------------------------------------------------------------------------------------ train
+    def train(self, batch_size=32, epochs=10, lr=0.0001, continue_training_at_step=0, num_workers=1, max_steps=None,
+              profile=False):
+        """Same contract as the reference's train (:74-176): returns ``prof`` (None unless profile=True) when max_steps is
+        reached, None on a NaN loss or when the epochs are exhausted.  ``batch_size`` is the per-process batch; under
+        torch.distributed the sampler draws batch_size * world_size indices and every rank takes its slice."""
+        device = self._device()
+        rank, world = self._world()
+        self.model.train()
+        fused = self._fused()
+        if fused:
+            from .engine import FusedAdam
+            self.model._flatten_parameters(device)
+            optimizer = FusedAdam(self.model, lr=lr)
+            self.model.link_grads()
+        else:
+            self.model._flatten_parameters(device)
+            optimizer = self.optimizer(self.model.parameters(), lr=lr)
+        sampler = FileBatchSampler(index_count_per_file=self.dataset.get_example_count_per_file(),
+                                   batch_size=batch_size * world, file_batch_size=self.file_batch_size, drop_last=True,
+                                   verbose=self.verbose)
+        self.training_step = continue_training_at_step
+        pending = []          # (step, device scalars) not yet read back
+
+        def flush():
+            for step, vals in pending:
+                loss_v, score_v = (float(v) for v in vals.tolist()[:2])
+                if self.logger is not None:
+                    self.logger.loss_meter.update(loss_v)
+                    self.logger.score_meter.update(score_v)
+                    self.logger.log(step)
+                elif self.verbose:
+                    print("loss at step step " + str(step) + ":", loss_v)
+                if math.isnan(loss_v):
+                    pending.clear()
+                    return step
+            pending.clear()
+            return None
+
+        prof = None
+        for current_epoch in range(epochs):
+            if self.verbose:
+                print("epoch", current_epoch)
+            ctx = torch.autograd.profiler.profile(use_device="cuda", enabled=profile)
+            with ctx as prof_ctx:
+                for batch in self._batches(self.dataset, sampler, device, num_workers, True, rank, world):
+                    if fused:
+                        eng = self.model.engine(batch.shape[0], batch.shape[1], device)
+                        out = eng.loss_and_grads(batch.contiguous(), softplus=self.score_function is softplus_score_function,
+                                                 regularization=float(self.regularization))
+                        if world > 1:
+                            import torch.distributed as dist
+                            dist.all_reduce(self.model._flat_grad)
+                        optimizer.step(grad_scale=1.0 / world)
+                        vals = out[:2].clone()
+                    else:
+                        vals = self._generic_step(batch, batch.shape[0], optimizer, world)
+                    pending.append((self.training_step, vals))
+                    if len(pending) >= self.host_sync_interval:
+                        nan_step = flush()
+                        if nan_step is not None:
+                            print("nan loss")
+                            print("returned with nan loss at step", nan_step)
+                            return None
+                    self.training_step += 1
+                    if max_steps is not None and self.training_step >= max_steps:
+                        flush()
+                        return prof_ctx if profile else None
+            prof = prof_ctx if profile else None
+        flush()
+        return None
+
+    def _generic_step(self, batch, batch_size, optimizer, world):
+        predicted_z, targets, _, _ = self.model(batch.unsqueeze(1))
+        scores = self.score_function(predicted_z, targets)
+        scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, self.prediction_steps,
+                                                          self.score_over_all_timesteps)
+        prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=1)
+        loss = torch.mean(prediction_losses)
+        loss = loss + self.regularization * torch.mean(torch.mean(scores, dim=1) ** 2)
+        self.model.zero_grad()
+        loss.backward()
+        if world > 1:
+            import torch.distributed as dist
+            for p in self.model.parameters():
+                dist.all_reduce(p.grad)
+                p.grad.div_(world)
+        optimizer.step()
+        return torch.stack([loss.detach(), torch.max(scores).detach()])
+
+    # ------------------------------------------------------------------------------------------ validate
+    def validate(self, batch_size=64, num_workers=1, max_steps=None):
+        """Reference validate (:178-269): per-step loss (with the reference's dim=0 mean over the reinterpreted view),
+        argmax accuracy, mean score, mutual-information lower bound log(n) - loss."""
+        if self.validation_set is None:
+            print("No validation set")
+            return 0, 0
+        device = self._device()
+        self.model.eval()
+        sampler = FileBatchSampler(index_count_per_file=self.validation_set.get_example_count_per_file(),
+                                   batch_size=batch_size, file_batch_size=8, drop_last=True, seed=0, verbose=self.verbose)
+        K = self.prediction_steps
+        total_prediction_losses = torch.zeros(K, device=device)
+        total_accurate_predictions = torch.zeros(K, device=device)
+        n = batch_size * K if self.score_over_all_timesteps else batch_size
+        template = torch.arange(0, n, dtype=torch.long, device=device)
+        template = template.view(batch_size, K) if self.score_over_all_timesteps else template.unsqueeze(1).repeat(1, K)
+        total_score = 0
+        n_batches = len(list(iter(FileBatchSampler(self.validation_set.get_example_count_per_file(), batch_size, 8, True,
+                                                   seed=0, verbose=False))))
+        max_steps = n_batches if max_steps is None else min(max_steps, n_batches)
+        with torch.no_grad():
+            for step, batch in enumerate(self._batches(self.validation_set, sampler, device, num_workers, False, 0, 1)):
+                predicted_z, targets, _, _ = self.model(batch.unsqueeze(1))
+                scores = self.score_function(predicted_z, targets)
+                scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, K, self.score_over_all_timesteps)
+                prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=0)
+                max_score = torch.argmax(scores.view(batch_size, K, -1), dim=2)
+                correctly_predicted = torch.eq(template, max_score)
+                prediction_accuracy = torch.sum(correctly_predicted, dim=0).type_as(batch) / n
+                total_prediction_losses += prediction_losses
+                total_accurate_predictions += prediction_accuracy
+                total_score += torch.mean(scores).item()
+                if step + 1 >= max_steps:
+                    break
+        total_prediction_losses /= max_steps
+        total_accurate_predictions /= max_steps
+        total_score /= max_steps
+        mean_mutual_information_lb = math.log(n) - total_prediction_losses
+        self.model.train()
+        return total_prediction_losses, total_accurate_predictions, total_score, mean_mutual_information_lb
+
+    def calc_test_task_data(self, batch_size=64, num_workers=1):
+        """Context vectors c of every item of the test-task set (reference :271-303)."""
+        if self.test_task_set is None:
+            print("No test task set")
+        device = self._device()
+        num_items = len(self.test_task_set)
+        self.model.eval()
+        task_data = torch.zeros(num_items, self.ar_size)
+        task_labels = torch.zeros(num_items, dtype=torch.long)
+        loader = torch.utils.data.DataLoader(self.test_task_set, batch_size=batch_size, num_workers=num_workers)
+        with torch.no_grad():
+            for step, (batch, labels) in enumerate(iter(loader)):
+                _, _, _, c = self.model(batch.to(device).unsqueeze(1))
+                task_data[step * batch_size:step * batch_size + c.shape[0], :] = c.cpu()
+                task_labels[step * batch_size:step * batch_size + c.shape[0]] = labels
+        self.model.train()
+        return task_data.numpy(), task_labels.numpy()
+
+    def test_task(self, task_data, task_labels, evaluation_ratio=0.2):
+        raise NotImplementedError("the downstream MLP probe (reference :305-350) is outside the hot path (SURVEY.md 8f rank 4)")
+
+
+class DeterministicSampler(torch.utils.data.Sampler):
+    """Shuffles range(len(data_source)) with a fixed seed: same order on every pass (reference :363-382)."""
+
+    def __init__(self, data_source, seed=0):
+        self.data_source = data_source
+        self.seed = seed
+
+    def __iter__(self):
+        order = list(range(len(self.data_source)))
+        random.seed(self.seed)
+        random.shuffle(order)
+        return iter(order)
+
+    def __len__(self):
+        return len(self.data_source)
+
+
+def grad_mean_var(module):
+    """{parameter name: [mean(grad), var(grad)]} (reference :385-391)."""
+    out = {}
+    for name, p in module.named_parameters():
+        if p.grad is not None:
+            out[name] = [torch.mean(p.grad).item(), torch.var(p.grad).item()]
+    return out

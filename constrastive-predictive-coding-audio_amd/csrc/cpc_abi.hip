@@ -144,10 +144,10 @@ int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void
 
 long long cpc_nce_workspace_floats(int B, int K) { return nce_workspace_floats(B, K); }
 
-int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus,
+int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus,
                  float regularization, int dtype, void* stream) {
     if (!S || !dS || !dST || !out || !workspace) return CPC_EINVAL;
-    return launch_nce(S, dS, dST, out, workspace, B, K, softplus, regularization, dtype, (hipStream_t)stream);
+    return launch_nce(S, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
 }
 
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,

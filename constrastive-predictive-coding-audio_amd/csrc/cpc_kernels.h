@@ -52,7 +52,7 @@ int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const v
                    int V, int H, int dtype, hipStream_t stream);
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
 long long nce_workspace_floats(int B, int K);
-int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus, float reg,
+int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
                 float grad_scale, hipStream_t stream);

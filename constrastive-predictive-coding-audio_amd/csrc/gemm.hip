@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fg * 4;
-            if (n >= p.N) continue;
+            if (n >= p.N) continue;      // a group straddling N stores zeros into the (caller-provided) pad columns
             f32x4 v = acc[i][j];
             if (p.bias) {
                 const f32x4 bv = *(const f32x4*)(p.bias + n);
@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
-    if (p.K % ch || p.lda % ch || p.ldb % ch || p.N % 4 || p.ldc % 4) return CPC_EINVAL;
+    if (p.K % ch || p.lda % ch || p.ldb % ch || p.ldc % 4) return CPC_EINVAL;
+    if ((p.N % 4) && (p.bias || p.mask)) return CPC_EINVAL;       // vector epilogue loads need whole groups of 4
+    if (p.ldc < (p.N + 3) / 4 * 4 && p.c_rpi == 0 && p.M > 1) return CPC_EINVAL;
     if (p.a_rpi && p.a_item % ch) return CPC_EINVAL;
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (p.c_rpi && p.c_item % 4) return CPC_EINVAL;
@@ -365,7 +367,8 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.I <= 0 || p.J <= 0 || batch <= 0 || nsplit <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
-    if (p.I % ch || p.J % ch || p.lda % ch || p.ldb % ch || p.ldc % 4) return CPC_EINVAL;
+    if (p.J % ch || p.lda % ch || p.ldb % ch || p.ldc % 4) return CPC_EINVAL;
+    if ((p.I % ch) && p.lda < (p.I + ch - 1) / ch * ch) return CPC_EINVAL;   // ragged I needs padded A rows
     if (p.a_rpi && p.a_item % ch) return CPC_EINVAL;
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (nsplit > 1 && (p.m_chunk <= 0 || (long long)p.m_chunk * nsplit < p.M)) return CPC_EINVAL;

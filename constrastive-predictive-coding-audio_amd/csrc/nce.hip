@@ -24,17 +24,17 @@ __device__ __forceinline__ float score_grad(float x, int softplus) {
 
 // One thread per (k, b') column: logsumexp over b.  grid = ceil(K*B / 256).  Writes lse[k][b'] and a per-block partial sum.
 __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
-                                                      float* __restrict__ partial, int B, int K, int softplus) {
+                                                      float* __restrict__ partial, int B, int K, int ld, int softplus) {
     __shared__ float red[256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float mine = 0.f;
     if (idx < K * B) {
         const int k = idx / B, bp = idx % B;
-        const float* col = S + (long long)k * B * B + bp;
+        const float* col = S + (long long)k * B * ld + bp;
         float mx = -INFINITY;
-        for (int b = 0; b < B; ++b) mx = fmaxf(mx, score_tf(col[(long long)b * B], softplus));
+        for (int b = 0; b < B; ++b) mx = fmaxf(mx, score_tf(col[(long long)b * ld], softplus));
         float sum = 0.f;
-        for (int b = 0; b < B; ++b) sum += expf(score_tf(col[(long long)b * B], softplus) - mx);
+        for (int b = 0; b < B; ++b) sum += expf(score_tf(col[(long long)b * ld], softplus) - mx);
         mine = mx + logf(sum);
         lse[idx] = mine;
     }
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
                                                        T* __restrict__ dS, T* __restrict__ dST,
-                                                       float* __restrict__ partial, int B, int K, int softplus,
+                                                       float* __restrict__ partial, int B, int K, int ld, int softplus,
                                                        float reg) {
     __shared__ float tile[32][33];
     __shared__ float red[3][256];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         float m = 0.f;
         if (b < B && bp < B) {
             for (int k = 0; k < K; ++k) {
-                const float sp = score_tf(S[((long long)k * B + b) * B + bp], softplus);
+                const float sp = score_tf(S[((long long)k * B + b) * ld + bp], softplus);
                 m += sp;
                 mx = fmaxf(mx, sp);
                 if (b == bp) valid += sp;
@@ -85,20 +85,20 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
             const int b = b0 + ty + 8 * r, bp = bp0 + tx;
             float g = 0.f;
             if (b < B && bp < B) {
-                const float x = S[((long long)k * B + b) * B + bp];
+                const float x = S[((long long)k * B + b) * ld + bp];
                 const float sp = score_tf(x, softplus);
                 float dsp = expf(sp - lse[k * B + bp]) * inv_bk + reg_c * mean[r];
                 if (b == bp) dsp -= inv_bk;
                 g = dsp * score_grad(x, softplus);
-                dS[((long long)k * B + b) * B + bp] = from_f32<T>(g);
             }
+            if (b < B && bp < ld) dS[((long long)k * B + b) * ld + bp] = from_f32<T>(g);
             tile[ty + 8 * r][tx] = g;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int bp = bp0 + ty + 8 * r, b = b0 + tx;
-            if (b < B && bp < B) dST[((long long)k * B + bp) * B + b] = from_f32<T>(tile[tx][ty + 8 * r]);
+            if (b < ld && bp < B) dST[((long long)k * B + bp) * ld + b] = from_f32<T>(tile[tx][ty + 8 * r]);
         }
     }
     red[0][threadIdx.x] = valid;
@@ -145,25 +145,25 @@ __global__ void nce_finalize_kernel(const float* __restrict__ col_partial, int n
 
 // workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
 long long nce_workspace_floats(int B, int K) {
-    const long long nb = (B + 31) / 32;
+    const long long nb = (B + 8 + 31) / 32;     // room for a leading dimension padded up to a multiple of 8
     return (long long)K * B + ((long long)K * B + 255) / 256 + 3 * nb * nb;
 }
 
-int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus, float reg,
+int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream) {
-    if (B <= 0 || K <= 0) return CPC_EINVAL;
+    if (B <= 0 || K <= 0 || ld < B) return CPC_EINVAL;
     float* lse = workspace;
     const int ncol = (K * B + 255) / 256;
     float* colp = lse + (long long)K * B;
     float* gradp = colp + ncol;
-    const int nb = (B + 31) / 32;
-    hipLaunchKernelGGL(nce_col_kernel, dim3(ncol), dim3(256), 0, stream, S, lse, colp, B, K, softplus);
+    const int nb = (ld + 31) / 32;
+    hipLaunchKernelGGL(nce_col_kernel, dim3(ncol), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus);
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
-                           gradp, B, K, softplus, reg);
+                           gradp, B, K, ld, softplus, reg);
     else if (dtype == CPC_DTYPE_F32)
         hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (float*)dS, (float*)dST, gradp,
-                           B, K, softplus, reg);
+                           B, K, ld, softplus, reg);
     else
         return CPC_EINVAL;
     hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);

@@ -115,12 +115,13 @@ int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void
                 int V, int H, int dtype, void* stream);
 
 /* InfoNCE loss of ContrastiveEstimationTrainer.train, default branch score_over_all_timesteps=False
- * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32), with the score
+ * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32, rows of ld >= B
+ * floats; dS / dST use the same ld and get zeros in the pad columns), with the score
  * function folded in (softplus != 0: softplus_score_function :12-16, else linear_score_function :19-22).
  *   out[0] = loss (incl. regulariser), out[1] = max score (logger value, :166), out[2..4] = -mean valid, mean lse, reg
  *   dS[k][b][b'], dST[k][b'][b] (T): d loss / d linear score.  workspace: cpc_nce_workspace_floats(B,K) f32. */
 long long cpc_nce_workspace_floats(int B, int K);
-int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int softplus,
+int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus,
                  float regularization, int dtype, void* stream);
 
 /* torch.optim.Adam.step with default betas/eps semantics over one flat f32 buffer

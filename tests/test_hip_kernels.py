@@ -312,13 +312,18 @@ def test_nce_loss(dt, softplus, B, K, reg):
     S = torch.randn(K, B, B, generator=g) * 3.0
     S[0, 0, 0] = 25.0                                  # exercises the softplus threshold branch
     code = _hip.dtype_code(dt)
-    dS_in = dev(S)
-    dS = torch.full((K, B, B), float("nan"), device=DEV, dtype=dt)
-    dST = torch.full((K, B, B), float("nan"), device=DEV, dtype=dt)
+    ld = (B + 7) // 8 * 8                               # leading dimension padded as the engine does
+    Sp = torch.full((K, B, ld), 7.0)                    # pad columns hold junk the kernel must ignore
+    Sp[:, :, :B] = S
+    dS_in = dev(Sp)
+    dSp = torch.full((K, B, ld), float("nan"), device=DEV, dtype=dt)
+    dSTp = torch.full((K, B, ld), float("nan"), device=DEV, dtype=dt)
     out = torch.full((8,), float("nan"), device=DEV)
     ws = torch.empty(_hip.lib().cpc_nce_workspace_floats(B, K), device=DEV)
-    _hip.call("cpc_nce_loss", _hip.ptr(dS_in), _hip.ptr(dS), _hip.ptr(dST), _hip.ptr(out), _hip.ptr(ws), B, K, softplus,
+    _hip.call("cpc_nce_loss", _hip.ptr(dS_in), _hip.ptr(dSp), _hip.ptr(dSTp), _hip.ptr(out), _hip.ptr(ws), B, K, ld, softplus,
               C.c_float(reg), code)
+    assert (dSp[:, :, B:] == 0).all() and (dSTp[:, :, B:] == 0).all()
+    dS, dST = dSp[:, :, :B], dSTp[:, :, :B]
     # oracle on the 4-D score tensor whose equal-step diagonal is S (other entries irrelevant in this branch)
     lin = S.double().requires_grad_(True)
     full = torch.zeros(B, K, B, K, dtype=torch.float64)

@@ -1,0 +1,156 @@
+"""CPU-side tests: host logic of the product package, the C-ABI surface (symbols only — no compute without a GPU),
+and the multi-process (gloo, world size 2) data-parallel plumbing."""
+import json
+import os
+import random
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import cpc_audio_amd
+from cpc_audio_amd import _hip
+from cpc_audio_amd.audio_dataset import FileBatchSampler, SyntheticAudioDataset
+from cpc_audio_amd.audio_model import (AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel, encoder_default_dict)
+from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer, DeterministicSampler
+from cpc_audio_amd.engine import EncoderGeometry
+from oracle import cpc_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_file_batch_sampler_bit_exact(golden_dir):
+    s = json.load(open(os.path.join(golden_dir, "samplers.json")))
+    for case in s["file_batch_sampler"]:
+        if case["seed"] is None:
+            random.seed(case["global_seed"])
+        sampler = FileBatchSampler(case["counts"], case["batch_size"], case["file_batch_size"], case["drop_last"],
+                                   case["seed"], verbose=False)
+        assert len(sampler) == case["len"]
+        assert [list(b) for b in iter(sampler)] == case["batches"], case
+    d = s["deterministic_sampler"]
+    assert list(iter(DeterministicSampler(list(range(d["n"])), seed=d["seed"]))) == d["order"]
+
+
+def test_encoder_attributes_match_reference_test():
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [32] * 5, 'bias': False})
+    assert enc.downsampling_factor == 160 and enc.receptive_field == 465     # reference tests/test_audioEncoder.py:20,28
+    assert all(l.bias is None for l in enc.layers)
+
+
+def test_geometry():
+    g = EncoderGeometry(20480, [5, 4, 2, 2, 2], [10, 8, 4, 4, 4])
+    assert g.valid == [4095, 1022, 510, 254, 126]
+    assert g.alloc == [4096, 1024, 512, 256, 128]
+    for length in (465 + 16 * 160, 4800, 12465, 18385, 3222):
+        g = EncoderGeometry(length, [5, 4, 2, 2, 2], [10, 8, 4, 4, 4])
+        assert g.valid == O.encoder_layer_lengths(length, O.DEFAULT_STRIDES, O.DEFAULT_KERNELS)
+        for l in range(5):
+            assert g.alloc[l] >= g.valid[l] + g.taps[l] - 1
+            if l:
+                assert g.alloc[l - 1] == g.strides[l] * g.alloc[l]
+    with pytest.raises(ValueError):
+        EncoderGeometry(300, [5, 4, 2, 2, 2], [10, 8, 4, 4, 4])
+
+
+def test_model_surface_and_state_dict_keys():
+    torch.manual_seed(0)
+    enc = AudioEncoder(encoder_default_dict)
+    ar = AudioGRUModel(input_size=512, hidden_size=256)
+    model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=100, prediction_steps=12)
+    assert model.parameter_count() == 7414784            # measured on the reference
+    assert model.item_length == 18385
+    keys = list(model.state_dict().keys())
+    expect = [f"encoder.layers.{l}.{n}" for l in range(5) for n in ("weight", "bias")]
+    expect += ["autoregressive_model.gruCell." + n for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    expect += ["prediction_model.weight"]
+    assert keys == expect
+    # same seed + same construction order => same initial values as the oracle's init (i.e. as the reference modules)
+    ref = O.init_params(seed=0)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    # no CPU fallback: a CPU batch must fail loudly
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 1, 18385))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libcpc_hip.so loads on a CPU-only host and exports exactly what include/cpc_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "cpc_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|long long)\s+(cpc_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    handle = _hip.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in the header but not exported"
+    assert declared == set(_hip.EXPORTED_SYMBOLS)
+    assert handle.cpc_abi_version() == 1
+    nm = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cpc_\w+)", nm))
+    assert exported == declared
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_hip.HipLibraryMissing):
+        _hip.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "constrastive-predictive-coding-audio_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py") and fn != "engine.py":
+            assert "oracle" not in open(os.path.join(pkg, fn)).read(), fn
+    # engine.py may reference the oracle only inside smoke_check (the __graft_entry__.smoke() checker)
+    src = open(os.path.join(pkg, "engine.py")).read()
+    head, _, tail = src.partition("def smoke_check")
+    assert "oracle" not in head
+
+
+WORKER = r'''
+import os, sys, random, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cpc_audio_amd.audio_dataset import FileBatchSampler, SyntheticAudioDataset
+from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+ds = SyntheticAudioDataset(32, 50, seed=3)
+random.seed(1000 + rank)            # deliberately different RNG state per rank: rank 0's lists must win
+sampler = FileBatchSampler(ds.get_example_count_per_file(), batch_size=4 * world, verbose=False)
+tr = ContrastiveEstimationTrainer.__new__(ContrastiveEstimationTrainer)
+batches = [b.clone() for b in tr._batches(ds, sampler, torch.device("cpu"), 0, False, rank, world)]
+mine = torch.stack(batches)                                  # (n_batches, 4, 50)
+gathered = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(gathered, mine)
+# gradient averaging as the trainer does it: all-reduce(sum) of the flat buffer, then scale by 1/world
+flat = torch.full((10,), float(rank + 1))
+dist.all_reduce(flat)
+flat *= 1.0 / world
+if rank == 0:
+    glob = torch.cat(gathered, dim=1)                        # (n_batches, 8, 50): the global batches
+    rows = glob.reshape(-1, 50)
+    # every global batch consists of distinct dataset rows, and the two shards are disjoint
+    for b in range(glob.shape[0]):
+        idx = [int((ds.data == glob[b, i]).all(1).nonzero()[0]) for i in range(glob.shape[1])]
+        assert len(set(idx)) == 8, idx
+    assert glob.shape[0] == 32 // 8
+    assert torch.allclose(flat, torch.full((10,), 1.5))
+    print("DP-OK")
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_plumbing_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DP-OK" in outs[0]

@@ -1,0 +1,245 @@
+"""End-to-end parity of the HIP path against (a) the committed golden vectors produced by the reference itself and
+(b) the CPU oracle on seeded inputs.  fp32 mode is the parity mode (tolerances ~1e-4); bf16 mode (the benchmark
+configuration) is held to 1e-3 relative on the loss, as BASELINE.json's north star states, and to bf16-rounding-sized
+bounds on tensors."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cpc_audio_amd.audio_dataset import TensorAudioDataset, SyntheticAudioDataset  # noqa: E402
+from cpc_audio_amd.audio_model import AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel  # noqa: E402
+from cpc_audio_amd.contrastive_estimation_training import (ContrastiveEstimationTrainer, linear_score_function,  # noqa: E402
+                                                           softplus_score_function)
+from oracle import cpc_oracle as O  # noqa: E402
+
+DEV = torch.device("cuda:0")
+SCORE = {"softplus": softplus_score_function, "linear": linear_score_function}
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def _rel(got, ref):
+    got = torch.as_tensor(got).detach().double().cpu()
+    ref = torch.as_tensor(ref).detach().double().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def _small_model(g, meta, dtype):
+    C, H, K, V = meta["C"], meta["H"], meta["K"], meta["V"]
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+    ar = AudioGRUModel(input_size=C, hidden_size=H)
+    model = AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype=dtype)
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    model.load_state_dict(state)
+    return model.to(DEV)
+
+
+class Meter:
+    def __init__(self):
+        self.values = []
+
+    def update(self, v):
+        self.values.append(float(v))
+
+
+class Logger:
+    def __init__(self):
+        self.loss_meter, self.score_meter = Meter(), Meter()
+        self.steps = []
+
+    def log(self, step):
+        self.steps.append(step)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-4), ("bf16", 2.5e-2)])
+def test_small_model_forward_matches_reference(golden_dir, dtype, tol):
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    model = _small_model(g, meta, dtype)
+    x = torch.from_numpy(g["batch"]).unsqueeze(1).to(DEV)
+    with torch.no_grad():
+        pz, tg, z, c = model(x)
+    assert pz.shape == (meta["B"], meta["K"], meta["C"]) and tg.shape == (meta["B"], meta["C"], meta["K"])
+    assert z.shape == (meta["B"], meta["C"], meta["V"]) and c.shape == (meta["B"], meta["H"])
+    assert _rel(tg, g["fwd/targets"]) < tol
+    assert _rel(z, g["fwd/z"]) < tol
+    assert _rel(c, g["fwd/c"]) < tol
+    assert _rel(pz, g["fwd/predicted_z"]) < tol
+    # per-layer activations of the encoder (channels-last buffers vs the reference's (B, C, L))
+    eng = model.engine(meta["B"], meta["L"])
+    for l in range(5):
+        ref = torch.from_numpy(g[f"fwd/enc{l}"])
+        act = eng.act[l].view(meta["B"], eng.geo.alloc[l], meta["C"])
+        assert _rel(act[:, :ref.shape[2]].float().transpose(1, 2), ref) < tol, l
+        assert (act[:, ref.shape[2]:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_small_model_train_matches_reference(golden_dir, dtype):
+    """ContrastiveEstimationTrainer.train on the reference's data / seeds: batch composition (bit-exact), loss, max score,
+    gradients and parameters after the Adam steps, for every (score fn, all_timesteps, regularisation) fixture run."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"])
+    # This fixture scales the weights up so that the scores are far from degenerate (|score| ~ 5, loss 3..28, the
+    # regulariser = mean-score^2 dominating): a stress case for bf16 storage, held to 5e-3.  The north star's 1e-3
+    # bound on the loss at the real configuration is asserted in test_cfg1_trajectory / test_full_size_properties.
+    loss_tol = 1e-4 if dtype == "fp32" else 5e-3
+    grad_tol = 1e-3 if dtype == "fp32" else 6e-2
+    for run in meta["runs"]:
+        model = _small_model(g, meta, dtype)
+        ds = TensorAudioDataset(data, device=DEV)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                          score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                          prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+        assert tr.training_step == run["steps"]
+        for i in range(run["steps"]):
+            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= loss_tol * abs(run["loss"][i]) * (1 + 2 * i), (run["tag"], i)
+            assert abs(logger.score_meter.values[i] - run["max_score"][i]) <= 10 * loss_tol * abs(run["max_score"][i]) * (1 + 2 * i)
+        if run["steps"] == 1:
+            for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                name = k.split("/grad/")[1]
+                got = dict(model.named_parameters())[name].grad
+                assert got is not None, name
+                assert _rel(got, g[k]) < grad_tol, (run["tag"], name)
+        for k in [k for k in g if k.startswith(run["tag"] + "/param_after/")]:
+            name = k.split("/param_after/")[1]
+            got, ref = model.state_dict()[name].cpu(), torch.from_numpy(g[k])
+            err = (got - ref).abs()
+            assert err.max().item() <= run["lr"] * run["steps"] * 1.01 + 1e-6        # Adam moves <= lr per step
+            if dtype == "fp32":
+                tight = err <= 0.05 * run["lr"] * run["steps"] + 1e-4 * ref.abs()
+                assert tight.float().mean().item() > 0.97, (run["tag"], name, tight.float().mean().item())
+
+
+def test_validate_matches_reference(golden_dir):
+    g = _load(golden_dir, "validate.npz")
+    meta = json.load(open(os.path.join(golden_dir, "validate.json")))
+    data = torch.from_numpy(g["data"])
+    model = _small_model(g, meta, "fp32")
+    for run in meta["runs"]:
+        vs = TensorAudioDataset(data, counts=meta["counts"], device=DEV)
+        tr = ContrastiveEstimationTrainer(model=model, dataset=None, validation_set=vs, device=DEV,
+                                          score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                          prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        losses, acc, score, mi = tr.validate(batch_size=meta["B"], num_workers=0)
+        assert _rel(losses, g[run["tag"] + "/losses"]) < 2e-4
+        assert (acc.cpu() - torch.from_numpy(g[run["tag"] + "/accuracy"])).abs().max().item() < 1e-6
+        assert _rel(mi, g[run["tag"] + "/mi"]) < 2e-4
+        assert abs(score - run["mean_score"]) < 2e-4 * max(1.0, abs(run["mean_score"]))
+
+
+def test_encoder_reference_test_case(golden_dir):
+    """The reference's own encoder test: [7,1,4800] -> [7,32,28], downsampling 160, receptive field 465 by impulse
+    probing with all-0.1 weights (reference tests/test_audioEncoder.py:19-48)."""
+    g = _load(golden_dir, "encoder_ref_test.npz")
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [32] * 5, 'bias': False})
+    enc.load_state_dict({k[len("param/encoder."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")})
+    enc.to(DEV)
+    assert enc.downsampling_factor == 160
+    y = enc(torch.from_numpy(g["x"]).to(DEV))
+    assert list(y.shape) == [7, 32, 28]
+    assert _rel(y, g["y"]) < 2e-4
+    assert enc.receptive_field == 465
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.zero_()
+            p += 0.1
+    for name, idx, nonzero in (("inside", 464, True), ("outside", 465, False)):
+        t = torch.zeros(7, 1, 2000)
+        t[:, :, idx] += 1.0
+        out = enc(t.to(DEV))
+        assert _rel(out, g[f"probe_{name}"]) < 2e-4 or not nonzero
+        assert (out[0, 0, 0] != 0).item() == nonzero
+
+
+def test_generic_path_gradients_match_oracle():
+    """Autograd bridge: a user-side loss on (predicted_z, targets, c) backpropagates through the HIP backward."""
+    torch.manual_seed(5)
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [64] * 5, 'bias': True})
+    ar = AudioGRUModel(input_size=64, hidden_size=32)
+    model = AudioPredictiveCodingModel(enc, ar, enc_size=64, ar_size=32, visible_steps=7, prediction_steps=3, compute_dtype="fp32")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "encoder" in n and n.endswith("weight"):
+                p.mul_(3.0)
+    params = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    B, L = 5, 465 + 12 * 160 + 11
+    x = torch.randn(B, 1, L) * 0.5
+    wz = torch.randn(B, 64, 7)
+    pz, tg, z, c = model(x.to(DEV))
+    loss = (pz ** 2).mean() + (tg * 0.3).sum() + (c ** 3).sum() + (z * wz.to(DEV)).sum()
+    loss.backward()
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    rpz, rtg, rz, rc = O.cpc_forward(x, ref, 7, 3)
+    rloss = (rpz ** 2).mean() + (rtg * 0.3).sum() + (rc ** 3).sum() + (rz * wz).sum()
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 1e-4 * abs(rloss.item())
+    for n, p in model.named_parameters():
+        assert _rel(p.grad, ref[n].grad) < 1e-3, n
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 1e-3)])
+def test_cfg1_trajectory_matches_reference(golden_dir, dtype, tol):
+    """BASELINE config 1 (B=8, L=20480, 512 channels, GRU 256, K=12): 5-step loss trajectory recorded from the reference."""
+    meta = json.load(open(os.path.join(golden_dir, "cfg1_trajectory.json")))
+    for run in meta["runs"]:
+        torch.manual_seed(meta["model_seed"])
+        enc = AudioEncoder()
+        ar = AudioGRUModel(input_size=512, hidden_size=256)
+        model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=meta["V"],
+                                           prediction_steps=meta["K"], compute_dtype=dtype).to(DEV)
+        ds = SyntheticAudioDataset(meta["n_items"], meta["L"], seed=meta["data_seed"], device=DEV)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                          score_function=SCORE[run["score"]], prediction_steps=meta["K"], ar_size=256)
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=meta["B"], epochs=1, lr=meta["lr"], num_workers=0, max_steps=5)
+        for i in range(5):
+            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= tol * abs(run["loss"][i]) * (1 + i), (run["score"], i,
+                                                                                                           logger.loss_meter.values)
+
+
+def test_full_size_properties_b256():
+    """BASELINE config 2 size (B=256, L=20480): properties that need no oracle run — bf16 vs exact-f32 loss within
+    1e-3 relative, invariance of the loss under a permutation of the batch, and finite gradients everywhere."""
+    B, L = 256, 20480
+    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    losses = {}
+    for dtype in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256,
+                                           compute_dtype=dtype)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "encoder" in n and n.endswith("weight"):
+                    p.mul_(2.0)                               # make the scores non-degenerate
+        model.to(DEV)
+        eng = model.engine(B, L)
+        out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        losses[dtype] = float(out[0])
+        assert torch.isfinite(model._flat_grad).all()
+        assert model._flat_grad.abs().max().item() > 0
+        if dtype == "fp32":
+            perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
+            out2 = eng.loss_and_grads(x[perm].contiguous(), softplus=True, regularization=1.0)
+            assert abs(float(out2[0]) - losses["fp32"]) < 2e-5 * abs(losses["fp32"])
+        del eng, model
+        torch.cuda.empty_cache()
+    assert abs(losses["bf16"] - losses["fp32"]) < 1e-3 * abs(losses["fp32"]), losses
