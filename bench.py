@@ -1,0 +1,181 @@
+"""CPC train-step benchmark: encoder output frames per second through one full train step
+(AudioEncoder -> GRU -> predictor -> InfoNCE -> backward -> [RCCL all-reduce] -> Adam), inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload: BASELINE.json configs[1] — AudioPredictiveCodingModel (5-layer strided AudioEncoder 512 ch + AudioGRUModel 256,
+12 prediction steps, 100 visible steps), batch 256 per GPU, 20480-sample 16 kHz synthetic clips, bf16 storage / f32
+accumulation, softplus score, regularisation 1.0, Adam lr 1e-4.  Weak scaling: every rank runs its own 256 clips with its
+own in-batch negatives; gradients are averaged with one RCCL all-reduce per step.
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
+  roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
+                FLOPs of its launches / their HIP-event durations measured inside the timed region.
+  cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+DOMINANT = "gemm_nt<bf16,bf16>"
+
+
+def build_model(dtype, device, seed=0):
+    from cpc_audio_amd.audio_model import AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel
+    torch.manual_seed(seed)
+    model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256,
+                                       visible_steps=100, prediction_steps=12, compute_dtype=dtype)
+    return model.to(device)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's train step (torch CPU ops, f32) on BASELINE config 1's shape (B=8 clips of 20480 samples)."""
+    from oracle import cpc_oracle as O
+    threads = torch.get_num_threads()
+    B, L = 8, 20480
+    params = O.init_params(seed=0)
+    tr = O.OracleTrainer(params, 100, 12, score="softplus", regularization=1.0, lr=1e-4)
+    data = torch.randn(4 * B, L, generator=torch.Generator().manual_seed(0))
+    tr.step(data[:B])                                        # warm-up
+    t0, steps = time.perf_counter(), 0
+    while True:
+        tr.step(data[(steps % 4) * B:(steps % 4 + 1) * B])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 40:
+            break
+    return {"value": round(B * 126 * steps / el, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps of B=8 x 20480 samples (config 1 shape), f32, {threads} torch threads, "
+                      f"{el / steps * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from cpc_audio_amd import _hip
+    from cpc_audio_amd.engine import FusedAdam
+
+    B, L, T = args.batch, 20480, 126
+    model = build_model(args.dtype, device, seed=0)                 # identical parameters on every rank
+    eng = model.engine(B, L)
+    opt = FusedAdam(model, lr=1e-4)
+    gen = torch.Generator().manual_seed(1000 + rank)                # rank r draws its own clips
+    pool = [(torch.randn(B, L, generator=gen)).to(device) for _ in range(4)]
+
+    def step(i):
+        out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0)
+        if world > 1:
+            dist.all_reduce(model._flat_grad)
+        opt.step(grad_scale=1.0 / world)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT])
+    _hip.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    _hip.set_timer(None)
+    loss = float(out[0])
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    summary = timer.summary()
+    if rank == 0:
+        frames = B * T * world * args.steps
+        n, ms, flops = summary.get(DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32>", (0, 0.0, 0.0))
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("gemm_nt_bf16_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "CPC train-step audio frames/sec (enc+AR+InfoNCE)",
+            "value": round(frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: AudioEncoder(5x512, strides 5/4/2/2/2) + AudioGRUModel(256) + 12 "
+                                   "prediction steps, 100 visible, softplus score, reg 1.0, Adam; per-GPU batch "
+                                   f"{B} x 20480 samples (126 frames/clip)",
+                       "global_batch": B * world, "clip_samples": L, "parallelism": f"dp{world}",
+                       "loss_last_step": round(loss, 6)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "kernel": "gemm_nt_kernel<bf16,bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<f32,f32>",
+                         "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
+                         "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
+        }
+        if args.breakdown:
+            rows = sorted(summary.items(), key=lambda kv: -kv[1][1])
+            tot = sum(v[1] for _, v in rows)
+            print(f"# kernel breakdown over {args.steps} steps (event-timed; sum {tot / args.steps:.3f} ms/step, "
+                  f"wall {elapsed / args.steps * 1e3:.3f} ms/step)", file=sys.stderr)
+            for k, (cnt, kms, w) in rows:
+                tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
+                print(f"#   {k:28s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step {tf}", file=sys.stderr)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

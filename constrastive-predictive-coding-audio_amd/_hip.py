@@ -117,12 +117,61 @@ def ptr(t, offset_elems: int = 0):
     return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
 
 
+# ----------------------------------------------------------------------------- optional per-kernel timing
+class KernelTimer:
+    """Brackets selected launches with HIP events on the launch stream (torch's current stream is the stream every
+    kernel here is launched on).  ``only`` limits the bracketing to the named kernel symbols (None = all)."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only is not None else None
+        self.records = {}
+
+    def run(self, key, work, fn):
+        if self.only is not None and key not in self.only:
+            return fn()
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        fn()
+        end.record()
+        self.records.setdefault(key, []).append((start, end, work))
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """{key: (launches, total_ms, total_work)} — synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, recs in self.records.items():
+            out[key] = (len(recs), sum(s.elapsed_time(e) for s, e, _ in recs), sum(w for _, _, w in recs))
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _variant(dtype, flags):
+    if dtype == F32:
+        return "<f32,f32>"
+    return "<bf16,f32>" if flags & GEMM_OUT_F32 else "<bf16,bf16>"
+
+
 # ----------------------------------------------------------------------------- thin call wrappers
 def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None, a_rpi=0, a_item=0, b_rpi=0, b_item=0,
             c_rpi=0, c_item=0, c_valid=0, a_batch=0, b_batch=0, c_batch=0, batch=1, flags=0):
     """A, Bt, Cout, bias, mask are ctypes void pointers (see ptr())."""
     args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
                       c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
+    if _timer is not None:
+        _timer.run("gemm_nt" + _variant(dtype, flags), 2.0 * M * N * K * batch,
+                   lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"))
+        return
     _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt")
 
 
@@ -130,10 +179,18 @@ def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_r
             c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0):
     args = GemmTNArgs(A, B, Cout, M, I, J, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, a_batch, b_batch, c_batch, batch,
                       nsplit, m_chunk, slab_stride, flags, dtype)
+    if _timer is not None:
+        _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32), 2.0 * M * I * J * batch,
+                   lambda: _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn"))
+        return
     _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")
 
 
-def call(name, *args):
-    """Generic call of an exported function; appends the current stream and checks the status."""
+def call(name, *args, key=None, work=0.0):
+    """Generic call of an exported function; appends the current stream and checks the status.
+    ``key`` / ``work``: kernel symbol and algorithmic FLOPs (or bytes) this launch is booked under by a KernelTimer."""
     fn = getattr(lib(), name)
+    if _timer is not None:
+        _timer.run(key or name, work, lambda: _check(fn(*args, stream_ptr()), name))
+        return
     _check(fn(*args, stream_ptr()), name)

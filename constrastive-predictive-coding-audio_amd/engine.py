@@ -204,7 +204,8 @@ class CPCEngine:
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
-                      La[l], Lv[l], 1 if l < self.n - 1 else 0, code)
+                      La[l], Lv[l], 1 if l < self.n - 1 else 0, code, key="gemm_nt" + _hip._variant(code, 0),
+                      work=2.0 * B * La[l] * self.channels[l] * self.kernels[l] * self.channels[l - 1])
 
     def context_forward(self):
         """AudioGRUModel.forward over z = frames [T-K-V, T-K) (audio_model.py:198-202, :66-77) + prediction_model (:208)."""
@@ -313,12 +314,14 @@ class CPCEngine:
             bname = f"encoder.layers.{l}.bias"
             if bname in g:
                 self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout)
+            flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.slabs), B, cin, cout, kw, s,
-                      La[l], self.nsplit[l], code)
+                      La[l], self.nsplit[l], code, key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32), work=flops)
             _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), kw * cin, cout,
                       self.nsplit[l], kw * cin * cout, cin, cin * kw, 1, kw)
             _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
-                      _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code)
+                      _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
+                      key="gemm_nt" + _hip._variant(code, 0), work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
         nblk = self.c1_blocks
