@@ -289,6 +289,244 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- fast paths
+// Register-staged, LDS double-buffered variants with ONE barrier per stage, used whenever the reduction extent is a
+// whole number of stages (NT: K % BK == 0).  The next stage's global loads are issued before the MFMAs of the current
+// stage and written to the other LDS buffer after them (issue-early / write-late), so HBM/L2 latency hides under the
+// matrix work.  Out-of-range tile rows / columns are CLAMPED to the last valid one instead of zero-filled wherever they
+// only feed outputs that are never stored.
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BK = 8 * CH;
+    constexpr int STAGE = 2 * 128 * 128;                 // A tile + B tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int numM = (p.M + BM - 1) / BM, numN = (p.N + BN - 1) / BN;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mt = (slot / numN) * 8 + xcd, nt = slot % numN;
+    if (mt >= numM) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
+    const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
+
+    // staging: chunk c = tid + 256*i -> tile row (tid>>3) + 32*i, chunk tid&7 (rows clamped into range)
+    const int ch = tid & 7, srow = tid >> 3;
+    const T* ga0 = Ab + row_off(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga1 = Ab + row_off(min(m0 + srow + 32, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga2 = Ab + row_off(min(m0 + srow + 64, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga3 = Ab + row_off(min(m0 + srow + 96, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* gb0 = Bb + row_off(min(n0 + srow, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const T* gb1 = Bb + row_off(min(n0 + srow + 32, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const T* gb2 = Bb + row_off(min(n0 + srow + 64, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const T* gb3 = Bb + row_off(min(n0 + srow + 96, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const int so0 = lds_off(srow, ch), so1 = lds_off(srow + 32, ch), so2 = lds_off(srow + 64, ch), so3 = lds_off(srow + 96, ch);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NT_GLOAD(k0)                                                                   \
+    do {                                                                               \
+        ra0 = *(const uint4*)(ga0 + (k0)); rb0 = *(const uint4*)(gb0 + (k0));          \
+        ra1 = *(const uint4*)(ga1 + (k0)); rb1 = *(const uint4*)(gb1 + (k0));          \
+        ra2 = *(const uint4*)(ga2 + (k0)); rb2 = *(const uint4*)(gb2 + (k0));          \
+        ra3 = *(const uint4*)(ga3 + (k0)); rb3 = *(const uint4*)(gb3 + (k0));          \
+    } while (0)
+#define NT_LSTORE(base)                                                                \
+    do {                                                                               \
+        unsigned char* da = (base);                                                    \
+        unsigned char* db = da + 128 * 128;                                            \
+        *(uint4*)(da + so0) = ra0; *(uint4*)(db + so0) = rb0;                          \
+        *(uint4*)(da + so1) = ra1; *(uint4*)(db + so1) = rb1;                          \
+        *(uint4*)(da + so2) = ra2; *(uint4*)(db + so2) = rb2;                          \
+        *(uint4*)(da + so3) = ra3; *(uint4*)(db + so3) = rb3;                          \
+    } while (0)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4;
+    int offA[2][4], offB[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            offA[kk][i] = lds_off(wm * 64 + i * 16 + frow, kk * 4 + fg);
+            offB[kk][i] = 128 * 128 + lds_off(wn * 64 + i * 16 + frow, kk * 4 + fg);
+        }
+    const int nk = p.K / BK;
+    NT_GLOAD(0);
+    NT_LSTORE(lds);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* cur = lds + (t & 1) * STAGE;
+        const bool more = t + 1 < nk;
+        if (more) NT_GLOAD((long long)(t + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *(const uint4*)(cur + offA[kk][i]);
+                fb[i] = *(const uint4*)(cur + offB[kk][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
+        }
+        if (more) NT_LSTORE(lds + ((t + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+#undef NT_GLOAD
+#undef NT_LSTORE
+
+    TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch;
+    const T* Mb = (const T*)p.mask;
+    const bool relu = p.flags & GEMM_RELU;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        if (m >= p.M) continue;
+        const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
+        const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (Mb) {
+                const f32x4 mk = load4(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
+            if (!row_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            store4(Cb + coff + n, v);
+        }
+    }
+}
+
+// TN fast path (bf16): stage = 64 reduction rows x 128 columns per operand, LDS rows padded to 288 B (conflict-free
+// transposed reads, see tn_frag_bf16), double-buffered, one barrier per stage.  Reduction rows beyond the split's end
+// are zeroed in registers (they would otherwise add to the sums); out-of-range columns are clamped.
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
+    typedef bf16_t T;
+    constexpr int BKM = 64, ROWB = 288;
+    constexpr int TILE = BKM * ROWB;                     // 18432 B per operand
+    constexpr int STAGE = 2 * TILE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 73728 B -> 2 workgroups per CU
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int numJ = (p.J + 127) / 128;
+    const int it = blockIdx.x / numJ, jt = blockIdx.x % numJ;
+    const int i0 = it * 128, j0 = jt * 128;
+    const int split = blockIdx.y;
+    const int m_begin = split * p.m_chunk;
+    const int m_end = min(p.M, m_begin + p.m_chunk);
+
+    const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
+    const T* Bb = (const T*)p.B + (long long)blockIdx.z * p.b_batch;
+
+    // staging: 64 rows x 16 chunks = 1024 chunks per operand; thread -> chunk tid&15 of rows (tid>>4) + 16*i
+    const int ch = tid & 15, srow = tid >> 4;
+    const long long acol = min(i0 + ch * 8, p.I - 8);
+    const long long bcol = min(j0 + ch * 8, p.J - 8);
+    const bool plain = (p.a_rpi == 0) && (p.b_rpi == 0);
+    const int sdst = srow * ROWB + ch * 16;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define TN_LOAD1(RA, RB, mrow)                                                                               \
+    do {                                                                                                     \
+        const int m_ = (mrow);                                                                               \
+        const int mc_ = min(m_, p.M - 1);                                                                    \
+        const long long ao_ = plain ? (long long)mc_ * p.lda : row_off(mc_, p.a_rpi, p.a_item, p.lda);       \
+        const long long bo_ = plain ? (long long)mc_ * p.ldb : row_off(mc_, p.b_rpi, p.b_item, p.ldb);       \
+        RA = *(const uint4*)(Ab + ao_ + acol);                                                               \
+        RB = *(const uint4*)(Bb + bo_ + bcol);                                                               \
+        if (m_ >= m_end) { RA = zero4; RB = zero4; }                                                         \
+    } while (0)
+#define TN_GLOAD(mb)                              \
+    do {                                          \
+        TN_LOAD1(ra0, rb0, (mb) + srow);          \
+        TN_LOAD1(ra1, rb1, (mb) + srow + 16);     \
+        TN_LOAD1(ra2, rb2, (mb) + srow + 32);     \
+        TN_LOAD1(ra3, rb3, (mb) + srow + 48);     \
+    } while (0)
+#define TN_LSTORE(base)                                                                      \
+    do {                                                                                     \
+        unsigned char* da = (base) + sdst;                                                   \
+        unsigned char* db = da + TILE;                                                       \
+        *(uint4*)(da) = ra0;             *(uint4*)(db) = rb0;                                \
+        *(uint4*)(da + 16 * ROWB) = ra1; *(uint4*)(db + 16 * ROWB) = rb1;                    \
+        *(uint4*)(da + 32 * ROWB) = ra2; *(uint4*)(db + 32 * ROWB) = rb2;                    \
+        *(uint4*)(da + 48 * ROWB) = ra3; *(uint4*)(db + 48 * ROWB) = rb3;                    \
+    } while (0)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nst = (m_end - m_begin + BKM - 1) / BKM;
+    if (nst > 0) {
+        TN_GLOAD(m_begin);
+        TN_LSTORE(lds);
+    }
+    __syncthreads();
+    for (int t = 0; t < nst; ++t) {
+        const unsigned char* ldsA = lds + (t & 1) * STAGE;
+        const unsigned char* ldsB = ldsA + TILE;
+        const bool more = t + 1 < nst;
+        if (more) TN_GLOAD(m_begin + (t + 1) * BKM);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = tn_frag_bf16(ldsA, wi * 64 + i * 16, ks, lane, true);
+                fb[i] = tn_frag_bf16(ldsB, wj * 64 + i * 16, ks, lane, true);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_chunk<bf16_t>(acc[i][j], fb[j], fa[i]);
+        }
+        if (more) TN_LSTORE(lds + ((t + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+#undef TN_LOAD1
+#undef TN_GLOAD
+#undef TN_LSTORE
+
+    const int fidx = lane & 15, fg = lane >> 4;
+    TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ii = i0 + wi * 64 + i * 16 + fidx;
+        if (ii >= p.I) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j0 + wj * 64 + j * 16 + fg * 4;
+            if (jj >= p.J) continue;
+            store4(Cb + (long long)ii * p.ldc + jj, acc[i][j]);
+        }
+    }
+}
+
 // out[perm(i, j)] = (accumulate ? out : 0) + sum_z slab[z][i][j];   perm(i,j) = j*s_j + (i / cdiv)*s_hi + (i % cdiv)*s_lo
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int I, int J, int nslab, long long slab_stride,
@@ -352,11 +590,18 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
     const bool of32 = p.flags & GEMM_OUT_F32;
+    const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
     if (dtype == CPC_DTYPE_BF16) {
-        if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+        if (fast) {
+            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+        } else {
+            if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+        }
     } else if (dtype == CPC_DTYPE_F32) {
-        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
+        if (fast) hipLaunchKernelGGL((gemm_nt_fast_kernel<float, float>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else {
         return CPC_EINVAL;
     }
@@ -376,7 +621,15 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     const int numI = (p.I + 127) / 128, numJ = (p.J + 127) / 128;
     dim3 grid(numI * numJ, nsplit, batch);
     const bool of32 = p.flags & GEMM_OUT_F32;
-    if (dtype == CPC_DTYPE_BF16) {
+    const int eff_chunk = nsplit > 1 ? p.m_chunk : p.M;
+    const bool fast = dtype == CPC_DTYPE_BF16 && !(p.flags & (GEMM_FORCE_GENERIC | GEMM_TN_NO_TR)) && (p.I % 8 == 0) &&
+                      p.I >= 8 && p.J >= 8;
+    if (fast) {
+        GemmTN q = p;
+        q.m_chunk = eff_chunk;
+        if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float>), grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t>), grid, dim3(256), 0, stream, q);
+    } else if (dtype == CPC_DTYPE_BF16) {
         if (of32) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
     } else if (dtype == CPC_DTYPE_F32) {
