@@ -110,7 +110,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT])
+    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT], by_shape=args.breakdown)
     _hip.set_timer(timer)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -127,7 +127,10 @@ def main():
     summary = timer.summary()
     if rank == 0:
         frames = B * T * world * args.steps
-        n, ms, flops = summary.get(DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32>", (0, 0.0, 0.0))
+        dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32>"
+        n = sum(v[0] for k, v in summary.items() if k.startswith(dom))
+        ms = sum(v[1] for k, v in summary.items() if k.startswith(dom))
+        flops = sum(v[2] for k, v in summary.items() if k.startswith(dom))
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
         traffic = None
@@ -168,7 +171,7 @@ def main():
                   f"wall {elapsed / args.steps * 1e3:.3f} ms/step)", file=sys.stderr)
             for k, (cnt, kms, w) in rows:
                 tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
-                print(f"#   {k:28s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step {tf}", file=sys.stderr)
+                print(f"#   {k:58s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step {tf}", file=sys.stderr)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

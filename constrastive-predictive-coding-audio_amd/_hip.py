@@ -51,7 +51,8 @@ _SIGNATURES = {
     "cpc_reduce_slabs": ([_P, _P, _I, _I, _I, _L, _I, _L, _L, _L, _P], _I),
     "cpc_colsum": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _P], _I),
-    "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
+    "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
     "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_gru_set_streaming": ([_I], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P], _I),
@@ -122,13 +124,16 @@ class KernelTimer:
     """Brackets selected launches with HIP events on the launch stream (torch's current stream is the stream every
     kernel here is launched on).  ``only`` limits the bracketing to the named kernel symbols (None = all)."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, by_shape=False):
         self.only = set(only) if only is not None else None
+        self.by_shape = by_shape
         self.records = {}
 
-    def run(self, key, work, fn):
+    def run(self, key, work, fn, shape=None):
         if self.only is not None and key not in self.only:
             return fn()
+        if self.by_shape and shape is not None:
+            key = f"{key} {shape}"
         start = torch.cuda.Event(enable_timing=True)
         end = torch.cuda.Event(enable_timing=True)
         start.record()
@@ -170,7 +175,7 @@ def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None,
                       c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
     if _timer is not None:
         _timer.run("gemm_nt" + _variant(dtype, flags), 2.0 * M * N * K * batch,
-                   lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"))
+                   lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"), shape=(M, N, K, batch))
         return
     _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt")
 
@@ -181,16 +186,16 @@ def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_r
                       nsplit, m_chunk, slab_stride, flags, dtype)
     if _timer is not None:
         _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32), 2.0 * M * I * J * batch,
-                   lambda: _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn"))
+                   lambda: _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn"), shape=(M, I, J, batch, nsplit))
         return
     _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")
 
 
-def call(name, *args, key=None, work=0.0):
+def call(name, *args, key=None, work=0.0, shape=None):
     """Generic call of an exported function; appends the current stream and checks the status.
     ``key`` / ``work``: kernel symbol and algorithmic FLOPs (or bytes) this launch is booked under by a KernelTimer."""
     fn = getattr(lib(), name)
     if _timer is not None:
-        _timer.run(key or name, work, lambda: _check(fn(*args, stream_ptr()), name))
+        _timer.run(key or name, work, lambda: _check(fn(*args, stream_ptr()), name), shape=shape)
         return
     _check(fn(*args, stream_ptr()), name)

@@ -93,17 +93,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// grid: (nblk_t, B): block handles positions [bx*tpb, (bx+1)*tpb) of item b and writes a partial slab
-// slabs[(b*nblk_t + bx)][(kw+1)][C]  (row kw = bias grad).
+// grid: (nblk_t, nblk_b): block handles positions [bx*tpb, (bx+1)*tpb) of items by, by+nblk_b, ... and writes a partial
+// slab slabs[(by*nblk_t + bx)][(kw+1)][C]  (row kw = bias grad).
 template <typename T, int KW>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                        float* __restrict__ slabs, int C, int stride, int kw_rt,
+                                                        float* __restrict__ slabs, int B, int C, int stride, int kw_rt,
                                                         long long ldx, int L_valid, int L_alloc, int tpb) {
     const int kw = KW > 0 ? KW : kw_rt;
     constexpr int KA = (KW > 0 ? KW : C1_MAXK);
     __shared__ float xs[C1_POS * 8 + C1_MAXK + 8];
     __shared__ float red[256 * 8];                     // cross-row-lane reduction scratch
-    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lpr = C / 8;
     const int cg = tid % lpr, rl = tid / lpr, nrl = 256 / lpr;
@@ -116,6 +115,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
 
+    for (int b = blockIdx.y; b < B; b += gridDim.y)
     for (int t0 = t_begin; t0 < t_end; t0 += C1_POS) {
         const int npos = min(C1_POS, t_end - t0);
         const int nsamp = (npos - 1) * stride + kw;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         }
     }
     // reduce over the row lanes through LDS (one accumulator row at a time), then write the slab
-    float* slab = slabs + ((long long)b * gridDim.x + blockIdx.x) * (long long)(kw + 1) * C;
+    float* slab = slabs + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (long long)(kw + 1) * C;
 #pragma unroll
     for (int j = 0; j <= KA; ++j) {
         __syncthreads();
@@ -187,15 +187,16 @@ int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y,
     return CPC_OK;
 }
 
-// slabs: [B * nblk_t][(kw+1)][C] f32.  Reduce with reduce_slabs (I = kw+1, J = C).
+// slabs: [nblk_b * nblk_t][(kw+1)][C] f32.  Reduce with reduce_slabs (I = kw+1, J = C).
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
-                     int L_valid, int L_alloc, int nblk_t, int dtype, hipStream_t stream) {
-    if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid || nblk_t <= 0) return CPC_EINVAL;
+                     int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream) {
+    if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid || nblk_t <= 0 || nblk_b <= 0 || nblk_b > B)
+        return CPC_EINVAL;
     int tpb = (L_valid + nblk_t - 1) / nblk_t;
     tpb = (tpb + C1_POS - 1) / C1_POS * C1_POS;
-    dim3 grid(nblk_t, B);
+    dim3 grid(nblk_t, nblk_b);
 #define LAUNCH(T, KWT) \
-    hipLaunchKernelGGL((conv1_bwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, (const T*)dy, slabs, C, stride, kw, ldx, L_valid, L_alloc, tpb)
+    hipLaunchKernelGGL((conv1_bwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, (const T*)dy, slabs, B, C, stride, kw, ldx, L_valid, L_alloc, tpb)
     if (dtype == CPC_DTYPE_BF16) {
         if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);
     } else if (dtype == CPC_DTYPE_F32) {

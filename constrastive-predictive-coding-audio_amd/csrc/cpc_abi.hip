@@ -67,10 +67,15 @@ int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, in
 }
 
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx, int L_valid,
-                  int L_alloc, int nblk_t, int dtype, void* stream) {
+                  int L_alloc, int nblk_t, int nblk_b, int dtype, void* stream) {
     if (!x || !dy || !slabs) return CPC_EINVAL;
     if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
-    return launch_conv1_bwd(x, dy, slabs, B, C, stride, kw, ldx, L_valid, L_alloc, nblk_t, dtype, (hipStream_t)stream);
+    return launch_conv1_bwd(x, dy, slabs, B, C, stride, kw, ldx, L_valid, L_alloc, nblk_t, nblk_b, dtype, (hipStream_t)stream);
+}
+
+int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride, void* stream) {
+    if (!slabs || !out) return CPC_EINVAL;
+    return launch_reduce_conv_w(slabs, out, cin, cout, kw, nslab, slab_stride, (hipStream_t)stream);
 }
 
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw, int stride,
@@ -140,6 +145,13 @@ int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void
                 int H, int dtype, void* stream) {
     if (!dc || !Hall || !gates || !WTfrag || !dGi || !dGh) return CPC_EINVAL;
     return launch_gru_bwd(dc, Hall, gates, WTfrag, dGi, dGh, B, V, H, dtype, (hipStream_t)stream);
+}
+
+extern int g_gru_force_streaming;
+int cpc_gru_set_streaming(int on) {
+    const int old = g_gru_force_streaming;
+    g_gru_force_streaming = on ? 1 : 0;
+    return old;
 }
 
 long long cpc_nce_workspace_floats(int B, int K) { return nce_workspace_floats(B, K); }

@@ -46,7 +46,9 @@ int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
                      long long ldx, int L_valid, int L_alloc, int dtype, hipStream_t stream);
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
-                     int L_valid, int L_alloc, int nblk_t, int dtype, hipStream_t stream);
+                     int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
+int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
+                         hipStream_t stream);
 int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
                    int V, int H, int dtype, hipStream_t stream);
 int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,

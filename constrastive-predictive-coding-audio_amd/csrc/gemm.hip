@@ -543,6 +543,66 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+// Same reduction for SMALL outputs and many slabs (bias gradients, layer-1 weights): 256 threads = 16 output float4 x 16
+// slab lanes, lanes combined through LDS in a fixed order, so that the serial chain per thread is nslab / 16.
+__global__ __launch_bounds__(256) void reduce_slabs_small_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                                 int I, int J, int nslab, long long slab_stride, int cdiv,
+                                                                 long long s_j, long long s_hi, long long s_lo) {
+    __shared__ float red[16][16][4];
+    const int ol = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long total4 = (long long)I * J / 4;
+    const long long o4 = (long long)blockIdx.x * 16 + ol;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (o4 < total4)
+        for (int z = zl; z < nslab; z += 16) s += *(const f32x4*)(slabs + (long long)z * slab_stride + o4 * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[zl][ol][q] = s[q];
+    __syncthreads();
+    if (zl == 0 && o4 < total4) {
+        for (int r = 1; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] += red[r][ol][q];
+        const long long e = o4 * 4;
+        const int i = (int)(e / J), j = (int)(e % J);
+        const long long base = (long long)(i / cdiv) * s_hi + (long long)(i % cdiv) * s_lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[base + (long long)(j + q) * s_j] = s[q];
+    }
+}
+
+// Conv weight gradient: out[co][c][jj] = sum_z slabs[z][jj*cin + c][co]   (J = cout contiguous in the slabs).
+// A 32(c) x 32(co) x kw tile goes through LDS so that both the slab reads (along co) and the weight writes (along
+// (c, jj) for one co) are coalesced.  grid (cin/32, cout/32), kw <= 8.
+__global__ __launch_bounds__(256) void reduce_conv_w_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cin,
+                                                            int cout, int kw, int nslab, long long slab_stride) {
+    __shared__ float t[8][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    for (int jj = 0; jj < kw; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cl = ty + 8 * r;
+            const long long off = (long long)(jj * cin + c0 + cl) * cout + co0 + tx;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int z = 0;
+            for (; z + 3 < nslab; z += 4) {
+                s0 += slabs[(long long)z * slab_stride + off];
+                s1 += slabs[(long long)(z + 1) * slab_stride + off];
+                s2 += slabs[(long long)(z + 2) * slab_stride + off];
+                s3 += slabs[(long long)(z + 3) * slab_stride + off];
+            }
+            for (; z < nslab; ++z) s0 += slabs[(long long)z * slab_stride + off];
+            t[jj][cl][tx] = (s0 + s1) + (s2 + s3);
+        }
+    __syncthreads();
+    const int per_co = 32 * kw;
+    for (int idx = threadIdx.x; idx < 32 * per_co; idx += 256) {
+        const int col = idx / per_co, rem = idx % per_co;
+        const int cl = rem / kw, jj = rem % kw;
+        out[(long long)(co0 + col) * cin * kw + (long long)(c0 + cl) * kw + jj] = t[jj][cl][col];
+    }
+}
+
 // Column sums of a [M][N] T matrix into per-block partial slabs [gridDim.x][N] (f32); reduced by reduce_slabs.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ slabs, int M, int N,
@@ -645,6 +705,12 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream) {
     if (I <= 0 || J <= 0 || J % 4 || nslab <= 0 || cdiv <= 0) return CPC_EINVAL;
     const long long total4 = (long long)I * J / 4;
+    if (total4 <= 16384 && nslab >= 32) {
+        hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, stream, slabs, out, I,
+                           J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     const int blocks = (int)min((long long)2048, (total4 + 255) / 256);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, slabs, out, I, J, nslab, slab_stride,
                        cdiv, s_j, s_hi, s_lo);
@@ -661,6 +727,17 @@ int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int 
         hipLaunchKernelGGL((colsum_kernel<float>), dim3(nblocks), dim3(256), 0, stream, (const float*)X, slabs, M, N, ldx, rpb);
     else
         return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
+                         hipStream_t stream) {
+    if (cin <= 0 || cout <= 0 || kw <= 0 || nslab <= 0) return CPC_EINVAL;
+    if (cin % 32 || cout % 32 || kw > 8)      // generic permuting reduce
+        return launch_reduce_slabs(slabs, out, kw * cin, cout, nslab, slab_stride, cin, (long long)cin * kw, 1, kw, stream);
+    hipLaunchKernelGGL(reduce_conv_w_kernel, dim3(cin / 32, cout / 32), dim3(256), 0, stream, slabs, out, cin, cout, kw, nslab,
+                       slab_stride);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

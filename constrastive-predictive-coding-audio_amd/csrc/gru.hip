@@ -219,6 +219,230 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ----------------------------------------------------------------------------------------------- weight-resident bf16
+// bf16 path for H = 32*KC in {32, 64, 128, 256}: W_hh never leaves the CU during the sequence.  The r and u gate
+// fragments of a wave's hidden tiles live in its registers (one wave per SIMD -> 512 VGPRs), the n gate fragments in
+// LDS (H = 256: 256 registers + 128 KiB LDS), so a step costs 96 MFMAs + gate math per wave instead of a 393 KB
+// L2 read per workgroup.
+template <int NJT, int KC>
+__global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
+                                                             const float* __restrict__ bhh, bf16_t* __restrict__ Hall,
+                                                             bf16_t* __restrict__ gates, float* __restrict__ c_out, int B,
+                                                             int V) {
+    constexpr int H = 32 * KC, NT = H / 16;
+    constexpr int ROWB = H * 2 + 16;
+    constexpr int WN_BYTES = 4 * NJT * KC * 1024;
+    constexpr bool FULL = (NT == 4 * NJT);               // every (wave, q) pair maps to a real tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WN_BYTES + 2 * 16 * ROWB + 3 * H * 4];
+    unsigned char* wn = smem;
+    unsigned char* hbuf0 = smem + WN_BYTES;
+    unsigned char* hbuf1 = hbuf0 + 16 * ROWB;
+    float* bsh = (float*)(hbuf1 + 16 * ROWB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int b = b0 + frow;
+    const bool b_ok = b < B;
+
+    uint4 wr[NJT][2][KC];
+#pragma unroll
+    for (int q = 0; q < NJT; ++q) {
+        const int jt = wave + 4 * q;
+        const bool on = FULL || jt < NT;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                wr[q][g][kc] = on ? ldg16(Wfrag + ((long long)((g * NT + jt) * KC + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+            const uint4 w2 = on ? ldg16(Wfrag + ((long long)((2 * NT + jt) * KC + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+            *(uint4*)(wn + (((wave * NJT + q) * KC + kc) * 64 + lane) * 16) = w2;
+        }
+    }
+    for (int i = tid; i < 3 * H; i += 256) bsh[i] = bhh ? bhh[i] : 0.f;
+    for (int i = tid; i < 16 * ROWB / 4; i += 256) ((unsigned int*)hbuf0)[i] = 0u;
+    for (int i = tid; i < 16 * H; i += 256) {
+        const int rb = i / H, j = i % H;
+        if (b0 + rb < B) Hall[((long long)(b0 + rb) * (V + 1)) * H + j] = (bf16_t)0.f;
+    }
+    __syncthreads();
+
+    float hprev[NJT][4];
+#pragma unroll
+    for (int q = 0; q < NJT; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hprev[q][e] = 0.f;
+
+    for (int t = 0; t < V; ++t) {
+        const unsigned char* hcur = (t & 1) ? hbuf1 : hbuf0;
+        unsigned char* hnext = (t & 1) ? hbuf0 : hbuf1;
+        f32x4 gi[NJT][3];
+        f32x4 acc[NJT][3];
+#pragma unroll
+        for (int q = 0; q < NJT; ++q) {
+            const int jt = wave + 4 * q;
+            const bool on = FULL || jt < NT;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                gi[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (on) {
+                    if (b_ok) gi[q][g] = *(const f32x4*)(Gi + ((long long)b * V + t) * 3 * H + g * H + jt * 16 + fg * 4);
+                    acc[q][g] = *(const f32x4*)(bsh + g * H + jt * 16 + fg * 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const uint4 hf = *(const uint4*)(hcur + frow * ROWB + (kc * 4 + fg) * 16);
+#pragma unroll
+            for (int q = 0; q < NJT; ++q) {
+                const uint4 w2 = *(const uint4*)(wn + (((wave * NJT + q) * KC + kc) * 64 + lane) * 16);
+                mfma_chunk<bf16_t>(acc[q][0], wr[q][0][kc], hf);
+                mfma_chunk<bf16_t>(acc[q][1], wr[q][1][kc], hf);
+                mfma_chunk<bf16_t>(acc[q][2], w2, hf);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NJT; ++q) {
+            const int jt = wave + 4 * q;
+            if (FULL || jt < NT) {
+                const int j = jt * 16 + fg * 4;
+                f32x4 r4, u4, n4, q4, h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = 1.f / (1.f + expf(-(gi[q][0][e] + acc[q][0][e])));
+                    const float u = 1.f / (1.f + expf(-(gi[q][1][e] + acc[q][1][e])));
+                    const float qq = acc[q][2][e];
+                    const float n = tanhf(gi[q][2][e] + r * qq);
+                    const float hn = (1.f - u) * n + u * hprev[q][e];
+                    hprev[q][e] = hn;
+                    r4[e] = r; u4[e] = u; n4[e] = n; q4[e] = qq; h4[e] = hn;
+                }
+                store4((bf16_t*)(hnext + frow * ROWB) + j, h4);
+                if (b_ok) {
+                    store4(Hall + ((long long)b * (V + 1) + (t + 1)) * H + j, h4);
+                    bf16_t* gp = gates + (((long long)b * V + t) * 4) * H + j;
+                    store4(gp, r4);
+                    store4(gp + H, u4);
+                    store4(gp + 2 * H, n4);
+                    store4(gp + 3 * H, q4);
+                    if (t == V - 1) *(f32x4*)(c_out + (long long)b * H + j) = h4;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Backward twin: W_hh^T fragments for the r,u gate columns (k < 2H) in registers, the n gate columns in LDS.
+template <int NJT, int KC>
+__global__ __launch_bounds__(256, 1) void gru_bwd_res_kernel(const float* __restrict__ dc, const bf16_t* __restrict__ Hall,
+                                                             const bf16_t* __restrict__ gates, const bf16_t* __restrict__ WTfrag,
+                                                             bf16_t* __restrict__ dGi, bf16_t* __restrict__ dGh, int B, int V) {
+    constexpr int H = 32 * KC, NT = H / 16;
+    constexpr int KC3 = 3 * KC, KCR = 2 * KC, KCL = KC;
+    constexpr int ROWB = 3 * H * 2 + 16;
+    constexpr int WL_BYTES = 4 * NJT * KCL * 1024;
+    constexpr bool FULL = (NT == 4 * NJT);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WL_BYTES + 16 * ROWB];
+    unsigned char* wl = smem;
+    unsigned char* gcur = smem + WL_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int b = b0 + frow;
+    const bool b_ok = b < B;
+
+    uint4 wr[NJT][KCR];
+    float dh[NJT][4];
+#pragma unroll
+    for (int q = 0; q < NJT; ++q) {
+        const int jt = wave + 4 * q;
+        const bool on = FULL || jt < NT;
+#pragma unroll
+        for (int kc = 0; kc < KCR; ++kc)
+            wr[q][kc] = on ? ldg16(WTfrag + ((long long)(jt * KC3 + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int kc = 0; kc < KCL; ++kc) {
+            const uint4 w2 = on ? ldg16(WTfrag + ((long long)(jt * KC3 + KCR + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+            *(uint4*)(wl + (((wave * NJT + q) * KCL + kc) * 64 + lane) * 16) = w2;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dh[q][e] = 0.f;
+        if (on && b_ok) {
+            const f32x4 v = *(const f32x4*)(dc + (long long)b * H + jt * 16 + fg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dh[q][e] = v[e];
+        }
+    }
+    __syncthreads();
+
+    for (int t = V - 1; t >= 0; --t) {
+        float keep[NJT][4];
+#pragma unroll
+        for (int q = 0; q < NJT; ++q) {
+            const int jt = wave + 4 * q;
+            if (FULL || jt < NT) {
+                const int j = jt * 16 + fg * 4;
+                f32x4 hp = (f32x4){0.f, 0.f, 0.f, 0.f}, r4 = hp, u4 = hp, n4 = hp, q4 = hp;
+                if (b_ok) {
+                    hp = load4(Hall + ((long long)b * (V + 1) + t) * H + j);
+                    const bf16_t* gp = gates + (((long long)b * V + t) * 4) * H + j;
+                    r4 = load4(gp); u4 = load4(gp + H); n4 = load4(gp + 2 * H); q4 = load4(gp + 3 * H);
+                }
+                f32x4 dr4, du4, dn4, dnr4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = dh[q][e];
+                    const float dn = d * (1.f - u4[e]);
+                    const float du = d * (hp[e] - n4[e]);
+                    const float dn_pre = dn * (1.f - n4[e] * n4[e]);
+                    const float du_pre = du * u4[e] * (1.f - u4[e]);
+                    const float dr_pre = dn_pre * q4[e] * r4[e] * (1.f - r4[e]);
+                    dr4[e] = dr_pre; du4[e] = du_pre; dn4[e] = dn_pre; dnr4[e] = dn_pre * r4[e];
+                    keep[q][e] = d * u4[e];
+                }
+                bf16_t* grow = (bf16_t*)(gcur + frow * ROWB);
+                store4(grow + j, dr4);
+                store4(grow + H + j, du4);
+                store4(grow + 2 * H + j, dnr4);
+                if (b_ok) {
+                    bf16_t* gi = dGi + ((long long)b * V + t) * 3 * H + j;
+                    bf16_t* gh = dGh + ((long long)b * V + t) * 3 * H + j;
+                    store4(gi, dr4); store4(gi + H, du4); store4(gi + 2 * H, dn4);
+                    store4(gh, dr4); store4(gh + H, du4); store4(gh + 2 * H, dnr4);
+                }
+            }
+        }
+        __syncthreads();
+        f32x4 acc[NJT];
+#pragma unroll
+        for (int q = 0; q < NJT; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KCR; ++kc) {
+            const uint4 gf = *(const uint4*)(gcur + frow * ROWB + (kc * 4 + fg) * 16);
+#pragma unroll
+            for (int q = 0; q < NJT; ++q) mfma_chunk<bf16_t>(acc[q], wr[q][kc], gf);
+        }
+#pragma unroll
+        for (int kc = 0; kc < KCL; ++kc) {
+            const uint4 gf = *(const uint4*)(gcur + frow * ROWB + ((KCR + kc) * 4 + fg) * 16);
+#pragma unroll
+            for (int q = 0; q < NJT; ++q) {
+                const uint4 w2 = *(const uint4*)(wl + (((wave * NJT + q) * KCL + kc) * 64 + lane) * 16);
+                mfma_chunk<bf16_t>(acc[q], w2, gf);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NJT; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dh[q][e] = keep[q][e] + acc[q][e];
+        __syncthreads();
+    }
+}
+
 // dst (fragment order, T) from a row-major f32 matrix.  Logical operand Wn[n][k], n < R, k < Kd:
 //   transpose == 0: Wn[n][k] = src[n * ld + k];   transpose == 1: Wn[n][k] = src[k * ld + n]
 // dst[((nt * KC + kc) * 64 + lane) * CH + e] = Wn[nt*16 + (lane&15)][kc*4*CH + (lane>>4)*CH + e]
@@ -242,6 +466,9 @@ __global__ __launch_bounds__(256) void prep_frag_kernel(const float* __restrict_
 
 }  // namespace
 
+// Debug / A-B switch: 1 = always use the weight-streaming kernels (set through cpc_gru_set_streaming).
+int g_gru_force_streaming = 0;
+
 static bool gru_ok(int B, int V, int H, int dtype) {
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
     if (B <= 0 || V <= 0 || H <= 0) return false;
@@ -255,6 +482,15 @@ int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* H
     const int esz = dtype == CPC_DTYPE_BF16 ? 2 : 4;
     const size_t shm = 2 * 16 * (size_t)(H * esz + 16) + 3 * H * sizeof(float);
     dim3 grid((B + 15) / 16);
+    if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
+#define GRU_F(NJT, KC) \
+    hipLaunchKernelGGL((gru_fwd_res_kernel<NJT, KC>), grid, dim3(256), 0, stream, Gi, (const bf16_t*)Wfrag, bhh, (bf16_t*)Hall, \
+                       (bf16_t*)gates, c_out, B, V)
+        if (H == 256) GRU_F(4, 8); else if (H == 128) GRU_F(2, 4); else if (H == 64) GRU_F(1, 2); else GRU_F(1, 1);
+#undef GRU_F
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((gru_fwd_kernel<bf16_t>), grid, dim3(256), shm, stream, Gi, (const bf16_t*)Wfrag, bhh,
                            (bf16_t*)Hall, (bf16_t*)gates, c_out, B, V, H);
@@ -272,6 +508,15 @@ int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const v
     const size_t shm = 16 * (size_t)(3 * H * esz + 16);
     if (shm > 64 * 1024) return CPC_EINVAL;
     dim3 grid((B + 15) / 16);
+    if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
+#define GRU_B(NJT, KC) \
+    hipLaunchKernelGGL((gru_bwd_res_kernel<NJT, KC>), grid, dim3(256), 0, stream, dc, (const bf16_t*)Hall, (const bf16_t*)gates, \
+                       (const bf16_t*)WTfrag, (bf16_t*)dGi, (bf16_t*)dGh, B, V)
+        if (H == 256) GRU_B(4, 8); else if (H == 128) GRU_B(2, 4); else if (H == 64) GRU_B(1, 2); else GRU_B(1, 1);
+#undef GRU_B
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((gru_bwd_kernel<bf16_t>), grid, dim3(256), shm, stream, dc, (const bf16_t*)Hall,
                            (const bf16_t*)gates, (const bf16_t*)WTfrag, (bf16_t*)dGi, (bf16_t*)dGh, B, V, H);

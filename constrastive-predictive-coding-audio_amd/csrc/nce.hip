@@ -22,29 +22,39 @@ __device__ __forceinline__ float score_grad(float x, int softplus) {
     return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
 }
 
-// One thread per (k, b') column: logsumexp over b.  grid = ceil(K*B / 256).  Writes lse[k][b'] and a per-block partial sum.
+// logsumexp over b of every (k, b') column.  grid (ceil(B/32), K); block 256 = 32 columns x 8 row lanes, each lane keeps an
+// online (max, sum) over its rows, combined through LDS.  Writes lse[k][b'] and one partial sum of lse per block.
 __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
                                                       float* __restrict__ partial, int B, int K, int ld, int softplus) {
-    __shared__ float red[256];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    float mine = 0.f;
-    if (idx < K * B) {
-        const int k = idx / B, bp = idx % B;
+    __shared__ float smx[8][32], ssum[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k = blockIdx.y, bp = blockIdx.x * 32 + tx;
+    float mx = -INFINITY, sum = 0.f;
+    if (bp < B) {
         const float* col = S + (long long)k * B * ld + bp;
-        float mx = -INFINITY;
-        for (int b = 0; b < B; ++b) mx = fmaxf(mx, score_tf(col[(long long)b * ld], softplus));
-        float sum = 0.f;
-        for (int b = 0; b < B; ++b) sum += expf(score_tf(col[(long long)b * ld], softplus) - mx);
-        mine = mx + logf(sum);
-        lse[idx] = mine;
+        for (int b = ty; b < B; b += 8) {
+            const float v = score_tf(col[(long long)b * ld], softplus);
+            if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
+            else sum += expf(v - mx);
+        }
     }
-    red[threadIdx.x] = mine;
+    smx[ty][tx] = mx;
+    ssum[ty][tx] = sum;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
+    if (ty == 0) {
+        float m = mx;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) m = fmaxf(m, smx[r][tx]);
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tot += (smx[r][tx] == -INFINITY) ? 0.f : ssum[r][tx] * expf(smx[r][tx] - m);
+        const float l = (bp < B) ? m + logf(tot) : 0.f;
+        if (bp < B) lse[k * B + bp] = l;
+        // sum the 32 columns of this block (one wave-half): shuffle reduction
+        float acc = l;
+        for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
+        if (tx == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = acc;
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
 // One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
@@ -146,18 +156,19 @@ __global__ void nce_finalize_kernel(const float* __restrict__ col_partial, int n
 // workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
 long long nce_workspace_floats(int B, int K) {
     const long long nb = (B + 8 + 31) / 32;     // room for a leading dimension padded up to a multiple of 8
-    return (long long)K * B + ((long long)K * B + 255) / 256 + 3 * nb * nb;
+    return (long long)K * B + (long long)K * ((B + 31) / 32) + 3 * nb * nb;
 }
 
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream) {
     if (B <= 0 || K <= 0 || ld < B) return CPC_EINVAL;
     float* lse = workspace;
-    const int ncol = (K * B + 255) / 256;
+    const int ncb = (B + 31) / 32;
+    const int ncol = K * ncb;
     float* colp = lse + (long long)K * B;
     float* gradp = colp + ncol;
     const int nb = (ld + 31) / 32;
-    hipLaunchKernelGGL(nce_col_kernel, dim3(ncol), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus);
+    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus);
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
                            gradp, B, K, ld, softplus, reg);

@@ -72,10 +72,19 @@ class CPCEngine:
         self.H = int(ar.hidden_size)
         self.K = int(model.prediction_steps)
         self.V = int(model.visible_steps)
-        self.geo = EncoderGeometry(self.L, self.strides, self.kernels)
+        full = EncoderGeometry(self.L, self.strides, self.kernels)
+        if full.frames < self.V + self.K:
+            raise ValueError(f"clips give {full.frames} encoder frames, need visible+prediction = {self.V + self.K}")
+        # The model only consumes the last V+K encoder frames (audio_model.py:197-198); frame t depends on samples
+        # >= t * downsampling only, so the leading frames the reference computes and discards are never computed here:
+        # the encoder runs on the clip from sample x_off on.  Results (outputs, loss, gradients) are unchanged.
+        self.frames_full = full.frames
+        skip = full.frames - (self.V + self.K) if (self.V + self.K) > 0 else 0
+        self.x_off = skip * int(enc.downsampling_factor)
+        self.L_eff = self.L - self.x_off
+        self.geo = EncoderGeometry(self.L_eff, self.strides, self.kernels)
         self.T = self.geo.frames
-        if self.T < self.V + self.K:
-            raise ValueError(f"clips give {self.T} encoder frames, need visible+prediction = {self.V + self.K}")
+        assert self.T == full.frames - skip
         if model.enc_size != self.E or model.ar_size != self.H or ar.input_size != self.E:
             raise ValueError("enc_size / ar_size do not match the encoder and autoregressive model")
         self._check_supported()
@@ -150,8 +159,9 @@ class CPCEngine:
             self.nsplit[l] = self._pick_split(I, J, M)
             need.append(self.nsplit[l] * I * J)
         self.c1_blocks = max(1, min(8, _ceil_div(self.geo.valid[0], 512)))
-        need.append(B * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
-        self.colsum_blocks = 256
+        self.c1_item_blocks = min(B, 128)
+        need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
+        self.colsum_blocks = 1024
         need.append(self.colsum_blocks * max(max(self.channels), 3 * H))
         self.split_ih = self._pick_split(3 * H, E, B * V)
         self.split_hh = self._pick_split(3 * H, H, B * V)
@@ -162,7 +172,7 @@ class CPCEngine:
     def _pick_split(self, I, J, M):
         tiles = _ceil_div(I, 128) * _ceil_div(J, 128)
         blk = 64 if self.dt == torch.bfloat16 else 32
-        want = _ceil_div(1024, tiles)
+        want = _ceil_div(512, tiles)
         return max(1, min(want, _ceil_div(M, 8 * blk), 64))
 
     def _chunk(self, M, nsplit):
@@ -199,13 +209,14 @@ class CPCEngine:
         """AudioEncoder.forward (audio_model.py:36-44): relu(conv) x (n-1), then a bare conv."""
         self._check_input(x)
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
-        _hip.call("cpc_conv1_fwd", _hip.ptr(x), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
+        _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0], code)
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
                       La[l], Lv[l], 1 if l < self.n - 1 else 0, code, key="gemm_nt" + _hip._variant(code, 0),
-                      work=2.0 * B * La[l] * self.channels[l] * self.kernels[l] * self.channels[l - 1])
+                      work=2.0 * B * La[l] * self.channels[l] * self.kernels[l] * self.channels[l - 1],
+                      shape=("fwd", B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1]))
 
     def context_forward(self):
         """AudioGRUModel.forward over z = frames [T-K-V, T-K) (audio_model.py:198-202, :66-77) + prediction_model (:208)."""
@@ -316,21 +327,23 @@ class CPCEngine:
                 self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout)
             flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.slabs), B, cin, cout, kw, s,
-                      La[l], self.nsplit[l], code, key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32), work=flops)
-            _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), kw * cin, cout,
-                      self.nsplit[l], kw * cin * cout, cin, cin * kw, 1, kw)
+                      La[l], self.nsplit[l], code, key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32), work=flops,
+                      shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
+            _hip.call("cpc_reduce_conv_w", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
+                      self.nsplit[l], kw * cin * cout)
             _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
                       _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
-                      key="gemm_nt" + _hip._variant(code, 0), work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout)
+                      key="gemm_nt" + _hip._variant(code, 0), work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
+                      shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
-        nblk = self.c1_blocks
-        _hip.call("cpc_conv1_bwd", _hip.ptr(x), _hip.ptr(self.dact[0]), _hip.ptr(self.slabs), B, c0, s0, k0, self.L, Lv[0], La[0],
-                  nblk, code)
+        nblk, nbb = self.c1_blocks, self.c1_item_blocks
+        _hip.call("cpc_conv1_bwd", _hip.ptr(x, self.x_off), _hip.ptr(self.dact[0]), _hip.ptr(self.slabs), B, c0, s0, k0, self.L, Lv[0], La[0],
+                  nblk, nbb, code)
         stride = (k0 + 1) * c0
-        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(g["encoder.layers.0.weight"]), k0, c0, B * nblk, stride, 1, k0, 1, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(g["encoder.layers.0.weight"]), k0, c0, nbb * nblk, stride, 1, k0, 1, 0)
         if "encoder.layers.0.bias" in g:
-            _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs, k0 * c0), _hip.ptr(g["encoder.layers.0.bias"]), 1, c0, B * nblk, stride,
+            _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs, k0 * c0), _hip.ptr(g["encoder.layers.0.bias"]), 1, c0, nbb * nblk, stride,
                       1, 1, 0, 0)
 
     # ------------------------------------------------------------------------------------------ whole step

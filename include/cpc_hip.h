@@ -73,6 +73,10 @@ int cpc_gemm_tn(const cpc_gemm_tn_args* args, void* stream);
 int cpc_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
                      long long s_j, long long s_hi, long long s_lo, void* stream);
 
+/* Conv weight gradient slabs (cpc_conv_wgrad) -> reference layout: out[co][c][j] = sum_z slabs[z][j*cin + c][co]. */
+int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
+                      void* stream);
+
 /* slabs[blk][n] = partial column sums of X[M][N] (T) — bias gradients; reduce with cpc_reduce_slabs(I=1). */
 int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nblocks, int dtype, void* stream);
 
@@ -80,9 +84,10 @@ int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nbl
  * (audio_model.py:38-39 for l == 0).  x: f32 [B][ldx]; w: f32 [C][kw] (reference layout); y: T [B][L_alloc][C]. */
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
                   long long ldx, int L_valid, int L_alloc, int dtype, void* stream);
-/* Weight/bias gradient of layer 1: slabs[B*nblk_t][(kw+1)][C] partials (row kw = bias); reduce with cpc_reduce_slabs. */
+/* Weight/bias gradient of layer 1: slabs[nblk_b*nblk_t][(kw+1)][C] partials (row kw = bias); reduce with
+ * cpc_reduce_slabs.  nblk_t blocks split the positions, nblk_b (<= B) blocks stride over the items. */
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
-                  int L_valid, int L_alloc, int nblk_t, int dtype, void* stream);
+                  int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, void* stream);
 
 /* Conv1d (layers >= 2) in channels-last layout, expressed through the GEMMs above.
  *   fwd  : y[(b,t)][co] = relu?(bias + sum_{j,c} x[(b, t*stride + j)][c] * w[co][c][j])       audio_model.py:38-41
@@ -114,6 +119,10 @@ int cpc_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall
  * WTfrag = cpc_prep_frag(weight_hh, transpose=1) ([H][3H] logical). */
 int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
                 int V, int H, int dtype, void* stream);
+
+/* A/B switch: on != 0 forces the weight-streaming GRU kernels where the weight-resident bf16 ones would be used
+ * (H in {32,64,128,256}); returns the previous setting.  Not stream-ordered (host-side flag). */
+int cpc_gru_set_streaming(int on);
 
 /* InfoNCE loss of ContrastiveEstimationTrainer.train, default branch score_over_all_timesteps=False
  * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32, rows of ld >= B

@@ -181,9 +181,9 @@ def test_conv1_fwd_bwd(dt, C, kw, stride):
     dy = torch.randn(B, La, C, generator=g)
     dy[:, Lv:] = 0
     ddy = dev(dy, dt)
-    nblk = 3
-    slabs = torch.full((B * nblk, kw + 1, C), float("nan"), device=DEV)
-    _hip.call("cpc_conv1_bwd", _hip.ptr(dx), _hip.ptr(ddy), _hip.ptr(slabs), B, C, stride, kw, L, Lv, La, nblk, code)
+    nblk, nbb = 3, 2
+    slabs = torch.full((nbb * nblk, kw + 1, C), float("nan"), device=DEV)
+    _hip.call("cpc_conv1_bwd", _hip.ptr(dx), _hip.ptr(ddy), _hip.ptr(slabs), B, C, stride, kw, L, Lv, La, nblk, nbb, code)
     pre = F.conv1d(xr, wr, br, stride=stride)
     (pre * rounded(dy, dt)[:, :Lv].transpose(1, 2)).sum().backward()
     got = slabs.sum(0)
@@ -253,6 +253,9 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
               nsplit, code)
     got = slabs.sum(0).view(kw, Cin, Cout).permute(2, 1, 0)
     assert rel_err(got, wr.grad) < tol(dt)
+    wg = torch.full((Cout, Cin, kw), float("nan"), device=DEV)
+    _hip.call("cpc_reduce_conv_w", _hip.ptr(slabs), _hip.ptr(wg), Cin, Cout, kw, nsplit, kw * Cin * Cout)
+    assert rel_err(wg, wr.grad) < tol(dt)
 
 
 # --------------------------------------------------------------------------------------- GRU
