@@ -4,6 +4,7 @@
 #include "cpc_kernels.h"
 #include "../../include/cpc_hip.h"
 
+static_assert(CPC_GEMM_FORCE_GENERIC == GEMM_FORCE_GENERIC && CPC_GEMM_SMALL_TILE == GEMM_SMALL_TILE, "flag mismatch");
 static_assert(CPC_GEMM_RELU == GEMM_RELU && CPC_GEMM_OUT_F32 == GEMM_OUT_F32 && CPC_GEMM_TN_NO_TR == GEMM_TN_NO_TR, "flag mismatch");
 static_assert(CPC_F32 == CPC_DTYPE_F32 && CPC_BF16 == CPC_DTYPE_BF16, "dtype mismatch");
 

@@ -50,7 +50,14 @@ __device__ __forceinline__ long long row_off(int m, int rpi, long long item, lon
     return (long long)q * item + (long long)(m - q * rpi) * ld;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): a GRU step is
+// latency-bound on 16 workgroups, and libm's expf / tanhf / IEEE division cost more than the step's 96 MFMAs.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
 
 // ---- MFMA on one 16-byte operand chunk per lane (D = A*B + C, 16x16 output tile) ----
 template <typename T>

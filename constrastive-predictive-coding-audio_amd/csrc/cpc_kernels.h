@@ -6,6 +6,7 @@
 #define GEMM_RELU 1        // NT: relu in the epilogue
 #define GEMM_OUT_F32 2     // output stored as f32 regardless of the storage dtype
 #define GEMM_TN_NO_TR 4    // TN/bf16: use scalar LDS reads instead of ds_read_b64_tr_b16 (debug / A-B check)
+#define GEMM_SMALL_TILE 16     // NT: keep the 128x128 tile even where the 256x256 one would be chosen (A-B check)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {

@@ -297,36 +297,45 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 // matrix work.  Out-of-range tile rows / columns are CLAMPED to the last valid one instead of zero-filled wherever they
 // only feed outputs that are never stored.
 
-template <typename T, typename TO>
-__global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
+// Tile configuration: WM x WN waves, each owning a (TI*16) x (TJ*16) output sub-tile.
+//   <2,2,4,4>: 128x128 tile, 256 threads, 2 x 32 KiB LDS  (two workgroups per CU)
+//   <2,4,8,4>: 256x256 tile, 512 threads, 2 x 64 KiB LDS  (one workgroup per CU): half the LDS write traffic and 3/4 of
+//              the LDS read traffic per MFMA of the small tile — the small tile is LDS-bound (ds_write_b128 ~79 B/clk/CU).
+template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
-    constexpr int STAGE = 2 * 128 * 128;                 // A tile + B tile
+    constexpr int TBM = WM * TI * 16, TBN = WN * TJ * 16, NTHR = 64 * WM * WN;
+    constexpr int ATILE = TBM * 128, BTILE = TBN * 128, STAGE = ATILE + BTILE;
+    constexpr int NA = TBM * 8 / NTHR, NB = TBN * 8 / NTHR, RSTEP = NTHR / 8;     // staged chunks per thread, row step
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int numM = (p.M + BM - 1) / BM, numN = (p.N + BN - 1) / BN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int numM = (p.M + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int mt = (slot / numN) * 8 + xcd, nt = slot % numN;
     if (mt >= numM) return;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * TBM, n0 = nt * TBN;
 
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
 
-    // staging: chunk c = tid + 256*i -> tile row (tid>>3) + 32*i, chunk tid&7 (rows clamped into range)
+    // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
+    // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
+    static_assert(NA == 4 && NB == 4, "staging code below is written for 4 chunks per operand per thread");
     const int ch = tid & 7, srow = tid >> 3;
     const T* ga0 = Ab + row_off(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga1 = Ab + row_off(min(m0 + srow + 32, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga2 = Ab + row_off(min(m0 + srow + 64, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga3 = Ab + row_off(min(m0 + srow + 96, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga1 = Ab + row_off(min(m0 + srow + RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga2 = Ab + row_off(min(m0 + srow + 2 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+    const T* ga3 = Ab + row_off(min(m0 + srow + 3 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
     const T* gb0 = Bb + row_off(min(n0 + srow, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb1 = Bb + row_off(min(n0 + srow + 32, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb2 = Bb + row_off(min(n0 + srow + 64, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb3 = Bb + row_off(min(n0 + srow + 96, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const int so0 = lds_off(srow, ch), so1 = lds_off(srow + 32, ch), so2 = lds_off(srow + 64, ch), so3 = lds_off(srow + 96, ch);
+    const T* gb1 = Bb + row_off(min(n0 + srow + RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const T* gb2 = Bb + row_off(min(n0 + srow + 2 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    const T* gb3 = Bb + row_off(min(n0 + srow + 3 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+    // RSTEP is a multiple of 8, so the swizzle term (row & 7) is the same for the 4 rows: one offset + constants
+    const int so = lds_off(srow, ch);
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define NT_GLOAD(k0)                                                                   \
     do {                                                                               \
@@ -337,29 +346,29 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
     } while (0)
 #define NT_LSTORE(base)                                                                \
     do {                                                                               \
-        unsigned char* da = (base);                                                    \
-        unsigned char* db = da + 128 * 128;                                            \
-        *(uint4*)(da + so0) = ra0; *(uint4*)(db + so0) = rb0;                          \
-        *(uint4*)(da + so1) = ra1; *(uint4*)(db + so1) = rb1;                          \
-        *(uint4*)(da + so2) = ra2; *(uint4*)(db + so2) = rb2;                          \
-        *(uint4*)(da + so3) = ra3; *(uint4*)(db + so3) = rb3;                          \
+        unsigned char* da = (base) + so;                                               \
+        unsigned char* db = da + ATILE;                                                \
+        *(uint4*)(da) = ra0;                   *(uint4*)(db) = rb0;                    \
+        *(uint4*)(da + RSTEP * 128) = ra1;     *(uint4*)(db + RSTEP * 128) = rb1;      \
+        *(uint4*)(da + 2 * RSTEP * 128) = ra2; *(uint4*)(db + 2 * RSTEP * 128) = rb2;  \
+        *(uint4*)(da + 3 * RSTEP * 128) = ra3; *(uint4*)(db + 3 * RSTEP * 128) = rb3;  \
     } while (0)
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    int offA[2][4], offB[2][4];
+    int offA[2][TI], offB[2][TJ];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            offA[kk][i] = lds_off(wm * 64 + i * 16 + frow, kk * 4 + fg);
-            offB[kk][i] = 128 * 128 + lds_off(wn * 64 + i * 16 + frow, kk * 4 + fg);
-        }
+        for (int i = 0; i < TI; ++i) offA[kk][i] = lds_off(wm * TI * 16 + i * 16 + frow, kk * 4 + fg);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) offB[kk][j] = ATILE + lds_off(wn * TJ * 16 + j * 16 + frow, kk * 4 + fg);
+    }
     const int nk = p.K / BK;
     NT_GLOAD(0);
     NT_LSTORE(lds);
@@ -370,16 +379,15 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
         if (more) NT_GLOAD((long long)(t + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[4], fb[4];
+            uint4 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *(const uint4*)(cur + offA[kk][i]);
-                fb[i] = *(const uint4*)(cur + offB[kk][i]);
-            }
+            for (int i = 0; i < TI; ++i) fa[i] = *(const uint4*)(cur + offA[kk][i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TJ; ++j) fb[j] = *(const uint4*)(cur + offB[kk][j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
         }
         if (more) NT_LSTORE(lds + ((t + 1) & 1) * STAGE);
         __syncthreads();
@@ -391,14 +399,14 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
     const T* Mb = (const T*)p.mask;
     const bool relu = p.flags & GEMM_RELU;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + frow;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * TI * 16 + i * 16 + frow;
         if (m >= p.M) continue;
         const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
         const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + wn * TJ * 16 + j * 16 + fg * 4;
             if (n >= p.N) continue;
             f32x4 v = acc[i][j];
             if (p.bias) v += *(const f32x4*)(p.bias + n);
@@ -417,22 +425,36 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(GemmNT p) {
     }
 }
 
-// TN fast path (bf16): stage = 64 reduction rows x 128 columns per operand, LDS rows padded to 288 B (conflict-free
-// transposed reads, see tn_frag_bf16), double-buffered, one barrier per stage.  Reduction rows beyond the split's end
-// are zeroed in registers (they would otherwise add to the sums); out-of-range columns are clamped.
-template <typename TO>
-__global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
+// TN fast path (bf16): stage = 64 reduction rows x (tile width) columns per operand, LDS rows padded by 32 B so that the
+// 8 rows a half-wave touches in one transposed read start 8 banks apart, double-buffered, one barrier per stage.
+// Reduction rows beyond the split's end are zeroed in registers (they would otherwise add to the sums); out-of-range
+// columns are clamped.  Tile configurations as for the NT kernel: <2,2,4,4> = 128x128, <2,4,8,4> = 256x256.
+__device__ __forceinline__ uint4 tn_frag_rb(const unsigned char* tile, int rowb, int cb, int ks, int lane) {
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const unsigned char* a1 = tile + (ks * 32 + 4 * g + q) * rowb + (cb + 4 * pp) * 2;
+    const unsigned char* a2 = a1 + 16 * rowb;
+    s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a2);
+    uint2 lo = __builtin_bit_cast(uint2, v1), hi = __builtin_bit_cast(uint2, v2);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <typename TO, int WI, int WJ, int TI, int TJ>
+__global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
     typedef bf16_t T;
-    constexpr int BKM = 64, ROWB = 288;
-    constexpr int TILE = BKM * ROWB;                     // 18432 B per operand
-    constexpr int STAGE = 2 * TILE;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // 73728 B -> 2 workgroups per CU
+    constexpr int BKM = 64;
+    constexpr int TBI = WI * TI * 16, TBJ = WJ * TJ * 16, NTHR = 64 * WI * WJ;
+    constexpr int ROWA = TBI * 2 + 32, ROWB_ = TBJ * 2 + 32;
+    constexpr int ATILE = BKM * ROWA, BTILE = BKM * ROWB_, STAGE = ATILE + BTILE;
+    constexpr int CPRA = TBI / 8, CPRB = TBJ / 8;                  // 16-byte chunks per tile row
+    static_assert(NTHR / CPRA == 16 && NTHR / CPRB == 16, "staging below assumes 16 rows per pass, 4 passes");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int numJ = (p.J + 127) / 128;
+    const int wi = wave / WJ, wj = wave % WJ;
+    const int numJ = (p.J + TBJ - 1) / TBJ;
     const int it = blockIdx.x / numJ, jt = blockIdx.x % numJ;
-    const int i0 = it * 128, j0 = jt * 128;
+    const int i0 = it * TBI, j0 = jt * TBJ;
     const int split = blockIdx.y;
     const int m_begin = split * p.m_chunk;
     const int m_end = min(p.M, m_begin + p.m_chunk);
@@ -440,12 +462,11 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.B + (long long)blockIdx.z * p.b_batch;
 
-    // staging: 64 rows x 16 chunks = 1024 chunks per operand; thread -> chunk tid&15 of rows (tid>>4) + 16*i
-    const int ch = tid & 15, srow = tid >> 4;
-    const long long acol = min(i0 + ch * 8, p.I - 8);
-    const long long bcol = min(j0 + ch * 8, p.J - 8);
+    const int cha = tid % CPRA, chb = tid % CPRB, srow = tid / CPRA;
+    const long long acol = min(i0 + cha * 8, p.I - 8);
+    const long long bcol = min(j0 + chb * 8, p.J - 8);
     const bool plain = (p.a_rpi == 0) && (p.b_rpi == 0);
-    const int sdst = srow * ROWB + ch * 16;
+    const int sda = srow * ROWA + cha * 16, sdb = ATILE + srow * ROWB_ + chb * 16;
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #define TN_LOAD1(RA, RB, mrow)                                                                               \
@@ -467,19 +488,19 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
     } while (0)
 #define TN_LSTORE(base)                                                                      \
     do {                                                                                     \
-        unsigned char* da = (base) + sdst;                                                   \
-        unsigned char* db = da + TILE;                                                       \
+        unsigned char* da = (base) + sda;                                                    \
+        unsigned char* db = (base) + sdb;                                                    \
         *(uint4*)(da) = ra0;             *(uint4*)(db) = rb0;                                \
-        *(uint4*)(da + 16 * ROWB) = ra1; *(uint4*)(db + 16 * ROWB) = rb1;                    \
-        *(uint4*)(da + 32 * ROWB) = ra2; *(uint4*)(db + 32 * ROWB) = rb2;                    \
-        *(uint4*)(da + 48 * ROWB) = ra3; *(uint4*)(db + 48 * ROWB) = rb3;                    \
+        *(uint4*)(da + 16 * ROWA) = ra1; *(uint4*)(db + 16 * ROWB_) = rb1;                   \
+        *(uint4*)(da + 32 * ROWA) = ra2; *(uint4*)(db + 32 * ROWB_) = rb2;                   \
+        *(uint4*)(da + 48 * ROWA) = ra3; *(uint4*)(db + 48 * ROWB_) = rb3;                   \
     } while (0)
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nst = (m_end - m_begin + BKM - 1) / BKM;
     if (nst > 0) {
@@ -489,21 +510,20 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
     __syncthreads();
     for (int t = 0; t < nst; ++t) {
         const unsigned char* ldsA = lds + (t & 1) * STAGE;
-        const unsigned char* ldsB = ldsA + TILE;
+        const unsigned char* ldsB = ldsA + ATILE;
         const bool more = t + 1 < nst;
         if (more) TN_GLOAD(m_begin + (t + 1) * BKM);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 fa[4], fb[4];
+            uint4 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = tn_frag_bf16(ldsA, wi * 64 + i * 16, ks, lane, true);
-                fb[i] = tn_frag_bf16(ldsB, wj * 64 + i * 16, ks, lane, true);
-            }
+            for (int i = 0; i < TI; ++i) fa[i] = tn_frag_rb(ldsA, ROWA, (wi * TI + i) * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TJ; ++j) fb[j] = tn_frag_rb(ldsB, ROWB_, (wj * TJ + j) * 16, ks, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mfma_chunk<bf16_t>(acc[i][j], fb[j], fa[i]);
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) mfma_chunk<bf16_t>(acc[i][j], fb[j], fa[i]);
         }
         if (more) TN_LSTORE(lds + ((t + 1) & 1) * STAGE);
         __syncthreads();
@@ -515,12 +535,12 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(GemmTN p) {
     const int fidx = lane & 15, fg = lane >> 4;
     TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch + (long long)split * p.slab_stride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ii = i0 + wi * 64 + i * 16 + fidx;
+    for (int i = 0; i < TI; ++i) {
+        const int ii = i0 + (wi * TI + i) * 16 + fidx;
         if (ii >= p.I) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int jj = j0 + wj * 64 + j * 16 + fg * 4;
+        for (int j = 0; j < TJ; ++j) {
+            const int jj = j0 + (wj * TJ + j) * 16 + fg * 4;
             if (jj >= p.J) continue;
             store4(Cb + (long long)ii * p.ldc + jj, acc[i][j]);
         }
@@ -645,22 +665,27 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.a_rpi && p.a_item % ch) return CPC_EINVAL;
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (p.c_rpi && p.c_item % 4) return CPC_EINVAL;
-    const int numM = (p.M + BM - 1) / BM, numN = (p.N + BN - 1) / BN;
+    const bool of32 = p.flags & GEMM_OUT_F32;
+    const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
+    const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE);
+    const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
+    const int numM = (p.M + tbm - 1) / tbm, numN = (p.N + tbn - 1) / tbn;
     const long long blocks = (long long)((numM + 7) / 8) * 8 * numN;
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
-    const bool of32 = p.flags & GEMM_OUT_F32;
-    const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
     if (dtype == CPC_DTYPE_BF16) {
-        if (fast) {
-            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+        if (big) {
+            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, p);
+        } else if (fast) {
+            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
         } else {
             if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
         }
     } else if (dtype == CPC_DTYPE_F32) {
-        if (fast) hipLaunchKernelGGL((gemm_nt_fast_kernel<float, float>), grid, dim3(256), 0, stream, p);
+        if (fast) hipLaunchKernelGGL((gemm_nt_fast_kernel<float, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else {
         return CPC_EINVAL;
@@ -678,17 +703,24 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (nsplit > 1 && (p.m_chunk <= 0 || (long long)p.m_chunk * nsplit < p.M)) return CPC_EINVAL;
     if (nsplit > 1 && !(p.flags & GEMM_OUT_F32)) return CPC_EINVAL;   // slabs are f32
-    const int numI = (p.I + 127) / 128, numJ = (p.J + 127) / 128;
-    dim3 grid(numI * numJ, nsplit, batch);
     const bool of32 = p.flags & GEMM_OUT_F32;
     const int eff_chunk = nsplit > 1 ? p.m_chunk : p.M;
     const bool fast = dtype == CPC_DTYPE_BF16 && !(p.flags & (GEMM_FORCE_GENERIC | GEMM_TN_NO_TR)) && (p.I % 8 == 0) &&
                       p.I >= 8 && p.J >= 8;
+    const bool big = fast && p.I >= 256 && p.J >= 256 && eff_chunk >= 1024 && !(p.flags & GEMM_SMALL_TILE);
+    const int tb = big ? 256 : 128;
+    const int numI = (p.I + tb - 1) / tb, numJ = (p.J + tb - 1) / tb;
+    dim3 grid(numI * numJ, nsplit, batch);
     if (fast) {
         GemmTN q = p;
         q.m_chunk = eff_chunk;
-        if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float>), grid, dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t>), grid, dim3(256), 0, stream, q);
+        if (big) {
+            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
+        } else {
+            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
+        }
     } else if (dtype == CPC_DTYPE_BF16) {
         if (of32) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);

@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
                 f32x4 r4, u4, n4, q4, h4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float r = 1.f / (1.f + expf(-(gi[q][0][e] + acc[q][0][e])));
-                    const float u = 1.f / (1.f + expf(-(gi[q][1][e] + acc[q][1][e])));
+                    const float r = fast_sigmoid(gi[q][0][e] + acc[q][0][e]);
+                    const float u = fast_sigmoid(gi[q][1][e] + acc[q][1][e]);
                     const float qq = acc[q][2][e];
-                    const float n = tanhf(gi[q][2][e] + r * qq);
+                    const float n = fast_tanh(gi[q][2][e] + r * qq);
                     const float hn = (1.f - u) * n + u * hprev[q][e];
                     hprev[q][e] = hn;
                     r4[e] = r; u4[e] = u; n4[e] = n; q4[e] = qq; h4[e] = hn;
@@ -220,19 +220,19 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------- weight-resident bf16
-// bf16 path for H = 32*KC in {32, 64, 128, 256}: W_hh never leaves the CU during the sequence.  The r and u gate
-// fragments of a wave's hidden tiles live in its registers (one wave per SIMD -> 512 VGPRs), the n gate fragments in
-// LDS (H = 256: 256 registers + 128 KiB LDS), so a step costs 96 MFMAs + gate math per wave instead of a 393 KB
-// L2 read per workgroup.
+// bf16 path for H = 32*KC in {32, 64, 128, 256}: W_hh never leaves the CU during the sequence.  8 waves per workgroup
+// (two per SIMD, so one wave's LDS / MFMA latency hides under the other's); the r and u gate fragments of a wave's
+// hidden tiles live in its registers (H = 256: 128 VGPRs per lane), the n gate fragments in LDS (128 KiB), so a step
+// costs 48 MFMAs + gate math per wave instead of a 393 KB L2 read per workgroup.
 template <int NJT, int KC>
-__global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
+__global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
                                                              const float* __restrict__ bhh, bf16_t* __restrict__ Hall,
                                                              bf16_t* __restrict__ gates, float* __restrict__ c_out, int B,
                                                              int V) {
     constexpr int H = 32 * KC, NT = H / 16;
     constexpr int ROWB = H * 2 + 16;
-    constexpr int WN_BYTES = 4 * NJT * KC * 1024;
-    constexpr bool FULL = (NT == 4 * NJT);               // every (wave, q) pair maps to a real tile
+    constexpr int WN_BYTES = 8 * NJT * KC * 1024;
+    constexpr bool FULL = (NT == 8 * NJT);               // every (wave, q) pair maps to a real tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[WN_BYTES + 2 * 16 * ROWB + 3 * H * 4];
     unsigned char* wn = smem;
     unsigned char* hbuf0 = smem + WN_BYTES;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __rest
     uint4 wr[NJT][2][KC];
 #pragma unroll
     for (int q = 0; q < NJT; ++q) {
-        const int jt = wave + 4 * q;
+        const int jt = wave + 8 * q;
         const bool on = FULL || jt < NT;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __rest
             *(uint4*)(wn + (((wave * NJT + q) * KC + kc) * 64 + lane) * 16) = w2;
         }
     }
-    for (int i = tid; i < 3 * H; i += 256) bsh[i] = bhh ? bhh[i] : 0.f;
-    for (int i = tid; i < 16 * ROWB / 4; i += 256) ((unsigned int*)hbuf0)[i] = 0u;
-    for (int i = tid; i < 16 * H; i += 256) {
+    for (int i = tid; i < 3 * H; i += 512) bsh[i] = bhh ? bhh[i] : 0.f;
+    for (int i = tid; i < 16 * ROWB / 4; i += 512) ((unsigned int*)hbuf0)[i] = 0u;
+    for (int i = tid; i < 16 * H; i += 512) {
         const int rb = i / H, j = i % H;
         if (b0 + rb < B) Hall[((long long)(b0 + rb) * (V + 1)) * H + j] = (bf16_t)0.f;
     }
@@ -276,11 +276,13 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __rest
     for (int t = 0; t < V; ++t) {
         const unsigned char* hcur = (t & 1) ? hbuf1 : hbuf0;
         unsigned char* hnext = (t & 1) ? hbuf0 : hbuf1;
+        // input-projection terms of this step: issued first, consumed after the MFMA loop (the SIMD's other wave and
+        // the MFMAs cover their latency)
         f32x4 gi[NJT][3];
         f32x4 acc[NJT][3];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 4 * q;
+            const int jt = wave + 8 * q;
             const bool on = FULL || jt < NT;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -305,16 +307,16 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __rest
         }
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 4 * q;
+            const int jt = wave + 8 * q;
             if (FULL || jt < NT) {
                 const int j = jt * 16 + fg * 4;
                 f32x4 r4, u4, n4, q4, h4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float r = 1.f / (1.f + expf(-(gi[q][0][e] + acc[q][0][e])));
-                    const float u = 1.f / (1.f + expf(-(gi[q][1][e] + acc[q][1][e])));
+                    const float r = fast_sigmoid(gi[q][0][e] + acc[q][0][e]);
+                    const float u = fast_sigmoid(gi[q][1][e] + acc[q][1][e]);
                     const float qq = acc[q][2][e];
-                    const float n = tanhf(gi[q][2][e] + r * qq);
+                    const float n = fast_tanh(gi[q][2][e] + r * qq);
                     const float hn = (1.f - u) * n + u * hprev[q][e];
                     hprev[q][e] = hn;
                     r4[e] = r; u4[e] = u; n4[e] = n; q4[e] = qq; h4[e] = hn;
@@ -337,14 +339,14 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_res_kernel(const float* __rest
 
 // Backward twin: W_hh^T fragments for the r,u gate columns (k < 2H) in registers, the n gate columns in LDS.
 template <int NJT, int KC>
-__global__ __launch_bounds__(256, 1) void gru_bwd_res_kernel(const float* __restrict__ dc, const bf16_t* __restrict__ Hall,
+__global__ __launch_bounds__(512) void gru_bwd_res_kernel(const float* __restrict__ dc, const bf16_t* __restrict__ Hall,
                                                              const bf16_t* __restrict__ gates, const bf16_t* __restrict__ WTfrag,
                                                              bf16_t* __restrict__ dGi, bf16_t* __restrict__ dGh, int B, int V) {
     constexpr int H = 32 * KC, NT = H / 16;
     constexpr int KC3 = 3 * KC, KCR = 2 * KC, KCL = KC;
     constexpr int ROWB = 3 * H * 2 + 16;
-    constexpr int WL_BYTES = 4 * NJT * KCL * 1024;
-    constexpr bool FULL = (NT == 4 * NJT);
+    constexpr int WL_BYTES = 8 * NJT * KCL * 1024;
+    constexpr bool FULL = (NT == 8 * NJT);
     __shared__ __attribute__((aligned(16))) unsigned char smem[WL_BYTES + 16 * ROWB];
     unsigned char* wl = smem;
     unsigned char* gcur = smem + WL_BYTES;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_res_kernel(const float* __rest
     float dh[NJT][4];
 #pragma unroll
     for (int q = 0; q < NJT; ++q) {
-        const int jt = wave + 4 * q;
+        const int jt = wave + 8 * q;
         const bool on = FULL || jt < NT;
 #pragma unroll
         for (int kc = 0; kc < KCR; ++kc)
@@ -379,18 +381,43 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_res_kernel(const float* __rest
     }
     __syncthreads();
 
+    // saved activations of step t-1 are prefetched while step t runs (bf16x4 = 8 bytes each)
+    bf16x4 sv[NJT][5], svn[NJT][5];
+#pragma unroll
+    for (int q = 0; q < NJT; ++q) {
+        const int jt = wave + 8 * q;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            sv[q][k] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            svn[q][k] = sv[q][k];
+        }
+        if ((FULL || jt < NT) && b_ok) {
+            const int j = jt * 16 + fg * 4;
+            sv[q][0] = *(const bf16x4*)(Hall + ((long long)b * (V + 1) + (V - 1)) * H + j);
+            const bf16_t* gp = gates + (((long long)b * V + (V - 1)) * 4) * H + j;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[q][1 + k] = *(const bf16x4*)(gp + k * H);
+        }
+    }
+
     for (int t = V - 1; t >= 0; --t) {
         float keep[NJT][4];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 4 * q;
+            const int jt = wave + 8 * q;
             if (FULL || jt < NT) {
                 const int j = jt * 16 + fg * 4;
-                f32x4 hp = (f32x4){0.f, 0.f, 0.f, 0.f}, r4 = hp, u4 = hp, n4 = hp, q4 = hp;
-                if (b_ok) {
-                    hp = load4(Hall + ((long long)b * (V + 1) + t) * H + j);
-                    const bf16_t* gp = gates + (((long long)b * V + t) * 4) * H + j;
-                    r4 = load4(gp); u4 = load4(gp + H); n4 = load4(gp + 2 * H); q4 = load4(gp + 3 * H);
+                if (b_ok && t > 0) {
+                    svn[q][0] = *(const bf16x4*)(Hall + ((long long)b * (V + 1) + (t - 1)) * H + j);
+                    const bf16_t* gpn = gates + (((long long)b * V + (t - 1)) * 4) * H + j;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) svn[q][1 + k] = *(const bf16x4*)(gpn + k * H);
+                }
+                f32x4 hp, r4, u4, n4, q4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hp[e] = (float)sv[q][0][e]; r4[e] = (float)sv[q][1][e]; u4[e] = (float)sv[q][2][e];
+                    n4[e] = (float)sv[q][3][e]; q4[e] = (float)sv[q][4][e];
                 }
                 f32x4 dr4, du4, dn4, dnr4;
 #pragma unroll
@@ -436,9 +463,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_res_kernel(const float* __rest
             }
         }
 #pragma unroll
-        for (int q = 0; q < NJT; ++q)
+        for (int q = 0; q < NJT; ++q) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) dh[q][e] = keep[q][e] + acc[q][e];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sv[q][k] = svn[q][k];
+        }
         __syncthreads();
     }
 }
@@ -484,9 +514,9 @@ int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* H
     dim3 grid((B + 15) / 16);
     if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
 #define GRU_F(NJT, KC) \
-    hipLaunchKernelGGL((gru_fwd_res_kernel<NJT, KC>), grid, dim3(256), 0, stream, Gi, (const bf16_t*)Wfrag, bhh, (bf16_t*)Hall, \
+    hipLaunchKernelGGL((gru_fwd_res_kernel<NJT, KC>), grid, dim3(512), 0, stream, Gi, (const bf16_t*)Wfrag, bhh, (bf16_t*)Hall, \
                        (bf16_t*)gates, c_out, B, V)
-        if (H == 256) GRU_F(4, 8); else if (H == 128) GRU_F(2, 4); else if (H == 64) GRU_F(1, 2); else GRU_F(1, 1);
+        if (H == 256) GRU_F(2, 8); else if (H == 128) GRU_F(1, 4); else if (H == 64) GRU_F(1, 2); else GRU_F(1, 1);
 #undef GRU_F
         CPC_CHECK_LAUNCH();
         return CPC_OK;
@@ -510,9 +540,9 @@ int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const v
     dim3 grid((B + 15) / 16);
     if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
 #define GRU_B(NJT, KC) \
-    hipLaunchKernelGGL((gru_bwd_res_kernel<NJT, KC>), grid, dim3(256), 0, stream, dc, (const bf16_t*)Hall, (const bf16_t*)gates, \
+    hipLaunchKernelGGL((gru_bwd_res_kernel<NJT, KC>), grid, dim3(512), 0, stream, dc, (const bf16_t*)Hall, (const bf16_t*)gates, \
                        (const bf16_t*)WTfrag, (bf16_t*)dGi, (bf16_t*)dGh, B, V)
-        if (H == 256) GRU_B(4, 8); else if (H == 128) GRU_B(2, 4); else if (H == 64) GRU_B(1, 2); else GRU_B(1, 1);
+        if (H == 256) GRU_B(2, 8); else if (H == 128) GRU_B(1, 4); else if (H == 64) GRU_B(1, 2); else GRU_B(1, 1);
 #undef GRU_B
         CPC_CHECK_LAUNCH();
         return CPC_OK;

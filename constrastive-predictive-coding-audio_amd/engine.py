@@ -170,9 +170,11 @@ class CPCEngine:
         self.slabs = torch.empty(max(need), device=dev, dtype=f32)
 
     def _pick_split(self, I, J, M):
-        tiles = _ceil_div(I, 128) * _ceil_div(J, 128)
+        big = self.dt == torch.bfloat16 and I >= 256 and J >= 256       # 256x256 tiles, one workgroup per CU
+        tile = 256 if big else 128
+        tiles = _ceil_div(I, tile) * _ceil_div(J, tile)
         blk = 64 if self.dt == torch.bfloat16 else 32
-        want = _ceil_div(512, tiles)
+        want = _ceil_div(256 if big else 512, tiles)
         return max(1, min(want, _ceil_div(M, 8 * blk), 64))
 
     def _chunk(self, M, nsplit):
@@ -301,8 +303,16 @@ class CPCEngine:
         # predictor: dW_p = dpred^T c ;  dc = dpred W_p
         _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(self.Hall, V * H), _hip.ptr(g["prediction_model.weight"]), B, K * E, H,
                      K * E, H, H, code, b_rpi=1, b_item=(V + 1) * H, flags=_hip.GEMM_OUT_F32)
-        _hip.gemm_nt(_hip.ptr(self.dpred), _hip.ptr(self.w_p_t), _hip.ptr(self.dc), B, H, K * E, K * E, K * E, H, code,
-                     flags=_hip.GEMM_OUT_F32)
+        # (a B x H output with a K*E-long reduction: split the reduction over workgroups, sum the slabs in fixed order)
+        ke = K * E
+        ksplit = ke // 256 if (ke % 256 == 0 and ke >= 1024 and self.slabs.numel() >= (ke // 256) * B * H) else 1
+        if ksplit > 1:
+            _hip.gemm_nt(_hip.ptr(self.dpred), _hip.ptr(self.w_p_t), _hip.ptr(self.slabs), B, H, 256, ke, ke, H, code,
+                         a_batch=256, b_batch=256, c_batch=B * H, batch=ksplit, flags=_hip.GEMM_OUT_F32)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(self.dc), B, H, ksplit, B * H, 1, 1, H, 0)
+        else:
+            _hip.gemm_nt(_hip.ptr(self.dpred), _hip.ptr(self.w_p_t), _hip.ptr(self.dc), B, H, ke, ke, ke, H, code,
+                         flags=_hip.GEMM_OUT_F32)
         if add_dc is not None:
             self.dc.add_(add_dc)
         _hip.call("cpc_gru_bwd", _hip.ptr(self.dc), _hip.ptr(self.Hall), _hip.ptr(self.gates), _hip.ptr(self.w_hh_t_frag),

@@ -62,6 +62,27 @@ def test_gemm_nt_plain(dt, M, N, K):
     assert not torch.isnan(out32).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 300, 128), (2048, 512, 1024), (1024, 264, 64)])
+def test_gemm_nt_tile_variants_agree(M, N, K):
+    """bf16: 256x256-tile kernel vs 128x128-tile kernel vs generic kernel on the same operands (incl. ragged M, N)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    mask = torch.randn(M, N, generator=g)
+    dA, dB, db, dM = dev(A, torch.bfloat16), dev(Bt, torch.bfloat16), dev(bias), dev(mask, torch.bfloat16)
+    ref = torch.relu(rounded(A, torch.bfloat16) @ rounded(Bt, torch.bfloat16).T + bias.double())
+    ref = torch.where(rounded(mask, torch.bfloat16) > 0, ref, torch.zeros_like(ref))
+    outs = []
+    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC):
+        out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, N, K, K, K, N, _hip.BF16, bias=_hip.ptr(db), mask=_hip.ptr(dM),
+                     flags=_hip.GEMM_RELU | extra)
+        assert rel_err(out, ref) < tol(torch.bfloat16)
+        outs.append(out)
+    # same accumulation order per output element in all three kernels -> bitwise identical results
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_nt_addressing_mask_batch(dt):
     """Overlapping rows (strided-conv view), item addressing on A and C, pad-row zeroing, relu mask, batch strides."""
@@ -138,6 +159,24 @@ def test_gemm_tn(dt, flags, M, I, J):
     outT = torch.full((I, J), float("nan"), device=DEV, dtype=dt)
     _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(outT), M, I, J, I, J, J, code, flags=flags)
     assert rel_err(outT, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("M,I,J,nsplit", [(4096, 264, 256, 2), (2050, 512, 520, 1), (8192, 4096, 512, 4)])
+def test_gemm_tn_tile_variants_agree(M, I, J, nsplit):
+    g = torch.Generator().manual_seed(M + I)
+    A, B = torch.randn(M, I, generator=g), torch.randn(M, J, generator=g)
+    dA, dB = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    ref = rounded(A, torch.bfloat16).T @ rounded(B, torch.bfloat16)
+    chunk = -(-(-(-M // nsplit)) // 64) * 64 if nsplit > 1 else 0
+    chunk = ((M + nsplit - 1) // nsplit + 63) // 64 * 64
+    outs = []
+    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC):
+        slabs = torch.full((nsplit, I, J), float("nan"), device=DEV)
+        _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(slabs), M, I, J, I, J, J, _hip.BF16, nsplit=nsplit, m_chunk=chunk,
+                     slab_stride=I * J, flags=_hip.GEMM_OUT_F32 | extra)
+        assert rel_err(slabs.sum(0), ref) < 2e-3
+        outs.append(slabs)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dt", DTYPES)
