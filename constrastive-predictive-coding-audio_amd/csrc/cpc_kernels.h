@@ -7,6 +7,8 @@
 #define GEMM_OUT_F32 2     // output stored as f32 regardless of the storage dtype
 #define GEMM_TN_NO_TR 4    // TN/bf16: use scalar LDS reads instead of ds_read_b64_tr_b16 (debug / A-B check)
 #define GEMM_SMALL_TILE 16     // NT: keep the 128x128 tile even where the 256x256 one would be chosen (A-B check)
+#define GEMM_NARROW_EPI 32     // NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A-B check)
+#define GEMM_WIDE_EPI 0x10000  // internal: set by the launcher when the LDS-staged epilogue applies
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {

@@ -308,7 +308,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int TBM = WM * TI * 16, TBN = WN * TJ * 16, NTHR = 64 * WM * WN;
     constexpr int ATILE = TBM * 128, BTILE = TBN * 128, STAGE = ATILE + BTILE;
     constexpr int NA = TBM * 8 / NTHR, NB = TBN * 8 / NTHR, RSTEP = NTHR / 8;     // staged chunks per thread, row step
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    constexpr int EPI_RS = TBN * 2 + 16;                                            // bf16 output tile row stride in LDS
+    constexpr int EPI_BYTES = sizeof(TO) == 2 ? TBM * EPI_RS : 0;
+    constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -398,6 +401,60 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch;
     const T* Mb = (const T*)p.mask;
     const bool relu = p.flags & GEMM_RELU;
+    if constexpr (sizeof(TO) == 2) {
+        if (p.flags & GEMM_WIDE_EPI) {
+            // Storage-dtype output through LDS: the accumulator fragments (4 consecutive columns per lane) are written
+            // to a row-major tile image, then every thread moves whole 16-byte chunks of full rows, so the mask read and
+            // the store are 512-byte row segments instead of 32-byte ones.  (The K loop ended on a barrier.)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int ml = (wm * TI + i) * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int nl = (wn * TJ + j) * 16 + fg * 4;
+                    f32x4 v = acc[i][j];
+                    if (p.bias) v += *(const f32x4*)(p.bias + min(n0 + nl, p.N - 4));
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    store4((TO*)(lds + ml * EPI_RS) + nl, v);
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = TBN / 8;                 // 16-byte chunks per tile row
+            constexpr int RPP = NTHR / CPR;              // rows per pass
+            const int cc = tid % CPR, rr = tid / CPR;
+            const int n = n0 + cc * 8;
+            if (n < p.N) {
+#pragma unroll 4
+                for (int r = rr; r < TBM; r += RPP) {
+                    const int m = m0 + r;
+                    if (m >= p.M) break;
+                    const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
+                    uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
+                    if (Mb) {
+                        const uint4 mk = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
+                        // bf16 > 0  <=>  sign bit clear and not zero
+                        const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                        unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned lo = mw[e] & 0xffffu, hi = mw[e] >> 16;
+                            const unsigned keep = ((lo != 0u && lo < 0x8000u) ? 0xffffu : 0u) |
+                                                  ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+                            vw[e] &= keep;
+                        }
+                        v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                    }
+                    const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
+                    if (!row_valid) v = make_uint4(0, 0, 0, 0);
+                    *(uint4*)(Cb + coff + n) = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int m = m0 + wm * TI * 16 + i * 16 + frow;
@@ -668,6 +725,10 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const bool of32 = p.flags & GEMM_OUT_F32;
     const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
     const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE);
+    GemmNT q = p;
+    if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
+        p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
+        q.flags |= GEMM_WIDE_EPI;
     const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
     const int numM = (p.M + tbm - 1) / tbm, numN = (p.N + tbn - 1) / tbn;
     const long long blocks = (long long)((numM + 7) / 8) * 8 * numN;
@@ -675,11 +736,11 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     dim3 grid((unsigned)blocks, 1, batch);
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
-            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, p);
+            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
         } else if (fast) {
-            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
+            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
         } else {
             if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);

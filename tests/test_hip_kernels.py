@@ -62,7 +62,7 @@ def test_gemm_nt_plain(dt, M, N, K):
     assert not torch.isnan(out32).any()
 
 
-@pytest.mark.parametrize("M,N,K", [(1100, 300, 128), (2048, 512, 1024), (1024, 264, 64)])
+@pytest.mark.parametrize("M,N,K", [(1100, 300, 128), (2048, 512, 1024), (1024, 264, 64), (1500, 136, 192)])
 def test_gemm_nt_tile_variants_agree(M, N, K):
     """bf16: 256x256-tile kernel vs 128x128-tile kernel vs generic kernel on the same operands (incl. ragged M, N)."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -73,14 +73,15 @@ def test_gemm_nt_tile_variants_agree(M, N, K):
     ref = torch.relu(rounded(A, torch.bfloat16) @ rounded(Bt, torch.bfloat16).T + bias.double())
     ref = torch.where(rounded(mask, torch.bfloat16) > 0, ref, torch.zeros_like(ref))
     outs = []
-    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC):
+    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC, _hip.GEMM_NARROW_EPI, _hip.GEMM_NARROW_EPI | _hip.GEMM_SMALL_TILE):
         out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, N, K, K, K, N, _hip.BF16, bias=_hip.ptr(db), mask=_hip.ptr(dM),
                      flags=_hip.GEMM_RELU | extra)
         assert rel_err(out, ref) < tol(torch.bfloat16)
         outs.append(out)
     # same accumulation order per output element in all three kernels -> bitwise identical results
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
