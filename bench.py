@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-DOMINANT = "gemm_nt<bf16,bf16>"
+DOMINANT = "gemm_nt<bf16,bf16,256>"      # = gemm_nt_fast_kernel<bf16, bf16, 2, 4, 8, 4> (256x256 tile)
 
 
 def build_model(dtype, device, seed=0):
@@ -42,6 +42,14 @@ def build_model(dtype, device, seed=0):
 def cpu_baseline(budget_s=20.0):
     """The oracle's train step (torch CPU ops, f32) on BASELINE config 1's shape (B=8 clips of 20480 samples)."""
     from oracle import cpc_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # cgroup v2 CPU quota of the GPU box's container, when present
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
     threads = torch.get_num_threads()
     B, L = 8, 20480
     params = O.init_params(seed=0)
@@ -110,7 +118,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT], by_shape=args.breakdown)
+    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"],
+                             by_shape=args.breakdown)
     _hip.set_timer(timer)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -127,7 +136,7 @@ def main():
     summary = timer.summary()
     if rank == 0:
         frames = B * T * world * args.steps
-        dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32>"
+        dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"
         n = sum(v[0] for k, v in summary.items() if k.startswith(dom))
         ms = sum(v[1] for k, v in summary.items() if k.startswith(dom))
         flops = sum(v[2] for k, v in summary.items() if k.startswith(dom))
@@ -137,7 +146,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("gemm_nt_bf16_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("gemm_nt_fast_bf16_256_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -160,7 +169,7 @@ def main():
                        "loss_last_step": round(loss, 6)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "kernel": "gemm_nt_kernel<bf16,bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<f32,f32>",
+                         "kernel": "gemm_nt_fast_kernel<bf16,bf16,2,4,8,4>" if args.dtype == "bf16" else "gemm_nt_fast_kernel<f32,f32,2,2,4,4>",
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
         }

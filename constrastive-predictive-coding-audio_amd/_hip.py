@@ -161,10 +161,26 @@ def set_timer(timer):
     _timer = timer
 
 
-def _variant(dtype, flags):
+def _variant(dtype, flags, tile=None):
+    """Kernel-symbol label used by the timer: storage/output dtypes and, when known, the output tile (128 or 256)."""
+    t = f",{tile}" if tile else ""
     if dtype == F32:
-        return "<f32,f32>"
-    return "<bf16,f32>" if flags & GEMM_OUT_F32 else "<bf16,bf16>"
+        return f"<f32,f32{t}>"
+    return f"<bf16,f32{t}>" if flags & GEMM_OUT_F32 else f"<bf16,bf16{t}>"
+
+
+def nt_tile(dtype, M, N, K, flags=0):
+    """Mirror of the launcher's tile choice for gemm_nt (csrc/gemm.hip launch_gemm_nt)."""
+    ch = 8 if dtype == BF16 else 4
+    fast = K % (8 * ch) == 0 and not (flags & GEMM_FORCE_GENERIC)
+    return 256 if (fast and dtype == BF16 and M >= 1024 and N >= 256 and not (flags & GEMM_SMALL_TILE)) else 128
+
+
+def tn_tile(dtype, M, I, J, nsplit, m_chunk, flags=0):
+    """Mirror of the launcher's tile choice for gemm_tn (csrc/gemm.hip launch_gemm_tn)."""
+    eff = m_chunk if nsplit > 1 else M
+    fast = dtype == BF16 and not (flags & (GEMM_FORCE_GENERIC | GEMM_TN_NO_TR)) and I % 8 == 0 and I >= 8 and J >= 8
+    return 256 if (fast and I >= 256 and J >= 256 and eff >= 1024 and not (flags & GEMM_SMALL_TILE)) else 128
 
 
 # ----------------------------------------------------------------------------- thin call wrappers
@@ -174,7 +190,7 @@ def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None,
     args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
                       c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
     if _timer is not None:
-        _timer.run("gemm_nt" + _variant(dtype, flags), 2.0 * M * N * K * batch,
+        _timer.run("gemm_nt" + _variant(dtype, flags, nt_tile(dtype, M, N, K, flags)), 2.0 * M * N * K * batch,
                    lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"), shape=(M, N, K, batch))
         return
     _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt")
@@ -185,7 +201,8 @@ def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_r
     args = GemmTNArgs(A, B, Cout, M, I, J, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, a_batch, b_batch, c_batch, batch,
                       nsplit, m_chunk, slab_stride, flags, dtype)
     if _timer is not None:
-        _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32), 2.0 * M * I * J * batch,
+        _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32,
+                                        tn_tile(dtype, M, I, J, nsplit, m_chunk, flags)), 2.0 * M * I * J * batch,
                    lambda: _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn"), shape=(M, I, J, batch, nsplit))
         return
     _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")

@@ -297,6 +297,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 // matrix work.  Out-of-range tile rows / columns are CLAMPED to the last valid one instead of zero-filled wherever they
 // only feed outputs that are never stored.
 
+// XCD-aware tile order for the NT kernels.  Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, used for
+// speed only).  The weight operand (Bt) of a conv GEMM is 2-4 MB — a whole per-XCD L2 — and every M-panel re-reads it, so
+// the tiles that run together on one XCD are chosen to share ONE N-tile (its Bt rows stay L2-resident) while the
+// activation panels stream through:
+//   numN % 8 == 0 : XCD x owns the N-tiles x, x+8, ...; within one N-tile it walks the M-panels
+//   numN in {1,2,4}: 8/numN XCDs share each N-tile and split the M-panels between them
+//   otherwise      : the N-tiles of one M-panel back to back on one XCD
+__host__ __device__ __forceinline__ long long nt_grid_blocks(int numM, int numN) {
+    if (numN % 8 == 0) return 8LL * numM * (numN / 8);
+    if (numN == 1 || numN == 2 || numN == 4) return 8LL * ((numM + 8 / numN - 1) / (8 / numN));
+    return 8LL * ((numM + 7) / 8) * numN;
+}
+__device__ __forceinline__ void nt_tile_of_block(int bid, int numM, int numN, int& mt, int& nt) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    if (numN % 8 == 0) {
+        nt = xcd + 8 * (slot / numM);
+        mt = slot % numM;
+    } else if (numN == 1 || numN == 2 || numN == 4) {
+        const int cx = 8 / numN;
+        nt = xcd % numN;
+        mt = slot * cx + xcd / numN;
+    } else {
+        mt = (slot / numN) * 8 + xcd;
+        nt = slot % numN;
+    }
+}
+
 // Tile configuration: WM x WN waves, each owning a (TI*16) x (TJ*16) output sub-tile.
 //   <2,2,4,4>: 128x128 tile, 256 threads, 2 x 32 KiB LDS  (two workgroups per CU)
 //   <2,4,8,4>: 256x256 tile, 512 threads, 2 x 64 KiB LDS  (one workgroup per CU): half the LDS write traffic and 3/4 of
@@ -316,9 +343,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int numM = (p.M + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int mt = (slot / numN) * 8 + xcd, nt = slot % numN;
+    int mt, nt;
+    nt_tile_of_block(blockIdx.x, numM, numN, mt, nt);
     if (mt >= numM) return;
     const int m0 = mt * TBM, n0 = nt * TBN;
 
@@ -509,10 +535,12 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / WJ, wj = wave % WJ;
+    // grid (nsplit, tiles): consecutive blocks are the splits of one tile, so with nsplit a multiple of 8 the tiles of one
+    // split — which read the same reduction rows of both operands — run together on one XCD and share them through its L2
     const int numJ = (p.J + TBJ - 1) / TBJ;
-    const int it = blockIdx.x / numJ, jt = blockIdx.x % numJ;
+    const int it = blockIdx.y / numJ, jt = blockIdx.y % numJ;
     const int i0 = it * TBI, j0 = jt * TBJ;
-    const int split = blockIdx.y;
+    const int split = blockIdx.x;
     const int m_begin = split * p.m_chunk;
     const int m_end = min(p.M, m_begin + p.m_chunk);
 
@@ -731,7 +759,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         q.flags |= GEMM_WIDE_EPI;
     const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
     const int numM = (p.M + tbm - 1) / tbm, numN = (p.N + tbn - 1) / tbn;
-    const long long blocks = (long long)((numM + 7) / 8) * 8 * numN;
+    const long long blocks = fast ? nt_grid_blocks(numM, numN) : (long long)((numM + 7) / 8) * 8 * numN;
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
     if (dtype == CPC_DTYPE_BF16) {
@@ -775,6 +803,7 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     if (fast) {
         GemmTN q = p;
         q.m_chunk = eff_chunk;
+        grid = dim3(nsplit, numI * numJ, batch);
         if (big) {
             if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
             else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);

@@ -216,7 +216,8 @@ class CPCEngine:
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
-                      La[l], Lv[l], 1 if l < self.n - 1 else 0, code, key="gemm_nt" + _hip._variant(code, 0),
+                      La[l], Lv[l], 1 if l < self.n - 1 else 0, code,
+                      key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1])),
                       work=2.0 * B * La[l] * self.channels[l] * self.kernels[l] * self.channels[l - 1],
                       shape=("fwd", B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1]))
 
@@ -337,13 +338,17 @@ class CPCEngine:
                 self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout)
             flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.slabs), B, cin, cout, kw, s,
-                      La[l], self.nsplit[l], code, key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32), work=flops,
+                      La[l], self.nsplit[l], code,
+                      key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32, _hip.tn_tile(code, B * La[l], kw * cin, cout, self.nsplit[l],
+                                                                                             self._chunk(B * La[l], self.nsplit[l]))),
+                      work=flops,
                       shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
             _hip.call("cpc_reduce_conv_w", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                       self.nsplit[l], kw * cin * cout)
             _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
                       _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
-                      key="gemm_nt" + _hip._variant(code, 0), work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
+                      key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
+                      work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
                       shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
