@@ -40,7 +40,7 @@ class GemmTNArgs(C.Structure):
                 ("b_rpi", C.c_int), ("b_item", C.c_longlong),
                 ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
                 ("nsplit", C.c_int), ("m_chunk", C.c_int), ("slab_stride", C.c_longlong),
-                ("flags", C.c_int), ("dtype", C.c_int)]
+                ("flags", C.c_int), ("dtype", C.c_int), ("c_rpi", C.c_int), ("c_item", C.c_longlong)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
@@ -64,6 +64,8 @@ _SIGNATURES = {
     "cpc_gru_set_streaming": ([_I], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
+    "cpc_nce_all_workspace_floats": ([_I, _I], _L),
+    "cpc_nce_loss_all": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P], _I),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -197,9 +199,9 @@ def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None,
 
 
 def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_rpi=0, b_item=0, a_batch=0, b_batch=0,
-            c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0):
+            c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0, c_rpi=0, c_item=0):
     args = GemmTNArgs(A, B, Cout, M, I, J, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, a_batch, b_batch, c_batch, batch,
-                      nsplit, m_chunk, slab_stride, flags, dtype)
+                      nsplit, m_chunk, slab_stride, flags, dtype, c_rpi, c_item)
     if _timer is not None:
         _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32,
                                         tn_tile(dtype, M, I, J, nsplit, m_chunk, flags)), 2.0 * M * I * J * batch,

@@ -3,11 +3,11 @@
 Mirrors the reference's ``contrastive_estimation_training.py`` (score functions :12-33, trainer :36-269,
 DeterministicSampler :363-382, grad_mean_var :385-391).  ``train`` has two routes:
 
-* fused (the hot path): AudioEncoder + AudioGRUModel model, softplus/linear score, same-step scores
-  (``score_over_all_timesteps=False``), Adam.  Forward, InfoNCE loss, analytic backward and the Adam update all run as
+* fused (the hot path): AudioEncoder + AudioGRUModel model, softplus/linear score (either ``score_over_all_timesteps``
+  setting), Adam.  Forward, InfoNCE loss, analytic backward and the Adam update all run as
   HIP kernels (engine.CPCEngine); with torch.distributed initialised, one process per GPU, the flat gradient buffer is
   all-reduced over RCCL before the update (per-GPU in-batch negatives).
-* generic: any other score function / ``score_over_all_timesteps=True``: the model forward and backward still run on
+* generic: any other score function or optimizer: the model forward and backward still run on
   the HIP path (through the autograd bridge); the loss itself is assembled with torch ops on the GPU exactly as the
   reference does (:106-122, :141).
 """
@@ -105,8 +105,7 @@ class ContrastiveEstimationTrainer:
         return next(self.model.parameters()).device
 
     def _fused(self):
-        return (self.score_function in (softplus_score_function, linear_score_function)
-                and not self.score_over_all_timesteps and self.optimizer is torch.optim.Adam)
+        return self.score_function in (softplus_score_function, linear_score_function) and self.optimizer is torch.optim.Adam
 
     @staticmethod
     def _world():
@@ -187,7 +186,8 @@ class ContrastiveEstimationTrainer:
                     if fused:
                         eng = self.model.engine(batch.shape[0], batch.shape[1], device)
                         out = eng.loss_and_grads(batch.contiguous(), softplus=self.score_function is softplus_score_function,
-                                                 regularization=float(self.regularization))
+                                                 regularization=float(self.regularization),
+                                                 all_timesteps=bool(self.score_over_all_timesteps))
                         if world > 1:
                             import torch.distributed as dist
                             dist.all_reduce(self.model._flat_grad)

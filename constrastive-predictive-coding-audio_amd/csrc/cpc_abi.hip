@@ -39,6 +39,7 @@ int cpc_gemm_tn(const cpc_gemm_tn_args* a, void* stream) {
     p.a_rpi = a->a_rpi; p.a_item = a->a_item;
     p.b_rpi = a->b_rpi; p.b_item = a->b_item;
     p.a_batch = a->a_batch; p.b_batch = a->b_batch; p.c_batch = a->c_batch;
+    p.c_rpi = a->c_rpi; p.c_item = a->c_item;
     const int nsplit = a->nsplit > 0 ? a->nsplit : 1;
     p.m_chunk = nsplit > 1 ? a->m_chunk : a->M;
     p.slab_stride = a->slab_stride;
@@ -161,6 +162,14 @@ int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspa
                  float regularization, int dtype, void* stream) {
     if (!S || !dS || !dST || !out || !workspace) return CPC_EINVAL;
     return launch_nce(S, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
+}
+
+long long cpc_nce_all_workspace_floats(int B, int K) { return nce_all_workspace_floats(B, K); }
+
+int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
+                     int softplus, float regularization, int dtype, void* stream) {
+    if (!S || !ST || !dS || !dST || !out || !workspace) return CPC_EINVAL;
+    return launch_nce_all(S, ST, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
 }
 
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,

@@ -35,6 +35,7 @@ struct GemmTN {
     int a_rpi; long long a_item;
     int b_rpi; long long b_item;
     long long a_batch, b_batch, c_batch;
+    int c_rpi; long long c_item;      // output row i at row_off(i, c_rpi, c_item, ldc)  (c_rpi == 0: plain i * ldc)
     int m_chunk;          // reduction rows per split
     long long slab_stride;
     int flags;
@@ -58,6 +59,9 @@ int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const v
                    int V, int H, int dtype, hipStream_t stream);
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
 long long nce_workspace_floats(int B, int K);
+long long nce_all_workspace_floats(int B, int K);
+int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
+                   int softplus, float reg, int dtype, hipStream_t stream);
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
         for (int j = 0; j < 4; ++j) {
             const int jj = j0 + wj * 64 + j * 16 + fg * 4;
             if (jj >= p.J) continue;
-            store4(Cb + (long long)ii * p.ldc + jj, acc[i][j]);
+            store4(Cb + row_off(ii, p.c_rpi, p.c_item, p.ldc) + jj, acc[i][j]);
         }
     }
 }
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
         for (int j = 0; j < TJ; ++j) {
             const int jj = j0 + (wj * TJ + j) * 16 + fg * 4;
             if (jj >= p.J) continue;
-            store4(Cb + (long long)ii * p.ldc + jj, acc[i][j]);
+            store4(Cb + row_off(ii, p.c_rpi, p.c_item, p.ldc) + jj, acc[i][j]);
         }
     }
 }
@@ -792,6 +792,7 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (nsplit > 1 && (p.m_chunk <= 0 || (long long)p.m_chunk * nsplit < p.M)) return CPC_EINVAL;
     if (nsplit > 1 && !(p.flags & GEMM_OUT_F32)) return CPC_EINVAL;   // slabs are f32
+    if (p.c_rpi && (p.c_item % 4 || nsplit > 1)) return CPC_EINVAL;
     const bool of32 = p.flags & GEMM_OUT_F32;
     const int eff_chunk = nsplit > 1 ? p.m_chunk : p.M;
     const bool fast = dtype == CPC_DTYPE_BF16 && !(p.flags & (GEMM_FORCE_GENERIC | GEMM_TN_NO_TR)) && (p.I % 8 == 0) &&

@@ -131,6 +131,87 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
     }
 }
 
+// score_over_all_timesteps=True branch (contrastive_estimation_training.py:108-114, :141): S is the full R x R score
+// matrix, R = B*K, row r = (b,k) a prediction, column c = (b',k') a target.  lse[c] (over ALL rows) comes from
+// nce_col_kernel(K=1, B=R).  Gradient w.r.t. the linear scores:
+//   dsp[r][c] = (exp(sp[r][c] - lse[c]) - [r == c]) / R + 2 reg / (B B K K) * m[b][c],   m[b][c] = mean_k sp[(b,k)][c]
+// The kernel is element-wise given lse, so it runs once on S (writing dS) and once on S^T (writing dS^T) with the
+// roles of the two strides swapped — no transposes.  Element (r=(b,k), c) of the input sits at c*sc + (b*K+k)*sr.
+// FAST_C: consecutive threads walk c (S, sc = 1) or b (S^T, sr = 1; a thread then owns K contiguous elements).
+template <typename T, bool FAST_C>
+__global__ __launch_bounds__(256) void nce_all_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
+                                                           T* __restrict__ dS, float* __restrict__ partial, int B, int K,
+                                                           long long sc, long long sr, int softplus, float reg,
+                                                           int want_partials) {
+    __shared__ float red[3][256];
+    const int R = B * K;
+    const long long total = (long long)B * R;                 // (b, c) pairs
+    const float inv_r = 1.f / (float)R;
+    const float reg_c = 2.f * reg / ((float)B * (float)B * (float)K * (float)K);
+    float valid = 0.f, msq = 0.f, mx = -INFINITY;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int b = FAST_C ? (int)(idx / R) : (int)(idx % B);
+        const int c = FAST_C ? (int)(idx % R) : (int)(idx / B);
+        const float* base = S + (long long)c * sc + (long long)b * K * sr;
+        float m = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float sp = score_tf(base[(long long)k * sr], softplus);
+            m += sp;
+            mx = fmaxf(mx, sp);
+            if (b * K + k == c) valid += sp;
+        }
+        m /= (float)K;
+        msq += m * m;
+        const float l = lse[c];
+        T* obase = dS + (long long)c * sc + (long long)b * K * sr;
+        for (int k = 0; k < K; ++k) {
+            const float x = base[(long long)k * sr];
+            const float sp = score_tf(x, softplus);
+            float dsp = expf(sp - l) * inv_r + reg_c * m;
+            if (b * K + k == c) dsp -= inv_r;
+            obase[(long long)k * sr] = from_f32<T>(dsp * score_grad(x, softplus));
+        }
+    }
+    if (!want_partials) return;
+    red[0][threadIdx.x] = valid;
+    red[1][threadIdx.x] = msq;
+    red[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s2];
+            red[2][threadIdx.x] = fmaxf(red[2][threadIdx.x], red[2][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 3 + 0] = red[0][0];
+        partial[blockIdx.x * 3 + 1] = red[1][0];
+        partial[blockIdx.x * 3 + 2] = red[2][0];
+    }
+}
+
+// all-timesteps finalize: out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term
+__global__ void nce_all_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
+                                        int ngrad, float* __restrict__ out, int B, int K, float reg) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
+    for (int i = 0; i < ncol; ++i) lse_sum += col_partial[i];
+    for (int i = 0; i < ngrad; ++i) {
+        valid += grad_partial[i * 3 + 0];
+        msq += grad_partial[i * 3 + 1];
+        mx = fmaxf(mx, grad_partial[i * 3 + 2]);
+    }
+    const float r = (float)B * (float)K;
+    const float t_valid = -valid / r, t_lse = lse_sum / r, t_reg = reg * msq / ((float)B * (float)B * (float)K);
+    out[0] = t_valid + t_lse + t_reg;
+    out[1] = mx;
+    out[2] = t_valid;
+    out[3] = t_lse;
+    out[4] = t_reg;
+}
+
 // out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
 __global__ void nce_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
                                     int ngrad, float* __restrict__ out, int B, int K, float reg) {
@@ -178,6 +259,43 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
     else
         return CPC_EINVAL;
     hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+// ---- score_over_all_timesteps = True ----
+static const int NCE_ALL_BLOCKS = 1024;
+// workspace: lse [R] + col partials [ceil(R/32)] + grad partials [3 * NCE_ALL_BLOCKS]
+long long nce_all_workspace_floats(int B, int K) {
+    const long long R = (long long)B * K;
+    return R + (R + 31) / 32 + 3LL * NCE_ALL_BLOCKS;
+}
+
+int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
+                   int softplus, float reg, int dtype, hipStream_t stream) {
+    const int R = B * K;
+    if (B <= 0 || K <= 0 || ld < R) return CPC_EINVAL;
+    float* lse = workspace;
+    const int ncb = (R + 31) / 32;
+    float* colp = lse + R;
+    float* gradp = colp + ncb;
+    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus);
+    const long long total = (long long)B * R;
+    const int blocks = (int)min((long long)NCE_ALL_BLOCKS, (total + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16) {
+        hipLaunchKernelGGL((nce_all_grad_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, S, lse, (bf16_t*)dS, gradp, B, K,
+                           1LL, (long long)ld, softplus, reg, 1);
+        hipLaunchKernelGGL((nce_all_grad_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, ST, lse, (bf16_t*)dST, gradp, B,
+                           K, (long long)ld, 1LL, softplus, reg, 0);
+    } else if (dtype == CPC_DTYPE_F32) {
+        hipLaunchKernelGGL((nce_all_grad_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, S, lse, (float*)dS, gradp, B, K,
+                           1LL, (long long)ld, softplus, reg, 1);
+        hipLaunchKernelGGL((nce_all_grad_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, ST, lse, (float*)dST, gradp, B, K,
+                           (long long)ld, 1LL, softplus, reg, 0);
+    } else {
+        return CPC_EINVAL;
+    }
+    hipLaunchKernelGGL(nce_all_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncb, gradp, blocks, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

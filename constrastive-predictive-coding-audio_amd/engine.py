@@ -273,6 +273,34 @@ class CPCEngine:
         _hip.gemm_tn(_hip.ptr(self.dS), _hip.ptr(self.pred), _hip.ptr(dtop, (T - K) * E), B, B, E, ld, K * E, Ltop * E, code,
                      a_batch=B * ld, b_batch=E, c_batch=E, batch=K)
 
+    def nce_all_forward_backward(self, softplus: bool, regularization: float):
+        """score_over_all_timesteps=True (contrastive_estimation_training.py:108-114, :141): the full (B K) x (B K) score
+        matrix (and its transpose, as a second tiny GEMM, so that both gradient layouts are written coalesced), the
+        log-sum-exp over ALL predictions for every (target item, step), and d loss / d (predicted_z, targets)."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T = self.geo.alloc[-1], self.T
+        top, dtop = self.act[-1], self.dact[-1]
+        R = B * K
+        ld = _ceil_div(R, 8) * 8
+        if getattr(self, "S_all", None) is None:
+            f32 = torch.float32
+            self.S_all = torch.zeros(R * ld, device=self.device, dtype=f32)
+            self.ST_all = torch.zeros(R * ld, device=self.device, dtype=f32)
+            self.dS_all = torch.zeros(R * ld, device=self.device, dtype=self.dt)
+            self.dST_all = torch.zeros(R * ld, device=self.device, dtype=self.dt)
+            self.nce_all_ws = torch.empty(int(_hip.lib().cpc_nce_all_workspace_floats(B, K)), device=self.device, dtype=f32)
+        tg = (T - K) * E
+        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
+                     b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+        _hip.gemm_nt(_hip.ptr(top, tg), _hip.ptr(self.pred), _hip.ptr(self.ST_all), R, R, E, E, E, ld, code,
+                     a_rpi=K, a_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+        _hip.call("cpc_nce_loss_all", _hip.ptr(self.S_all), _hip.ptr(self.ST_all), _hip.ptr(self.dS_all), _hip.ptr(self.dST_all),
+                  _hip.ptr(self.nce_out), _hip.ptr(self.nce_all_ws), B, K, ld, 1 if softplus else 0, C.c_float(regularization), code)
+        # d predicted_z[(b,k)][:] = sum_c dS[(b,k)][c] * targets[c][:]
+        _hip.gemm_tn(_hip.ptr(self.dST_all), _hip.ptr(top, tg), _hip.ptr(self.dpred), R, R, E, ld, E, E, code, b_rpi=K, b_item=Ltop * E)
+        # d targets[c][:] = sum_r dS[r][c] * predicted_z[r][:]   -> rows T-K+k' of item b' of the top-layer gradient
+        _hip.gemm_tn(_hip.ptr(self.dS_all), _hip.ptr(self.pred), _hip.ptr(dtop, tg), R, R, E, ld, E, E, code, c_rpi=K, c_item=Ltop * E)
+
     # ------------------------------------------------------------------------------------------ backward
     def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, perm=(1, None, None, None), **kw):
         """grad[perm(i,j)] = sum_m A[m][i] B[m][j] via f32 slabs + deterministic reduction."""
@@ -362,10 +390,13 @@ class CPCEngine:
                       1, 1, 0, 0)
 
     # ------------------------------------------------------------------------------------------ whole step
-    def loss_and_grads(self, x, softplus: bool, regularization: float):
+    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False):
         """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg] (no sync)."""
         self.forward(x)
-        self.nce_forward_backward(softplus, regularization)
+        if all_timesteps:
+            self.nce_all_forward_backward(softplus, regularization)
+        else:
+            self.nce_forward_backward(softplus, regularization)
         self.backward(x)
         return self.nce_out
 

@@ -68,6 +68,7 @@ typedef struct cpc_gemm_tn_args {
     long long a_batch, b_batch, c_batch; int batch;
     int nsplit; int m_chunk; long long slab_stride;
     int flags; int dtype;
+    int c_rpi; long long c_item;          /* output row i at the item address (nsplit == 1 only); 0 = plain i*ldc */
 } cpc_gemm_tn_args;
 int cpc_gemm_tn(const cpc_gemm_tn_args* args, void* stream);
 
@@ -135,6 +136,13 @@ int cpc_gru_set_streaming(int on);
 long long cpc_nce_workspace_floats(int B, int K);
 int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus,
                  float regularization, int dtype, void* stream);
+
+/* Same loss with score_over_all_timesteps=True (contrastive_estimation_training.py:108-114, :141): S is the full
+ * (B*K) x (B*K) score matrix, row (b,k) = prediction, column (b',k') = target, ST its transpose (both f32, rows of ld
+ * floats, produced by two cpc_gemm_nt calls); dS / dST (T, same ld) receive d loss / d linear score and its transpose. */
+long long cpc_nce_all_workspace_floats(int B, int K);
+int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
+                     int softplus, float regularization, int dtype, void* stream);
 
 /* torch.optim.Adam.step with default betas/eps semantics over one flat f32 buffer
  * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first. */

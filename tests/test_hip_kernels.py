@@ -382,6 +382,37 @@ def test_nce_loss(dt, softplus, B, K, reg):
     assert rel_err(dST, lin.grad.transpose(1, 2)) < t
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("softplus", [0, 1])
+@pytest.mark.parametrize("B,K,reg", [(6, 4, 1.0), (10, 3, 0.01), (32, 12, 0.5)])
+def test_nce_loss_all_timesteps(dt, softplus, B, K, reg):
+    g = torch.Generator().manual_seed(B * 5 + K)
+    R = B * K
+    S = torch.randn(R, R, generator=g) * 3.0
+    S[0, 0] = 25.0
+    ld = (R + 7) // 8 * 8
+    Sp = torch.full((R, ld), 7.0); Sp[:, :R] = S
+    STp = torch.full((R, ld), 7.0); STp[:, :R] = S.T
+    code = _hip.dtype_code(dt)
+    dSp = torch.zeros((R, ld), device=DEV, dtype=dt)
+    dSTp = torch.zeros((R, ld), device=DEV, dtype=dt)
+    out = torch.full((8,), float("nan"), device=DEV)
+    ws = torch.empty(_hip.lib().cpc_nce_all_workspace_floats(B, K), device=DEV)
+    dSin, dSTin = dev(Sp), dev(STp)          # keep the device copies alive across the (asynchronous) launch
+    _hip.call("cpc_nce_loss_all", _hip.ptr(dSin), _hip.ptr(dSTin), _hip.ptr(dSp), _hip.ptr(dSTp), _hip.ptr(out), _hip.ptr(ws),
+              B, K, ld, softplus, C.c_float(reg), code)
+    lin = S.double().requires_grad_(True)
+    full = lin.view(B, K, B, K)
+    sc = F.softplus(full) if softplus else full
+    loss, smax = O.info_nce_loss(sc, all_timesteps=True, regularization=reg)
+    loss.backward()
+    assert abs(out[0].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert abs(out[1].item() - smax.item()) < 1e-5 * max(1.0, abs(smax.item()))
+    t = 2e-5 if dt == torch.float32 else 1e-2
+    assert rel_err(dSp[:, :R], lin.grad) < t
+    assert rel_err(dSTp[:, :R], lin.grad.T) < t
+
+
 # --------------------------------------------------------------------------------------- Adam
 def test_adam_matches_torch():
     g = torch.Generator().manual_seed(0)
