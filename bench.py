@@ -94,7 +94,7 @@ def main():
     torch.cuda.set_device(device)
 
     from cpc_audio_amd import _hip
-    from cpc_audio_amd.engine import FusedAdam
+    from cpc_audio_amd.engine import FusedAdam, GradAllReduce
 
     B, L, T = args.batch, 20480, 126
     model = build_model(args.dtype, device, seed=0)                 # identical parameters on every rank
@@ -103,10 +103,13 @@ def main():
     gen = torch.Generator().manual_seed(1000 + rank)                # rank r draws its own clips
     pool = [(torch.randn(B, L, generator=gen)).to(device) for _ in range(4)]
 
+    sync = GradAllReduce(model) if world > 1 else None
+
     def step(i):
-        out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0)
-        if world > 1:
-            dist.all_reduce(model._flat_grad)
+        out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0,
+                                 grad_ready_hook=sync.hook if sync is not None else None)
+        if sync is not None:
+            sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer, two overlapped pieces
         opt.step(grad_scale=1.0 / world)
         return out
 

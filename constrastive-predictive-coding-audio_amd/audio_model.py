@@ -162,7 +162,7 @@ class AudioPredictiveCodingModel(nn.Module):
             total += (p.numel() + 63) // 64 * 64
         flat = torch.zeros(total, device=device, dtype=torch.float32)
         grad = torch.zeros(total, device=device, dtype=torch.float32)
-        self._param, self._grad = {}, {}
+        self._param, self._grad, self._offset = {}, {}, dict(offsets)
         with torch.no_grad():
             for n, p in named:
                 view = flat[offsets[n]:offsets[n] + p.numel()].view(p.shape)

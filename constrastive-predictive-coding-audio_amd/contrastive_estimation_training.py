@@ -148,10 +148,11 @@ class ContrastiveEstimationTrainer:
         self.model.train()
         fused = self._fused()
         if fused:
-            from .engine import FusedAdam
+            from .engine import FusedAdam, GradAllReduce
             self.model._flatten_parameters(device)
             optimizer = FusedAdam(self.model, lr=lr)
             self.model.link_grads()
+            sync = GradAllReduce(self.model) if world > 1 else None
         else:
             self.model._flatten_parameters(device)
             optimizer = self.optimizer(self.model.parameters(), lr=lr)
@@ -187,10 +188,10 @@ class ContrastiveEstimationTrainer:
                         eng = self.model.engine(batch.shape[0], batch.shape[1], device)
                         out = eng.loss_and_grads(batch.contiguous(), softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
-                                                 all_timesteps=bool(self.score_over_all_timesteps))
-                        if world > 1:
-                            import torch.distributed as dist
-                            dist.all_reduce(self.model._flat_grad)
+                                                 all_timesteps=bool(self.score_over_all_timesteps),
+                                                 grad_ready_hook=sync.hook if sync is not None else None)
+                        if sync is not None:
+                            sync.finish()
                         optimizer.step(grad_scale=1.0 / world)
                         vals = out[:2].clone()
                     else:

@@ -318,11 +318,13 @@ class CPCEngine:
         _hip.call("cpc_colsum", X, _hip.ptr(self.slabs), M, N, N, nb, self.code)
         _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad), 1, N, nb, N, 1, 1, 0, 0)
 
-    def backward(self, x, add_dc: Optional[torch.Tensor] = None, add_dz: Optional[torch.Tensor] = None):
+    def backward(self, x, add_dc: Optional[torch.Tensor] = None, add_dz: Optional[torch.Tensor] = None, grad_ready_hook=None):
         """Gradients of everything upstream of (predicted_z, targets, z, c) into the model's flat gradient buffer.
 
         Expects ``dpred`` and rows [T-K, T) of the top-layer gradient to be filled (by nce_forward_backward or by the
-        autograd bridge).  Rows [T-K-V, T-K) are overwritten here with the GRU's input gradient (+ add_dz (B,E,V))."""
+        autograd bridge).  Rows [T-K-V, T-K) are overwritten here with the GRU's input gradient (+ add_dz (B,E,V)).
+        ``grad_ready_hook(lo, hi)`` is called as soon as the flat-gradient range [lo, hi) is final, so that a caller can
+        start reducing it across ranks while the remaining layers are still being differentiated."""
         g, code = self.model._grad, self.code
         B, V, H, E, K, n = self.B, self.V, self.H, self.E, self.K, self.n
         La, Lv = self.geo.alloc, self.geo.valid
@@ -373,6 +375,10 @@ class CPCEngine:
                       shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
             _hip.call("cpc_reduce_conv_w", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                       self.nsplit[l], kw * cin * cout)
+            if grad_ready_hook is not None and l == 2 and n > 2:
+                # everything from encoder layer index 2 upwards (+ GRU, predictor: later in the flat buffer) is final
+                lo = self.model._offset["encoder.layers.2.weight"]
+                grad_ready_hook(lo, self.model._flat_grad.numel())
             _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
                       _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
                       key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
@@ -390,15 +396,45 @@ class CPCEngine:
                       1, 1, 0, 0)
 
     # ------------------------------------------------------------------------------------------ whole step
-    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False):
+    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None):
         """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg] (no sync)."""
         self.forward(x)
         if all_timesteps:
             self.nce_all_forward_backward(softplus, regularization)
         else:
             self.nce_forward_backward(softplus, regularization)
-        self.backward(x)
+        self.backward(x, grad_ready_hook=grad_ready_hook)
         return self.nce_out
+
+
+class GradAllReduce:
+    """Data-parallel gradient exchange: ONE sum over ranks of the model's flat f32 gradient buffer per step (RCCL over
+    xGMI with backend "nccl"), issued in two pieces so that the larger, earlier-finished piece (encoder layers >= 3,
+    GRU, predictor: 63 % of the bytes) travels while encoder layers 2 and 1 are still being differentiated.
+    The mean is taken by FusedAdam's ``grad_scale = 1 / world``."""
+
+    def __init__(self, model):
+        import torch.distributed as dist
+        self.dist = dist
+        self.model = model
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.pending = []
+        self.split = None
+
+    def hook(self, lo, hi):
+        """Pass as ``grad_ready_hook``: starts the asynchronous all-reduce of flat_grad[lo:hi]."""
+        self.split = lo
+        self.pending.append(self.dist.all_reduce(self.model._flat_grad[lo:hi], async_op=True))
+
+    def finish(self):
+        """Reduces what the hook has not covered and makes the current stream wait for all pieces."""
+        flat = self.model._flat_grad
+        rest = flat if self.split is None else flat[:self.split]
+        if rest.numel():
+            self.pending.append(self.dist.all_reduce(rest, async_op=True))
+        for work in self.pending:
+            work.wait()
+        self.pending, self.split = [], None
 
 
 class FusedAdam:

@@ -258,3 +258,39 @@ def test_full_size_properties_b256():
     for n, g32 in grads["fp32"].items():
         cos = torch.dot(g32, grads["bf16"][n]) / (g32.norm() * grads["bf16"][n].norm() + 1e-30)
         assert cos.item() > 0.995, (n, cos.item())
+
+
+def test_gradient_allreduce_path_single_rank_nccl():
+    """The data-parallel code path (RCCL process group, two overlapped all-reduce pieces, grad_scale) run with a world of
+    one rank gives exactly the single-process step."""
+    import torch.distributed as dist
+    from cpc_audio_amd.engine import FusedAdam, GradAllReduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+        started = True
+    try:
+        results = []
+        for use_sync in (False, True):
+            torch.manual_seed(3)
+            enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [64] * 5, 'bias': True})
+            model = AudioPredictiveCodingModel(enc, AudioGRUModel(64, 64), enc_size=64, ar_size=64, visible_steps=10,
+                                               prediction_steps=4, compute_dtype="fp32").to(DEV)
+            x = (torch.randn(8, 465 + 14 * 160, generator=torch.Generator().manual_seed(4)) * 0.5).to(DEV)
+            eng = model.engine(8, x.shape[1])
+            opt = FusedAdam(model, lr=1e-3)
+            sync = GradAllReduce(model) if use_sync else None
+            out = eng.loss_and_grads(x, softplus=True, regularization=1.0, grad_ready_hook=sync.hook if sync else None)
+            if sync:
+                assert sync.split == model._offset["encoder.layers.2.weight"] and len(sync.pending) == 1
+                sync.finish()
+            opt.step(grad_scale=1.0)
+            torch.cuda.synchronize()
+            results.append((float(out[0]), model._flat_grad.clone(), model._flat_param.clone()))
+        assert results[0][0] == results[1][0]
+        assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    finally:
+        if started:
+            dist.destroy_process_group()

@@ -1,0 +1,42 @@
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py r01
+
+Writes profiles/<tag>_kernel_stats.csv (copy of the --stats summary), profiles/<tag>_traffic.json (per-kernel HBM bytes
+per launch from the FETCH_SIZE / WRITE_SIZE passes) and profiles/traffic_latest.json (read by bench.py).
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports exactly half of the bytes of a 16-byte-
+per-lane streaming read (MI355X_MICROARCH.md, HBM section) — calibrated here on conv1_bwd_kernel, whose only large read
+is the 0.956 GB layer-1 gradient: FETCH_SIZE reads 0.488 GB for it."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_bench_b256_bf16.csv"))
+
+
+def per_kernel(counter, sub):
+    f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = per_kernel("FETCH_SIZE", "fetch"), per_kernel("WRITE_SIZE", "write")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
+    out[k] = {"launches_sampled": len(f), "fetch_size_kb_avg": sum(f) / len(f), "write_size_kb_avg": sum(w) / len(w),
+              "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024}
+json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+dom = [k for k in out if "gemm_nt_fast_kernel" in k and "Li2ELi4ELi8ELi4E" in k and "DF16bDF16b" in k]
+latest = {"source": f"profiles/{tag}_traffic.json", "kernel": dom[0] if dom else None,
+          "gemm_nt_fast_bf16_256_hbm_bytes_per_launch": out[dom[0]]["hbm_bytes_per_launch"] if dom else None}
+json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(latest, indent=1))
