@@ -11,7 +11,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI = 1, 2, 4, 8, 16, 32
+GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA = 1, 2, 4, 8, 16, 32, 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")

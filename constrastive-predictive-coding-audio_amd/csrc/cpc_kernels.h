@@ -9,6 +9,7 @@
 #define GEMM_SMALL_TILE 16     // NT: keep the 128x128 tile even where the 256x256 one would be chosen (A-B check)
 #define GEMM_NARROW_EPI 32     // NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A-B check)
 #define GEMM_WIDE_EPI 0x10000  // internal: set by the launcher when the LDS-staged epilogue applies
+#define GEMM_NO_DMA 64         // NT fast path: register-staged global->LDS copies instead of LDS-DMA (A-B check)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {

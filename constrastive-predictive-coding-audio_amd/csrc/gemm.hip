@@ -328,7 +328,23 @@ __device__ __forceinline__ void nt_tile_of_block(int bid, int numM, int numN, in
 //   <2,2,4,4>: 128x128 tile, 256 threads, 2 x 32 KiB LDS  (two workgroups per CU)
 //   <2,4,8,4>: 256x256 tile, 512 threads, 2 x 64 KiB LDS  (one workgroup per CU): half the LDS write traffic and 3/4 of
 //              the LDS read traffic per MFMA of the small tile — the small tile is LDS-bound (ds_write_b128 ~79 B/clk/CU).
-template <typename T, typename TO, int WM, int WN, int TI, int TJ>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// ds_read_b128 the compiler does not see (see the DMA variant below); OFF is the instruction's immediate offset.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16_asm(unsigned addr) {
+    u32x4 d;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
+    return d;
+}
+__device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+
+// DMA = true: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write traffic —
+// the register-staged variant is bound by the ds_write_b128 rate).  hipcc drains vmcnt(0) in front of every LDS read it
+// can see while an LDS-DMA is in flight, which would serialise load and MFMA; so here the fragment reads are inline-asm
+// ds_read_b128 with hand-counted lgkmcnt waits (each wait statement names the fragments it releases as "+v" operands
+// and is followed by sched_barrier(0), so no MFMA can be scheduled above it).
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
@@ -351,38 +367,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
 
-    // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
-    // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
-    static_assert(NA == 4 && NB == 4, "staging code below is written for 4 chunks per operand per thread");
-    const int ch = tid & 7, srow = tid >> 3;
-    const T* ga0 = Ab + row_off(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga1 = Ab + row_off(min(m0 + srow + RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga2 = Ab + row_off(min(m0 + srow + 2 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* ga3 = Ab + row_off(min(m0 + srow + 3 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-    const T* gb0 = Bb + row_off(min(n0 + srow, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb1 = Bb + row_off(min(n0 + srow + RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb2 = Bb + row_off(min(n0 + srow + 2 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    const T* gb3 = Bb + row_off(min(n0 + srow + 3 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
-    // RSTEP is a multiple of 8, so the swizzle term (row & 7) is the same for the 4 rows: one offset + constants
-    const int so = lds_off(srow, ch);
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define NT_GLOAD(k0)                                                                   \
-    do {                                                                               \
-        ra0 = *(const uint4*)(ga0 + (k0)); rb0 = *(const uint4*)(gb0 + (k0));          \
-        ra1 = *(const uint4*)(ga1 + (k0)); rb1 = *(const uint4*)(gb1 + (k0));          \
-        ra2 = *(const uint4*)(ga2 + (k0)); rb2 = *(const uint4*)(gb2 + (k0));          \
-        ra3 = *(const uint4*)(ga3 + (k0)); rb3 = *(const uint4*)(gb3 + (k0));          \
-    } while (0)
-#define NT_LSTORE(base)                                                                \
-    do {                                                                               \
-        unsigned char* da = (base) + so;                                               \
-        unsigned char* db = da + ATILE;                                                \
-        *(uint4*)(da) = ra0;                   *(uint4*)(db) = rb0;                    \
-        *(uint4*)(da + RSTEP * 128) = ra1;     *(uint4*)(db + RSTEP * 128) = rb1;      \
-        *(uint4*)(da + 2 * RSTEP * 128) = ra2; *(uint4*)(db + 2 * RSTEP * 128) = rb2;  \
-        *(uint4*)(da + 3 * RSTEP * 128) = ra3; *(uint4*)(db + 3 * RSTEP * 128) = rb3;  \
-    } while (0)
-
     f32x4 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -399,30 +383,156 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         for (int j = 0; j < TJ; ++j) offB[kk][j] = ATILE + lds_off(wn * TJ * 16 + j * 16 + frow, kk * 4 + fg);
     }
     const int nk = p.K / BK;
-    NT_GLOAD(0);
-    NT_LSTORE(lds);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* cur = lds + (t & 1) * STAGE;
-        const bool more = t + 1 < nk;
-        if (more) NT_GLOAD((long long)(t + 1) * BK);
+    if constexpr (!DMA) {
+        // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
+        // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
+        static_assert(NA == 4 && NB == 4, "staging code below is written for 4 chunks per operand per thread");
+        const int ch = tid & 7, srow = tid >> 3;
+        const T* ga0 = Ab + row_off(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+        const T* ga1 = Ab + row_off(min(m0 + srow + RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+        const T* ga2 = Ab + row_off(min(m0 + srow + 2 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+        const T* ga3 = Ab + row_off(min(m0 + srow + 3 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+        const T* gb0 = Bb + row_off(min(n0 + srow, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+        const T* gb1 = Bb + row_off(min(n0 + srow + RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+        const T* gb2 = Bb + row_off(min(n0 + srow + 2 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+        const T* gb3 = Bb + row_off(min(n0 + srow + 3 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
+        // RSTEP is a multiple of 8, so the swizzle term (row & 7) is the same for the 4 rows: one offset + constants
+        const int so = lds_off(srow, ch);
+        uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NT_GLOAD(k0)                                                                   \
+        do {                                                                               \
+            ra0 = *(const uint4*)(ga0 + (k0)); rb0 = *(const uint4*)(gb0 + (k0));          \
+            ra1 = *(const uint4*)(ga1 + (k0)); rb1 = *(const uint4*)(gb1 + (k0));          \
+            ra2 = *(const uint4*)(ga2 + (k0)); rb2 = *(const uint4*)(gb2 + (k0));          \
+            ra3 = *(const uint4*)(ga3 + (k0)); rb3 = *(const uint4*)(gb3 + (k0));          \
+        } while (0)
+#define NT_LSTORE(base)                                                                \
+        do {                                                                               \
+            unsigned char* da = (base) + so;                                               \
+            unsigned char* db = da + ATILE;                                                \
+            *(uint4*)(da) = ra0;                   *(uint4*)(db) = rb0;                    \
+            *(uint4*)(da + RSTEP * 128) = ra1;     *(uint4*)(db + RSTEP * 128) = rb1;      \
+            *(uint4*)(da + 2 * RSTEP * 128) = ra2; *(uint4*)(db + 2 * RSTEP * 128) = rb2;  \
+            *(uint4*)(da + 3 * RSTEP * 128) = ra3; *(uint4*)(db + 3 * RSTEP * 128) = rb3;  \
+        } while (0)
+
+        NT_GLOAD(0);
+        NT_LSTORE(lds);
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* cur = lds + (t & 1) * STAGE;
+            const bool more = t + 1 < nk;
+            if (more) NT_GLOAD((long long)(t + 1) * BK);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[TI], fb[TJ];
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fa[TI], fb[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = *(const uint4*)(cur + offA[kk][i]);
+                for (int i = 0; i < TI; ++i) fa[i] = *(const uint4*)(cur + offA[kk][i]);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = *(const uint4*)(cur + offB[kk][j]);
+                for (int j = 0; j < TJ; ++j) fb[j] = *(const uint4*)(cur + offB[kk][j]);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
+            }
+            if (more) NT_LSTORE(lds + ((t + 1) & 1) * STAGE);
+            __syncthreads();
+        }
+#undef NT_GLOAD
+#undef NT_LSTORE
+
+    } else {
+        static_assert(TJ == 4 && (TI == 4 || TI == 8), "fragment wait statements below are written for these tiles");
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // LDS-DMA staging: wave-instruction j = wave*4 + i fills tile rows 8j .. 8j+7 (1 KiB, lane-linear); lane -> row
+        // 8j + (lane>>3), LDS chunk lane&7, SOURCE chunk (lane&7) ^ (row&7) = (lane&7) ^ (lane>>3)  (swizzle on the source)
+        const int srow = lane >> 3, sch = (lane & 7) ^ (lane >> 3);
+        const int r0 = (wave_u * 4) * 8 + srow;
+        const T* ga0 = Ab + row_off(min(m0 + r0, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
+        const T* ga1 = Ab + row_off(min(m0 + r0 + 8, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
+        const T* ga2 = Ab + row_off(min(m0 + r0 + 16, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
+        const T* ga3 = Ab + row_off(min(m0 + r0 + 24, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
+        const T* gb0 = Bb + row_off(min(n0 + r0, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb1 = Bb + row_off(min(n0 + r0 + 8, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb2 = Bb + row_off(min(n0 + r0 + 16, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb3 = Bb + row_off(min(n0 + r0 + 24, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        typedef __attribute__((address_space(3))) unsigned char lds_byte;
+        lds_byte* const lds3 = (lds_byte*)lds;
+        const unsigned wdst = wave_u * 4096;                   // this wave's 4 KiB slice of an operand tile
+#define NT_DMA1(g, dst)                                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                         \
+                                     (__attribute__((address_space(3))) void*)(lds3 + (dst)), 16, 0, 0)
+#define NT_DMA_STAGE(buf, k0)                                                                                    \
+    do {                                                                                                         \
+        const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
+        NT_DMA1(ga0 + (k0), da);        NT_DMA1(ga1 + (k0), da + 1024);                                          \
+        NT_DMA1(ga2 + (k0), da + 2048); NT_DMA1(ga3 + (k0), da + 3072);                                          \
+        NT_DMA1(gb0 + (k0), db);        NT_DMA1(gb1 + (k0), db + 1024);                                          \
+        NT_DMA1(gb2 + (k0), db + 2048); NT_DMA1(gb3 + (k0), db + 3072);                                          \
+    } while (0)
+        const unsigned lds_u32 = (unsigned)(unsigned long long)(lds3);
+        // fragment addresses: rows i*16 apart differ by 2048 B with the same swizzle term -> one base per (operand, kk)
+        const unsigned aA0 = lds_u32 + offA[0][0], aA1 = lds_u32 + offA[1][0];
+        const unsigned aB0 = lds_u32 + offB[0][0], aB1 = lds_u32 + offB[1][0];
+
+        NT_DMA_STAGE(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const unsigned cur = (t & 1) * STAGE;
+            if (t + 1 < nk) NT_DMA_STAGE((t + 1) & 1, (long long)(t + 1) * BK);
+            u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+            // issue every fragment read of this stage, k-half 0 first
+            fb0[0] = lds_read16_asm<0>(aB0 + cur); fb0[1] = lds_read16_asm<2048>(aB0 + cur);
+            fb0[2] = lds_read16_asm<4096>(aB0 + cur); fb0[3] = lds_read16_asm<6144>(aB0 + cur);
+            fa0[0] = lds_read16_asm<0>(aA0 + cur); fa0[1] = lds_read16_asm<2048>(aA0 + cur);
+            fa0[2] = lds_read16_asm<4096>(aA0 + cur); fa0[3] = lds_read16_asm<6144>(aA0 + cur);
+            if constexpr (TI == 8) {
+                fa0[4] = lds_read16_asm<8192>(aA0 + cur); fa0[5] = lds_read16_asm<10240>(aA0 + cur);
+                fa0[6] = lds_read16_asm<12288>(aA0 + cur); fa0[7] = lds_read16_asm<14336>(aA0 + cur);
+            }
+            fb1[0] = lds_read16_asm<0>(aB1 + cur); fb1[1] = lds_read16_asm<2048>(aB1 + cur);
+            fb1[2] = lds_read16_asm<4096>(aB1 + cur); fb1[3] = lds_read16_asm<6144>(aB1 + cur);
+            fa1[0] = lds_read16_asm<0>(aA1 + cur); fa1[1] = lds_read16_asm<2048>(aA1 + cur);
+            fa1[2] = lds_read16_asm<4096>(aA1 + cur); fa1[3] = lds_read16_asm<6144>(aA1 + cur);
+            if constexpr (TI == 8) {
+                fa1[4] = lds_read16_asm<8192>(aA1 + cur); fa1[5] = lds_read16_asm<10240>(aA1 + cur);
+                fa1[6] = lds_read16_asm<12288>(aA1 + cur); fa1[7] = lds_read16_asm<14336>(aA1 + cur);
+            }
+            // k-half 0 has landed once at most the TI+TJ reads of k-half 1 are outstanding
+            if constexpr (TI == 8)
+                asm volatile("s_waitcnt lgkmcnt(12)"
+                             : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa0[4]), "+v"(fa0[5]), "+v"(fa0[6]),
+                               "+v"(fa0[7]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]),
+                               "+v"(fb0[3]));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], fb[j], fa[i]);
+                for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));
+            if constexpr (TI == 8)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fa1[4]), "+v"(fa1[5]), "+v"(fa1[6]),
+                               "+v"(fa1[7]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]),
+                               "+v"(fb1[3]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], as_uint4(fb1[j]), as_uint4(fa1[i]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        if (more) NT_LSTORE(lds + ((t + 1) & 1) * STAGE);
-        __syncthreads();
+#undef NT_DMA1
+#undef NT_DMA_STAGE
     }
-#undef NT_GLOAD
-#undef NT_LSTORE
+
 
     TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch;
     const T* Mb = (const T*)p.mask;
@@ -762,23 +872,30 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const long long blocks = fast ? nt_grid_blocks(numM, numN) : (long long)((numM + 7) / 8) * 8 * numN;
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
+    const bool dma = !(p.flags & GEMM_NO_DMA);       // LDS-DMA staging (default) vs register staging (A-B check)
+#define NT_LAUNCH(TT, TOO, WMM, WNN, TII, TJJ, NTH, ARG)                                                              \
+    do {                                                                                                             \
+        if (dma) hipLaunchKernelGGL((gemm_nt_fast_kernel<TT, TOO, WMM, WNN, TII, TJJ, true>), grid, dim3(NTH), 0, stream, ARG);  \
+        else hipLaunchKernelGGL((gemm_nt_fast_kernel<TT, TOO, WMM, WNN, TII, TJJ, false>), grid, dim3(NTH), 0, stream, ARG);     \
+    } while (0)
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
-            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
+            if (of32) NT_LAUNCH(bf16_t, float, 2, 4, 8, 4, 512, q);
+            else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {
-            if (of32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
+            if (of32) NT_LAUNCH(bf16_t, float, 2, 2, 4, 4, 256, q);
+            else NT_LAUNCH(bf16_t, bf16_t, 2, 2, 4, 4, 256, q);
         } else {
             if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
         }
     } else if (dtype == CPC_DTYPE_F32) {
-        if (fast) hipLaunchKernelGGL((gemm_nt_fast_kernel<float, float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, p);
+        if (fast) NT_LAUNCH(float, float, 2, 2, 4, 4, 256, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else {
         return CPC_EINVAL;
     }
+#undef NT_LAUNCH
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

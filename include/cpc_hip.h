@@ -28,6 +28,7 @@ extern "C" {
 #define CPC_GEMM_TN_NO_TR 4  /* TN/bf16 only: scalar LDS reads instead of ds_read_b64_tr_b16 (A/B check) */
 #define CPC_GEMM_FORCE_GENERIC 8 /* use the generic (any-shape) kernel even where the double-buffered fast path applies */
 #define CPC_GEMM_NARROW_EPI 32   /* NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A/B check) */
+#define CPC_GEMM_NO_DMA 64       /* NT fast path: register-staged global->LDS copies instead of LDS-DMA (A/B check) */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
 int cpc_abi_version(void);

@@ -73,7 +73,8 @@ def test_gemm_nt_tile_variants_agree(M, N, K):
     ref = torch.relu(rounded(A, torch.bfloat16) @ rounded(Bt, torch.bfloat16).T + bias.double())
     ref = torch.where(rounded(mask, torch.bfloat16) > 0, ref, torch.zeros_like(ref))
     outs = []
-    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC, _hip.GEMM_NARROW_EPI, _hip.GEMM_NARROW_EPI | _hip.GEMM_SMALL_TILE):
+    for extra in (0, _hip.GEMM_SMALL_TILE, _hip.GEMM_FORCE_GENERIC, _hip.GEMM_NARROW_EPI, _hip.GEMM_NARROW_EPI | _hip.GEMM_SMALL_TILE,
+                  _hip.GEMM_NO_DMA, _hip.GEMM_NO_DMA | _hip.GEMM_SMALL_TILE):
         out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, N, K, K, K, N, _hip.BF16, bias=_hip.ptr(db), mask=_hip.ptr(dM),
                      flags=_hip.GEMM_RELU | extra)
