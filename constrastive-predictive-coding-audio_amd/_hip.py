@@ -59,8 +59,9 @@ _SIGNATURES = {
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
+    "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    "cpc_gru_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_gru_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_set_streaming": ([_I], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),

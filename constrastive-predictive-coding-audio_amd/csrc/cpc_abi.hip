@@ -137,21 +137,26 @@ int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int 
     return launch_prep_frag(src, dst, R, Kd, ld, transpose, dtype, (hipStream_t)stream);
 }
 
-int cpc_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B, int V,
+long long cpc_gru_tape_elems(int B, int V, int H, int dtype) { return gru_tape_elems(B, V, H, dtype); }
+
+int cpc_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B, int V,
                 int H, int dtype, void* stream) {
-    if (!Gi || !Wfrag || !Hall || !gates || !c_out) return CPC_EINVAL;
-    return launch_gru_fwd(Gi, Wfrag, bhh, Hall, gates, c_out, B, V, H, dtype, (hipStream_t)stream);
+    if (!Gi || !Wfrag || !Hall || !tape || !c_out) return CPC_EINVAL;
+    return launch_gru_fwd(Gi, Wfrag, bhh, Hall, tape, c_out, B, V, H, dtype, (hipStream_t)stream);
 }
 
-int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B, int V,
-                int H, int dtype, void* stream) {
-    if (!dc || !Hall || !gates || !WTfrag || !dGi || !dGh) return CPC_EINVAL;
-    return launch_gru_bwd(dc, Hall, gates, WTfrag, dGi, dGh, B, V, H, dtype, (hipStream_t)stream);
+int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype, void* stream) {
+    if (!dc || !tape || !WTfrag || !dG) return CPC_EINVAL;
+    return launch_gru_bwd(dc, tape, WTfrag, dG, B, V, H, dtype, (hipStream_t)stream);
 }
 
 extern int g_gru_force_streaming;
+extern int g_gru_waves;
+extern int g_gru_debug;
 int cpc_gru_set_streaming(int on) {
     const int old = g_gru_force_streaming;
+    if (on == 8 || on == 16) { g_gru_waves = on; return old; }      // 8 / 16: waves per workgroup at H = 256 (tuning knob)
+    if (on >= 100 && on < 108) { g_gru_debug = on - 100; return old; } // 100 + bits: timing experiments (see gru.hip)
     g_gru_force_streaming = on ? 1 : 0;
     return old;
 }

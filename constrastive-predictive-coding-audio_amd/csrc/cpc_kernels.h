@@ -54,10 +54,11 @@ int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
 int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
                          hipStream_t stream);
-int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
+long long gru_tape_elems(int B, int V, int H, int dtype);
+int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B,
                    int V, int H, int dtype, hipStream_t stream);
-int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
-                   int V, int H, int dtype, hipStream_t stream);
+int launch_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
+                   hipStream_t stream);
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
 long long nce_workspace_floats(int B, int K);
 long long nce_all_workspace_floats(int B, int K);

@@ -19,9 +19,9 @@ __device__ __forceinline__ uint4 ldg16(const T* p) { return *(const uint4*)p; }
 
 // grid: ceil(B/16); block 256.
 template <typename T>
-__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ Gi, const T* __restrict__ Wfrag,
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const T* __restrict__ Gi, const T* __restrict__ Wfrag,
                                                       const float* __restrict__ bhh, T* __restrict__ Hall,
-                                                      T* __restrict__ gates, float* __restrict__ c_out, int B, int V,
+                                                      T* __restrict__ tape, float* __restrict__ c_out, int B, int V,
                                                       int H) {
     constexpr int CH = Elem<T>::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
             for (int g = 0; g < 3; ++g) {
                 gi[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (jt < ntile && b_ok)
-                    gi[q][g] = *(const f32x4*)(Gi + ((long long)b * V + t) * 3 * H + g * H + jt * 16 + fg * 4);
+                    gi[q][g] = load4(Gi + ((long long)b * V + t) * 3 * H + g * H + jt * 16 + fg * 4);
             }
         }
         f32x4 acc[GRU_MAXJT][3];
@@ -99,13 +99,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
             const int jt = wave + 4 * q;
             if (jt < ntile) {
                 const int j = jt * 16 + fg * 4;
-                f32x4 r4, u4, n4, q4, h4;
+                f32x4 r4, u4, n4, q4, h4, hp4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float r = fast_sigmoid(gi[q][0][e] + acc[q][0][e]);
                     const float u = fast_sigmoid(gi[q][1][e] + acc[q][1][e]);
                     const float qq = acc[q][2][e];
                     const float n = fast_tanh(gi[q][2][e] + r * qq);
+                    hp4[e] = hprev[q][e];
                     const float hn = (1.f - u) * n + u * hprev[q][e];
                     hprev[q][e] = hn;
                     r4[e] = r; u4[e] = u; n4[e] = n; q4[e] = qq; h4[e] = hn;
@@ -113,11 +114,12 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
                 store4((T*)(hnext + frow * rowb) + j, h4);
                 if (b_ok) {
                     store4(Hall + ((long long)b * (V + 1) + (t + 1)) * H + j, h4);
-                    T* gp = gates + (((long long)b * V + t) * 4) * H + j;
+                    T* gp = tape + (((long long)b * V + t) * 5) * H + j;      // streaming tape: [b][t][r,u,n,q,h_prev][H]
                     store4(gp, r4);
                     store4(gp + H, u4);
                     store4(gp + 2 * H, n4);
                     store4(gp + 3 * H, q4);
+                    store4(gp + 4 * H, hp4);
                     if (t == V - 1) *(f32x4*)(c_out + (long long)b * H + j) = h4;
                 }
             }
@@ -128,9 +130,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 
 // grid: ceil(B/16); block 256.  WTfrag: fragment-ordered W_hh^T ([H][3H] logical: rows = hidden unit, k = gate column).
 template <typename T>
-__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dc, const T* __restrict__ Hall,
-                                                      const T* __restrict__ gates, const T* __restrict__ WTfrag,
-                                                      T* __restrict__ dGi, T* __restrict__ dGh, int B, int V, int H) {
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dc, const T* __restrict__ tape,
+                                                      const T* __restrict__ WTfrag, T* __restrict__ dG, int B, int V, int H) {
     constexpr int CH = Elem<T>::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rowb = 3 * H * (int)sizeof(T) + 16;
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
                 const int j = jt * 16 + fg * 4;
                 f32x4 hp = (f32x4){0.f, 0.f, 0.f, 0.f}, r4 = hp, u4 = hp, n4 = hp, q4 = hp;
                 if (b_ok) {
-                    hp = load4(Hall + ((long long)b * (V + 1) + t) * H + j);
-                    const T* gp = gates + (((long long)b * V + t) * 4) * H + j;
+                    const T* gp = tape + (((long long)b * V + t) * 5) * H + j;
                     r4 = load4(gp); u4 = load4(gp + H); n4 = load4(gp + 2 * H); q4 = load4(gp + 3 * H);
+                    hp = load4(gp + 4 * H);
                 }
                 f32x4 dr4, du4, dn4, dnr4;
 #pragma unroll
@@ -187,10 +188,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
                 store4(grow + H + j, du4);
                 store4(grow + 2 * H + j, dnr4);
                 if (b_ok) {
-                    T* gi = dGi + ((long long)b * V + t) * 3 * H + j;
-                    T* gh = dGh + ((long long)b * V + t) * 3 * H + j;
-                    store4(gi, dr4); store4(gi + H, du4); store4(gi + 2 * H, dn4);
-                    store4(gh, dr4); store4(gh + H, du4); store4(gh + 2 * H, dnr4);
+                    T* go = dG + ((long long)b * V + t) * 4 * H + j;          // [dr | du | dn | dn*r]
+                    store4(go, dr4); store4(go + H, du4); store4(go + 2 * H, dn4); store4(go + 3 * H, dnr4);
                 }
             }
         }
@@ -220,24 +219,61 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------- weight-resident bf16
-// bf16 path for H = 32*KC in {32, 64, 128, 256}: W_hh never leaves the CU during the sequence.  8 waves per workgroup
-// (two per SIMD, so one wave's LDS / MFMA latency hides under the other's); the r and u gate fragments of a wave's
-// hidden tiles live in its registers (H = 256: 128 VGPRs per lane), the n gate fragments in LDS (128 KiB), so a step
-// costs 48 MFMAs + gate math per wave instead of a 393 KB L2 read per workgroup.
-template <int NJT, int KC>
-__global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
-                                                             const float* __restrict__ bhh, bf16_t* __restrict__ Hall,
-                                                             bf16_t* __restrict__ gates, float* __restrict__ c_out, int B,
-                                                             int V) {
-    constexpr int H = 32 * KC, NT = H / 16;
-    constexpr int ROWB = H * 2 + 16;
-    constexpr int WN_BYTES = 8 * NJT * KC * 1024;
-    constexpr bool FULL = (NT == 8 * NJT);               // every (wave, q) pair maps to a real tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WN_BYTES + 2 * 16 * ROWB + 3 * H * 4];
+// bf16 path for H = 32*KC in {32, 64, 128, 256}: W_hh never leaves the CU during the sequence and every global access
+// of the recurrence is a full-row / 16-byte-per-lane coalesced one (a step is latency-bound on B/16 workgroups; the
+// first version of these kernels spent 80 % of a step in 8-byte scattered loads and stores).
+//   * 8 waves per workgroup; wave w owns the hidden tiles w, w+8: their r/u-gate MFMA fragments live in registers
+//     (H = 256: 136 VGPRs per lane), the n-gate fragments in LDS (112 KiB).
+//   * forward: the input-projection rows of the NEXT step are loaded row-contiguous into registers at the top of a
+//     step and parked in an LDS tile once this step's gate math has read the current one; h_{t+1} goes to HBM from
+//     the LDS tile that also feeds the next step's MFMAs; the saved activations go to a "tape" in lane-fragment
+//     order (1 KiB per wave-instruction), which the backward kernel reads back with the same lane mapping.
+//   * backward: gate gradients are assembled in an LDS tile [16][dr | du | dn | dn*r]; that tile is both the MFMA
+//     operand of dh_{t-1} = dh*u + dgh W_hh and the source of the coalesced row stores of dG[b][t][0:4H).
+constexpr int GRU_NW = 8;
+template <int KC> struct GruCfg {
+    static constexpr int H = 32 * KC, NT = H / 16;
+    static constexpr int NJT = (NT + GRU_NW - 1) / GRU_NW;
+    static constexpr bool FULL = (NT == GRU_NW * NJT);
+    static constexpr int KCL = KC == 8 ? 7 : KC;          // k-chunks of the LDS-resident weight part (n gate)
+    static constexpr int SLOTS = 2 * NJT + 1;             // tape: (r,u), (n,q) per tile + one slot of h_prev
+};
+__host__ __device__ __forceinline__ long long gru_tape_elems_res(int B, int V, int KC) {
+    const int njt = ((32 * KC / 16) + GRU_NW - 1) / GRU_NW;
+    return (long long)((B + 15) / 16) * V * GRU_NW * (2 * njt + 1) * 64 * 8;
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)a[e]; o[4 + e] = (bf16_t)b[e]; }
+    return __builtin_bit_cast(uint4, o);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, f32x4& a, f32x4& b) {
+    const bf16x8 i = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = (float)i[e]; b[e] = (float)i[4 + e]; }
+}
+
+template <int KC>
+__global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
+                                                                  const float* __restrict__ bhh, bf16_t* __restrict__ Hall,
+                                                                  bf16_t* __restrict__ tape, float* __restrict__ c_out, int B,
+                                                                  int V) {
+    typedef GruCfg<KC> Cfg;
+    constexpr int H = Cfg::H, NT = Cfg::NT, NJT = Cfg::NJT, KCL = Cfg::KCL, KCRN = KC - KCL, NW = GRU_NW, NTHR = 64 * NW;
+    constexpr bool FULL = Cfg::FULL;
+    constexpr int ROWB = H * 2 + 16;                      // h tile row stride
+    constexpr int GROW = 3 * H * 2 + 16;                  // input-projection tile row stride
+    constexpr int WN_BYTES = NW * NJT * KCL * 1024;
+    constexpr int GCHUNKS = 16 * 3 * H / 8;               // 16-byte chunks of one input-projection tile
+    constexpr int GPT = (GCHUNKS + NTHR - 1) / NTHR;      // chunks per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WN_BYTES + 2 * 16 * ROWB + 16 * GROW + 3 * H * 4];
     unsigned char* wn = smem;
     unsigned char* hbuf0 = smem + WN_BYTES;
     unsigned char* hbuf1 = hbuf0 + 16 * ROWB;
-    float* bsh = (float*)(hbuf1 + 16 * ROWB);
+    unsigned char* gtile = hbuf1 + 16 * ROWB;
+    float* bsh = (float*)(gtile + 16 * GROW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fg = lane >> 4;
@@ -246,9 +282,10 @@ __global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restric
     const bool b_ok = b < B;
 
     uint4 wr[NJT][2][KC];
+    uint4 wrn[NJT][KCRN > 0 ? KCRN : 1];
 #pragma unroll
     for (int q = 0; q < NJT; ++q) {
-        const int jt = wave + 8 * q;
+        const int jt = wave + NW * q;
         const bool on = FULL || jt < NT;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -256,14 +293,27 @@ __global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restric
             for (int g = 0; g < 2; ++g)
                 wr[q][g][kc] = on ? ldg16(Wfrag + ((long long)((g * NT + jt) * KC + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
             const uint4 w2 = on ? ldg16(Wfrag + ((long long)((2 * NT + jt) * KC + kc) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
-            *(uint4*)(wn + (((wave * NJT + q) * KC + kc) * 64 + lane) * 16) = w2;
+            if (kc < KCL) *(uint4*)(wn + (((wave * NJT + q) * KCL + kc) * 64 + lane) * 16) = w2;
+            else wrn[q][kc - KCL < (KCRN > 0 ? KCRN : 1) ? kc - KCL : 0] = w2;
         }
     }
-    for (int i = tid; i < 3 * H; i += 512) bsh[i] = bhh ? bhh[i] : 0.f;
-    for (int i = tid; i < 16 * ROWB / 4; i += 512) ((unsigned int*)hbuf0)[i] = 0u;
-    for (int i = tid; i < 16 * H; i += 512) {
-        const int rb = i / H, j = i % H;
-        if (b0 + rb < B) Hall[((long long)(b0 + rb) * (V + 1)) * H + j] = (bf16_t)0.f;
+    for (int i = tid; i < 3 * H; i += NTHR) bsh[i] = bhh ? bhh[i] : 0.f;
+    for (int i = tid; i < 16 * ROWB / 4; i += NTHR) ((unsigned int*)hbuf0)[i] = 0u;
+    // Hall[:, 0, :] = 0 and the input-projection tile of step 0 (row-contiguous 16-byte chunks)
+    for (int i = tid; i < 16 * H / 8; i += NTHR) {
+        const int rb = i / (H / 8), cc = i % (H / 8);
+        if (b0 + rb < B) *(uint4*)(Hall + ((long long)(b0 + rb) * (V + 1)) * H + cc * 8) = make_uint4(0, 0, 0, 0);
+    }
+    uint4 gpre[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        const int i = tid + u * NTHR;
+        gpre[u] = make_uint4(0, 0, 0, 0);
+        if (i < GCHUNKS) {
+            const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
+            if (b0 + rb < B) gpre[u] = *(const uint4*)(Gi + ((long long)(b0 + rb) * V) * 3 * H + cc * 8);
+            *(uint4*)(gtile + rb * GROW + cc * 16) = gpre[u];
+        }
     }
     __syncthreads();
 
@@ -272,26 +322,30 @@ __global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restric
     for (int q = 0; q < NJT; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) hprev[q][e] = 0.f;
+    const long long tape_bt = (long long)blockIdx.x * V;
 
     for (int t = 0; t < V; ++t) {
         const unsigned char* hcur = (t & 1) ? hbuf1 : hbuf0;
         unsigned char* hnext = (t & 1) ? hbuf0 : hbuf1;
-        // input-projection terms of this step: issued first, consumed after the MFMA loop (the SIMD's other wave and
-        // the MFMAs cover their latency)
-        f32x4 gi[NJT][3];
+        // next step's input-projection rows: issued now, parked in LDS after this step's gate math
+        if (t + 1 < V) {
+#pragma unroll
+            for (int u = 0; u < GPT; ++u) {
+                const int i = tid + u * NTHR;
+                if (i < GCHUNKS) {
+                    const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
+                    if (b0 + rb < B) gpre[u] = *(const uint4*)(Gi + ((long long)(b0 + rb) * V + t + 1) * 3 * H + cc * 8);
+                }
+            }
+        }
         f32x4 acc[NJT][3];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 8 * q;
-            const bool on = FULL || jt < NT;
+            const int jt = wave + NW * q;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                gi[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (on) {
-                    if (b_ok) gi[q][g] = *(const f32x4*)(Gi + ((long long)b * V + t) * 3 * H + g * H + jt * 16 + fg * 4);
-                    acc[q][g] = *(const f32x4*)(bsh + g * H + jt * 16 + fg * 4);
-                }
+                if (FULL || jt < NT) acc[q][g] = *(const f32x4*)(bsh + g * H + jt * 16 + fg * 4);
             }
         }
 #pragma unroll
@@ -299,54 +353,78 @@ __global__ __launch_bounds__(512) void gru_fwd_res_kernel(const float* __restric
             const uint4 hf = *(const uint4*)(hcur + frow * ROWB + (kc * 4 + fg) * 16);
 #pragma unroll
             for (int q = 0; q < NJT; ++q) {
-                const uint4 w2 = *(const uint4*)(wn + (((wave * NJT + q) * KC + kc) * 64 + lane) * 16);
+                uint4 w2;
+                if (kc < KCL) w2 = *(const uint4*)(wn + (((wave * NJT + q) * KCL + kc) * 64 + lane) * 16);
+                else w2 = wrn[q][kc - KCL < (KCRN > 0 ? KCRN : 1) ? kc - KCL : 0];
                 mfma_chunk<bf16_t>(acc[q][0], wr[q][0][kc], hf);
                 mfma_chunk<bf16_t>(acc[q][1], wr[q][1][kc], hf);
                 mfma_chunk<bf16_t>(acc[q][2], w2, hf);
             }
         }
+        f32x4 hp_keep[NJT];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 8 * q;
+            const int jt = wave + NW * q;
+            hp_keep[q] = (f32x4){hprev[q][0], hprev[q][1], hprev[q][2], hprev[q][3]};
             if (FULL || jt < NT) {
                 const int j = jt * 16 + fg * 4;
+                const bf16_t* grow = (const bf16_t*)(gtile + frow * GROW);
+                const f32x4 gr = load4(grow + j), gu = load4(grow + H + j), gn = load4(grow + 2 * H + j);
                 f32x4 r4, u4, n4, q4, h4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float r = fast_sigmoid(gi[q][0][e] + acc[q][0][e]);
-                    const float u = fast_sigmoid(gi[q][1][e] + acc[q][1][e]);
+                    const float r = fast_sigmoid(gr[e] + acc[q][0][e]);
+                    const float u = fast_sigmoid(gu[e] + acc[q][1][e]);
                     const float qq = acc[q][2][e];
-                    const float n = fast_tanh(gi[q][2][e] + r * qq);
+                    const float n = fast_tanh(gn[e] + r * qq);
                     const float hn = (1.f - u) * n + u * hprev[q][e];
                     hprev[q][e] = hn;
                     r4[e] = r; u4[e] = u; n4[e] = n; q4[e] = qq; h4[e] = hn;
                 }
                 store4((bf16_t*)(hnext + frow * ROWB) + j, h4);
-                if (b_ok) {
-                    store4(Hall + ((long long)b * (V + 1) + (t + 1)) * H + j, h4);
-                    bf16_t* gp = gates + (((long long)b * V + t) * 4) * H + j;
-                    store4(gp, r4);
-                    store4(gp + H, u4);
-                    store4(gp + 2 * H, n4);
-                    store4(gp + 3 * H, q4);
-                    if (t == V - 1) *(f32x4*)(c_out + (long long)b * H + j) = h4;
+                bf16_t* tp = tape + (((tape_bt + t) * NW + wave) * Cfg::SLOTS + 2 * q) * 64 * 8 + lane * 8;
+                *(uint4*)tp = pack8(r4, u4);
+                *(uint4*)(tp + 64 * 8) = pack8(n4, q4);
+                if (b_ok && t == V - 1) *(f32x4*)(c_out + (long long)b * H + j) = h4;
+            }
+        }
+        {
+            bf16_t* tp = tape + (((tape_bt + t) * NW + wave) * Cfg::SLOTS + 2 * NJT) * 64 * 8 + lane * 8;
+            *(uint4*)tp = pack8(hp_keep[0], hp_keep[NJT > 1 ? 1 : 0]);
+        }
+        __syncthreads();            // h_{t+1} tile complete; every wave is done with the input-projection tile of step t
+        {
+            // h_{t+1}: LDS tile -> HBM as whole rows (16 rows x H bf16)
+            for (int i = tid; i < 16 * H / 8; i += NTHR) {
+                const int rb = i / (H / 8), cc = i % (H / 8);
+                if (b0 + rb < B)
+                    *(uint4*)(Hall + ((long long)(b0 + rb) * (V + 1) + t + 1) * H + cc * 8) = *(const uint4*)(hnext + rb * ROWB + cc * 16);
+            }
+            if (t + 1 < V) {
+#pragma unroll
+                for (int u = 0; u < GPT; ++u) {
+                    const int i = tid + u * NTHR;
+                    if (i < GCHUNKS) {
+                        const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
+                        *(uint4*)(gtile + rb * GROW + cc * 16) = gpre[u];
+                    }
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();            // input-projection tile of step t+1 visible
     }
 }
 
-// Backward twin: W_hh^T fragments for the r,u gate columns (k < 2H) in registers, the n gate columns in LDS.
-template <int NJT, int KC>
-__global__ __launch_bounds__(512) void gru_bwd_res_kernel(const float* __restrict__ dc, const bf16_t* __restrict__ Hall,
-                                                             const bf16_t* __restrict__ gates, const bf16_t* __restrict__ WTfrag,
-                                                             bf16_t* __restrict__ dGi, bf16_t* __restrict__ dGh, int B, int V) {
-    constexpr int H = 32 * KC, NT = H / 16;
-    constexpr int KC3 = 3 * KC, KCR = 2 * KC, KCL = KC;
-    constexpr int ROWB = 3 * H * 2 + 16;
-    constexpr int WL_BYTES = 8 * NJT * KCL * 1024;
-    constexpr bool FULL = (NT == 8 * NJT);
+template <int KC>
+__global__ __launch_bounds__(64 * GRU_NW) void gru_bwd_res_kernel(const float* __restrict__ dc, const bf16_t* __restrict__ tape,
+                                                                  const bf16_t* __restrict__ WTfrag, bf16_t* __restrict__ dG,
+                                                                  int B, int V, int dbg) {
+    typedef GruCfg<KC> Cfg;
+    constexpr int H = Cfg::H, NT = Cfg::NT, NJT = Cfg::NJT, NW = GRU_NW, NTHR = 64 * NW;
+    constexpr bool FULL = Cfg::FULL;
+    constexpr int KC3 = 3 * KC, KCL = Cfg::KCL, KCR = KC3 - KCL;
+    constexpr int ROWB = 4 * H * 2 + 16;                   // [dr | du | dn | dn*r]
+    constexpr int WL_BYTES = NW * NJT * KCL * 1024;
     __shared__ __attribute__((aligned(16))) unsigned char smem[WL_BYTES + 16 * ROWB];
     unsigned char* wl = smem;
     unsigned char* gcur = smem + WL_BYTES;
@@ -361,7 +439,7 @@ __global__ __launch_bounds__(512) void gru_bwd_res_kernel(const float* __restric
     float dh[NJT][4];
 #pragma unroll
     for (int q = 0; q < NJT; ++q) {
-        const int jt = wave + 8 * q;
+        const int jt = wave + NW * q;
         const bool on = FULL || jt < NT;
 #pragma unroll
         for (int kc = 0; kc < KCR; ++kc)
@@ -379,46 +457,34 @@ __global__ __launch_bounds__(512) void gru_bwd_res_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) dh[q][e] = v[e];
         }
     }
+    const long long tape_bt = (long long)blockIdx.x * V;
+    // tape of step t: slots (r,u) and (n,q) per tile + h_prev; prefetched one step ahead
+    uint4 sv[Cfg::SLOTS], svn[Cfg::SLOTS];
+    {
+        const bf16_t* tp = tape + ((tape_bt + (V - 1)) * NW + wave) * Cfg::SLOTS * 64 * 8 + lane * 8;
+#pragma unroll
+        for (int k = 0; k < Cfg::SLOTS; ++k) { sv[k] = *(const uint4*)(tp + k * 64 * 8); svn[k] = sv[k]; }
+    }
     __syncthreads();
 
-    // saved activations of step t-1 are prefetched while step t runs (bf16x4 = 8 bytes each)
-    bf16x4 sv[NJT][5], svn[NJT][5];
-#pragma unroll
-    for (int q = 0; q < NJT; ++q) {
-        const int jt = wave + 8 * q;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            sv[q][k] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-            svn[q][k] = sv[q][k];
-        }
-        if ((FULL || jt < NT) && b_ok) {
-            const int j = jt * 16 + fg * 4;
-            sv[q][0] = *(const bf16x4*)(Hall + ((long long)b * (V + 1) + (V - 1)) * H + j);
-            const bf16_t* gp = gates + (((long long)b * V + (V - 1)) * 4) * H + j;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sv[q][1 + k] = *(const bf16x4*)(gp + k * H);
-        }
-    }
-
     for (int t = V - 1; t >= 0; --t) {
+        if (t > 0 && !(dbg & 2)) {
+            const bf16_t* tp = tape + ((tape_bt + (t - 1)) * NW + wave) * Cfg::SLOTS * 64 * 8 + lane * 8;
+#pragma unroll
+            for (int k = 0; k < Cfg::SLOTS; ++k) svn[k] = *(const uint4*)(tp + k * 64 * 8);
+        }
         float keep[NJT][4];
+        f32x4 hp_all[2];
+        unpack8(sv[2 * NJT], hp_all[0], hp_all[1]);
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
-            const int jt = wave + 8 * q;
+            const int jt = wave + NW * q;
             if (FULL || jt < NT) {
                 const int j = jt * 16 + fg * 4;
-                if (b_ok && t > 0) {
-                    svn[q][0] = *(const bf16x4*)(Hall + ((long long)b * (V + 1) + (t - 1)) * H + j);
-                    const bf16_t* gpn = gates + (((long long)b * V + (t - 1)) * 4) * H + j;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) svn[q][1 + k] = *(const bf16x4*)(gpn + k * H);
-                }
-                f32x4 hp, r4, u4, n4, q4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hp[e] = (float)sv[q][0][e]; r4[e] = (float)sv[q][1][e]; u4[e] = (float)sv[q][2][e];
-                    n4[e] = (float)sv[q][3][e]; q4[e] = (float)sv[q][4][e];
-                }
+                f32x4 r4, u4, n4, q4;
+                unpack8(sv[2 * q], r4, u4);
+                unpack8(sv[2 * q + 1], n4, q4);
+                const f32x4 hp = hp_all[q & 1];
                 f32x4 dr4, du4, dn4, dnr4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -434,41 +500,43 @@ __global__ __launch_bounds__(512) void gru_bwd_res_kernel(const float* __restric
                 bf16_t* grow = (bf16_t*)(gcur + frow * ROWB);
                 store4(grow + j, dr4);
                 store4(grow + H + j, du4);
-                store4(grow + 2 * H + j, dnr4);
-                if (b_ok) {
-                    bf16_t* gi = dGi + ((long long)b * V + t) * 3 * H + j;
-                    bf16_t* gh = dGh + ((long long)b * V + t) * 3 * H + j;
-                    store4(gi, dr4); store4(gi + H, du4); store4(gi + 2 * H, dn4);
-                    store4(gh, dr4); store4(gh + H, du4); store4(gh + 2 * H, dnr4);
-                }
+                store4(grow + 2 * H + j, dn4);
+                store4(grow + 3 * H + j, dnr4);
             }
         }
         __syncthreads();
+        // the gradient tile goes to HBM as whole rows (16 rows x 4H bf16) while the MFMAs below read it
+        if (!(dbg & 1)) {
+            for (int i = tid; i < 16 * 4 * H / 8; i += NTHR) {
+                const int rb = i / (4 * H / 8), cc = i % (4 * H / 8);
+                if (b0 + rb < B)
+                    *(uint4*)(dG + ((long long)(b0 + rb) * V + t) * 4 * H + cc * 8) = *(const uint4*)(gcur + rb * ROWB + cc * 16);
+            }
+        }
         f32x4 acc[NJT];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 4)) {
 #pragma unroll
-        for (int kc = 0; kc < KCR; ++kc) {
-            const uint4 gf = *(const uint4*)(gcur + frow * ROWB + (kc * 4 + fg) * 16);
+            for (int kc = 0; kc < KC3; ++kc) {
+                // k-chunk kc of dgh = (dr, du, dn*r): columns [0, 2H) of the tile, then [3H, 4H)
+                const int chunk = (kc < 2 * KC ? kc * 4 : (3 * H / 8) + (kc - 2 * KC) * 4) + fg;
+                const uint4 gf = *(const uint4*)(gcur + frow * ROWB + chunk * 16);
 #pragma unroll
-            for (int q = 0; q < NJT; ++q) mfma_chunk<bf16_t>(acc[q], wr[q][kc], gf);
-        }
-#pragma unroll
-        for (int kc = 0; kc < KCL; ++kc) {
-            const uint4 gf = *(const uint4*)(gcur + frow * ROWB + ((KCR + kc) * 4 + fg) * 16);
-#pragma unroll
-            for (int q = 0; q < NJT; ++q) {
-                const uint4 w2 = *(const uint4*)(wl + (((wave * NJT + q) * KCL + kc) * 64 + lane) * 16);
-                mfma_chunk<bf16_t>(acc[q], w2, gf);
+                for (int q = 0; q < NJT; ++q) {
+                    uint4 w;
+                    if (kc < KCR) w = wr[q][kc < KCR ? kc : 0];
+                    else w = *(const uint4*)(wl + (((wave * NJT + q) * KCL + (kc - KCR)) * 64 + lane) * 16);
+                    mfma_chunk<bf16_t>(acc[q], w, gf);
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < NJT; ++q) {
+        for (int q = 0; q < NJT; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dh[q][e] = keep[q][e] + acc[q][e];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) sv[q][k] = svn[q][k];
-        }
+        for (int k = 0; k < Cfg::SLOTS; ++k) sv[k] = svn[k];
         __syncthreads();
     }
 }
@@ -498,6 +566,8 @@ __global__ __launch_bounds__(256) void prep_frag_kernel(const float* __restrict_
 
 // Debug / A-B switch: 1 = always use the weight-streaming kernels (set through cpc_gru_set_streaming).
 int g_gru_force_streaming = 0;
+int g_gru_debug = 0;             // timing experiments only (bit0: no gradient stores, bit1: no prefetch, bit2: no MFMA phase)
+int g_gru_waves = 8;   // (unused since the tape layout fixes 8 waves)            // waves per workgroup of the weight-resident kernels at H = 256 (8 or 16)
 
 static bool gru_ok(int B, int V, int H, int dtype) {
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
@@ -506,53 +576,59 @@ static bool gru_ok(int B, int V, int H, int dtype) {
     return dtype == CPC_DTYPE_BF16 || dtype == CPC_DTYPE_F32;
 }
 
-int launch_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
+long long gru_tape_elems(int B, int V, int H, int dtype) {
+    if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256))
+        return gru_tape_elems_res(B, V, H / 32);
+    return (long long)B * V * 5 * H;
+}
+
+int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B,
                    int V, int H, int dtype, hipStream_t stream) {
     if (!gru_ok(B, V, H, dtype)) return CPC_EINVAL;
     const int esz = dtype == CPC_DTYPE_BF16 ? 2 : 4;
     const size_t shm = 2 * 16 * (size_t)(H * esz + 16) + 3 * H * sizeof(float);
     dim3 grid((B + 15) / 16);
     if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
-#define GRU_F(NJT, KC) \
-    hipLaunchKernelGGL((gru_fwd_res_kernel<NJT, KC>), grid, dim3(512), 0, stream, Gi, (const bf16_t*)Wfrag, bhh, (bf16_t*)Hall, \
-                       (bf16_t*)gates, c_out, B, V)
-        if (H == 256) GRU_F(2, 8); else if (H == 128) GRU_F(1, 4); else if (H == 64) GRU_F(1, 2); else GRU_F(1, 1);
+#define GRU_F(KC) \
+    hipLaunchKernelGGL((gru_fwd_res_kernel<KC>), grid, dim3(64 * GRU_NW), 0, stream, (const bf16_t*)Gi, (const bf16_t*)Wfrag, bhh, \
+                       (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V)
+        if (H == 256) GRU_F(8); else if (H == 128) GRU_F(4); else if (H == 64) GRU_F(2); else GRU_F(1);
 #undef GRU_F
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
     if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((gru_fwd_kernel<bf16_t>), grid, dim3(256), shm, stream, Gi, (const bf16_t*)Wfrag, bhh,
-                           (bf16_t*)Hall, (bf16_t*)gates, c_out, B, V, H);
+        hipLaunchKernelGGL((gru_fwd_kernel<bf16_t>), grid, dim3(256), shm, stream, (const bf16_t*)Gi, (const bf16_t*)Wfrag, bhh,
+                           (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V, H);
     else
-        hipLaunchKernelGGL((gru_fwd_kernel<float>), grid, dim3(256), shm, stream, Gi, (const float*)Wfrag, bhh,
-                           (float*)Hall, (float*)gates, c_out, B, V, H);
+        hipLaunchKernelGGL((gru_fwd_kernel<float>), grid, dim3(256), shm, stream, (const float*)Gi, (const float*)Wfrag, bhh,
+                           (float*)Hall, (float*)tape, c_out, B, V, H);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
-int launch_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
-                   int V, int H, int dtype, hipStream_t stream) {
+int launch_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
+                   hipStream_t stream) {
     if (!gru_ok(B, V, H, dtype)) return CPC_EINVAL;
     const int esz = dtype == CPC_DTYPE_BF16 ? 2 : 4;
     const size_t shm = 16 * (size_t)(3 * H * esz + 16);
     if (shm > 64 * 1024) return CPC_EINVAL;
     dim3 grid((B + 15) / 16);
     if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
-#define GRU_B(NJT, KC) \
-    hipLaunchKernelGGL((gru_bwd_res_kernel<NJT, KC>), grid, dim3(512), 0, stream, dc, (const bf16_t*)Hall, (const bf16_t*)gates, \
-                       (const bf16_t*)WTfrag, (bf16_t*)dGi, (bf16_t*)dGh, B, V)
-        if (H == 256) GRU_B(2, 8); else if (H == 128) GRU_B(1, 4); else if (H == 64) GRU_B(1, 2); else GRU_B(1, 1);
+#define GRU_B(KC) \
+    hipLaunchKernelGGL((gru_bwd_res_kernel<KC>), grid, dim3(64 * GRU_NW), 0, stream, dc, (const bf16_t*)tape, (const bf16_t*)WTfrag, \
+                       (bf16_t*)dG, B, V, g_gru_debug)
+        if (H == 256) GRU_B(8); else if (H == 128) GRU_B(4); else if (H == 64) GRU_B(2); else GRU_B(1);
 #undef GRU_B
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
     if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((gru_bwd_kernel<bf16_t>), grid, dim3(256), shm, stream, dc, (const bf16_t*)Hall,
-                           (const bf16_t*)gates, (const bf16_t*)WTfrag, (bf16_t*)dGi, (bf16_t*)dGh, B, V, H);
+        hipLaunchKernelGGL((gru_bwd_kernel<bf16_t>), grid, dim3(256), shm, stream, dc, (const bf16_t*)tape, (const bf16_t*)WTfrag,
+                           (bf16_t*)dG, B, V, H);
     else
-        hipLaunchKernelGGL((gru_bwd_kernel<float>), grid, dim3(256), shm, stream, dc, (const float*)Hall,
-                           (const float*)gates, (const float*)WTfrag, (float*)dGi, (float*)dGh, B, V, H);
+        hipLaunchKernelGGL((gru_bwd_kernel<float>), grid, dim3(256), shm, stream, dc, (const float*)tape, (const float*)WTfrag,
+                           (float*)dG, B, V, H);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -136,9 +136,9 @@ class CPCEngine:
         self.w_p = torch.empty(K * E * H, device=dev, dtype=dt)           # [K*E][H]
         self.w_p_t = torch.empty(H * K * E, device=dev, dtype=dt)         # [H][K*E]
         # GRU / predictor / loss state
-        self.Gi = torch.empty(B * V * 3 * H, device=dev, dtype=f32)
+        self.Gi = torch.empty(B * V * 3 * H, device=dev, dtype=dt)
         self.Hall = torch.empty(B * (V + 1) * H, device=dev, dtype=dt)
-        self.gates = torch.empty(B * V * 4 * H, device=dev, dtype=dt)
+        self.tape = torch.zeros(max(1, int(_hip.lib().cpc_gru_tape_elems(B, max(V, 1), H, self.code))), device=dev, dtype=dt)
         self.c = torch.empty(B, H, device=dev, dtype=f32)
         self.pred = torch.empty(B * K * E, device=dev, dtype=dt)
         self.ldS = _ceil_div(B, 8) * 8
@@ -149,8 +149,7 @@ class CPCEngine:
         self.nce_ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(B, K)), device=dev, dtype=f32)
         self.dpred = torch.zeros(B * K * E, device=dev, dtype=dt)
         self.dc = torch.zeros(B, H, device=dev, dtype=f32)
-        self.dGi = torch.empty(B * V * 3 * H, device=dev, dtype=dt)
-        self.dGh = torch.empty(B * V * 3 * H, device=dev, dtype=dt)
+        self.dG = torch.empty(B * V * 4 * H, device=dev, dtype=dt)       # [dr | du | dn | dn*r] per (item, step)
         # split-reduction workspace (f32 slabs), sized for the largest user
         need = [1]
         self.nsplit = [1] * n
@@ -162,7 +161,7 @@ class CPCEngine:
         self.c1_item_blocks = min(B, 128)
         need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
         self.colsum_blocks = 1024
-        need.append(self.colsum_blocks * max(max(self.channels), 3 * H))
+        need.append(self.colsum_blocks * max(max(self.channels), 4 * H))
         self.split_ih = self._pick_split(3 * H, E, B * V)
         self.split_hh = self._pick_split(3 * H, H, B * V)
         need.append(self.split_ih * 3 * H * E)
@@ -228,10 +227,9 @@ class CPCEngine:
         t0 = self.T - K - V
         top = self.act[-1]
         _hip.gemm_nt(_hip.ptr(top, t0 * E), _hip.ptr(self.w_ih), _hip.ptr(self.Gi), B * V, 3 * H, E, E, E, 3 * H, code,
-                     bias=_hip.ptr(p.get("autoregressive_model.gruCell.bias_ih")), a_rpi=V, a_item=Ltop * E,
-                     flags=_hip.GEMM_OUT_F32)
+                     bias=_hip.ptr(p.get("autoregressive_model.gruCell.bias_ih")), a_rpi=V, a_item=Ltop * E)
         _hip.call("cpc_gru_fwd", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get("autoregressive_model.gruCell.bias_hh")),
-                  _hip.ptr(self.Hall), _hip.ptr(self.gates), _hip.ptr(self.c), B, V, H, code)
+                  _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(self.c), B, V, H, code)
         _hip.gemm_nt(_hip.ptr(self.Hall, V * H), _hip.ptr(self.w_p), _hip.ptr(self.pred), B, K * E, H, H, H, K * E, code,
                      a_rpi=1, a_item=(V + 1) * H)
 
@@ -302,16 +300,13 @@ class CPCEngine:
         _hip.gemm_tn(_hip.ptr(self.dS_all), _hip.ptr(self.pred), _hip.ptr(dtop, tg), R, R, E, ld, E, E, code, c_rpi=K, c_item=Ltop * E)
 
     # ------------------------------------------------------------------------------------------ backward
-    def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, perm=(1, None, None, None), **kw):
-        """grad[perm(i,j)] = sum_m A[m][i] B[m][j] via f32 slabs + deterministic reduction."""
+    def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, grad_offset=0, **kw):
+        """grad[grad_offset + i*J + j] = sum_m A[m][i] B[m][j] via f32 slabs + deterministic reduction."""
         code = self.code
         chunk = self._chunk(M, nsplit)
         _hip.gemm_tn(A, B_, _hip.ptr(self.slabs), M, I, J, lda, ldb, J, code, nsplit=nsplit, m_chunk=chunk, slab_stride=I * J,
                      flags=_hip.GEMM_OUT_F32, **kw)
-        cdiv, s_j, s_hi, s_lo = perm
-        if s_j is None:
-            cdiv, s_j, s_hi, s_lo = 1, 1, J, 0
-        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad), I, J, nsplit, I * J, cdiv, s_j, s_hi, s_lo)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad, grad_offset), I, J, nsplit, I * J, 1, 1, J, 0)
 
     def _colsum_to_grad(self, X, grad, M, N):
         nb = min(self.colsum_blocks, max(1, M // 64))
@@ -346,17 +341,27 @@ class CPCEngine:
                          flags=_hip.GEMM_OUT_F32)
         if add_dc is not None:
             self.dc.add_(add_dc)
-        _hip.call("cpc_gru_bwd", _hip.ptr(self.dc), _hip.ptr(self.Hall), _hip.ptr(self.gates), _hip.ptr(self.w_hh_t_frag),
-                  _hip.ptr(self.dGi), _hip.ptr(self.dGh), B, V, H, code)
-        self._tn_to_grad(_hip.ptr(self.dGi), _hip.ptr(top, t0 * E), g["autoregressive_model.gruCell.weight_ih"], B * V, 3 * H, E,
-                         3 * H, E, self.split_ih, b_rpi=V, b_item=Ltop * E)
-        self._tn_to_grad(_hip.ptr(self.dGh), _hip.ptr(self.Hall), g["autoregressive_model.gruCell.weight_hh"], B * V, 3 * H, H,
-                         3 * H, H, self.split_hh, b_rpi=V, b_item=(V + 1) * H)
+        _hip.call("cpc_gru_bwd", _hip.ptr(self.dc), _hip.ptr(self.tape), _hip.ptr(self.w_hh_t_frag), _hip.ptr(self.dG), B, V, H, code)
+        # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
+        # [3H,4H) that of the recurrent term
+        g_ih, g_hh = g["autoregressive_model.gruCell.weight_ih"], g["autoregressive_model.gruCell.weight_hh"]
+        self._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
+                         b_rpi=V, b_item=Ltop * E)
+        self._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
+                         b_rpi=V, b_item=(V + 1) * H)
+        self._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
+                         b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H)
         if "autoregressive_model.gruCell.bias_ih" in g:
-            self._colsum_to_grad(_hip.ptr(self.dGi), g["autoregressive_model.gruCell.bias_ih"], B * V, 3 * H)
-            self._colsum_to_grad(_hip.ptr(self.dGh), g["autoregressive_model.gruCell.bias_hh"], B * V, 3 * H)
+            g_bi, g_bh = g["autoregressive_model.gruCell.bias_ih"], g["autoregressive_model.gruCell.bias_hh"]
+            M = B * V
+            nb = min(self.colsum_blocks, max(1, M // 64))
+            _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(self.slabs), M, 4 * H, 4 * H, nb, code)
+            sl = self.slabs
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
         # dz -> rows [t0, t0+V) of the top-layer gradient
-        _hip.gemm_nt(_hip.ptr(self.dGi), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 3 * H, 3 * H, E, code,
+        _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
                      c_rpi=V, c_item=Ltop * E, c_valid=V)
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2))

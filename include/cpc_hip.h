@@ -113,16 +113,20 @@ int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long lon
 int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, void* stream);
 
 /* AudioGRUModel.forward's python loop over nn.GRUCell (audio_model.py:66-77) as one persistent launch.
- *   Gi    f32 [B][V][3H]  = x_t W_ih^T + b_ih for all steps (cpc_gemm_nt), gate order r, z, n
+ *   Gi    T   [B][V][3H]  = x_t W_ih^T + b_ih for all steps (cpc_gemm_nt), gate order r, z, n
  *   Wfrag T   cpc_prep_frag(weight_hh [3H][H]);  bhh f32 [3H]
- *   Hall  T   [B][V+1][H] hidden states (Hall[:,0] = 0);  gates T [B][V][4][H] = r, z, n, (W_hn h + b_hn)
+ *   Hall  T   [B][V+1][H] hidden states (Hall[:,0] = 0)
+ *   tape  T   cpc_gru_tape_elems(B,V,H,dtype) elements: saved activations (r, z, n, W_hn h + b_hn, h_{t-1}) in a layout
+ *             private to the fwd/bwd kernel pair (lane-fragment order for the weight-resident bf16 kernels)
  *   c_out f32 [B][H] last hidden state (what AudioGRUModel.forward returns). */
-int cpc_gru_fwd(const float* Gi, const void* Wfrag, const float* bhh, void* Hall, void* gates, float* c_out, int B,
-                int V, int H, int dtype, void* stream);
-/* Backward through time: dc f32 [B][H] -> dGi, dGh T [B][V][3H] (gradients w.r.t. the two pre-activation terms).
+long long cpc_gru_tape_elems(int B, int V, int H, int dtype);
+int cpc_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B, int V,
+                int H, int dtype, void* stream);
+/* Backward through time: dc f32 [B][H] -> dG T [B][V][4H] = [d r_pre | d z_pre | d n_pre | d n_pre * r]: columns [0,3H) are
+ * the gradient w.r.t. the input-projection term, columns [0,2H) and [3H,4H) the gradient w.r.t. h W_hh^T + b_hh.
  * WTfrag = cpc_prep_frag(weight_hh, transpose=1) ([H][3H] logical). */
-int cpc_gru_bwd(const float* dc, const void* Hall, const void* gates, const void* WTfrag, void* dGi, void* dGh, int B,
-                int V, int H, int dtype, void* stream);
+int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
+                void* stream);
 
 /* A/B switch: on != 0 forces the weight-streaming GRU kernels where the weight-resident bf16 ones would be used
  * (H in {32,64,128,256}); returns the previous setting.  Not stream-ordered (host-side flag). */

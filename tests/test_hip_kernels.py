@@ -315,13 +315,14 @@ def test_gru_fwd_bwd(dt, B, V, H):
     _hip.call("cpc_prep_frag", _hip.ptr(dW), _hip.ptr(wfrag), 3 * H, H, H, 0, code)
     _hip.call("cpc_prep_frag", _hip.ptr(dW), _hip.ptr(wTfrag), H, 3 * H, H, 1, code)
     Hall = torch.full((B, V + 1, H), float("nan"), device=DEV, dtype=dt)
-    gates = torch.full((B, V, 4, H), float("nan"), device=DEV, dtype=dt)
+    tape = torch.zeros(_hip.lib().cpc_gru_tape_elems(B, V, H, code), device=DEV, dtype=dt)
     c = torch.full((B, H), float("nan"), device=DEV)
-    _hip.call("cpc_gru_fwd", _hip.ptr(dGi_in), _hip.ptr(wfrag), _hip.ptr(db), _hip.ptr(Hall), _hip.ptr(gates), _hip.ptr(c), B, V, H, code)
+    dGi_T = dev(Gi, dt)           # the input projection is stored in the storage dtype
+    _hip.call("cpc_gru_fwd", _hip.ptr(dGi_T), _hip.ptr(wfrag), _hip.ptr(db), _hip.ptr(Hall), _hip.ptr(tape), _hip.ptr(c), B, V, H, code)
     # reference (float64) with the weights as the device sees them
     wr = rounded(w_hh, dt).requires_grad_(True)
     br = b_hh.double().requires_grad_(True)
-    gir = Gi.double().requires_grad_(True)
+    gir = rounded(Gi, dt).requires_grad_(True)
     h = torch.zeros(B, H, dtype=torch.float64)
     hs = [h]
     for t in range(V):
@@ -335,9 +336,10 @@ def test_gru_fwd_bwd(dt, B, V, H):
     assert rel_err(c, h) < t_f
     assert rel_err(Hall, torch.stack(hs, 1)) < t_f
     (h * dc.double()).sum().backward()
-    dGi = torch.full((B, V, 3 * H), float("nan"), device=DEV, dtype=dt)
-    dGh = torch.full((B, V, 3 * H), float("nan"), device=DEV, dtype=dt)
-    _hip.call("cpc_gru_bwd", _hip.ptr(ddc), _hip.ptr(Hall), _hip.ptr(gates), _hip.ptr(wTfrag), _hip.ptr(dGi), _hip.ptr(dGh), B, V, H, code)
+    dG = torch.full((B, V, 4 * H), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_gru_bwd", _hip.ptr(ddc), _hip.ptr(tape), _hip.ptr(wTfrag), _hip.ptr(dG), B, V, H, code)
+    dGi = dG[:, :, :3 * H]
+    dGh = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], dim=2)
     t_b = 5e-5 if dt == torch.float32 else 4e-2
     assert rel_err(dGi, gir.grad) < t_b
     # dGh: gradient wrt (h W_hh^T + b_hh): its column sums are the b_hh gradient
