@@ -11,7 +11,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA = 1, 2, 4, 8, 16, 32, 64
+GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA, GEMM_SKIP_PAD_ROWS = 1, 2, 4, 8, 16, 32, 64, 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")
@@ -57,6 +57,9 @@ _SIGNATURES = {
     "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_relu_row_bwd": ([_P, _P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),

@@ -107,6 +107,61 @@ class AudioGRUModel(nn.Module):
         raise NotImplementedError("AudioGRUModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
 
 
+class ConvolutionalArBlock(nn.Module):
+    """[MaxPool1d(pooling, ceil)] -> Conv1d -> [BatchNorm1d] -> ReLU (+ optional residual branch); parameter holder with the
+    reference's module indices (audio_model.py:80-136), so ``main_modules.N.weight`` keys line up."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, pooling=1, stride=1, bias=True, residual=False, batch_norm=False,
+                 name='ar_block', activation_register=None):
+        super().__init__()
+        self.name = name
+        self.main_modules = nn.ModuleList()
+        if pooling > 1:
+            self.main_modules.append(nn.MaxPool1d(pooling, ceil_mode=True))
+        self.main_modules.append(_ConvParams(in_channels, out_channels, kernel_size, stride, bias=bias))
+        if batch_norm:
+            self.main_modules.append(nn.BatchNorm1d(out_channels))
+        self.main_modules.append(nn.ReLU())
+        self.residual = residual
+        self.residual_modules = None
+        if residual:
+            self.residual_modules = nn.ModuleList()
+            if pooling * stride > 1:
+                self.residual_modules.append(nn.MaxPool1d(pooling * stride, ceil_mode=True))
+            if in_channels != out_channels:
+                self.residual_modules.append(_ConvParams(in_channels, out_channels, 1, 1, bias=True))
+        self.output_activation_writer = ActivationWriter(register=activation_register, name=self.name)
+
+    def forward(self, x):
+        raise NotImplementedError("ConvolutionalArBlock runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+
+
+class ConvolutionalArModel(nn.Module):
+    """Convolutional context network (reference audio_model.py:139-161); ``forward`` would return x[:, :, -1]."""
+
+    def __init__(self, args_dict):
+        super().__init__()
+        self.kernel_sizes = list(args_dict['kernel_sizes'])
+        self.channel_count = list(args_dict['channel_count'])
+        self.strides = list(args_dict['stride'])
+        self.poolings = list(args_dict['pooling'])
+        self.batch_norm = bool(args_dict['batch_norm'])
+        self.residual = bool(args_dict['residual'])
+        self.module_list = nn.ModuleList()
+        for l in range(len(self.kernel_sizes)):
+            self.module_list.append(ConvolutionalArBlock(in_channels=self.channel_count[l], out_channels=self.channel_count[l + 1],
+                                                         kernel_size=self.kernel_sizes[l], stride=self.strides[l],
+                                                         pooling=self.poolings[l], bias=args_dict['bias'],
+                                                         batch_norm=self.batch_norm, residual=self.residual,
+                                                         name='ar_block_' + str(l),
+                                                         activation_register=args_dict.get('activation_register')))
+        self.encoding_size = self.channel_count[0]
+        self.ar_size = self.channel_count[-1]
+
+    def forward(self, x):
+        raise NotImplementedError("ConvolutionalArModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+
+
 class AudioPredictiveCodingModel(nn.Module):
     """encoder -> (targets, z) -> autoregressive context c -> W_k c predictions (reference audio_model.py:164-219).
 
@@ -134,8 +189,9 @@ class AudioPredictiveCodingModel(nn.Module):
         self._flat_grad = None
         self._param = {}
         self._grad = {}
-        if not isinstance(encoder, AudioEncoder) or not isinstance(autoregressive_model, AudioGRUModel):
-            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel (SURVEY.md section 8 rows a1-a4)")
+        if not isinstance(encoder, AudioEncoder) or not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel)):
+            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel / ConvolutionalArModel "
+                                      "(SURVEY.md section 8 rows a1-a5)")
 
     @property
     def item_length(self):

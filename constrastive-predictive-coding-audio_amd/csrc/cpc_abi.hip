@@ -5,6 +5,7 @@
 #include "../../include/cpc_hip.h"
 
 static_assert(CPC_GEMM_FORCE_GENERIC == GEMM_FORCE_GENERIC && CPC_GEMM_SMALL_TILE == GEMM_SMALL_TILE, "flag mismatch");
+static_assert(CPC_GEMM_SKIP_PAD_ROWS == GEMM_SKIP_PAD_ROWS && CPC_GEMM_NO_DMA == GEMM_NO_DMA, "flag mismatch");
 static_assert(CPC_GEMM_RELU == GEMM_RELU && CPC_GEMM_OUT_F32 == GEMM_OUT_F32 && CPC_GEMM_TN_NO_TR == GEMM_TN_NO_TR, "flag mismatch");
 static_assert(CPC_F32 == CPC_DTYPE_F32 && CPC_BF16 == CPC_DTYPE_BF16, "dtype mismatch");
 
@@ -125,6 +126,24 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype, void* stream) {
     if (!w || !w_fwd) return CPC_EINVAL;
     return launch_conv_w_prep(w, w_fwd, w_dgrad, Cout, Cin, kw, stride, dtype, (hipStream_t)stream);
+}
+
+int cpc_maxpool_fwd(const void* in, void* out, int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_valid, int Lout_alloc,
+                    int dtype, void* stream) {
+    if (!in || !out) return CPC_EINVAL;
+    return launch_maxpool_fwd(in, out, B, C, pool, Lin_valid, Lin_alloc, Lout_valid, Lout_alloc, dtype, (hipStream_t)stream);
+}
+
+int cpc_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_alloc,
+                    int dtype, void* stream) {
+    if (!in || !dout || !din) return CPC_EINVAL;
+    return launch_maxpool_bwd(in, dout, din, B, C, pool, Lin_valid, Lin_alloc, Lout_alloc, dtype, (hipStream_t)stream);
+}
+
+int cpc_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off, int dtype,
+                     void* stream) {
+    if (!dc || !y || !dy) return CPC_EINVAL;
+    return launch_relu_row_bwd(dc, y, dy, B, C, item_stride, row_off, dtype, (hipStream_t)stream);
 }
 
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {

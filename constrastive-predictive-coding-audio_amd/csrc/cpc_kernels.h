@@ -10,6 +10,7 @@
 #define GEMM_NARROW_EPI 32     // NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A-B check)
 #define GEMM_WIDE_EPI 0x10000  // internal: set by the launcher when the LDS-staged epilogue applies
 #define GEMM_NO_DMA 64         // NT fast path: register-staged global->LDS copies instead of LDS-DMA (A-B check)
+#define GEMM_SKIP_PAD_ROWS 128  // NT: rows with (m % c_rpi) >= c_valid are not stored at all (default: stored as zeros)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {
@@ -71,3 +72,10 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,
                        hipStream_t stream);
 int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, hipStream_t stream);
+
+int launch_maxpool_fwd(const void* in, void* out, int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_valid,
+                       int Lout_alloc, int dtype, hipStream_t stream);
+int launch_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C, int pool, int Lin_valid, int Lin_alloc,
+                       int Lout_alloc, int dtype, hipStream_t stream);
+int launch_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off, int dtype,
+                        hipStream_t stream);

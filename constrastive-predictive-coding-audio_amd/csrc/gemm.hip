@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
             }
-            if (!row_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!row_valid) {
+                if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             store4(Cb + coff + n, v);
         }
     }
@@ -584,7 +587,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                     }
                     const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
-                    if (!row_valid) v = make_uint4(0, 0, 0, 0);
+                    if (!row_valid) {
+                        if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+                        v = make_uint4(0, 0, 0, 0);
+                    }
                     *(uint4*)(Cb + coff + n) = v;
                 }
             }
@@ -612,7 +618,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
             }
-            if (!row_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!row_valid) {
+                if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             store4(Cb + coff + n, v);
         }
     }

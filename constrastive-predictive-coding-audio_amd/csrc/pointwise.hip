@@ -75,6 +75,75 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const float* __restrict__ s
     }
 }
 
+// MaxPool1d(pool, ceil_mode=True) over positions of a channels-last activation (ConvolutionalArBlock, audio_model.py:98-99).
+// out[b][p][c] = max_{i < pool, p*pool+i < Lin_valid} in[b][p*pool+i][c];  pad rows (p >= Lout_valid) get zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int C, int pool,
+                                                          int Lin_valid, int Lin_alloc, int Lout_valid, int Lout_alloc) {
+    const int c4n = C / 4;
+    const long long total = (long long)B * Lout_alloc * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int pp = (int)((idx / c4n) % Lout_alloc);
+        const int b = (int)(idx / ((long long)c4n * Lout_alloc));
+        f32x4 m = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pp < Lout_valid) {
+            const T* src = in + ((long long)b * Lin_alloc + (long long)pp * pool) * C + c4 * 4;
+            m = load4(src);
+            for (int i = 1; i < pool && pp * pool + i < Lin_valid; ++i) {
+                const f32x4 v = load4(src + (long long)i * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        store4(out + ((long long)b * Lout_alloc + pp) * C + c4 * 4, m);
+    }
+}
+
+// Backward of the pooling: the gradient of a window goes to its FIRST maximal element (torch semantics); everything
+// else, and the pad rows, get zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ in, const T* __restrict__ dout, T* __restrict__ din,
+                                                          int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_alloc) {
+    const int c4n = C / 4;
+    const long long total = (long long)B * Lin_alloc * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int x = (int)((idx / c4n) % Lin_alloc);
+        const int b = (int)(idx / ((long long)c4n * Lin_alloc));
+        f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (x < Lin_valid) {
+            const int pp = x / pool, me = x % pool;
+            const T* src = in + ((long long)b * Lin_alloc + (long long)pp * pool) * C + c4 * 4;
+            const f32x4 d = load4(dout + ((long long)b * Lout_alloc + pp) * C + c4 * 4);
+            f32x4 best = load4(src);
+            int arg[4] = {0, 0, 0, 0};
+            for (int i = 1; i < pool && pp * pool + i < Lin_valid; ++i) {
+                const f32x4 v = load4(src + (long long)i * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e]) { best[e] = v[e]; arg[e] = i; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = arg[e] == me ? d[e] : 0.f;
+        }
+        store4(din + ((long long)b * Lin_alloc + x) * C + c4 * 4, g);
+    }
+}
+
+// dy[b][row][c] = y[b][row][c] > 0 ? dc[b][c] : 0   (gradient entering the last ReLU of the conv context network at the one
+// position ConvolutionalArModel.forward returns, audio_model.py:161); dy is otherwise left untouched.
+template <typename T>
+__global__ __launch_bounds__(256) void relu_row_bwd_kernel(const float* __restrict__ dc, const T* __restrict__ y, T* __restrict__ dy,
+                                                           int B, int C, long long item_stride, long long row_off) {
+    const int total = B * C;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int b = idx / C, c = idx % C;
+        const long long o = (long long)b * item_stride + row_off + c;
+        dy[o] = from_f32<T>(to_f32(y[o]) > 0.f ? dc[idx] : 0.f);
+    }
+}
+
 }  // namespace
 
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
@@ -116,6 +185,60 @@ int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long 
         hipLaunchKernelGGL((cast2d_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, R, C, sr, sc);
     else if (dtype == CPC_DTYPE_F32)
         hipLaunchKernelGGL((cast2d_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, (float*)dst, R, C, sr, sc);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_maxpool_fwd(const void* in, void* out, int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_valid,
+                       int Lout_alloc, int dtype, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || C % 4 || pool < 1 || Lin_valid <= 0 || Lin_alloc < Lin_valid || Lout_valid <= 0 || Lout_alloc < Lout_valid ||
+        (long long)(Lout_valid - 1) * pool >= Lin_valid)
+        return CPC_EINVAL;
+    const long long total = (long long)B * Lout_alloc * (C / 4);
+    const int blocks = (int)min((long long)2048, (total + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, B, C, pool,
+                           Lin_valid, Lin_alloc, Lout_valid, Lout_alloc);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)in, (float*)out, B, C, pool,
+                           Lin_valid, Lin_alloc, Lout_valid, Lout_alloc);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C, int pool, int Lin_valid, int Lin_alloc,
+                       int Lout_alloc, int dtype, hipStream_t stream) {
+    if (B <= 0 || C <= 0 || C % 4 || pool < 1 || Lin_valid <= 0 || Lin_alloc < Lin_valid || Lout_alloc <= 0 ||
+        (Lin_valid - 1) / pool >= Lout_alloc)
+        return CPC_EINVAL;
+    const long long total = (long long)B * Lin_alloc * (C / 4);
+    const int blocks = (int)min((long long)2048, (total + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)in, (const bf16_t*)dout,
+                           (bf16_t*)din, B, C, pool, Lin_valid, Lin_alloc, Lout_alloc);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)in, (const float*)dout,
+                           (float*)din, B, C, pool, Lin_valid, Lin_alloc, Lout_alloc);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off, int dtype,
+                        hipStream_t stream) {
+    if (B <= 0 || C <= 0) return CPC_EINVAL;
+    const int blocks = min(1024, (B * C + 255) / 256);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((relu_row_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, dc, (const bf16_t*)y, (bf16_t*)dy, B, C,
+                           item_stride, row_off);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((relu_row_bwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, dc, (const float*)y, (float*)dy, B, C,
+                           item_stride, row_off);
     else
         return CPC_EINVAL;
     CPC_CHECK_LAUNCH();

@@ -69,7 +69,7 @@ class CPCEngine:
         self.channels = list(enc.channel_count)
         self.n = len(self.strides)
         self.E = self.channels[-1]
-        self.H = int(ar.hidden_size)
+        self.H = int(model.ar_size)
         self.K = int(model.prediction_steps)
         self.V = int(model.visible_steps)
         full = EncoderGeometry(self.L, self.strides, self.kernels)
@@ -85,10 +85,11 @@ class CPCEngine:
         self.geo = EncoderGeometry(self.L_eff, self.strides, self.kernels)
         self.T = self.geo.frames
         assert self.T == full.frames - skip
-        if model.enc_size != self.E or model.ar_size != self.H or ar.input_size != self.E:
-            raise ValueError("enc_size / ar_size do not match the encoder and autoregressive model")
+        if model.enc_size != self.E:
+            raise ValueError("enc_size does not match the encoder's last channel count")
         self._check_supported()
         model._flatten_parameters(self.device)
+        self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         self._alloc()
 
     # ------------------------------------------------------------------------------------------ setup
@@ -100,8 +101,6 @@ class CPCEngine:
         c0 = self.channels[0]
         if c0 % 8 or 256 % (c0 // 8) or self.kernels[0] > 16 or self.strides[0] > 8:
             raise NotImplementedError("HIP layer-1 kernel: channels in {8,16,...,2048}, kernel <= 16, stride <= 8")
-        if self.H % 16 or self.H % (4 * ch) or self.H > 256:
-            raise NotImplementedError("HIP GRU kernel: hidden size must be a multiple of 32 and <= 256")
         if self.E % ch:
             raise NotImplementedError("enc_size must be a multiple of 8")
 
@@ -129,16 +128,9 @@ class CPCEngine:
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             self.w_fwd[l] = torch.empty(cout * kw * cin, device=dev, dtype=dt)
             self.w_dgrad[l] = torch.empty(s * cin * self.geo.taps[l] * cout, device=dev, dtype=dt)
-        self.w_ih = torch.empty(3 * H * E, device=dev, dtype=dt)          # [3H][E]
-        self.w_ih_t = torch.empty(E * 3 * H, device=dev, dtype=dt)        # [E][3H]
-        self.w_hh_frag = torch.empty(3 * H * H, device=dev, dtype=dt)
-        self.w_hh_t_frag = torch.empty(3 * H * H, device=dev, dtype=dt)
         self.w_p = torch.empty(K * E * H, device=dev, dtype=dt)           # [K*E][H]
         self.w_p_t = torch.empty(H * K * E, device=dev, dtype=dt)         # [H][K*E]
-        # GRU / predictor / loss state
-        self.Gi = torch.empty(B * V * 3 * H, device=dev, dtype=dt)
-        self.Hall = torch.empty(B * (V + 1) * H, device=dev, dtype=dt)
-        self.tape = torch.zeros(max(1, int(_hip.lib().cpc_gru_tape_elems(B, max(V, 1), H, self.code))), device=dev, dtype=dt)
+        # predictor / loss state
         self.c = torch.empty(B, H, device=dev, dtype=f32)
         self.pred = torch.empty(B * K * E, device=dev, dtype=dt)
         self.ldS = _ceil_div(B, 8) * 8
@@ -149,7 +141,6 @@ class CPCEngine:
         self.nce_ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(B, K)), device=dev, dtype=f32)
         self.dpred = torch.zeros(B * K * E, device=dev, dtype=dt)
         self.dc = torch.zeros(B, H, device=dev, dtype=f32)
-        self.dG = torch.empty(B * V * 4 * H, device=dev, dtype=dt)       # [dr | du | dn | dn*r] per (item, step)
         # split-reduction workspace (f32 slabs), sized for the largest user
         need = [1]
         self.nsplit = [1] * n
@@ -161,11 +152,11 @@ class CPCEngine:
         self.c1_item_blocks = min(B, 128)
         need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
         self.colsum_blocks = 1024
-        need.append(self.colsum_blocks * max(max(self.channels), 4 * H))
-        self.split_ih = self._pick_split(3 * H, E, B * V)
-        self.split_hh = self._pick_split(3 * H, H, B * V)
-        need.append(self.split_ih * 3 * H * E)
-        need.append(self.split_hh * 3 * H * H)
+        need.append(self.colsum_blocks * max(self.channels))
+        need.append(_ceil_div(max(K * E, 1), 256) * B * H)               # split-K slabs of the dc GEMM
+        if self.ctx is not None:
+            self.ctx.allocate()
+            need.append(self.ctx.slab_floats())
         self.slabs = torch.empty(max(need), device=dev, dtype=f32)
 
     def _pick_split(self, I, J, M):
@@ -188,14 +179,10 @@ class CPCEngine:
             _hip.call("cpc_conv_w_prep", _hip.ptr(p[f"encoder.layers.{l}.weight"]), _hip.ptr(self.w_fwd[l]),
                       _hip.ptr(self.w_dgrad[l]), self.channels[l], self.channels[l - 1], self.kernels[l], self.strides[l], code)
         H, E, K = self.H, self.E, self.K
-        if K == 0:          # encoder-only engine (stand-alone AudioEncoder call)
+        if self.ctx is None:          # encoder-only engine (stand-alone AudioEncoder call)
             return
-        w_ih, w_hh = p["autoregressive_model.gruCell.weight_ih"], p["autoregressive_model.gruCell.weight_hh"]
+        self.ctx.prepare_weights()
         w_p = p["prediction_model.weight"]
-        _hip.call("cpc_cast2d", _hip.ptr(w_ih), _hip.ptr(self.w_ih), 3 * H, E, E, 1, code)
-        _hip.call("cpc_cast2d", _hip.ptr(w_ih), _hip.ptr(self.w_ih_t), E, 3 * H, 1, E, code)
-        _hip.call("cpc_prep_frag", _hip.ptr(w_hh), _hip.ptr(self.w_hh_frag), 3 * H, H, H, 0, code)
-        _hip.call("cpc_prep_frag", _hip.ptr(w_hh), _hip.ptr(self.w_hh_t_frag), H, 3 * H, H, 1, code)
         _hip.call("cpc_cast2d", _hip.ptr(w_p), _hip.ptr(self.w_p), K * E, H, H, 1, code)
         _hip.call("cpc_cast2d", _hip.ptr(w_p), _hip.ptr(self.w_p_t), H, K * E, 1, H, code)
 
@@ -221,17 +208,12 @@ class CPCEngine:
                       shape=("fwd", B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1]))
 
     def context_forward(self):
-        """AudioGRUModel.forward over z = frames [T-K-V, T-K) (audio_model.py:198-202, :66-77) + prediction_model (:208)."""
-        p, code, B, V, H, E, K = self.model._param, self.code, self.B, self.V, self.H, self.E, self.K
-        Ltop = self.geo.alloc[-1]
-        t0 = self.T - K - V
-        top = self.act[-1]
-        _hip.gemm_nt(_hip.ptr(top, t0 * E), _hip.ptr(self.w_ih), _hip.ptr(self.Gi), B * V, 3 * H, E, E, E, 3 * H, code,
-                     bias=_hip.ptr(p.get("autoregressive_model.gruCell.bias_ih")), a_rpi=V, a_item=Ltop * E)
-        _hip.call("cpc_gru_fwd", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get("autoregressive_model.gruCell.bias_hh")),
-                  _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(self.c), B, V, H, code)
-        _hip.gemm_nt(_hip.ptr(self.Hall, V * H), _hip.ptr(self.w_p), _hip.ptr(self.pred), B, K * E, H, H, H, K * E, code,
-                     a_rpi=1, a_item=(V + 1) * H)
+        """c = autoregressive_model(z) over z = frames [T-K-V, T-K) (audio_model.py:198-204), then prediction_model (:208)."""
+        code, B, H, E, K = self.code, self.B, self.H, self.E, self.K
+        self.ctx.forward()
+        ct, coff, cstride = self.ctx.c_operand()
+        _hip.gemm_nt(_hip.ptr(ct, coff), _hip.ptr(self.w_p), _hip.ptr(self.pred), B, K * E, H, H, H, K * E, code,
+                     a_rpi=1, a_item=cstride)
 
     def forward(self, x):
         self.prepare_weights()
@@ -249,7 +231,7 @@ class CPCEngine:
         pred = self.pred.view(self.B, K, self.E).float()
         targets = top[:, T - K:T, :].float().transpose(1, 2)
         z = top[:, T - K - V:T - K, :].float().transpose(1, 2)
-        return pred, targets, z, self.c.clone()
+        return pred, targets, z, self.ctx.c_float().clone()
 
     # ------------------------------------------------------------------------------------------ loss
     def nce_forward_backward(self, softplus: bool, regularization: float):
@@ -327,8 +309,9 @@ class CPCEngine:
         t0 = T - K - V
         top, dtop = self.act[-1], self.dact[-1]
         # predictor: dW_p = dpred^T c ;  dc = dpred W_p
-        _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(self.Hall, V * H), _hip.ptr(g["prediction_model.weight"]), B, K * E, H,
-                     K * E, H, H, code, b_rpi=1, b_item=(V + 1) * H, flags=_hip.GEMM_OUT_F32)
+        ct, coff, cstride = self.ctx.c_operand()
+        _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(ct, coff), _hip.ptr(g["prediction_model.weight"]), B, K * E, H,
+                     K * E, H, H, code, b_rpi=1, b_item=cstride, flags=_hip.GEMM_OUT_F32)
         # (a B x H output with a K*E-long reduction: split the reduction over workgroups, sum the slabs in fixed order)
         ke = K * E
         ksplit = ke // 256 if (ke % 256 == 0 and ke >= 1024 and self.slabs.numel() >= (ke // 256) * B * H) else 1
@@ -341,28 +324,7 @@ class CPCEngine:
                          flags=_hip.GEMM_OUT_F32)
         if add_dc is not None:
             self.dc.add_(add_dc)
-        _hip.call("cpc_gru_bwd", _hip.ptr(self.dc), _hip.ptr(self.tape), _hip.ptr(self.w_hh_t_frag), _hip.ptr(self.dG), B, V, H, code)
-        # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
-        # [3H,4H) that of the recurrent term
-        g_ih, g_hh = g["autoregressive_model.gruCell.weight_ih"], g["autoregressive_model.gruCell.weight_hh"]
-        self._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
-                         b_rpi=V, b_item=Ltop * E)
-        self._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
-                         b_rpi=V, b_item=(V + 1) * H)
-        self._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
-                         b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H)
-        if "autoregressive_model.gruCell.bias_ih" in g:
-            g_bi, g_bh = g["autoregressive_model.gruCell.bias_ih"], g["autoregressive_model.gruCell.bias_hh"]
-            M = B * V
-            nb = min(self.colsum_blocks, max(1, M // 64))
-            _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(self.slabs), M, 4 * H, 4 * H, nb, code)
-            sl = self.slabs
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
-        # dz -> rows [t0, t0+V) of the top-layer gradient
-        _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
-                     c_rpi=V, c_item=Ltop * E, c_valid=V)
+        self.ctx.backward(self.dc)      # parameter gradients of the context network + dz into rows [t0, t0+V) of dtop
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2))
         # encoder, top layer down to layer 2
@@ -410,6 +372,238 @@ class CPCEngine:
             self.nce_forward_backward(softplus, regularization)
         self.backward(x, grad_ready_hook=grad_ready_hook)
         return self.nce_out
+
+
+class GRUContext:
+    """AudioGRUModel as the context network (audio_model.py:47-77): one batched input-projection GEMM for all V steps, the
+    persistent GRU kernels for the recurrence, GEMMs for the weight gradients and for dz."""
+
+    def __init__(self, eng, ar):
+        self.eng = eng
+        self.H = int(ar.hidden_size)
+        ch = 8 if eng.dt == torch.bfloat16 else 4
+        if ar.input_size != eng.E or self.H != eng.H:
+            raise ValueError("AudioGRUModel sizes do not match enc_size / ar_size")
+        if self.H % 16 or self.H % (4 * ch) or self.H > 256:
+            raise NotImplementedError("HIP GRU kernel: hidden size must be a multiple of 32 and <= 256")
+        self.prefix = "autoregressive_model.gruCell."
+
+    def allocate(self):
+        e = self.eng
+        B, V, H, E, dev, dt = e.B, e.V, self.H, e.E, e.device, e.dt
+        self.w_ih = torch.empty(3 * H * E, device=dev, dtype=dt)          # [3H][E]
+        self.w_ih_t = torch.empty(E * 3 * H, device=dev, dtype=dt)        # [E][3H]
+        self.w_hh_frag = torch.empty(3 * H * H, device=dev, dtype=dt)
+        self.w_hh_t_frag = torch.empty(3 * H * H, device=dev, dtype=dt)
+        self.Gi = torch.empty(B * V * 3 * H, device=dev, dtype=dt)
+        self.Hall = torch.empty(B * (V + 1) * H, device=dev, dtype=dt)
+        self.tape = torch.zeros(max(1, int(_hip.lib().cpc_gru_tape_elems(B, max(V, 1), H, e.code))), device=dev, dtype=dt)
+        self.dG = torch.empty(B * V * 4 * H, device=dev, dtype=dt)       # [dr | du | dn | dn*r] per (item, step)
+        self.split_ih = e._pick_split(3 * H, E, B * V)
+        self.split_hh = e._pick_split(2 * H, H, B * V)
+
+    def slab_floats(self):
+        e, H = self.eng, self.H
+        return max(self.split_ih * 3 * H * e.E, self.split_hh * 2 * H * H, e.colsum_blocks * 4 * H)
+
+    def prepare_weights(self):
+        e, H, E, code = self.eng, self.H, self.eng.E, self.eng.code
+        p = e.model._param
+        w_ih, w_hh = p[self.prefix + "weight_ih"], p[self.prefix + "weight_hh"]
+        _hip.call("cpc_cast2d", _hip.ptr(w_ih), _hip.ptr(self.w_ih), 3 * H, E, E, 1, code)
+        _hip.call("cpc_cast2d", _hip.ptr(w_ih), _hip.ptr(self.w_ih_t), E, 3 * H, 1, E, code)
+        _hip.call("cpc_prep_frag", _hip.ptr(w_hh), _hip.ptr(self.w_hh_frag), 3 * H, H, H, 0, code)
+        _hip.call("cpc_prep_frag", _hip.ptr(w_hh), _hip.ptr(self.w_hh_t_frag), H, 3 * H, H, 1, code)
+
+    def forward(self):
+        e, H = self.eng, self.H
+        p, code, B, V, E, K = e.model._param, e.code, e.B, e.V, e.E, e.K
+        Ltop, t0, top = e.geo.alloc[-1], e.T - K - V, e.act[-1]
+        _hip.gemm_nt(_hip.ptr(top, t0 * E), _hip.ptr(self.w_ih), _hip.ptr(self.Gi), B * V, 3 * H, E, E, E, 3 * H, code,
+                     bias=_hip.ptr(p.get(self.prefix + "bias_ih")), a_rpi=V, a_item=Ltop * E)
+        _hip.call("cpc_gru_fwd", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get(self.prefix + "bias_hh")),
+                  _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(e.c), B, V, H, code)
+
+    def c_operand(self):
+        """(tensor, element offset, item stride): storage-dtype rows of c, one per item (h_V inside the hidden-state buffer)."""
+        return self.Hall, self.eng.V * self.H, (self.eng.V + 1) * self.H
+
+    def c_float(self):
+        return self.eng.c
+
+    def backward(self, dc):
+        e, H = self.eng, self.H
+        g, code, B, V, E, K = e.model._grad, e.code, e.B, e.V, e.E, e.K
+        Ltop, t0, top, dtop = e.geo.alloc[-1], e.T - K - V, e.act[-1], e.dact[-1]
+        _hip.call("cpc_gru_bwd", _hip.ptr(dc), _hip.ptr(self.tape), _hip.ptr(self.w_hh_t_frag), _hip.ptr(self.dG), B, V, H, code)
+        # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
+        # [3H,4H) that of the recurrent term
+        g_ih, g_hh = g[self.prefix + "weight_ih"], g[self.prefix + "weight_hh"]
+        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
+                      b_rpi=V, b_item=Ltop * E)
+        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
+                      b_rpi=V, b_item=(V + 1) * H)
+        e._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
+                      b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H)
+        if (self.prefix + "bias_ih") in g:
+            g_bi, g_bh = g[self.prefix + "bias_ih"], g[self.prefix + "bias_hh"]
+            M = B * V
+            nb = min(e.colsum_blocks, max(1, M // 64))
+            _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(e.slabs), M, 4 * H, 4 * H, nb, code)
+            sl = e.slabs
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
+        # dz -> rows [t0, t0+V) of the top-layer gradient
+        _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
+                     c_rpi=V, c_item=Ltop * E, c_valid=V)
+
+
+class ConvArContext:
+    """ConvolutionalArModel as the context network (audio_model.py:80-161) for the plain configuration (no batch norm, no
+    residual branch; e.g. ``ar_conv_default_dict``): per block [MaxPool1d(pool, ceil)] -> Conv1d(k, stride 1) -> ReLU on
+    channels-last buffers; the convolutions are the same overlapped-row GEMMs as the encoder's; c = the last position."""
+
+    def __init__(self, eng, ar):
+        self.eng = eng
+        self.kernels = list(ar.kernel_sizes)
+        self.strides = list(ar.strides)
+        self.pools = list(ar.poolings)
+        self.channels = list(ar.channel_count)
+        self.nb = len(self.kernels)
+        if ar.batch_norm or ar.residual:
+            raise NotImplementedError("ConvolutionalArModel with batch_norm / residual is not part of the HIP path yet")
+        if any(s != 1 for s in self.strides):
+            raise NotImplementedError("ConvolutionalArModel: only stride-1 convolutions (all reference configs) are supported")
+        if self.channels[0] != eng.E or self.channels[-1] != eng.H:
+            raise ValueError("ConvolutionalArModel channel_count does not match enc_size / ar_size")
+        ch = 8 if eng.dt == torch.bfloat16 else 4
+        if any(c % 8 for c in self.channels) or any((k * c) % ch for k, c in zip(self.kernels, self.channels)):
+            raise NotImplementedError("ConvolutionalArModel channel counts must be multiples of 8")
+        # lengths: pooled input and conv output of every block
+        self.lp, self.lo = [], []
+        cur = eng.V
+        for l in range(self.nb):
+            cur = _ceil_div(cur, self.pools[l])
+            self.lp.append(cur)
+            cur = cur - self.kernels[l] + 1
+            if cur <= 0:
+                raise ValueError("visible_steps too short for this ConvolutionalArModel")
+            self.lo.append(cur)
+        # padded row counts per item: the conv input buffer of block l and its output share one value (stride 1) and keep
+        # >= kernel-1 zero pad rows, which is what the overlapped-row data-gradient GEMM needs between items
+        self.la = [max(self.lp[l], self.lo[l]) + self.kernels[l] for l in range(self.nb)]
+        self.conv_idx = [1 if self.pools[l] > 1 else 0 for l in range(self.nb)]
+
+    def _name(self, l, what):
+        return f"autoregressive_model.module_list.{l}.main_modules.{self.conv_idx[l]}.{what}"
+
+    def allocate(self):
+        e = self.eng
+        B, dev, dt = e.B, e.device, e.dt
+        self.x, self.dx, self.y, self.dy, self.w_fwd, self.w_dgrad, self.nsplit = [], [], [], [], [], [], []
+        self._keep = []
+        for l in range(self.nb):
+            cin, cout, kw = self.channels[l], self.channels[l + 1], self.kernels[l]
+            for store, cols in ((self.x, cin), (self.dx, cin), (self.y, cout), (self.dy, cout)):
+                if l == 0 and self.pools[0] == 1 and store in (self.x, self.dx):
+                    store.append(None)        # block 0 without pooling reads z straight out of the encoder's top buffer
+                    continue
+                full, view, _ = e._buf(B * self.la[l], cols)
+                self._keep.append(full)
+                store.append(view)
+            self.w_fwd.append(torch.empty(cout * kw * cin, device=dev, dtype=dt))
+            self.w_dgrad.append(torch.empty(cin * kw * cout, device=dev, dtype=dt))
+            self.nsplit.append(e._pick_split(kw * cin, cout, B * self.la[l]))
+        self.c32 = torch.empty(B, self.channels[-1], device=dev, dtype=torch.float32)
+
+    def slab_floats(self):
+        return max(self.nsplit[l] * self.kernels[l] * self.channels[l] * self.channels[l + 1] for l in range(self.nb)) + \
+            self.eng.colsum_blocks * max(self.channels)
+
+    def prepare_weights(self):
+        e = self.eng
+        p, code = e.model._param, e.code
+        for l in range(self.nb):
+            _hip.call("cpc_conv_w_prep", _hip.ptr(p[self._name(l, "weight")]), _hip.ptr(self.w_fwd[l]), _hip.ptr(self.w_dgrad[l]),
+                      self.channels[l + 1], self.channels[l], self.kernels[l], 1, code)
+
+    def _block_input(self, l):
+        """(pointer to the conv input rows of block l, a_rpi, a_item) — block 0 without pooling reads the encoder output."""
+        e = self.eng
+        if self.x[l] is None:
+            t0 = e.T - e.K - e.V
+            return _hip.ptr(e.act[-1], t0 * e.E), self.la[0], e.geo.alloc[-1] * e.E
+        return _hip.ptr(self.x[l]), 0, 0
+
+    def forward(self):
+        e = self.eng
+        p, code, B = e.model._param, e.code, e.B
+        for l in range(self.nb):
+            cin, cout, kw, la = self.channels[l], self.channels[l + 1], self.kernels[l], self.la[l]
+            if self.pools[l] > 1:
+                if l == 0:
+                    t0 = e.T - e.K - e.V
+                    raise NotImplementedError("pooling in the first ConvolutionalArBlock is not supported yet")
+                _hip.call("cpc_maxpool_fwd", _hip.ptr(self.y[l - 1]), _hip.ptr(self.x[l]), B, cin, self.pools[l], self.lo[l - 1],
+                          self.la[l - 1], self.lp[l], la, code)
+            elif l > 0:
+                raise NotImplementedError("ConvolutionalArBlock without pooling after the first block is not supported yet")
+            a, a_rpi, a_item = self._block_input(l)
+            _hip.gemm_nt(a, _hip.ptr(self.w_fwd[l]), _hip.ptr(self.y[l]), B * la, cout, kw * cin, cin, kw * cin, cout, code,
+                         bias=_hip.ptr(p.get(self._name(l, "bias"))), a_rpi=a_rpi, a_item=a_item, c_rpi=la, c_item=la * cout,
+                         c_valid=self.lo[l], flags=_hip.GEMM_RELU)
+
+    def c_operand(self):
+        l = self.nb - 1
+        return self.y[l], (self.lo[l] - 1) * self.channels[-1], self.la[l] * self.channels[-1]
+
+    def c_float(self):
+        l = self.nb - 1
+        H = self.channels[-1]
+        self.c32.copy_(self.y[l].view(self.eng.B, self.la[l], H)[:, self.lo[l] - 1, :])
+        return self.c32
+
+    def backward(self, dc):
+        e = self.eng
+        g, code, B = e.model._grad, e.code, e.B
+        last = self.nb - 1
+        H = self.channels[-1]
+        # gradient enters at the single position forward() returns; everything else of dy[last] stays zero
+        _hip.call("cpc_relu_row_bwd", _hip.ptr(dc), _hip.ptr(self.y[last]), _hip.ptr(self.dy[last]), B, H, self.la[last] * H,
+                  (self.lo[last] - 1) * H, code)
+        for l in range(last, -1, -1):
+            cin, cout, kw, la = self.channels[l], self.channels[l + 1], self.kernels[l], self.la[l]
+            bname = self._name(l, "bias")
+            if bname in g:
+                e._colsum_to_grad(_hip.ptr(self.dy[l]), g[bname], B * la, cout)
+            a, a_rpi, a_item = self._block_input(l)
+            chunk = e._chunk(B * la, self.nsplit[l])
+            _hip.gemm_tn(a, _hip.ptr(self.dy[l]), _hip.ptr(e.slabs), B * la, kw * cin, cout, cin, cout, cout, code, a_rpi=a_rpi,
+                         a_item=a_item, nsplit=self.nsplit[l], m_chunk=chunk, slab_stride=kw * cin * cout, flags=_hip.GEMM_OUT_F32)
+            _hip.call("cpc_reduce_conv_w", _hip.ptr(e.slabs), _hip.ptr(g[self._name(l, "weight")]), cin, cout, kw, self.nsplit[l],
+                      kw * cin * cout)
+            D = kw                                   # stride 1: every input position is touched by kw output rows
+            dy_shift = _hip.ptr(self.dy[l], -(D - 1) * cout)
+            if self.x[l] is None:
+                # data gradient straight into rows [t0, t0+V) of the encoder's top-layer gradient (no ReLU on that layer)
+                t0 = e.T - e.K - e.V
+                _hip.gemm_nt(dy_shift, _hip.ptr(self.w_dgrad[l]), _hip.ptr(e.dact[-1], t0 * e.E), B * la, cin, D * cout, cout,
+                             D * cout, cin, code, c_rpi=la, c_item=e.geo.alloc[-1] * e.E, c_valid=e.V, flags=_hip.GEMM_SKIP_PAD_ROWS)
+            else:
+                _hip.gemm_nt(dy_shift, _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.dx[l]), B * la, cin, D * cout, cout, D * cout, cin,
+                             code, mask=_hip.ptr(self.x[l]), c_rpi=la, c_item=la * cin, c_valid=self.lp[l])
+                _hip.call("cpc_maxpool_bwd", _hip.ptr(self.y[l - 1]), _hip.ptr(self.dx[l]), _hip.ptr(self.dy[l - 1]), B, cin,
+                          self.pools[l], self.lo[l - 1], self.la[l - 1], la, code)
+
+
+def make_context(eng, ar):
+    from .audio_model import AudioGRUModel, ConvolutionalArModel
+    if isinstance(ar, AudioGRUModel):
+        return GRUContext(eng, ar)
+    if isinstance(ar, ConvolutionalArModel):
+        return ConvArContext(eng, ar)
+    raise NotImplementedError(f"no HIP context network for {type(ar).__name__}")
 
 
 class GradAllReduce:

@@ -29,6 +29,7 @@ extern "C" {
 #define CPC_GEMM_FORCE_GENERIC 8 /* use the generic (any-shape) kernel even where the double-buffered fast path applies */
 #define CPC_GEMM_NARROW_EPI 32   /* NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A/B check) */
 #define CPC_GEMM_NO_DMA 64       /* NT fast path: register-staged global->LDS copies instead of LDS-DMA (A/B check) */
+#define CPC_GEMM_SKIP_PAD_ROWS 128 /* NT: rows with (m % c_rpi) >= c_valid are left untouched instead of zeroed */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
 int cpc_abi_version(void);
@@ -106,6 +107,17 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
                    int Lout_alloc, int nsplit, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
                     void* stream);
+
+/* ConvolutionalArBlock's MaxPool1d(pool, ceil_mode=True) over positions (audio_model.py:98-99) on channels-last
+ * activations [B][L_alloc][C], forward and backward (gradient to the first maximal element of each window). */
+int cpc_maxpool_fwd(const void* in, void* out, int B, int C, int pool, int Lin_valid, int Lin_alloc, int Lout_valid,
+                    int Lout_alloc, int dtype, void* stream);
+int cpc_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C, int pool, int Lin_valid, int Lin_alloc,
+                    int Lout_alloc, int dtype, void* stream);
+/* dy[b*item_stride + row_off + c] = y[...] > 0 ? dc[b][c] : 0 — the gradient entering the last ReLU of
+ * ConvolutionalArModel at the single position its forward returns (audio_model.py:161). */
+int cpc_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off,
+                     int dtype, void* stream);
 
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);

@@ -106,6 +106,22 @@ def gru_forward(z: torch.Tensor, params: Params, prefix: str = "autoregressive_m
     return (h, trace) if return_trace else h
 
 
+def conv_ar_forward(z: torch.Tensor, params: Params, kernel_sizes: Sequence[int], poolings: Sequence[int],
+                    prefix: str = "autoregressive_model.") -> torch.Tensor:
+    """ConvolutionalArModel.forward without batch norm / residual — audio_model.py:98-108 (block), :158-161 (model):
+    per block [MaxPool1d(pool, ceil_mode=True)] -> Conv1d(stride 1) -> ReLU; returns the last position (B, C_out)."""
+    x = z
+    for l, (k, pool) in enumerate(zip(kernel_sizes, poolings)):
+        idx = 0
+        if pool > 1:
+            x = F.max_pool1d(x, pool, ceil_mode=True)
+            idx = 1
+        w = params[f"{prefix}module_list.{l}.main_modules.{idx}.weight"]
+        b = params.get(f"{prefix}module_list.{l}.main_modules.{idx}.bias")
+        x = torch.relu(F.conv1d(x, w, b))
+    return x[:, :, -1]
+
+
 # ------------------------------------------------------------------------- CPC model
 def item_length(receptive_field: int, downsampling: int, visible_steps: int, prediction_steps: int) -> int:
     """audio_model.py:187-191."""
@@ -113,7 +129,7 @@ def item_length(receptive_field: int, downsampling: int, visible_steps: int, pre
 
 
 def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_steps: int,
-                strides: Sequence[int] = DEFAULT_STRIDES):
+                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None):
     """AudioPredictiveCodingModel.forward with AudioEncoder + AudioGRUModel — audio_model.py:193-211.
 
     Returns (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)); targets are NOT detached.
@@ -122,7 +138,10 @@ def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_
     K, V = prediction_steps, visible_steps
     targets = enc[:, :, -K:]
     z = enc[:, :, -(V + K):-K]
-    c = gru_forward(z, params)
+    if conv_ar is None:
+        c = gru_forward(z, params)
+    else:       # conv_ar = (kernel_sizes, poolings) of a ConvolutionalArModel
+        c = conv_ar_forward(z, params, conv_ar[0], conv_ar[1])
     w_p = params["prediction_model.weight"]
     predicted = (c @ w_p.t()).view(-1, K, enc.shape[1])
     return predicted, targets, z, c
@@ -211,7 +230,7 @@ class OracleTrainer:
 
     def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
                  strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
-                 all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4):
+                 all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None):
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
@@ -221,13 +240,14 @@ class OracleTrainer:
         self.all_timesteps = all_timesteps
         self.regularization = regularization
         self.lr = lr
+        self.conv_ar = conv_ar
         self.t = 0
 
     def loss_and_grads(self, batch: torch.Tensor):
         """batch (B, L) -> (loss, max_score, grads dict); does not update parameters."""
         for p in self.params.values():
             p.grad = None
-        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides)
+        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides, self.conv_ar)
         loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
         loss.backward()
         return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}

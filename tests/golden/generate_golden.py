@@ -18,6 +18,7 @@ Fixtures written (all float32 unless noted):
   validate.npz          ContrastiveEstimationTrainer.validate() outputs on a fixed set
   samplers.json         FileBatchSampler / DeterministicSampler index lists (integers)
   cfg1_trajectory.json  BASELINE config 1 (B=8, L=20480, 512 ch) loss for 5 train steps
+  conv_ar_model.npz     AudioEncoder + ConvolutionalArModel (k 9/9/9, pooling 1/2/2) forward, losses, gradients
 """
 import io
 import json
@@ -177,6 +178,67 @@ def gen_small_model():
     print("small_model: losses", [(r["score"], r["all_timesteps"], r["reg"], r["loss"][:2]) for r in meta["runs"]])
 
 
+# ------------------------------------------------------------------ conv-AR context model (BASELINE config 4 family)
+def gen_conv_ar():
+    C, H, K, V, B = 64, 64, 4, 60, 6
+    L = 465 + (V + K) * 160 + 23
+    ar_dict = {'kernel_sizes': [9, 9, 9], 'channel_count': [C, 64, 64, H], 'stride': [1, 1, 1], 'pooling': [1, 2, 2], 'bias': True,
+               'batch_norm': False, 'residual': False, 'activation_register': None, 'self_attention': [False] * 3}
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 2.0
+    for l, idx in enumerate([0, 1, 1]):
+        scale[f"autoregressive_model.module_list.{l}.main_modules.{idx}.weight"] = 1.5
+
+    def build():
+        torch.manual_seed(13)
+        enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        ar = ref_model.ConvolutionalArModel(ar_dict)
+        model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+        return model
+
+    out = {}
+    model = build()
+    for k, v in np_state(model).items():
+        out["param/" + k] = v
+    g = torch.Generator().manual_seed(6)
+    n_items = 18
+    data = torch.randn(n_items, L, generator=g) * 0.5
+    out["data"] = data.numpy()
+    with torch.no_grad():
+        pz, tg, z, c = model(data[:B].unsqueeze(1))
+        out["fwd/predicted_z"], out["fwd/targets"], out["fwd/z"], out["fwd/c"] = pz.numpy(), tg.numpy().copy(), z.numpy().copy(), c.numpy()
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "ar": {k: v for k, v in ar_dict.items() if k != 'activation_register'},
+            "runs": []}
+    rid = 0
+    for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
+                                                ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3),
+                                                ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4)):
+        model = build()
+        ds = TensorDataset(data)
+        logger = Logger()
+        with quiet():
+            tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                                                        score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H)
+            random.seed(55)
+            tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+        tag = f"run{rid}"
+        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+                             "python_seed": 55, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                             "loss": logger.loss_meter.values, "max_score": logger.score_meter.values})
+        if steps == 1:
+            for n, p in model.named_parameters():
+                out[f"{tag}/grad/{n}"] = p.grad.numpy().copy()
+        rid += 1
+    np.savez_compressed(os.path.join(OUT, "conv_ar_model.npz"), **out)
+    with open(os.path.join(OUT, "conv_ar_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("conv_ar:", [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]], "c mean", float(np.abs(out["fwd/c"]).mean()))
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -320,7 +382,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar"]
+    if "conv_ar" in which:
+        gen_conv_ar()
     if "small" in which:
         gen_small_model()
     if "encoder" in which:

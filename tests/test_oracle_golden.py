@@ -189,3 +189,29 @@ def test_cfg1_trajectory(golden_dir):
     for i in range(2):
         loss, _ = tr.step(data[batches[i]])
         assert abs(loss - run["loss"][i]) < 2e-5 * abs(run["loss"][i])
+
+
+def test_conv_ar_model(golden_dir):
+    """AudioEncoder + ConvolutionalArModel (no batch norm / residual): forward, losses and gradients vs the reference."""
+    g = _load(golden_dir, "conv_ar_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "conv_ar_model.json")))
+    p0 = _params(g)
+    conv_ar = (meta["ar"]["kernel_sizes"], meta["ar"]["pooling"])
+    data = torch.from_numpy(g["data"])
+    pz, tg, z, c = O.cpc_forward(data[:meta["B"]].unsqueeze(1), p0, meta["V"], meta["K"], conv_ar=conv_ar)
+    _close(c, g["fwd/c"], rtol=1e-4, atol=1e-5)
+    _close(pz, g["fwd/predicted_z"], rtol=1e-4, atol=1e-5)
+    for run in meta["runs"]:
+        tr = O.OracleTrainer(p0, meta["V"], meta["K"], score=run["score"], all_timesteps=run["all_timesteps"],
+                             regularization=run["reg"], lr=run["lr"], conv_ar=conv_ar)
+        for i, idx in enumerate(run["batches"]):
+            batch = data[idx]
+            if run["steps"] == 1:
+                loss, smax, grads = tr.loss_and_grads(batch)
+                for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                    name = k.split("/grad/")[1]
+                    ref = torch.from_numpy(g[k])
+                    scale = ref.abs().max().item() + 1e-12
+                    _close(grads[name] / scale, ref / scale, rtol=2e-4, atol=2e-5)
+            loss, smax = tr.step(batch)
+            assert abs(loss - run["loss"][i]) <= 5e-5 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
