@@ -189,9 +189,11 @@ class AudioPredictiveCodingModel(nn.Module):
         self._flat_grad = None
         self._param = {}
         self._grad = {}
-        if not isinstance(encoder, AudioEncoder) or not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel)):
-            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel / ConvolutionalArModel "
-                                      "(SURVEY.md section 8 rows a1-a5)")
+        from .attention_model import AttentionModel
+        if not isinstance(encoder, AudioEncoder) or \
+                not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel, AttentionModel)):
+            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel / ConvolutionalArModel / AttentionModel "
+                                      "(SURVEY.md section 8 rows a1-a6)")
 
     @property
     def item_length(self):

@@ -1,0 +1,331 @@
+// Kernels of the attention context network (AttentionModel, attention_model.py:38-82 with the vendored post-norm
+// TransformerEncoderLayer, transformer.py:223-272) that are not GEMMs: positional encoding, causal multi-head attention
+// for short sequences (<= 64 steps: the whole (item, head) problem lives in one workgroup's LDS), residual + LayerNorm,
+// mean over time.  All work on channels-last rows x[(b, t)][C]; arithmetic in f32, storage type T.
+#include "cpc_common.h"
+#include "cpc_kernels.h"
+
+namespace {
+
+constexpr int ATT_S = 64;       // max sequence length handled by the attention kernels
+constexpr int ATT_D = 64;       // max head dimension
+
+// x0[(b,t)][c] = z[b][t0+t][c] * scale + pe[t][c]      (PositionalEncoder.forward, attention_model.py:28-35)
+template <typename T>
+__global__ __launch_bounds__(256) void pe_scale_fwd_kernel(const T* __restrict__ top, const float* __restrict__ pe, T* __restrict__ x0,
+                                                           int B, int S, int C, long long item_stride, float scale) {
+    const int c4n = C / 4;
+    const long long total = (long long)B * S * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int t = (int)((idx / c4n) % S);
+        const int b = (int)(idx / ((long long)c4n * S));
+        const f32x4 v = load4(top + (long long)b * item_stride + (long long)t * C + c4 * 4);
+        const f32x4 p = *(const f32x4*)(pe + (long long)t * C + c4 * 4);
+        store4(x0 + ((long long)b * S + t) * C + c4 * 4, v * scale + p);
+    }
+}
+
+// dz[b][t0+t][c] = scale * (g1 + g2)[(b,t)][c]
+template <typename T>
+__global__ __launch_bounds__(256) void pe_scale_bwd_kernel(const T* __restrict__ g1, const T* __restrict__ g2, T* __restrict__ dtop,
+                                                           int B, int S, int C, long long item_stride, float scale) {
+    const int c4n = C / 4;
+    const long long total = (long long)B * S * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int t = (int)((idx / c4n) % S);
+        const int b = (int)(idx / ((long long)c4n * S));
+        const long long o = ((long long)b * S + t) * C + c4 * 4;
+        f32x4 v = load4(g1 + o);
+        if (g2) v += load4(g2 + o);
+        store4(dtop + (long long)b * item_stride + (long long)t * C + c4 * 4, v * scale);
+    }
+}
+
+// Causal multi-head self-attention for one (item, head) per workgroup.
+//   qkv [(b,t)][3C]: q | k | v column blocks, head h at columns h*d of each;   out [(b,t)][C];   P [(b*heads+h)][S][S]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ P, int S,
+                                                       int C, int heads, float scale) {
+    __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], p[ATT_S][ATT_S + 1];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
+    for (int idx = tid; idx < S * d; idx += 256) {
+        const int t = idx / d, c = idx % d;
+        const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
+        q[t][c] = to_f32(row[0]) * scale;
+        k[t][c] = to_f32(row[C]);
+        v[t][c] = to_f32(row[2 * C]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        float s = -INFINITY;
+        if (j <= i) {
+            s = 0.f;
+            for (int c = 0; c < d; ++c) s = fmaf(q[i][c], k[j][c], s);
+        }
+        p[i][j] = s;
+    }
+    __syncthreads();
+    if (tid < S) {
+        const int i = tid;
+        float mx = -INFINITY;
+        for (int j = 0; j <= i; ++j) mx = fmaxf(mx, p[i][j]);
+        float sum = 0.f;
+        for (int j = 0; j <= i; ++j) { const float e = expf(p[i][j] - mx); p[i][j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < S; ++j) p[i][j] = j <= i ? p[i][j] * inv : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * S; idx += 256) P[(long long)bh * S * S + idx] = from_f32<T>(p[idx / S][idx % S]);
+    for (int idx = tid; idx < S * d; idx += 256) {
+        const int i = idx / d, c = idx % d;
+        float o = 0.f;
+        for (int j = 0; j <= i; ++j) o = fmaf(p[i][j], v[j][c], o);
+        out[((long long)b * S + i) * C + h * d + c] = from_f32<T>(o);
+    }
+}
+
+// Backward: dqkv [(b,t)][3C] from dout [(b,t)][C], the saved P and qkv.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ P, const T* __restrict__ dout,
+                                                       T* __restrict__ dqkv, int S, int C, int heads, float scale) {
+    __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], go[ATT_S][ATT_D + 1];
+    __shared__ float p[ATT_S][ATT_S + 1], ds[ATT_S][ATT_S + 1];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
+    for (int idx = tid; idx < S * d; idx += 256) {
+        const int t = idx / d, c = idx % d;
+        const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
+        q[t][c] = to_f32(row[0]);
+        k[t][c] = to_f32(row[C]);
+        v[t][c] = to_f32(row[2 * C]);
+        go[t][c] = to_f32(dout[((long long)b * S + t) * C + h * d + c]);
+    }
+    for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] = to_f32(P[(long long)bh * S * S + idx]);
+    __syncthreads();
+    // dP[i][j] = sum_c dO[i][c] V[j][c]
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        float s = 0.f;
+        if (j <= i)
+            for (int c = 0; c < d; ++c) s = fmaf(go[i][c], v[j][c], s);
+        ds[i][j] = s;
+    }
+    __syncthreads();
+    if (tid < S) {
+        const int i = tid;
+        float dot = 0.f;
+        for (int j = 0; j <= i; ++j) dot = fmaf(ds[i][j], p[i][j], dot);
+        for (int j = 0; j < S; ++j) ds[i][j] = j <= i ? p[i][j] * (ds[i][j] - dot) * scale : 0.f;    // d (raw q.k score)
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * d; idx += 256) {
+        const int t = idx / d, c = idx % d;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j <= t; ++j) dq = fmaf(ds[t][j], k[j][c], dq);
+        for (int i = t; i < S; ++i) {
+            dk = fmaf(ds[i][t], q[i][c], dk);
+            dv = fmaf(p[i][t], go[i][c], dv);
+        }
+        T* row = dqkv + ((long long)b * S + t) * 3 * C + h * d + c;
+        row[0] = from_f32<T>(dq);
+        row[C] = from_f32<T>(dk);
+        row[2 * C] = from_f32<T>(dv);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// r = a + b (b may be null);  y = (r - mean) * rstd * w + bias   — one wave per row, torch.nn.LayerNorm (eps inside the sqrt)
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b2, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ r_out, T* __restrict__ y,
+                                                         float* __restrict__ stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4n = C / 4;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        float s1 = 0.f;
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            f32x4 v = load4(a + (long long)m * C + c4 * 4);
+            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+            if (r_out) store4(r_out + (long long)m * C + c4 * 4, v);
+            s1 += v[0] + v[1] + v[2] + v[3];
+        }
+        const float mean = wave_sum(s1) / (float)C;
+        float s2 = 0.f;
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            f32x4 v = load4(a + (long long)m * C + c4 * 4);
+            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s2 += (v[e] - mean) * (v[e] - mean);
+        }
+        const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+        if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            f32x4 v = load4(a + (long long)m * C + c4 * 4);
+            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+            const f32x4 wv = *(const f32x4*)(w + c4 * 4), bv = *(const f32x4*)(bias + c4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * wv[e] + bv[e];
+            store4(y + (long long)m * C + c4 * 4, o);
+        }
+    }
+}
+
+// LayerNorm backward.  dy = g1 (+ g2); with bcast > 0 the gradient row of m is g1[m / bcast] * gscale (mean over time).
+// dr = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * w.
+// Per-block partial sums of dw = sum dy * xhat and db = sum dy go to slabs[blk][2][C].
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ r,
+                                                     const float* __restrict__ stats, const float* __restrict__ w,
+                                                     T* __restrict__ dr, float* __restrict__ slabs, int M, int C, int bcast,
+                                                     float gscale) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4n = C / 4;
+    float* aw = acc + (long long)wave * 2 * C;
+    for (int i = lane; i < 2 * C; i += 64) aw[i] = 0.f;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+        const long long grow = bcast > 0 ? (long long)(m / bcast) * C : (long long)m * C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            f32x4 dy = load4(g1 + grow + c4 * 4) * gscale;
+            if (g2) dy += load4(g2 + (long long)m * C + c4 * 4);
+            const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
+            const f32x4 wv = *(const f32x4*)(w + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (rv[e] - mean) * rstd, dxh = dy[e] * wv[e];
+                s1 += dxh;
+                s2 += dxh * xh;
+                aw[c4 * 4 + e] += dy[e] * xh;
+                aw[C + c4 * 4 + e] += dy[e];
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            f32x4 dy = load4(g1 + grow + c4 * 4) * gscale;
+            if (g2) dy += load4(g2 + (long long)m * C + c4 * 4);
+            const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
+            const f32x4 wv = *(const f32x4*)(w + c4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (rv[e] - mean) * rstd;
+                o[e] = rstd * (dy[e] * wv[e] - m1 - xh * m2);
+            }
+            store4(dr + (long long)m * C + c4 * 4, o);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        slabs[(long long)blockIdx.x * 2 * C + i] = acc[i] + acc[2 * C + i] + acc[4 * C + i] + acc[6 * C + i];
+}
+
+// m[b][c] = (1/S) sum_t x[(b,t)][c]
+template <typename T>
+__global__ __launch_bounds__(256) void mean_time_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int S, int C) {
+    const int total = B * C;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int b = idx / C, c = idx % C;
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += to_f32(x[((long long)b * S + t) * C + c]);
+        out[idx] = from_f32<T>(s / (float)S);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32)     \
+    do {                                           \
+        if ((dtype) == CPC_DTYPE_BF16) { CALL_BF16; } \
+        else if ((dtype) == CPC_DTYPE_F32) { CALL_F32; } \
+        else return CPC_EINVAL;                    \
+    } while (0)
+
+int launch_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S, int C, long long item_stride, float scale,
+                        int dtype, hipStream_t st) {
+    if (B <= 0 || S <= 0 || C <= 0 || C % 4) return CPC_EINVAL;
+    const int blocks = (int)min((long long)2048, ((long long)B * S * (C / 4) + 255) / 256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((pe_scale_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)top, pe, (bf16_t*)x0, B, S, C, item_stride, scale),
+               hipLaunchKernelGGL((pe_scale_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)top, pe, (float*)x0, B, S, C, item_stride, scale));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
+                        int dtype, hipStream_t st) {
+    if (B <= 0 || S <= 0 || C <= 0 || C % 4) return CPC_EINVAL;
+    const int blocks = (int)min((long long)2048, ((long long)B * S * (C / 4) + 255) / 256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((pe_scale_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g1, (const bf16_t*)g2, (bf16_t*)dtop, B, S, C, item_stride, scale),
+               hipLaunchKernelGGL((pe_scale_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)g1, (const float*)g2, (float*)dtop, B, S, C, item_stride, scale));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool attn_ok(int B, int S, int C, int heads) {
+    return B > 0 && S > 0 && S <= ATT_S && heads > 0 && C % heads == 0 && C / heads <= ATT_D;
+}
+
+int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, hipStream_t st) {
+    if (!attn_ok(B, S, C, heads)) return CPC_EINVAL;
+    const float scale = 1.f / sqrtf((float)(C / heads));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)P, S, C, heads, scale),
+               hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (float*)out, (float*)P, S, C, heads, scale));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
+                    hipStream_t st) {
+    if (!attn_ok(B, S, C, heads)) return CPC_EINVAL;
+    const float scale = 1.f / sqrtf((float)(C / heads));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)P, (const bf16_t*)dout, (bf16_t*)dqkv, S, C, heads, scale),
+               hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (const float*)P, (const float*)dout, (float*)dqkv, S, C, heads, scale));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
+                      int C, float eps, int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C % 4 || !w || !bias) return CPC_EINVAL;
+    const int blocks = min(2048, (M + 3) / 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, w, bias, (bf16_t*)r_out, (bf16_t*)y, stats, M, C, eps),
+               hipLaunchKernelGGL((add_ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, w, bias, (float*)r_out, (float*)y, stats, M, C, eps));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
+                  int C, int bcast, float gscale, int nblocks, int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C % 4 || nblocks <= 0) return CPC_EINVAL;
+    const size_t shm = (size_t)4 * 2 * C * sizeof(float);
+    if (shm > 64 * 1024) return CPC_EINVAL;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(nblocks), dim3(256), shm, st, (const bf16_t*)g1, (const bf16_t*)g2, (const bf16_t*)r, stats, w, (bf16_t*)dr, slabs, M, C, bcast, gscale),
+               hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nblocks), dim3(256), shm, st, (const float*)g1, (const float*)g2, (const float*)r, stats, w, (float*)dr, slabs, M, C, bcast, gscale));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, hipStream_t st) {
+    if (B <= 0 || S <= 0 || C <= 0) return CPC_EINVAL;
+    const int blocks = min(1024, (B * C + 255) / 256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((mean_time_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, S, C),
+               hipLaunchKernelGGL((mean_time_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, B, S, C));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

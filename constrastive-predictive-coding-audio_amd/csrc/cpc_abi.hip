@@ -146,6 +146,46 @@ int cpc_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, lon
     return launch_relu_row_bwd(dc, y, dy, B, C, item_stride, row_off, dtype, (hipStream_t)stream);
 }
 
+int cpc_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S, int C, long long item_stride, float scale,
+                     int dtype, void* stream) {
+    if (!top || !pe || !x0) return CPC_EINVAL;
+    return launch_pe_scale_fwd(top, pe, x0, B, S, C, item_stride, scale, dtype, (hipStream_t)stream);
+}
+
+int cpc_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
+                     int dtype, void* stream) {
+    if (!g1 || !dtop) return CPC_EINVAL;
+    return launch_pe_scale_bwd(g1, g2, dtop, B, S, C, item_stride, scale, dtype, (hipStream_t)stream);
+}
+
+int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, void* stream) {
+    if (!qkv || !out || !P) return CPC_EINVAL;
+    return launch_attn_fwd(qkv, out, P, B, S, C, heads, dtype, (hipStream_t)stream);
+}
+
+int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
+                 void* stream) {
+    if (!qkv || !P || !dout || !dqkv) return CPC_EINVAL;
+    return launch_attn_bwd(qkv, P, dout, dqkv, B, S, C, heads, dtype, (hipStream_t)stream);
+}
+
+int cpc_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
+                   int C, float eps, int dtype, void* stream) {
+    if (!a || !y || !stats) return CPC_EINVAL;
+    return launch_add_ln_fwd(a, b, w, bias, r_out, y, stats, M, C, eps, dtype, (hipStream_t)stream);
+}
+
+int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
+               int C, int bcast, float gscale, int nblocks, int dtype, void* stream) {
+    if (!g1 || !r || !stats || !w || !dr || !slabs) return CPC_EINVAL;
+    return launch_ln_bwd(g1, g2, r, stats, w, dr, slabs, M, C, bcast, gscale, nblocks, dtype, (hipStream_t)stream);
+}
+
+int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream) {
+    if (!x || !out) return CPC_EINVAL;
+    return launch_mean_time(x, out, B, S, C, dtype, (hipStream_t)stream);
+}
+
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);

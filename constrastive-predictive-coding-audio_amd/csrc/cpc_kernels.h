@@ -79,3 +79,17 @@ int launch_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C
                        int Lout_alloc, int dtype, hipStream_t stream);
 int launch_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off, int dtype,
                         hipStream_t stream);
+
+// attention context network (attn.hip)
+int launch_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S, int C, long long item_stride, float scale,
+                        int dtype, hipStream_t stream);
+int launch_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
+                        int dtype, hipStream_t stream);
+int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, hipStream_t stream);
+int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
+                    hipStream_t stream);
+int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
+                      int C, float eps, int dtype, hipStream_t stream);
+int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
+                  int C, int bcast, float gscale, int nblocks, int dtype, hipStream_t stream);
+int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, hipStream_t stream);

@@ -231,6 +231,9 @@ class CPCEngine:
         pred = self.pred.view(self.B, K, self.E).float()
         targets = top[:, T - K:T, :].float().transpose(1, 2)
         z = top[:, T - K - V:T - K, :].float().transpose(1, 2)
+        zs = getattr(self.ctx, "z_scale", 1.0)       # AttentionModel rescales z in place (attention_model.py:30)
+        if zs != 1.0:
+            z = z * zs
         return pred, targets, z, self.ctx.c_float().clone()
 
     # ------------------------------------------------------------------------------------------ loss
@@ -326,7 +329,7 @@ class CPCEngine:
             self.dc.add_(add_dc)
         self.ctx.backward(self.dc)      # parameter gradients of the context network + dz into rows [t0, t0+V) of dtop
         if add_dz is not None:
-            dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2))
+            dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
         # encoder, top layer down to layer 2
         for l in range(n - 1, 0, -1):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
@@ -597,12 +600,187 @@ class ConvArContext:
                           self.pools[l], self.lo[l - 1], self.la[l - 1], la, code)
 
 
+class AttentionContext:
+    """AttentionModel as the context network (attention_model.py:38-82): positional encoding, ``num_layers`` post-norm
+    transformer encoder layers with a causal mask (transformer.py:262-271), a final LayerNorm, the mean over time and
+    ``end_layer``.  Rows are (item, step) with C channels; every Linear is a cpc_gemm_nt / cpc_gemm_tn call, the
+    per-(item, head) attention, the residual + LayerNorm and the mean are the kernels of csrc/attn.hip.
+    Dropout is not applied (p = 0 or eval mode only)."""
+
+    LN_EPS = 1e-5
+
+    def __init__(self, eng, ar):
+        self.eng = eng
+        self.C, self.N, self.heads, self.FF = ar.channels, ar.num_layers, ar.num_heads, ar.feedforward_size
+        self.out = ar.output_size
+        self.S = eng.V
+        self.ar = ar
+        if self.C != eng.E or self.out != eng.H:
+            raise ValueError("AttentionModel channels / output_size do not match enc_size / ar_size")
+        if self.S > ar.sequence_length:
+            raise ValueError("visible_steps exceeds the AttentionModel's sequence_length (positional table)")
+        if self.S > 64 or self.C % self.heads or self.C // self.heads > 64:
+            raise NotImplementedError("HIP attention kernel: visible_steps <= 64 and head size <= 64")
+        ch = 8 if eng.dt == torch.bfloat16 else 4
+        if self.C % 8 or self.FF % 8 or self.out % ch or self.C > 2048:
+            raise NotImplementedError("AttentionModel sizes must be multiples of 8 (channels <= 2048)")
+        self.z_scale = math.sqrt(self.C)
+        self.prefix = "autoregressive_model."
+
+    def _lname(self, l, what):
+        return f"{self.prefix}encoder.layers.{l}.{what}"
+
+    def allocate(self):
+        e = self.eng
+        B, dev, dt, f32 = e.B, e.device, e.dt, torch.float32
+        C, FF, S, N, H = self.C, self.FF, self.S, self.N, self.out
+        M = B * S
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+        self.pe = self.ar.positional_encoder.pe[:S, 0, :].detach().to(device=dev, dtype=f32).contiguous()
+        self.X = [new(M * C) for _ in range(N + 1)]
+        self.qkv = [new(M * 3 * C) for _ in range(N)]
+        self.P = [new(B * self.heads * S * S) for _ in range(N)]
+        self.att = [new(M * C) for _ in range(N)]
+        self.r1 = [new(M * C) for _ in range(N)]
+        self.x1 = [new(M * C) for _ in range(N)]
+        self.f1 = [new(M * FF) for _ in range(N)]
+        self.r2 = [new(M * C) for _ in range(N)]
+        self.st1 = [torch.empty(M * 2, device=dev, dtype=f32) for _ in range(N)]
+        self.st2 = [torch.empty(M * 2, device=dev, dtype=f32) for _ in range(N)]
+        self.stn = torch.empty(M * 2, device=dev, dtype=f32)
+        self.ytmp, self.xn = new(M * C), new(M * C)
+        self.mean, self.dmean = new(B * C), new(B * C)
+        self.c32 = torch.empty(B, H, device=dev, dtype=f32)
+        self.ct = self.c32 if dt == f32 else new(B * H)
+        self.dct = new(B * H)
+        # gradient scratch
+        self.gA, self.gB, self.gC, self.gD = new(M * C), new(M * C), new(M * C), new(M * C)
+        self.dqkv, self.df1, self.datt = new(M * 3 * C), new(M * FF), new(M * C)
+        # weight operands in the storage dtype: [out][in] for the forward GEMMs, [in][out] for the data gradients
+        shapes = {"in": (3 * C, C), "o": (C, C), "l1": (FF, C), "l2": (C, FF)}
+        self.w = [{k: new(r * c) for k, (r, c) in shapes.items()} for _ in range(N)]
+        self.wt = [{k: new(r * c) for k, (r, c) in shapes.items()} for _ in range(N)]
+        self.w_end, self.w_end_t = new(H * C), new(C * H)
+        self.ln_blocks = max(1, min(256, M // 16))
+        self.split = {k: e._pick_split(r, c, M) for k, (r, c) in shapes.items()}
+
+    def slab_floats(self):
+        C, FF = self.C, self.FF
+        shapes = {"in": 3 * C * C, "o": C * C, "l1": FF * C, "l2": C * FF}
+        return max([self.split[k] * n for k, n in shapes.items()] + [self.ln_blocks * 2 * C,
+                                                                     self.eng.colsum_blocks * max(3 * C, FF)])
+
+    _WNAMES = {"in": "self_attn.in_proj_weight", "o": "self_attn.out_proj.weight", "l1": "linear1.weight", "l2": "linear2.weight"}
+    _BNAMES = {"in": "self_attn.in_proj_bias", "o": "self_attn.out_proj.bias", "l1": "linear1.bias", "l2": "linear2.bias"}
+
+    def prepare_weights(self):
+        e = self.eng
+        p, code, C, FF, H = e.model._param, e.code, self.C, self.FF, self.out
+        shapes = {"in": (3 * C, C), "o": (C, C), "l1": (FF, C), "l2": (C, FF)}
+        for l in range(self.N):
+            for k, (r, c) in shapes.items():
+                src = _hip.ptr(p[self._lname(l, self._WNAMES[k])])
+                _hip.call("cpc_cast2d", src, _hip.ptr(self.w[l][k]), r, c, c, 1, code)
+                _hip.call("cpc_cast2d", src, _hip.ptr(self.wt[l][k]), c, r, 1, c, code)
+        src = _hip.ptr(p[self.prefix + "end_layer.weight"])
+        _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end), H, C, C, 1, code)
+        _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end_t), C, H, 1, C, code)
+
+    def _ln(self, a, b, wname, r_out, y, stats):
+        p = self.eng.model._param
+        _hip.call("cpc_add_ln_fwd", _hip.ptr(a), _hip.ptr(b), _hip.ptr(p[wname + ".weight"]), _hip.ptr(p[wname + ".bias"]),
+                  _hip.ptr(r_out), _hip.ptr(y), _hip.ptr(stats), self.eng.B * self.S, self.C, self.LN_EPS, self.eng.code)
+
+    def forward(self):
+        e = self.eng
+        p, code, B = e.model._param, e.code, e.B
+        C, FF, S, H = self.C, self.FF, self.S, self.out
+        M = B * S
+        Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
+        P = _hip.ptr
+        if self.ar.dropout > 0.0 and self.ar.training:
+            raise NotImplementedError("AttentionModel dropout is not part of the HIP path yet: use dropout 0 or model.eval()")
+        _hip.call("cpc_pe_scale_fwd", P(e.act[-1], t0 * C), P(self.pe), P(self.X[0]), B, S, C, Ltop * C, self.z_scale, code)
+        for l in range(self.N):
+            X, w = self.X[l], self.w[l]
+            bias = {k: P(p[self._lname(l, n)]) for k, n in self._BNAMES.items()}
+            _hip.gemm_nt(P(X), P(w["in"]), P(self.qkv[l]), M, 3 * C, C, C, C, 3 * C, code, bias=bias["in"])
+            _hip.call("cpc_attn_fwd", P(self.qkv[l]), P(self.att[l]), P(self.P[l]), B, S, C, self.heads, code)
+            _hip.gemm_nt(P(self.att[l]), P(w["o"]), P(self.ytmp), M, C, C, C, C, C, code, bias=bias["o"])
+            self._ln(X, self.ytmp, self._lname(l, "norm1"), self.r1[l], self.x1[l], self.st1[l])
+            _hip.gemm_nt(P(self.x1[l]), P(w["l1"]), P(self.f1[l]), M, FF, C, C, C, FF, code, bias=bias["l1"], flags=_hip.GEMM_RELU)
+            _hip.gemm_nt(P(self.f1[l]), P(w["l2"]), P(self.ytmp), M, C, FF, FF, FF, C, code, bias=bias["l2"])
+            self._ln(self.x1[l], self.ytmp, self._lname(l, "norm2"), self.r2[l], self.X[l + 1], self.st2[l])
+        self._ln(self.X[self.N], None, self.prefix + "encoder.norm", None, self.xn, self.stn)
+        _hip.call("cpc_mean_time", P(self.xn), P(self.mean), B, S, C, code)
+        b_end = P(p[self.prefix + "end_layer.bias"])
+        _hip.gemm_nt(P(self.mean), P(self.w_end), P(self.c32), B, H, C, C, C, H, code, bias=b_end, flags=_hip.GEMM_OUT_F32)
+        if self.ct is not self.c32:
+            _hip.gemm_nt(P(self.mean), P(self.w_end), P(self.ct), B, H, C, C, C, H, code, bias=b_end)
+
+    def c_operand(self):
+        return self.ct, 0, self.out
+
+    def c_float(self):
+        return self.c32
+
+    def _ln_bwd(self, g1, g2, r, stats, wname, dr, bcast=0, gscale=1.0):
+        e, C = self.eng, self.C
+        g, p = e.model._grad, e.model._param
+        nb = self.ln_blocks
+        _hip.call("cpc_ln_bwd", _hip.ptr(g1), _hip.ptr(g2), _hip.ptr(r), _hip.ptr(stats), _hip.ptr(p[wname + ".weight"]),
+                  _hip.ptr(dr), _hip.ptr(e.slabs), e.B * self.S, C, bcast, gscale, nb, e.code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[wname + ".weight"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, C), _hip.ptr(g[wname + ".bias"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
+
+    def backward(self, dc):
+        e = self.eng
+        g, code, B = e.model._grad, e.code, e.B
+        C, FF, S, H = self.C, self.FF, self.S, self.out
+        M = B * S
+        Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
+        P = _hip.ptr
+        # end_layer and the mean over time
+        _hip.call("cpc_cast2d", P(dc), P(self.dct), B, H, H, 1, code)
+        _hip.gemm_tn(P(self.dct), P(self.mean), P(g[self.prefix + "end_layer.weight"]), B, H, C, H, C, C, code, flags=_hip.GEMM_OUT_F32)
+        e._colsum_to_grad(P(self.dct), g[self.prefix + "end_layer.bias"], B, H)
+        _hip.gemm_nt(P(self.dct), P(self.w_end_t), P(self.dmean), B, C, H, H, H, C, code)
+        self._ln_bwd(self.dmean, None, self.X[self.N], self.stn, self.prefix + "encoder.norm", self.gA, bcast=S, gscale=1.0 / S)
+        g1, g2 = self.gA, None
+        for l in range(self.N - 1, -1, -1):
+            wt = self.wt[l]
+            gname = lambda k, names: g[self._lname(l, names[k])]
+            # norm2 over r2 = x1 + f2
+            self._ln_bwd(g1, g2, self.r2[l], self.st2[l], self._lname(l, "norm2"), self.gB)
+            e._colsum_to_grad(P(self.gB), gname("l2", self._BNAMES), M, C)
+            e._tn_to_grad(P(self.gB), P(self.f1[l]), gname("l2", self._WNAMES), M, C, FF, C, FF, self.split["l2"])
+            _hip.gemm_nt(P(self.gB), P(wt["l2"]), P(self.df1), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
+            e._colsum_to_grad(P(self.df1), gname("l1", self._BNAMES), M, FF)
+            e._tn_to_grad(P(self.df1), P(self.x1[l]), gname("l1", self._WNAMES), M, FF, C, FF, C, self.split["l1"])
+            _hip.gemm_nt(P(self.df1), P(wt["l1"]), P(self.gC), M, C, FF, FF, FF, C, code)
+            # norm1 over r1 = x + attention output projection
+            self._ln_bwd(self.gB, self.gC, self.r1[l], self.st1[l], self._lname(l, "norm1"), self.gA)
+            e._colsum_to_grad(P(self.gA), gname("o", self._BNAMES), M, C)
+            e._tn_to_grad(P(self.gA), P(self.att[l]), gname("o", self._WNAMES), M, C, C, C, C, self.split["o"])
+            _hip.gemm_nt(P(self.gA), P(wt["o"]), P(self.datt), M, C, C, C, C, C, code)
+            _hip.call("cpc_attn_bwd", P(self.qkv[l]), P(self.P[l]), P(self.datt), P(self.dqkv), B, S, C, self.heads, code)
+            e._colsum_to_grad(P(self.dqkv), gname("in", self._BNAMES), M, 3 * C)
+            e._tn_to_grad(P(self.dqkv), P(self.X[l]), gname("in", self._WNAMES), M, 3 * C, C, 3 * C, C, self.split["in"])
+            _hip.gemm_nt(P(self.dqkv), P(wt["in"]), P(self.gD), M, C, 3 * C, 3 * C, 3 * C, C, code)
+            g1, g2 = self.gA, self.gD
+        # positional encoder: dz = sqrt(C) * dx0 into rows [t0, t0+V) of the encoder's top-layer gradient
+        _hip.call("cpc_pe_scale_bwd", P(g1), P(g2), P(e.dact[-1], t0 * C), B, S, C, Ltop * C, self.z_scale, code)
+
+
 def make_context(eng, ar):
     from .audio_model import AudioGRUModel, ConvolutionalArModel
     if isinstance(ar, AudioGRUModel):
         return GRUContext(eng, ar)
     if isinstance(ar, ConvolutionalArModel):
         return ConvArContext(eng, ar)
+    from .attention_model import AttentionModel
+    if isinstance(ar, AttentionModel):
+        return AttentionContext(eng, ar)
     raise NotImplementedError(f"no HIP context network for {type(ar).__name__}")
 
 

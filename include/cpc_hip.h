@@ -119,6 +119,33 @@ int cpc_maxpool_bwd(const void* in, const void* dout, void* din, int B, int C, i
 int cpc_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, long long item_stride, long long row_off,
                      int dtype, void* stream);
 
+/* ---- AttentionModel as the context network (attention_model.py:38-82; layers: transformer.py:223-272) ----
+ * Everything works on channels-last rows x[(b,t)][C], t < S.  The linear maps are cpc_gemm_nt / cpc_gemm_tn calls.
+ *
+ * PositionalEncoder.forward (attention_model.py:28-35): x0[(b,t)] = top[b*item_stride + t*C ...] * scale + pe[t]
+ * (pe f32 [S][C]); its backward writes scale * (g1 + g2) (g2 may be NULL) into the same rows of dtop. */
+int cpc_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S, int C, long long item_stride, float scale,
+                     int dtype, void* stream);
+int cpc_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
+                     int dtype, void* stream);
+/* nn.MultiheadAttention core with the causal mask of attention_model.py:61-63, one (item, head) per workgroup:
+ *   qkv T [(b,t)][3C] (q | k | v, head h at columns h*C/heads);  out T [(b,t)][C];  P T [B*heads][S][S] softmax rows (saved).
+ * Limits: S <= 64, C/heads <= 64 (-EINVAL otherwise).  The backward gives dqkv in the layout of qkv. */
+int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, void* stream);
+int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
+                 void* stream);
+/* r = a + b (b may be NULL; r_out may be NULL), y = LayerNorm(r) * w + bias (transformer.py:262-271, eps inside the sqrt);
+ * stats f32 [M][2] = (mean, rstd) saved for the backward. */
+int cpc_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
+                   int C, float eps, int dtype, void* stream);
+/* LayerNorm backward: dy = g1 * gscale (+ g2); with bcast > 0 row m reads g1 row m / bcast (the mean over time of
+ * attention_model.py:79 folded in, gscale = 1/S).  dr = gradient of r; slabs f32 [nblocks][2][C] hold per-block partial
+ * sums of (dw, dbias), to be summed by cpc_reduce_slabs.  C*32 bytes of LDS must fit 64 KB. */
+int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
+               int C, int bcast, float gscale, int nblocks, int dtype, void* stream);
+/* out[b][c] = mean_t x[(b,t)][c]  (attention_model.py:79) */
+int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream);
+
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);
 /* MFMA fragment order of a [R][Kd] operand (transpose: logical[n][k] = src[k*ld + n]) for the GRU kernels. */

@@ -122,6 +122,57 @@ def conv_ar_forward(z: torch.Tensor, params: Params, kernel_sizes: Sequence[int]
     return x[:, :, -1]
 
 
+def positional_encoding(max_len: int, channels: int, max_wavelength: float = 10000.0) -> torch.Tensor:
+    """The constant table of PositionalEncoder.__init__ — attention_model.py:17-25 (note the exponent 2i/C with i the
+    even channel index itself, and the pi factor).  Returns (max_len, channels) float32."""
+    import math
+    pe = torch.zeros(max_len, channels)
+    for pos in range(max_len):
+        for i in range(0, channels, 2):
+            a = math.pi * pos / (max_wavelength ** ((2 * i) / channels))
+            pe[pos, i] = math.sin(a)
+            pe[pos, i + 1] = math.cos(a)
+    return pe
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def attention_forward(z: torch.Tensor, params: Params, num_layers: int, num_heads: int,
+                      prefix: str = "autoregressive_model."):
+    """AttentionModel.forward in eval mode / dropout 0 — attention_model.py:59-82, with the post-norm encoder layer of
+    transformer.py:262-271 (self-attention + residual + LayerNorm, Linear-ReLU-Linear + residual + LayerNorm), the final
+    LayerNorm of TransformerEncoder (transformer.py:167-168), the mean over time and end_layer.
+
+    z (B, C, S).  Returns (c (B, out), z * sqrt(C)): PositionalEncoder multiplies its input IN PLACE
+    (attention_model.py:30), and that input is a view of the z the model returns, so the returned z is the scaled one."""
+    import math
+    B, C, S = z.shape
+    d = C // num_heads
+    z_scaled = z * math.sqrt(C)
+    x = z_scaled.permute(2, 0, 1) + positional_encoding(S, C).unsqueeze(1)          # (S, B, C)
+    mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
+    for l in range(num_layers):
+        pl = f"{prefix}encoder.layers.{l}."
+        qkv = x @ params[pl + "self_attn.in_proj_weight"].t() + params[pl + "self_attn.in_proj_bias"]
+        q, k, v = (t.reshape(S, B * num_heads, d).transpose(0, 1) for t in qkv.split(C, dim=-1))   # (B*h, S, d)
+        scores = (q * d ** -0.5) @ k.transpose(1, 2) + mask
+        o = torch.softmax(scores, dim=-1) @ v                                          # (B*h, S, d)
+        o = o.transpose(0, 1).reshape(S, B, C)
+        y = o @ params[pl + "self_attn.out_proj.weight"].t() + params[pl + "self_attn.out_proj.bias"]
+        x = layer_norm(x + y, params[pl + "norm1.weight"], params[pl + "norm1.bias"])
+        f = torch.relu(x @ params[pl + "linear1.weight"].t() + params[pl + "linear1.bias"])
+        f = f @ params[pl + "linear2.weight"].t() + params[pl + "linear2.bias"]
+        x = layer_norm(x + f, params[pl + "norm2.weight"], params[pl + "norm2.bias"])
+    x = layer_norm(x, params[prefix + "encoder.norm.weight"], params[prefix + "encoder.norm.bias"])
+    m = x.sum(0) / S
+    c = m @ params[prefix + "end_layer.weight"].t() + params[prefix + "end_layer.bias"]
+    return c, z_scaled
+
+
 # ------------------------------------------------------------------------- CPC model
 def item_length(receptive_field: int, downsampling: int, visible_steps: int, prediction_steps: int) -> int:
     """audio_model.py:187-191."""
@@ -129,8 +180,9 @@ def item_length(receptive_field: int, downsampling: int, visible_steps: int, pre
 
 
 def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_steps: int,
-                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None):
+                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None, attention=None):
     """AudioPredictiveCodingModel.forward with AudioEncoder + AudioGRUModel — audio_model.py:193-211.
+    conv_ar = (kernel_sizes, poolings) selects ConvolutionalArModel, attention = (num_layers, num_heads) AttentionModel.
 
     Returns (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)); targets are NOT detached.
     """
@@ -138,7 +190,9 @@ def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_
     K, V = prediction_steps, visible_steps
     targets = enc[:, :, -K:]
     z = enc[:, :, -(V + K):-K]
-    if conv_ar is None:
+    if attention is not None:
+        c, z = attention_forward(z, params, attention[0], attention[1])
+    elif conv_ar is None:
         c = gru_forward(z, params)
     else:       # conv_ar = (kernel_sizes, poolings) of a ConvolutionalArModel
         c = conv_ar_forward(z, params, conv_ar[0], conv_ar[1])
@@ -230,7 +284,8 @@ class OracleTrainer:
 
     def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
                  strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
-                 all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None):
+                 all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None,
+                 attention=None):
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
@@ -241,13 +296,14 @@ class OracleTrainer:
         self.regularization = regularization
         self.lr = lr
         self.conv_ar = conv_ar
+        self.attention = attention
         self.t = 0
 
     def loss_and_grads(self, batch: torch.Tensor):
         """batch (B, L) -> (loss, max_score, grads dict); does not update parameters."""
         for p in self.params.values():
             p.grad = None
-        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides, self.conv_ar)
+        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides, self.conv_ar, self.attention)
         loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
         loss.backward()
         return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}

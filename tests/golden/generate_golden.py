@@ -19,6 +19,7 @@ Fixtures written (all float32 unless noted):
   samplers.json         FileBatchSampler / DeterministicSampler index lists (integers)
   cfg1_trajectory.json  BASELINE config 1 (B=8, L=20480, 512 ch) loss for 5 train steps
   conv_ar_model.npz     AudioEncoder + ConvolutionalArModel (k 9/9/9, pooling 1/2/2) forward, losses, gradients
+  attention_model.npz   AudioEncoder + AttentionModel (2 layers, 8 heads, dropout 0) forward, losses, gradients
 """
 import io
 import json
@@ -239,6 +240,73 @@ def gen_conv_ar():
     print("conv_ar:", [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]], "c mean", float(np.abs(out["fwd/c"]).mean()))
 
 
+def gen_attention():
+    from attention_model import AttentionModel
+    C, H, K, V, B, layers, heads, ff = 64, 48, 4, 60, 6, 2, 8, 96
+    L = 465 + (V + K) * 160 + 11
+    ar_dict = {'channels': C, 'num_layers': layers, 'num_heads': heads, 'feedforward_size': ff, 'dropout': 0.0,
+               'sequence_length': V, 'output_size': H}
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 1.0
+    scale["autoregressive_model.end_layer.weight"] = 1.5
+
+    def build():
+        torch.manual_seed(17)
+        enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        ar = AttentionModel(ar_dict)
+        model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K)
+        g = torch.Generator().manual_seed(23)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+                if n.startswith("autoregressive_model."):      # the default init (LayerNorm 1/0, zero attention biases; every
+                    if ".norm" in n and n.endswith("weight"):  # layer a deep copy of the first) would hide mix-ups
+                        p.add_(0.3 * torch.randn(p.shape, generator=g))
+                    elif n.endswith("bias"):
+                        p.add_(0.2 * torch.randn(p.shape, generator=g))
+                    elif "encoder.layers" in n:
+                        p.mul_(1.0 + 0.5 * torch.rand(p.shape, generator=g))
+        return model
+
+    out = {}
+    model = build()
+    for k, v in np_state(model).items():
+        out["param/" + k] = v
+    g = torch.Generator().manual_seed(8)
+    n_items = 18
+    data = torch.randn(n_items, L, generator=g) * 0.5
+    out["data"] = data.numpy()
+    with torch.no_grad():
+        pz, tg, z, c = model(data[:B].unsqueeze(1))
+        out["fwd/predicted_z"], out["fwd/targets"], out["fwd/z"], out["fwd/c"] = pz.numpy(), tg.numpy().copy(), z.numpy().copy(), c.numpy()
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "ar": ar_dict, "runs": []}
+    rid = 0
+    for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
+                                                ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3),
+                                                ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4)):
+        model = build()
+        ds = TensorDataset(data)
+        logger = Logger()
+        with quiet():
+            tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                                                        score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H)
+            random.seed(77)
+            tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+        tag = f"run{rid}"
+        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+                             "python_seed": 77, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                             "loss": logger.loss_meter.values, "max_score": logger.score_meter.values})
+        if steps == 1:
+            for n, p in model.named_parameters():
+                out[f"{tag}/grad/{n}"] = p.grad.numpy().copy()
+        rid += 1
+    np.savez_compressed(os.path.join(OUT, "attention_model.npz"), **out)
+    with open(os.path.join(OUT, "attention_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("attention:", [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]], "c mean", float(np.abs(out["fwd/c"]).mean()))
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -382,7 +450,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention"]
+    if "attention" in which:
+        gen_attention()
     if "conv_ar" in which:
         gen_conv_ar()
     if "small" in which:

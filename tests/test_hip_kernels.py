@@ -440,3 +440,103 @@ def test_unsupported_shapes_fail_loudly():
     a = torch.zeros(64, 12, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(_hip.HipCallError):
         _hip.gemm_nt(_hip.ptr(a), _hip.ptr(a), _hip.ptr(a), 64, 64, 12, 12, 12, 64, _hip.BF16)   # K % 8 != 0
+
+
+# --------------------------------------------------------------------------------------- attention context kernels
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,S,C,heads", [(3, 60, 64, 8), (2, 64, 128, 2), (5, 7, 32, 4)])
+def test_attention_fwd_bwd(dt, B, S, C, heads):
+    """cpc_attn_fwd / cpc_attn_bwd vs autograd of the definition (causal softmax(q k^T / sqrt(d)) v per head)."""
+    g = torch.Generator().manual_seed(S * 3 + C)
+    d = C // heads
+    qkv = rounded(torch.randn(B * S, 3 * C, generator=g), dt).requires_grad_(True)
+    dout = rounded(torch.randn(B * S, C, generator=g), dt)
+    q, k, v = (t.reshape(B, S, heads, d).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(d) + torch.triu(torch.full((S, S), float("-inf"), dtype=torch.double), 1)
+    P = torch.softmax(sc, -1)
+    out = (P @ v).permute(0, 2, 1, 3).reshape(B * S, C)
+    out.backward(dout)
+    code = _hip.dtype_code(dt)
+    d_qkv, d_dout = dev(qkv.detach().float(), dt), dev(dout.float(), dt)
+    o = torch.full((B * S, C), float("nan"), device=DEV, dtype=dt)
+    Pd = torch.full((B * heads, S, S), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_attn_fwd", _hip.ptr(d_qkv), _hip.ptr(o), _hip.ptr(Pd), B, S, C, heads, code)
+    assert rel_err(o, out) < tol(dt)
+    assert rel_err(Pd, P.reshape(B * heads, S, S)) < tol(dt)
+    dq = torch.full((B * S, 3 * C), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_attn_bwd", _hip.ptr(d_qkv), _hip.ptr(Pd), _hip.ptr(d_dout), _hip.ptr(dq), B, S, C, heads, code)
+    assert rel_err(dq, qkv.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
+
+
+def test_attention_unsupported_shapes():
+    x = torch.zeros(16, device=DEV)
+    p = _hip.ptr(x)
+    for B, S, C, heads in ((1, 65, 64, 8), (1, 8, 256, 2), (1, 8, 60, 8)):
+        with pytest.raises(_hip.HipCallError):
+            _hip.call("cpc_attn_fwd", p, p, p, B, S, C, heads, 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,C,bcast", [(180, 64, 0), (37, 512, 0), (120, 96, 60)])
+def test_add_layernorm_fwd_bwd(dt, M, C, bcast):
+    """cpc_add_ln_fwd / cpc_ln_bwd vs autograd of F.layer_norm(a + b); with bcast the incoming gradient is a per-item row
+    scaled by 1/bcast (the mean over time folded into the final norm's backward)."""
+    g = torch.Generator().manual_seed(M + C)
+    a = rounded(torch.randn(M, C, generator=g), dt).requires_grad_(True)
+    b = rounded(torch.randn(M, C, generator=g) * 0.5, dt)
+    w = (1 + 0.3 * torch.randn(C, generator=g)).double().requires_grad_(True)
+    bias = (0.2 * torch.randn(C, generator=g)).double().requires_grad_(True)
+    code = _hip.dtype_code(dt)
+    y_ref = F.layer_norm(a + b, (C,), w, bias, 1e-5)
+    if bcast:
+        gm = rounded(torch.randn(M // bcast, C, generator=g), dt)
+        dy = gm.repeat_interleave(bcast, 0) / bcast
+        g1, g2 = gm, None
+    else:
+        g1 = rounded(torch.randn(M, C, generator=g), dt)
+        g2 = rounded(torch.randn(M, C, generator=g), dt)
+        dy = g1 + g2
+    y_ref.backward(dy)
+    da, db, dw, dbias = dev(a.detach().float(), dt), dev(b.float(), dt), dev(w.detach().float()), dev(bias.detach().float())
+    r = torch.full((M, C), float("nan"), device=DEV, dtype=dt)
+    y = torch.full((M, C), float("nan"), device=DEV, dtype=dt)
+    stats = torch.full((M, 2), float("nan"), device=DEV)
+    _hip.call("cpc_add_ln_fwd", _hip.ptr(da), _hip.ptr(db), _hip.ptr(dw), _hip.ptr(dbias), _hip.ptr(r), _hip.ptr(y), _hip.ptr(stats),
+              M, C, 1e-5, code)
+    assert rel_err(y, y_ref) < tol(dt)
+    assert rel_err(r, a.detach() + b) < tol(dt)
+    nb = 5
+    slabs = torch.full((nb, 2, C), float("nan"), device=DEV)
+    dr = torch.full((M, C), float("nan"), device=DEV, dtype=dt)
+    dg1, dg2 = dev(g1.float(), dt), (dev(g2.float(), dt) if g2 is not None else None)
+    _hip.call("cpc_ln_bwd", _hip.ptr(dg1), _hip.ptr(dg2), _hip.ptr(r), _hip.ptr(stats), _hip.ptr(dw), _hip.ptr(dr), _hip.ptr(slabs),
+              M, C, bcast, (1.0 / bcast) if bcast else 1.0, nb, code)
+    t = 1e-4 if dt == torch.float32 else 2.5e-2
+    assert rel_err(dr, a.grad) < t
+    assert rel_err(slabs.sum(0)[0], w.grad) < t
+    assert rel_err(slabs.sum(0)[1], bias.grad) < t
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_positional_scale_and_time_mean(dt):
+    B, S, C, Ltop, t0 = 3, 11, 32, 20, 4
+    g = torch.Generator().manual_seed(2)
+    top = rounded(torch.randn(B, Ltop, C, generator=g), dt)
+    pe = O.positional_encoding(S, C)
+    code = _hip.dtype_code(dt)
+    d_top = dev(top.float(), dt)
+    x0 = torch.full((B * S, C), float("nan"), device=DEV, dtype=dt)
+    scale = math.sqrt(C)
+    _hip.call("cpc_pe_scale_fwd", _hip.ptr(d_top, t0 * C), _hip.ptr(dev(pe)), _hip.ptr(x0), B, S, C, Ltop * C, scale, code)
+    ref = (top[:, t0:t0 + S] * scale + pe.double()).reshape(B * S, C)
+    assert rel_err(x0, ref) < tol(dt)
+    g1 = rounded(torch.randn(B * S, C, generator=g), dt)
+    g2 = rounded(torch.randn(B * S, C, generator=g), dt)
+    dtop = torch.zeros(B, Ltop, C, device=DEV, dtype=dt)
+    d1, d2 = dev(g1.float(), dt), dev(g2.float(), dt)
+    _hip.call("cpc_pe_scale_bwd", _hip.ptr(d1), _hip.ptr(d2), _hip.ptr(dtop, t0 * C), B, S, C, Ltop * C, scale, code)
+    assert rel_err(dtop[:, t0:t0 + S], ((g1 + g2) * scale).reshape(B, S, C)) < tol(dt)
+    assert dtop[:, :t0].abs().max().item() == 0 and dtop[:, t0 + S:].abs().max().item() == 0
+    m = torch.full((B, C), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_mean_time", _hip.ptr(x0), _hip.ptr(m), B, S, C, code)
+    assert rel_err(m, x0.double().cpu().reshape(B, S, C).mean(1)) < tol(dt)

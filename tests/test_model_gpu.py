@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 from cpc_audio_amd.audio_dataset import TensorAudioDataset, SyntheticAudioDataset  # noqa: E402
 from cpc_audio_amd.audio_model import AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel, ConvolutionalArModel  # noqa: E402
+from cpc_audio_amd.attention_model import AttentionModel  # noqa: E402
 from cpc_audio_amd.contrastive_estimation_training import (ContrastiveEstimationTrainer, linear_score_function,  # noqa: E402
                                                            softplus_score_function)
 from oracle import cpc_oracle as O  # noqa: E402
@@ -341,3 +342,79 @@ def test_conv_ar_model_matches_reference(golden_dir, dtype):
                 ref = torch.from_numpy(g[k]).double()
                 l2 = ((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
                 assert l2 < (1e-3 if dtype == "fp32" else 0.12), (run["tag"], name, l2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_attention_model_matches_reference(golden_dir, dtype):
+    """AttentionModel (2 layers, 8 heads, dropout 0) as the context network — forward outputs (z is returned scaled by
+    sqrt(C), the reference's in-place multiply), trainer losses and all parameter gradients vs fixtures from the reference."""
+    g = _load(golden_dir, "attention_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    C, H, K, V, B = meta["C"], meta["H"], meta["K"], meta["V"], meta["B"]
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+
+    def build():
+        enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        model = AudioPredictiveCodingModel(enc, AttentionModel(meta["ar"]), enc_size=C, ar_size=H, visible_steps=V,
+                                           prediction_steps=K, compute_dtype=dtype)
+        assert list(model.state_dict().keys()) == list(state.keys())
+        assert torch.equal(model.state_dict()["autoregressive_model.positional_encoder.pe"],
+                           state["autoregressive_model.positional_encoder.pe"])
+        model.load_state_dict(state)
+        return model.to(DEV)
+
+    data = torch.from_numpy(g["data"])
+    tol = 2e-4 if dtype == "fp32" else 4e-2
+    model = build()
+    with torch.no_grad():
+        pz, tg, z, c = model(data[:B].unsqueeze(1).to(DEV))
+    assert _rel(z, g["fwd/z"]) < tol and _rel(tg, g["fwd/targets"]) < tol
+    assert _rel(c, g["fwd/c"]) < tol and _rel(pz, g["fwd/predicted_z"]) < tol
+    for run in meta["runs"]:
+        model = build()
+        ds = TensorAudioDataset(data, device=DEV)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                          score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                          prediction_steps=K, ar_size=H)
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=B, epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+        ltol = 1e-4 if dtype == "fp32" else 2e-2
+        for i in range(run["steps"]):
+            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= ltol * abs(run["loss"][i]) * (1 + 4 * i), (run["tag"], i)
+        if run["steps"] == 1:
+            for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                name = k.split("/grad/")[1]
+                got = dict(model.named_parameters())[name].grad
+                ref = torch.from_numpy(g[k]).double()
+                l2 = ((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+                assert l2 < (1e-3 if dtype == "fp32" else 0.12), (run["tag"], name, l2)
+
+
+def test_attention_model_autograd_bridge(golden_dir):
+    """model(x) with AttentionModel is autograd-connected: gradients of a loss that also touches z (returned scaled) match
+    the oracle's."""
+    g = _load(golden_dir, "attention_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    C, H, K, V, B = meta["C"], meta["H"], meta["K"], meta["V"], meta["B"]
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, AttentionModel(meta["ar"]), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K,
+                                       compute_dtype="fp32")
+    model.load_state_dict(state)
+    model = model.to(DEV)
+    x = torch.from_numpy(g["data"][:B])
+    pz, tg, z, c = model(x.unsqueeze(1).to(DEV))
+    wz = torch.linspace(-1, 1, z.numel(), device=DEV).view_as(z)
+    loss = (pz ** 2).mean() + (tg * 0.3).sum() + (z * wz).sum() * 0.01 + (c ** 2).sum()
+    loss.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items() if not k.endswith("positional_encoder.pe")}
+    opz, otg, oz, oc = O.cpc_forward(x.unsqueeze(1), params, V, K, attention=(meta["ar"]["num_layers"], meta["ar"]["num_heads"]))
+    oloss = (opz ** 2).mean() + (otg * 0.3).sum() + (oz * wz.cpu()).sum() * 0.01 + (oc ** 2).sum()
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
+    for n, p in model.named_parameters():
+        ref = params[n].grad.double()
+        l2 = ((p.grad.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+        assert l2 < 1e-3, (n, l2)

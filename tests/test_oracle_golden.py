@@ -215,3 +215,35 @@ def test_conv_ar_model(golden_dir):
                     _close(grads[name] / scale, ref / scale, rtol=2e-4, atol=2e-5)
             loss, smax = tr.step(batch)
             assert abs(loss - run["loss"][i]) <= 5e-5 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
+
+
+def test_attention_model(golden_dir):
+    """AudioEncoder + AttentionModel (dropout 0): positional table, forward (incl. the in-place scaled z), losses and
+    gradients vs the reference (attention_model.py:38-82)."""
+    g = _load(golden_dir, "attention_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    pe_key = "autoregressive_model.positional_encoder.pe"
+    pe = g["param/" + pe_key]
+    assert np.array_equal(O.positional_encoding(pe.shape[0], pe.shape[2]).numpy(), pe[:, 0, :])
+    p0 = {k: v for k, v in _params(g).items() if k != pe_key}
+    attention = (meta["ar"]["num_layers"], meta["ar"]["num_heads"])
+    data = torch.from_numpy(g["data"])
+    pz, tg, z, c = O.cpc_forward(data[:meta["B"]].unsqueeze(1), p0, meta["V"], meta["K"], attention=attention)
+    _close(z, g["fwd/z"], rtol=1e-4, atol=1e-5)
+    _close(tg, g["fwd/targets"], rtol=1e-4, atol=1e-5)
+    _close(c, g["fwd/c"], rtol=1e-4, atol=2e-5)
+    _close(pz, g["fwd/predicted_z"], rtol=1e-4, atol=2e-5)
+    for run in meta["runs"]:
+        tr = O.OracleTrainer(p0, meta["V"], meta["K"], score=run["score"], all_timesteps=run["all_timesteps"],
+                             regularization=run["reg"], lr=run["lr"], attention=attention)
+        for i, idx in enumerate(run["batches"]):
+            batch = data[idx]
+            if run["steps"] == 1:
+                loss, smax, grads = tr.loss_and_grads(batch)
+                for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                    name = k.split("/grad/")[1]
+                    ref = torch.from_numpy(g[k])
+                    scale = ref.abs().max().item() + 1e-12
+                    _close(grads[name] / scale, ref / scale, rtol=2e-4, atol=3e-5)
+            loss, smax = tr.step(batch)
+            assert abs(loss - run["loss"][i]) <= 1e-4 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
