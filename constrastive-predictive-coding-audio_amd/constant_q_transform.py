@@ -1,0 +1,160 @@
+"""Constant-Q filter bank front end on the HIP path (reference constant_q_transform.py:94-172, :268-286).
+
+``CQT`` keeps the reference's structure — one strided 1-D filter bank per octave group, real rows then imaginary rows in
+``conv_modules.N.weight`` (2*n_g, 1, size_g), not trainable — so state_dicts interchange.  Its forward is one f32
+``cpc_gemm_nt`` per group over overlapped waveform rows (row t of clip b = x[b, offset_g + t*hop : ... + size_g]).
+
+Filter design: the reference calls ``librosa.filters.constant_q`` (third party, not vendored, version unpinned — SURVEY.md
+8c).  ``constant_q_filters`` below restates that published design (Hann-windowed complex exponentials of length
+Q*sr/f_k, L1-normalised, centre-padded to a power of two); coefficient parity with any particular librosa release is
+UNPINNED.  Everything downstream of the coefficients is pinned: pass ``filters=(complex [n_bins, len], lengths)`` from
+librosa, or load a reference state_dict, and the outputs follow the reference exactly.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip
+
+pi = np.pi
+
+
+def cqt_frequencies(n_bins, fmin, bins_per_octave=12):
+    """Centre frequencies fmin * 2**(k / bins_per_octave) (librosa.time_frequency.cqt_frequencies, tuning 0)."""
+    return float(fmin) * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
+
+
+def constant_q_filters(sr, fmin, n_bins, bins_per_octave, filter_scale):
+    """Restated librosa.filters.constant_q(window='hann', pad_fft=True, norm=1): returns (complex128 [n_bins, P], lengths)
+    with P the next power of two >= the longest filter."""
+    freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+    q = float(filter_scale) / (2.0 ** (1.0 / bins_per_octave) - 1.0)
+    lengths = q * sr / freqs
+    sigs = []
+    for ilen, freq in zip(lengths, freqs):
+        n = np.arange(-ilen // 2, ilen // 2, dtype=np.float64)
+        sig = np.exp(n * 1j * 2 * np.pi * freq / sr)
+        n_min, n_max = int(np.floor(len(sig))), int(np.ceil(len(sig)))
+        k = np.arange(n_min, dtype=np.float64)
+        window = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n_min)        # periodic Hann
+        if len(window) < n_max:
+            window = np.pad(window, (0, n_max - len(window)))
+        sig = sig * window
+        sig = sig / np.sum(np.abs(sig))
+        sigs.append(sig)
+    max_len = int(2.0 ** np.ceil(np.log2(max(len(s) for s in sigs))))
+    bank = np.zeros((n_bins, max_len), dtype=np.complex128)
+    for k, sig in enumerate(sigs):
+        lpad = (max_len - len(sig)) // 2
+        bank[k, lpad:lpad + len(sig)] = sig
+    return bank, lengths
+
+
+class _FilterBank(nn.Module):
+    """Holds ``weight`` (2*n, 1, size) like the reference's bias-free nn.Conv1d; ``stride`` = hop length."""
+
+    def __init__(self, weight, stride):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=False)
+        self.stride = (stride,)
+        self.kernel_size = (weight.shape[-1],)
+
+
+class CQT(nn.Module):
+    def __init__(self, sr=16000, fmin=30, n_bins=256, bins_per_octave=32, filter_scale=1., hop_length=128, trainable=False,
+                 filters=None):
+        super().__init__()
+        self.sr, self.fmin, self.n_bins = sr, fmin, n_bins
+        self.bins_per_octave, self.filter_scale, self.hop_length = bins_per_octave, filter_scale, hop_length
+        if filters is None:
+            filters = constant_q_filters(sr, fmin, n_bins, bins_per_octave, filter_scale)
+        cqt_filters, lengths = filters
+        self.cqt_filter_lengths = lengths
+        # one filter bank per octave: bins whose power-of-two rounded length is the same (reference :113-128)
+        self.conv_kernel_sizes, self.conv_index_ranges = [], []
+        current, last_change = None, 0
+        for i, l in enumerate(lengths):
+            size = 2 ** math.ceil(np.log2(l))
+            if current is not None and size >= current:
+                continue
+            self.conv_kernel_sizes.append(size)
+            current = size
+            if i != 0:
+                self.conv_index_ranges.append(range(last_change, i))
+            last_change = i
+        self.conv_index_ranges.append(range(last_change, len(lengths)))
+        total = cqt_filters.shape[-1]
+        self.conv_modules = nn.ModuleList()
+        for size, rng in zip(self.conv_kernel_sizes, self.conv_index_ranges):
+            off = (total - size) // 2
+            part = cqt_filters[rng, off:total - off] if off > 0 else cqt_filters[rng, :]
+            w = torch.cat([torch.from_numpy(np.real(part).copy()), torch.from_numpy(np.imag(part).copy())], dim=0).float()
+            self.conv_modules.append(_FilterBank(w.unsqueeze(1), hop_length))
+        self._trainable = False
+        if trainable:
+            raise NotImplementedError("trainable CQT filters are not part of the HIP path (every reference config freezes them)")
+        self._operands = None
+
+    @property
+    def trainable(self):
+        return self._trainable
+
+    def frames(self, length):
+        return (length - 1 - self.conv_kernel_sizes[0]) // self.hop_length + 1
+
+    # ------------------------------------------------------------------ device operands
+    def _prepare(self, device):
+        key = (str(device),) + tuple((m.weight.data_ptr(), m.weight._version) for m in self.conv_modules)
+        if self._operands is not None and self._operands[0] == key:
+            return self._operands[1]
+        ops = []
+        for m, rng in zip(self.conv_modules, self.conv_index_ranges):
+            w = m.weight.detach().to(device=device, dtype=torch.float32)[:, 0, :]          # (2n, size): real rows, imag rows
+            n = len(rng)
+            npad = (2 * n + 3) // 4 * 4
+            inter = torch.zeros(npad, w.shape[1], device=device, dtype=torch.float32)
+            inter[0:2 * n:2] = w[:n]
+            inter[1:2 * n:2] = w[n:]
+            ops.append((inter.contiguous(), npad, rng.start))
+        self._operands = (key, ops)
+        return ops
+
+    def transform(self, x):
+        """x (B, 1, L) or (B, L) f32 on the GPU -> (cq f32 [B][Tn][ldq] with (re, im) interleaved per bin, Tn, ldq)."""
+        if x.dim() == 3:
+            x = x[:, 0, :]
+        if x.device.type != "cuda":
+            raise RuntimeError("the CQT runs on the GPU only (no CPU fallback)")
+        x = x.detach().float().contiguous()
+        B, L = x.shape
+        if L % 4:
+            x = torch.nn.functional.pad(x, (0, 4 - L % 4))
+        Tn = self.frames(L)
+        if Tn < 1:
+            raise ValueError(f"clip of {L} samples is shorter than the longest CQT filter ({self.conv_kernel_sizes[0]})")
+        ldq = 2 * self.n_bins + 8
+        cq = torch.empty(B, Tn, ldq, device=x.device, dtype=torch.float32)
+        k0, hop = self.conv_kernel_sizes[0], self.hop_length
+        for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
+            offset = (k0 - size) // 2
+            _hip.gemm_nt(_hip.ptr(x, offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, size, hop, size, ldq, _hip.F32,
+                         a_rpi=Tn, a_item=x.shape[1])
+        return cq, Tn, ldq
+
+    def forward(self, x):
+        """(B, 1, L) -> (B, n_bins, frames, 2) like the reference (a strided view of the interleaved buffer)."""
+        cq, Tn, ldq = self.transform(x)
+        return cq[:, :, :2 * self.n_bins].view(cq.shape[0], Tn, self.n_bins, 2).permute(0, 2, 1, 3)
+
+
+class PhaseDifference(nn.Module):
+    """Per-bin expected phase advance and 1/ln(f) scaling (reference :268-280); applied inside cpc_scalogram_pointwise."""
+
+    def __init__(self, sr=16000, fmin=30, n_bins=256, bins_per_octave=32, hop_length=128):
+        super().__init__()
+        freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+        fixed = (((1.0 * freqs * hop_length / sr) + 0.5) % 1 - 0.5) * 2 * np.pi
+        self.fixed_phase_diff = nn.Parameter(torch.from_numpy(fixed).float().view(1, -1, 1), requires_grad=False)
+        self.scaling = nn.Parameter(torch.from_numpy(1 / np.log(freqs)).float().view(1, -1, 1), requires_grad=False)

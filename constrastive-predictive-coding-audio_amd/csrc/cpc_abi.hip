@@ -186,6 +186,13 @@ int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void
     return launch_mean_time(x, out, B, S, C, dtype, (hipStream_t)stream);
 }
 
+int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
+                            long long ldq, int phase, float offset, float log_offset, float norm, float power, void* stream) {
+    if (!cq || !out) return CPC_EINVAL;
+    return launch_scalogram_pointwise(cq, fixed_pd, pd_scale, out, B, Tn, bins, ldq, phase, offset, log_offset, norm, power,
+                                      (hipStream_t)stream);
+}
+
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);

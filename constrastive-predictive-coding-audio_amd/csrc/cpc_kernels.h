@@ -93,3 +93,8 @@ int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float*
 int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
                   int C, int bcast, float gscale, int nblocks, int dtype, hipStream_t stream);
 int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, hipStream_t stream);
+
+// scalogram front end / 2-D encoder (scalogram.hip)
+int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
+                               long long ldq, int phase, float offset, float log_offset, float norm, float power,
+                               hipStream_t stream);

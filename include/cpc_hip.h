@@ -146,6 +146,15 @@ int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats
 /* out[b][c] = mean_t x[(b,t)][c]  (attention_model.py:79) */
 int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream);
 
+/* ---- scalogram front end (constant_q_transform.py, scalogram_model.py:34-102) ----
+ * CQT.forward (constant_q_transform.py:161-172) is one f32 cpc_gemm_nt per octave group over overlapped waveform rows
+ * (lda = hop) into cq f32 [B][Tn][ldq] with (re, im) interleaved per bin.  This call is the rest of
+ * PreprocessingModule.forward: |z|^2 -> log(. + offset) + log_offset, and with phase != 0 the wrapped phase advance
+ * (atan2 difference along time + fixed_pd[bin], single wrap into (-pi, pi], * pd_scale[bin]); then * norm and ** power.
+ * out f32 channels-last [B][W][bins][Cc]: phase: W = Tn-1, Cc = 2 (amp of frame w+1, phase difference); else W = Tn, Cc = 1. */
+int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
+                            long long ldq, int phase, float offset, float log_offset, float norm, float power, void* stream);
+
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);
 /* MFMA fragment order of a [R][Kd] operand (transpose: logical[n][k] = src[k*ld + n]) for the GRU kernels. */

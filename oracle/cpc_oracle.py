@@ -173,6 +173,81 @@ def attention_forward(z: torch.Tensor, params: Params, num_layers: int, num_head
     return c, z_scaled
 
 
+# ------------------------------------------------------------------ scalogram front end
+def cqt_frequencies(n_bins: int, fmin: float, bins_per_octave: int):
+    """librosa.time_frequency.cqt_frequencies (tuning 0): fmin * 2**(k / bins_per_octave).  Third-party, absent here."""
+    import numpy as np
+    return float(fmin) * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
+
+
+def constant_q_filters(sr, fmin, n_bins, bins_per_octave, filter_scale):
+    """Restatement of librosa.filters.constant_q(window='hann', norm=1, pad_fft=True) — the third-party call of
+    constant_q_transform.py:108-112 (librosa is not vendored and its version is not pinned by the reference: coefficient
+    parity UNPINNED; everything downstream is pinned by running the reference on these coefficients).
+    Filter k: exp(2 pi i f_k n / sr) for n in [-l/2, l/2), l = Q sr / f_k, Q = filter_scale / (2**(1/bpo) - 1), times a
+    periodic Hann window, L1-normalised, centre-padded to the next power of two.  Returns (complex128 [n_bins, P], lengths)."""
+    import numpy as np
+    freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+    q = float(filter_scale) / (2.0 ** (1.0 / bins_per_octave) - 1.0)
+    lengths = q * sr / freqs
+    sigs = []
+    for ilen, freq in zip(lengths, freqs):
+        sig = np.exp(np.arange(-ilen // 2, ilen // 2, dtype=np.float64) * 1j * 2 * np.pi * freq / sr)
+        n = len(sig)
+        sig = sig * (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n))
+        sigs.append(sig / np.sum(np.abs(sig)))
+    max_len = int(2.0 ** np.ceil(np.log2(max(len(s) for s in sigs))))
+    bank = np.zeros((n_bins, max_len), dtype=np.complex128)
+    for k, sig in enumerate(sigs):
+        lpad = (max_len - len(sig)) // 2
+        bank[k, lpad:lpad + len(sig)] = sig
+    return bank, lengths
+
+
+def cqt_forward(x: torch.Tensor, weights: Sequence[torch.Tensor], hop: int) -> torch.Tensor:
+    """CQT.forward — constant_q_transform.py:161-172.  weights[g] (2 n_g, 1, size_g): real rows then imaginary rows, sizes
+    decreasing.  x (B, 1, L) -> (B, n_bins, T, 2)."""
+    k0 = weights[0].shape[-1]
+    real, imag = [], []
+    for w in weights:
+        offset = (k0 - w.shape[-1]) // 2
+        res = F.conv1d(x[:, :, offset:-(offset + 1)], w, stride=hop)
+        r, i = torch.chunk(res, 2, dim=1)
+        real.append(r)
+        imag.append(i)
+    return torch.stack([torch.cat(real, dim=1), torch.cat(imag, dim=1)], dim=3)
+
+
+def phase_difference_constants(sr, fmin, n_bins, bins_per_octave, hop):
+    """PhaseDifference.__init__ — constant_q_transform.py:272-280: (fixed advance, 1/ln f) per bin, float32."""
+    import numpy as np
+    freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+    fixed = (((1.0 * freqs * hop / sr) + 0.5) % 1 - 0.5) * 2 * np.pi
+    return torch.from_numpy(fixed).float(), torch.from_numpy(1 / np.log(freqs)).float()
+
+
+def preprocessing_forward(cq: torch.Tensor, phase_consts=None, offset_zero: bool = False, output_power: float = 1.0,
+                          scaling: float = 1.0) -> torch.Tensor:
+    """PreprocessingModule.forward after the CQT (no pooling) — scalogram_model.py:77-97 with abs / angle / unwrap /
+    PhaseDifference.forward of constant_q_transform.py:36-52, :69-72, :281-285.  cq (B, bins, T, 2)."""
+    import math
+    offset = 1e-9 if offset_zero else 0.0
+    log_offset = -math.log(offset) if offset_zero else 0.0
+    norm = scaling / log_offset if offset_zero else scaling
+    mag = torch.sqrt(cq[..., 0] ** 2 + cq[..., 1] ** 2)
+    if phase_consts is not None:
+        fixed, pscale = phase_consts
+        amp = torch.log(mag[:, :, 1:] ** 2 + offset) + log_offset
+        ang = torch.atan2(cq[..., 1], cq[..., 0])
+        pd = ang[:, :, 1:] - ang[:, :, :-1] + fixed.view(1, -1, 1)
+        pd = torch.where(pd > math.pi, pd - 2 * math.pi, pd)
+        pd = torch.where(pd < -math.pi, pd + 2 * math.pi, pd)
+        x = torch.stack([amp, pd * pscale.view(1, -1, 1)], dim=1)
+    else:
+        x = (torch.log(mag ** 2 + offset) + log_offset).unsqueeze(1)
+    return (x * norm) ** output_power
+
+
 # ------------------------------------------------------------------------- CPC model
 def item_length(receptive_field: int, downsampling: int, visible_steps: int, prediction_steps: int) -> int:
     """audio_model.py:187-191."""

@@ -20,6 +20,7 @@ Fixtures written (all float32 unless noted):
   cfg1_trajectory.json  BASELINE config 1 (B=8, L=20480, 512 ch) loss for 5 train steps
   conv_ar_model.npz     AudioEncoder + ConvolutionalArModel (k 9/9/9, pooling 1/2/2) forward, losses, gradients
   attention_model.npz   AudioEncoder + AttentionModel (2 layers, 8 heads, dropout 0) forward, losses, gradients
+  cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
 """
 import io
 import json
@@ -307,6 +308,58 @@ def gen_attention():
     print("attention:", [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]], "c mean", float(np.abs(out["fwd/c"]).mean()))
 
 
+def _install_librosa_stand_in():
+    """The reference's CQT / PhaseDifference constructors call two librosa functions (constant_q_transform.py:108-112,
+    :272-274); librosa is absent, so the oracle's restatement of their published algorithm stands in (coefficients
+    unpinned, see oracle/cpc_oracle.py).  Everything else — octave grouping, real/imag stacking, the per-group strided
+    convolutions, abs/angle/unwrap, PreprocessingModule.forward — is the reference's own code running."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import cpc_oracle as O
+    lr = sys.modules["librosa"]
+    lr.filters = types.SimpleNamespace(
+        constant_q=lambda sr, fmin=None, n_bins=84, bins_per_octave=12, filter_scale=1, **kw: O.constant_q_filters(sr, fmin, n_bins, bins_per_octave, filter_scale))
+    lr.time_frequency = types.SimpleNamespace(
+        cqt_frequencies=lambda fmin=None, bins_per_octave=12, n_bins=84, **kw: O.cqt_frequencies(n_bins, fmin, bins_per_octave))
+    return O
+
+
+CQT_SMALL = {'sample_rate': 16000, 'fmin': 560, 'n_bins': 24, 'bins_per_octave': 8, 'filter_scale': 0.5, 'hop_length': 32,
+             'trainable_cqt': False}
+
+
+def gen_cqt():
+    _install_librosa_stand_in()
+    import scalogram_model as ref_scal
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    B, hop = 3, CQT_SMALL['hop_length']
+    variants = {"phase": dict(phase=True), "power": dict(phase=False, offset_zero=True, output_power=2., scaling=10.),
+                "plain": dict(phase=False)}
+    meta = {"cqt": CQT_SMALL, "variants": variants}
+    for name, kw in variants.items():
+        pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, **kw)
+        if name == "phase":
+            meta["kernel_sizes"] = [int(k) for k in pre.cqt.conv_kernel_sizes]
+            meta["index_ranges"] = [[r.start, r.stop] for r in pre.cqt.conv_index_ranges]
+            L = pre.cqt.conv_kernel_sizes[0] + hop * 40 + 5
+            meta["L"] = int(L)
+            x = torch.randn(B, 1, L, generator=g) * 0.3
+            out["x"] = x.numpy()
+            for i, m in enumerate(pre.cqt.conv_modules):
+                out[f"weight/{i}"] = m.weight.detach().numpy()
+            with torch.no_grad():
+                out["cqt"] = pre.cqt(x).numpy()
+            out["fixed_phase_diff"] = pre.phase_diff.fixed_phase_diff.detach().numpy()
+            out["scaling"] = pre.phase_diff.scaling.detach().numpy()
+            meta["receptive_field"], meta["downsampling_factor"] = int(pre.receptive_field), int(pre.downsampling_factor)
+        with torch.no_grad():
+            out["pre/" + name] = pre(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "cqt_small.npz"), **out)
+    with open(os.path.join(OUT, "cqt_small.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("cqt:", meta["kernel_sizes"], meta["index_ranges"], out["cqt"].shape, {k: v.shape for k, v in out.items() if k.startswith("pre/")})
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -450,7 +503,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt"]
+    if "cqt" in which:
+        gen_cqt()
     if "attention" in which:
         gen_attention()
     if "conv_ar" in which:

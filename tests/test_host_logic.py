@@ -154,3 +154,19 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP-OK" in outs[0]
+
+
+def test_cqt_filter_design_matches_oracle_restatement():
+    """Product and oracle hold independent restatements of the (absent, unpinned) librosa filter design; they must agree
+    bit for bit, and the octave grouping must be the one the reference derives for its default bank."""
+    import numpy as np
+    from cpc_audio_amd import constant_q_transform as cq
+    for args in ((16000, 30, 256, 32, 0.5), (16000, 560, 24, 8, 0.5), (44100, 30, 292, 32, 0.5)):
+        a, la = cq.constant_q_filters(*args)
+        b, lb = O.constant_q_filters(*args)
+        assert a.shape == b.shape and np.array_equal(a, b) and np.array_equal(la, lb)
+    m = cq.CQT(sr=16000, fmin=30, n_bins=256, bins_per_octave=32, filter_scale=0.5, hop_length=128)
+    assert m.conv_kernel_sizes == [16384, 8192, 4096, 2048, 1024, 512, 256, 128, 64]
+    assert [len(r) for r in m.conv_index_ranges] == [19, 32, 32, 32, 32, 32, 32, 32, 13]
+    assert list(m.state_dict().keys()) == [f"conv_modules.{i}.weight" for i in range(9)]
+    assert m.frames(97024) == 630

@@ -247,3 +247,33 @@ def test_attention_model(golden_dir):
                     _close(grads[name] / scale, ref / scale, rtol=2e-4, atol=3e-5)
             loss, smax = tr.step(batch)
             assert abs(loss - run["loss"][i]) <= 1e-4 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
+
+
+def test_cqt_and_preprocessing(golden_dir):
+    """CQT.forward and PreprocessingModule.forward restatements vs the reference run on the same filter coefficients
+    (the coefficients themselves come from the restated librosa design: unpinned, see the oracle's header)."""
+    g = _load(golden_dir, "cqt_small.npz")
+    meta = json.load(open(os.path.join(golden_dir, "cqt_small.json")))
+    c = meta["cqt"]
+    bank, lengths = O.constant_q_filters(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["filter_scale"])
+    weights = [torch.from_numpy(g[f"weight/{i}"]) for i in range(len(meta["kernel_sizes"]))]
+    for (lo, hi), size, w in zip(meta["index_ranges"], meta["kernel_sizes"], weights):
+        off = (bank.shape[1] - size) // 2
+        part = bank[lo:hi, off:bank.shape[1] - off] if off else bank[lo:hi]
+        assert np.array_equal(np.concatenate([part.real, part.imag]).astype(np.float32), w[:, 0].numpy())
+    x = torch.from_numpy(g["x"])
+    cq = O.cqt_forward(x, weights, c["hop_length"])
+    _close(cq, g["cqt"], rtol=1e-5, atol=1e-6)
+    consts = O.phase_difference_constants(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["hop_length"])
+    assert np.array_equal(consts[0].numpy(), g["fixed_phase_diff"].reshape(-1))
+    assert np.array_equal(consts[1].numpy(), g["scaling"].reshape(-1))
+    for name, kw in meta["variants"].items():
+        got = O.preprocessing_forward(cq, consts if kw.get("phase") else None, kw.get("offset_zero", False),
+                                      kw.get("output_power", 1.0), kw.get("scaling", 1.0))
+        ref = torch.from_numpy(g["pre/" + name])
+        if kw.get("phase"):
+            # the wrapped phase difference may legitimately flip by 2 pi * scaling where it sits within rounding of +-pi
+            bad = (got - ref).abs() > 1e-4
+            assert bad.float().mean().item() < 1e-3
+            got = torch.where(bad, ref, got)
+        _close(got, ref, rtol=1e-4, atol=1e-4)
