@@ -43,7 +43,7 @@ class GemmTNArgs(C.Structure):
                 ("flags", C.c_int), ("dtype", C.c_int), ("c_rpi", C.c_int), ("c_item", C.c_longlong)]
 
 
-_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 _SIGNATURES = {
     "cpc_abi_version": ([], _I),
     "cpc_gemm_nt": ([C.POINTER(GemmNTArgs), _P], _I),
@@ -68,6 +68,18 @@ _SIGNATURES = {
     "cpc_ln_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P], _I),
     "cpc_mean_time": ([_P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _P], _I),
+    "cpc_im2col2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_col2im2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_bn_stats": ([_P, _P, _L, _I, _I, _I, _P], _I),
+    "cpc_bn_finalize": ([_P, _I, _I, _D, _F, _F, _P, _P, _P, _P], _I),
+    "cpc_bn_apply": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "cpc_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _I, _I, _I, _I, _P], _I),
+    "cpc_maxpool2d_fwd": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "cpc_maxpool2d_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "cpc_residual_add": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_residual_add_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_relu_mask": ([_P, _P, _L, _I, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),

@@ -190,10 +190,12 @@ class AudioPredictiveCodingModel(nn.Module):
         self._param = {}
         self._grad = {}
         from .attention_model import AttentionModel
-        if not isinstance(encoder, AudioEncoder) or \
+        from .scalogram_model import ScalogramResidualEncoder
+        self._scalogram = isinstance(encoder, ScalogramResidualEncoder)
+        if not isinstance(encoder, (AudioEncoder, ScalogramResidualEncoder)) or \
                 not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel, AttentionModel)):
-            raise NotImplementedError("the HIP path covers AudioEncoder + AudioGRUModel / ConvolutionalArModel / AttentionModel "
-                                      "(SURVEY.md section 8 rows a1-a6)")
+            raise NotImplementedError("the HIP path covers AudioEncoder / ScalogramResidualEncoder + AudioGRUModel / "
+                                      "ConvolutionalArModel / AttentionModel (SURVEY.md section 8 rows a1-a10)")
 
     @property
     def item_length(self):
@@ -238,26 +240,41 @@ class AudioPredictiveCodingModel(nn.Module):
             p.grad = self._grad[n]
 
     def engine(self, batch_size, length, device=None):
+        """The cached train-step engine for ``batch_size`` clips of ``length`` samples — or, with a
+        ScalogramResidualEncoder, for scalogram batches of shape ``length = (channels, bins, frames)``."""
         from .engine import CPCEngine
         if device is None:
             device = next(self.parameters()).device
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("the CPC hot path runs on the GPU only (no CPU fallback): call model.to('cuda') first")
-        key = (int(batch_size), int(length), self.compute_dtype, str(device))
+        shape = tuple(int(v) for v in length) if self._scalogram else int(length)
+        key = (int(batch_size), shape, self.compute_dtype, str(device))
         eng = self._engines.get(key)
         if eng is None or self._flat_param is None or any(
                 p.data_ptr() != self._param[n].data_ptr() for n, p in self.named_parameters()):
             self._flatten_parameters(device)
-            eng = CPCEngine(self, batch_size, length, device, self.compute_dtype)
+            if self._scalogram:
+                from .scalogram_engine import ScalogramCPCEngine
+                eng = ScalogramCPCEngine(self, (int(batch_size),) + shape, device, self.compute_dtype)
+            else:
+                eng = CPCEngine(self, batch_size, length, device, self.compute_dtype)
             self._engines[key] = eng
         return eng
 
-    def encode(self, x):
+    def engine_for(self, x):
+        """Engine matching an input batch: (B, 1, L) waveforms or (B, C, bins, frames) scalograms."""
+        if self._scalogram:
+            if x.dim() != 4:
+                raise ValueError("expected a scalogram batch of shape (batch, channels, bins, frames)")
+            return self.engine(x.shape[0], tuple(x.shape[1:]), x.device)
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError("expected input of shape (batch, 1, samples)")
-        eng = self.engine(x.shape[0], x.shape[2], x.device)
-        xin = x.detach()[:, 0, :].contiguous().float()
+        return self.engine(x.shape[0], x.shape[2], x.device)
+
+    def encode(self, x):
+        eng = self.engine_for(x)
+        xin = x.detach().float() if x.dim() == 4 else x.detach()[:, 0, :].contiguous().float()
         eng.prepare_weights()
         eng.encoder_forward(xin)
         return eng.view_top()[:, :eng.T, :].float().transpose(1, 2)
@@ -266,9 +283,7 @@ class AudioPredictiveCodingModel(nn.Module):
         """x (B, 1, L) -> (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)), autograd-connected to the
         parameters (targets are not detached, as in the reference audio_model.py:197)."""
         x = self.input_activation_writer(x)
-        if x.dim() != 3 or x.shape[1] != 1:
-            raise ValueError("expected input of shape (batch, 1, samples)")
-        eng = self.engine(x.shape[0], x.shape[2], x.device)
+        eng = self.engine_for(x)
         params = [p for _, p in self.named_parameters()]
         predicted_z, targets, z, c = _CPCForward.apply(eng, x, *params)
         z = self.z_activation_writer(z)
@@ -292,7 +307,7 @@ class _CPCForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, x, *params):
-        xin = x.detach()[:, 0, :].contiguous().float()
+        xin = x.detach().float() if x.dim() == 4 else x.detach()[:, 0, :].contiguous().float()
         eng.forward(xin)
         ctx.eng, ctx.xin = eng, xin
         ctx.set_materialize_grads(False)

@@ -93,8 +93,6 @@ class ContrastiveEstimationTrainer:
         if wasserstein_gradient_penalty:
             raise NotImplementedError("the Wasserstein gradient penalty (double backward through the encoder) is not "
                                       "part of the HIP path yet (SURVEY.md section 8f, rank 3)")
-        if preprocessing is not None:
-            raise NotImplementedError("the CQT preprocessing variant is not part of the HIP path yet (SURVEY.md 8a, a7-a10)")
         if self.verbose:
             print("use score function", self.score_function)
 
@@ -103,6 +101,14 @@ class ContrastiveEstimationTrainer:
         if self.device is not None:
             return torch.device(self.device)
         return next(self.model.parameters()).device
+
+    def _model_input(self, batch):
+        """(B, L) device batch -> what the model is called with: (B, 1, L), or the scalogram when a preprocessing module
+        (scalogram_model.PreprocessingModule) is set — reference :99-103, :221-223, :289-291."""
+        x = batch.unsqueeze(1)
+        if self.preprocessing is not None:
+            x = self.preprocessing(x)
+        return x
 
     def _fused(self):
         return self.score_function in (softplus_score_function, linear_score_function) and self.optimizer is torch.optim.Adam
@@ -185,8 +191,13 @@ class ContrastiveEstimationTrainer:
             with ctx as prof_ctx:
                 for batch in self._batches(self.dataset, sampler, device, num_workers, True, rank, world):
                     if fused:
-                        eng = self.model.engine(batch.shape[0], batch.shape[1], device)
-                        out = eng.loss_and_grads(batch.contiguous(), softplus=self.score_function is softplus_score_function,
+                        if self.preprocessing is not None:
+                            x_eng = self._model_input(batch)
+                            eng = self.model.engine_for(x_eng)
+                        else:
+                            x_eng = batch.contiguous()
+                            eng = self.model.engine(batch.shape[0], batch.shape[1], device)
+                        out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),
                                                  grad_ready_hook=sync.hook if sync is not None else None)
@@ -212,7 +223,7 @@ class ContrastiveEstimationTrainer:
         return None
 
     def _generic_step(self, batch, batch_size, optimizer, world):
-        predicted_z, targets, _, _ = self.model(batch.unsqueeze(1))
+        predicted_z, targets, _, _ = self.model(self._model_input(batch))
         scores = self.score_function(predicted_z, targets)
         scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, self.prediction_steps,
                                                           self.score_over_all_timesteps)
@@ -252,7 +263,7 @@ class ContrastiveEstimationTrainer:
         max_steps = n_batches if max_steps is None else min(max_steps, n_batches)
         with torch.no_grad():
             for step, batch in enumerate(self._batches(self.validation_set, sampler, device, num_workers, False, 0, 1)):
-                predicted_z, targets, _, _ = self.model(batch.unsqueeze(1))
+                predicted_z, targets, _, _ = self.model(self._model_input(batch))
                 scores = self.score_function(predicted_z, targets)
                 scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, K, self.score_over_all_timesteps)
                 prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=0)
@@ -283,7 +294,7 @@ class ContrastiveEstimationTrainer:
         loader = torch.utils.data.DataLoader(self.test_task_set, batch_size=batch_size, num_workers=num_workers)
         with torch.no_grad():
             for step, (batch, labels) in enumerate(iter(loader)):
-                _, _, _, c = self.model(batch.to(device).unsqueeze(1))
+                _, _, _, c = self.model(self._model_input(batch.to(device)))
                 task_data[step * batch_size:step * batch_size + c.shape[0], :] = c.cpu()
                 task_labels[step * batch_size:step * batch_size + c.shape[0]] = labels
         self.model.train()

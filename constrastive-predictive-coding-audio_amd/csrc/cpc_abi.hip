@@ -193,6 +193,76 @@ int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float*
                                       (hipStream_t)stream);
 }
 
+int cpc_im2col2d(const void* in, void* col, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                 int in_f32, int dtype, void* stream) {
+    if (!in || !col) return CPC_EINVAL;
+    return launch_im2col2d(in, col, grid, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, in_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                 int accumulate, int dtype, void* stream) {
+    if (!dcol || !din) return CPC_EINVAL;
+    return launch_col2im2d(dcol, din, grid, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate, dtype, (hipStream_t)stream);
+}
+
+int cpc_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, void* stream) {
+    if (!x || !slabs) return CPC_EINVAL;
+    return launch_bn_stats(x, slabs, rows, C, nblocks, dtype, (hipStream_t)stream);
+}
+
+int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
+                    float* run_var, void* stream) {
+    if (!slabs || !stats) return CPC_EINVAL;
+    return launch_bn_finalize(slabs, nslab, C, count, eps, momentum, stats, run_mean, run_var, (hipStream_t)stream);
+}
+
+int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                 int relu, int x_f32, int dtype, void* stream) {
+    if (!x || !out || !stats || !gamma || !beta) return CPC_EINVAL;
+    return launch_bn_apply(x, gx, out, go, stats, gamma, beta, relu, x_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
+                      int relu, int nblocks, int x_f32, int dtype, void* stream) {
+    if (!dy || !x || !stats || !slabs || (relu && !y)) return CPC_EINVAL;
+    return launch_bn_bwd_reduce(dy, y, gy, x, gx, stats, slabs, relu, nblocks, x_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                     const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
+                     int dtype, void* stream) {
+    if (!dy || !x || !dx || !stats || !gamma || (relu && !y)) return CPC_EINVAL;
+    return launch_bn_bwd_apply(dy, y, gy, x, dx, gx, stats, gamma, dgamma, dbeta, count, relu, train, x_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, void* stream) {
+    if (!in || !out) return CPC_EINVAL;
+    return launch_maxpool2d_fwd(in, gi, out, go, p, in_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
+                      void* stream) {
+    if (!in || !din || !dout) return CPC_EINVAL;
+    return launch_maxpool2d_bwd(in, din, gi, dout, go, p, accumulate, dtype, (hipStream_t)stream);
+}
+
+int cpc_residual_add(const void* a, const int* ga, const void* r, const int* gr, void* out, const int* go, int oh, int ow, int relu,
+                     int r_f32, int dtype, void* stream) {
+    if (!a || !r || !out) return CPC_EINVAL;
+    return launch_residual_add(a, ga, r, gr, out, go, oh, ow, relu, r_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
+                         int ow, int relu, int r_f32, int dtype, void* stream) {
+    if (!dout || !da || !dr || (relu && !out)) return CPC_EINVAL;
+    return launch_residual_add_bwd(dout, out, go, da, ga, dr, gr, oh, ow, relu, r_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream) {
+    if (!g || !y) return CPC_EINVAL;
+    return launch_relu_mask(g, y, n, dtype, (hipStream_t)stream);
+}
+
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);

@@ -98,3 +98,25 @@ int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, h
 int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
                                long long ldq, int phase, float offset, float log_offset, float norm, float power,
                                hipStream_t stream);
+int launch_im2col2d(const void* in, void* col, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                    int in_f32, int dtype, hipStream_t stream);
+int launch_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
+                    int Kp, int accumulate, int dtype, hipStream_t stream);
+int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, hipStream_t stream);
+int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
+                       float* run_var, hipStream_t stream);
+int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                    int relu, int x_f32, int dtype, hipStream_t stream);
+int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
+                         int relu, int nblocks, int x_f32, int dtype, hipStream_t stream);
+int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                        const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
+                        int dtype, hipStream_t stream);
+int launch_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, hipStream_t stream);
+int launch_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
+                         hipStream_t stream);
+int launch_residual_add(const void* a, const int* ga, const void* r, const int* gr, void* out, const int* go, int oh, int ow, int relu,
+                        int r_f32, int dtype, hipStream_t stream);
+int launch_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
+                            int ow, int relu, int r_f32, int dtype, hipStream_t stream);
+int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);

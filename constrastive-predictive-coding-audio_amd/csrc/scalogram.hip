@@ -5,6 +5,7 @@
 //   * BatchNorm (batch statistics) forward / backward, MaxPool2d(ceil), cropped residual add.
 #include "cpc_common.h"
 #include "cpc_kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -41,6 +42,344 @@ __global__ __launch_bounds__(256) void scalogram_pointwise_kernel(const float* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Channels-last 2-D activations: element (b, w, h, c) of a "grid" lives at ((b*W + w)*Ha + top + h)*C + c — the frequency
+// axis h is the fast row axis (so that the reference's tall (k,1) kernels are overlapped-row GEMMs), Ha >= top + H rows
+// are allocated per (b, w) column, rows outside [top, top + H) stay zero.
+struct Grid {
+    int B, W, H, Ha, top, C;
+};
+__device__ __forceinline__ long long grid_off(const Grid& g, int b, int w, int h) {
+    return (((long long)b * g.W + w) * g.Ha + g.top + h) * g.C;
+}
+
+// col[((b*Wo + wo)*Ho + ho)][(dh*kw + dw)*C + c] = in(b, wo*sw + dw - pw, ho*sh + dh - ph, c), zero outside / for k >= kh*kw*C
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void im2col2d_kernel(const TI* __restrict__ in, T* __restrict__ col, Grid g, int kh, int kw,
+                                                       int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp) {
+    const long long rows = (long long)g.B * Wo * Ho;
+    const long long total = rows * Kp;
+    const int K = kh * kw * g.C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int k = (int)(idx % Kp);
+        const long long row = idx / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int c = k % g.C, tap = k / g.C, dw = tap % kw, dh = tap / kw;
+            const int ho = (int)(row % Ho), wo = (int)((row / Ho) % Wo), b = (int)(row / ((long long)Ho * Wo));
+            const int h = ho * sh + dh - ph, w = wo * sw + dw - pw;
+            if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = to_f32(in[grid_off(g, b, w, h) + c]);
+        }
+        col[idx] = from_f32<T>(v);
+    }
+}
+
+// din(b, w, h, c) (+)= sum over taps of dcol[row(b, wo, ho)][(dh*kw + dw)*C + c] with wo*sw + dw - pw == w, ho*sh + dh - ph == h
+template <typename T>
+__global__ __launch_bounds__(256) void col2im2d_kernel(const T* __restrict__ dcol, T* __restrict__ din, Grid g, int kh, int kw,
+                                                       int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp, int accumulate) {
+    const long long total = (long long)g.B * g.W * g.H * g.C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % g.C);
+        const int h = (int)((idx / g.C) % g.H);
+        const int w = (int)((idx / ((long long)g.C * g.H)) % g.W);
+        const int b = (int)(idx / ((long long)g.C * g.H * g.W));
+        float acc = 0.f;
+        for (int dh = 0; dh < kh; ++dh) {
+            const int hn = h + ph - dh;
+            if (hn < 0 || hn % sh) continue;
+            const int ho = hn / sh;
+            if (ho >= Ho) continue;
+            for (int dw = 0; dw < kw; ++dw) {
+                const int wn = w + pw - dw;
+                if (wn < 0 || wn % sw) continue;
+                const int wo = wn / sw;
+                if (wo >= Wo) continue;
+                acc += to_f32(dcol[(((long long)b * Wo + wo) * Ho + ho) * Kp + (dh * kw + dw) * g.C + c]);
+            }
+        }
+        const long long o = grid_off(g, b, w, h) + c;
+        if (accumulate) acc += to_f32(din[o]);
+        din[o] = from_f32<T>(acc);
+    }
+}
+
+// Per-block partial sums over rows of x[rows][C]: slabs[blk][0][c] = sum x, slabs[blk][1][c] = sum x^2  (BatchNorm statistics;
+// pad rows of a grid are zero and drop out).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ slabs, long long rows, int C,
+                                                       long long rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const int c4n = C / 4;
+    // thread t owns column group t % c4n and row phase t / c4n (c4n <= 256 divides into the block; host guarantees C <= 1024)
+    const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n, nrp = 256 / c4n;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (rp < nrp)
+        for (long long r = r0 + rp; r < r1; r += nrp) {
+            const f32x4 v = load4(x + r * C + cg * 4);
+            s1 += v;
+            s2 += v * v;
+        }
+    __shared__ float red[2048];          // [nrp][2][C]: 256 / (C/4) * 2 * C = 2048 floats for every C
+    if (rp < nrp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(rp * 2 + 0) * C + cg * 4 + e] = s1[e];
+            red[(rp * 2 + 1) * C + cg * 4 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < nrp; ++q) acc += red[q * 2 * C + i];          // fixed order: deterministic
+        slabs[(long long)blockIdx.x * 2 * C + i] = acc;
+    }
+}
+
+// mean / rstd from the partial sums (fixed summation order, double accumulation); optional running-statistics update with
+// torch's conventions (momentum on the batch mean and the UNBIASED batch variance).   stats[0][c] = mean, stats[1][c] = rstd
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ slabs, int nslab, int C, double count, float eps,
+                                                          float momentum, float* __restrict__ stats, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int z = 0; z < nslab; ++z) {
+        s1 += (double)slabs[(long long)z * 2 * C + c];
+        s2 += (double)slabs[(long long)z * 2 * C + C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * mean);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unbiased);
+    }
+}
+
+// out(b,w,h,c) = act((x(b,w,h,c) - mean[c]) * rstd[c] * gamma[c] + beta[c]) on the valid rows of two grids of equal B, W, H, C
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, Grid gx, T* __restrict__ out, Grid go,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu) {
+    const int c4n = gx.C / 4;
+    const long long total = (long long)gx.B * gx.W * gx.H * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int h = (int)((idx / c4n) % gx.H);
+        const long long col = idx / ((long long)c4n * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const f32x4 v = load4(x + grid_off(gx, b, w, h) + c4 * 4);
+        const f32x4 mu = *(const f32x4*)(stats + c4 * 4), rs = *(const f32x4*)(stats + gx.C + c4 * 4);
+        const f32x4 ga = *(const f32x4*)(gamma + c4 * 4), be = *(const f32x4*)(beta + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+            if (relu) o[e] = fmaxf(o[e], 0.f);
+        }
+        store4(out + grid_off(go, b, w, h) + c4 * 4, o);
+    }
+}
+
+// Backward reductions: g = dy * (y > 0 if relu);  slabs[blk][0][c] = sum g * xhat,  slabs[blk][1][c] = sum g
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, Grid gy,
+                                                            const TX* __restrict__ x, Grid gx, const float* __restrict__ stats,
+                                                            float* __restrict__ slabs, int relu, long long cols_per_block) {
+    const int C = gx.C, c4n = C / 4;
+    const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n, nrp = 256 / c4n;
+    const long long ncol = (long long)gx.B * gx.W;
+    const long long q0 = (long long)blockIdx.x * cols_per_block, q1 = min(ncol, q0 + cols_per_block);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (rp < nrp) {
+        const f32x4 mu = *(const f32x4*)(stats + cg * 4), rs = *(const f32x4*)(stats + C + cg * 4);
+        for (long long r = q0 * gx.H + rp; r < q1 * gx.H; r += nrp) {
+            const long long q = r / gx.H;
+            const int h = (int)(r % gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
+            const long long oy = grid_off(gy, b, w, h) + cg * 4;
+            f32x4 g = load4(dy + oy);
+            if (relu) {
+                const f32x4 yy = load4(y + oy);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 xv = load4(x + grid_off(gx, b, w, h) + cg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+                s2[e] += g[e];
+            }
+        }
+    }
+    __shared__ float red[2048];          // [nrp][2][C]: 256 / (C/4) * 2 * C = 2048 floats for every C
+    if (rp < nrp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(rp * 2 + 0) * C + cg * 4 + e] = s1[e];
+            red[(rp * 2 + 1) * C + cg * 4 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < nrp; ++q) acc += red[q * 2 * C + i];          // fixed order: deterministic
+        slabs[(long long)blockIdx.x * 2 * C + i] = acc;
+    }
+}
+
+// dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n)   (train: batch statistics)   or   g * gamma * rstd   (eval)
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, Grid gy,
+                                                           const TX* __restrict__ x, TX* __restrict__ dx, Grid gx,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           float inv_count, int relu, int train) {
+    const int C = gx.C, c4n = C / 4;
+    const long long total = (long long)gx.B * gx.W * gx.H * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int h = (int)((idx / c4n) % gx.H);
+        const long long col = idx / ((long long)c4n * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const long long oy = grid_off(gy, b, w, h) + c4 * 4, ox = grid_off(gx, b, w, h) + c4 * 4;
+        f32x4 g = load4(dy + oy);
+        if (relu) {
+            const f32x4 yy = load4(y + oy);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 xv = load4(x + ox);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            const float rs = stats[C + c], ga = gamma[c];
+            if (train) {
+                const float xh = (xv[e] - stats[c]) * rs;
+                o[e] = ga * rs * (g[e] - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
+            } else {
+                o[e] = g[e] * ga * rs;
+            }
+        }
+        store4(dx + ox, o);
+    }
+}
+
+// MaxPool2d(kernel = stride = p, ceil_mode=True, no padding) on grids (residual branches, scalogram_model.py:434-436).
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TI* __restrict__ in, Grid gi, T* __restrict__ out, Grid go, int p) {
+    const long long total = (long long)go.B * go.W * go.H * go.C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % go.C);
+        const int ho = (int)((idx / go.C) % go.H);
+        const int wo = (int)((idx / ((long long)go.C * go.H)) % go.W);
+        const int b = (int)(idx / ((long long)go.C * go.H * go.W));
+        float m = -INFINITY;
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) m = fmaxf(m, to_f32(in[grid_off(gi, b, w, h) + c]));
+            }
+        out[grid_off(go, b, wo, ho) + c] = from_f32<T>(m);
+    }
+}
+
+// din(window) += dout at the first position holding the window maximum (torch's tie rule: first in (h, w) scan order)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const T* __restrict__ in, T* __restrict__ din, Grid gi,
+                                                            const T* __restrict__ dout, Grid go, int p, int accumulate) {
+    const long long total = (long long)go.B * go.W * go.H * go.C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % go.C);
+        const int ho = (int)((idx / go.C) % go.H);
+        const int wo = (int)((idx / ((long long)go.C * go.H)) % go.W);
+        const int b = (int)(idx / ((long long)go.C * go.H * go.W));
+        float m = -INFINITY;
+        int bh = -1, bw = -1;
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const float v = to_f32(in[grid_off(gi, b, w, h) + c]);
+                    if (v > m) { m = v; bh = h; bw = w; }
+                }
+            }
+        const float g = to_f32(dout[grid_off(go, b, wo, ho) + c]);
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const long long o = grid_off(gi, b, w, h) + c;
+                    const float add = (h == bh && w == bw) ? g : 0.f;
+                    din[o] = from_f32<T>(accumulate ? to_f32(din[o]) + add : add);
+                }
+            }
+    }
+}
+
+// out = act(main + res(w + ow, h + oh))   (ScalogramEncoderBlock.forward's cropped residual add, scalogram_model.py:453-472,
+// and the F.relu between blocks, :525-526)
+template <typename TR, typename T>
+__global__ __launch_bounds__(256) void residual_add_kernel(const T* __restrict__ a, Grid ga, const TR* __restrict__ r, Grid gr,
+                                                           T* __restrict__ out, Grid go, int oh, int ow, int relu) {
+    const int c4n = go.C / 4;
+    const long long total = (long long)go.B * go.W * go.H * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int h = (int)((idx / c4n) % go.H);
+        const long long col = idx / ((long long)c4n * go.H);
+        const int w = (int)(col % go.W), b = (int)(col / go.W);
+        f32x4 v = load4(a + grid_off(ga, b, w, h) + c4 * 4) + load4(r + grid_off(gr, b, w + ow, h + oh) + c4 * 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        store4(out + grid_off(go, b, w, h) + c4 * 4, v);
+    }
+}
+
+// g = dout * (out > 0 if relu);  da = g;  dr(w + ow, h + oh) = g  (dr must be zero elsewhere: the caller clears it)
+template <typename TR, typename T>
+__global__ __launch_bounds__(256) void residual_add_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, Grid go,
+                                                               T* __restrict__ da, Grid ga, TR* __restrict__ dr, Grid gr, int oh,
+                                                               int ow, int relu) {
+    const int c4n = go.C / 4;
+    const long long total = (long long)go.B * go.W * go.H * c4n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int h = (int)((idx / c4n) % go.H);
+        const long long col = idx / ((long long)c4n * go.H);
+        const int w = (int)(col % go.W), b = (int)(col / go.W);
+        const long long oo = grid_off(go, b, w, h) + c4 * 4;
+        f32x4 g = load4(dout + oo);
+        if (relu) {
+            const f32x4 y = load4(out + oo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+        }
+        store4(da + grid_off(ga, b, w, h) + c4 * 4, g);
+        store4(dr + grid_off(gr, b, w + ow, h + oh) + c4 * 4, g);
+    }
+}
+
+// g[i] = y[i] > 0 ? g[i] : 0 over flat buffers (ReLU backward where no fused epilogue applies)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mask_kernel(T* __restrict__ g, const T* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 gv = load4(g + i * 4);
+        const f32x4 yv = load4(y + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+        store4(g + i * 4, gv);
+    }
+}
+
 }  // namespace
 
 int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
@@ -52,6 +391,196 @@ int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const flo
     const int blocks = (int)min((long long)4096, (total + 255) / 256);
     hipLaunchKernelGGL(scalogram_pointwise_kernel, dim3(blocks), dim3(256), 0, st, cq, fixed_pd, pd_scale, out, B, Tn, bins, ldq,
                        phase, offset, log_offset, norm, power);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool grid_ok(const int* g) {      // {B, W, H, Ha, top, C}
+    return g && g[0] > 0 && g[1] > 0 && g[2] > 0 && g[4] >= 0 && g[3] >= g[4] + g[2] && g[5] > 0;
+}
+static Grid mk(const int* g) { return Grid{g[0], g[1], g[2], g[3], g[4], g[5]}; }
+static int blocks_for(long long total) { return (int)std::min<long long>(8192, (total + 255) / 256); }
+
+#define DISPATCH2(dtype, KERNEL_BF16, KERNEL_F32) \
+    do {                                            \
+        if ((dtype) == CPC_DTYPE_BF16) { KERNEL_BF16; } \
+        else if ((dtype) == CPC_DTYPE_F32) { KERNEL_F32; } \
+        else return CPC_EINVAL;                     \
+    } while (0)
+
+int launch_im2col2d(const void* in, void* col, const int* g, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                    int in_f32, int dtype, hipStream_t st) {
+    if (!grid_ok(g) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || Ho <= 0 || Wo <= 0) return CPC_EINVAL;
+    if (Kp < kh * kw * g[5]) return CPC_EINVAL;
+    if ((Ho - 1) * sh + kh - ph > g[2] + ph || (Wo - 1) * sw + kw - pw > g[1] + pw) return CPC_EINVAL;   // windows inside the padded input
+    const Grid gg = mk(g);
+    const int nb = blocks_for((long long)g[0] * Wo * Ho * Kp);
+    if (in_f32) {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((im2col2d_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)in, (bf16_t*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp),
+                  hipLaunchKernelGGL((im2col2d_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, (float*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp));
+    } else {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((im2col2d_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp),
+                  hipLaunchKernelGGL((im2col2d_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, (float*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp));
+    }
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_col2im2d(const void* dcol, void* din, const int* g, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                    int accumulate, int dtype, hipStream_t st) {
+    if (!grid_ok(g) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || Ho <= 0 || Wo <= 0) return CPC_EINVAL;
+    if (Kp < kh * kw * g[5]) return CPC_EINVAL;
+    const Grid gg = mk(g);
+    const int nb = blocks_for((long long)g[0] * g[1] * g[2] * g[5]);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((col2im2d_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)din, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate),
+              hipLaunchKernelGGL((col2im2d_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dcol, (float*)din, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool bn_c_ok(int C) { return C > 0 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }    // 4, 8, 16, ..., 1024
+
+int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, hipStream_t st) {
+    if (rows <= 0 || !bn_c_ok(C) || nblocks <= 0) return CPC_EINVAL;
+    const long long rpb = (rows + nblocks - 1) / nblocks;
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)x, slabs, rows, C, rpb),
+              hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const float*)x, slabs, rows, C, rpb));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
+                       float* run_var, hipStream_t st) {
+    if (nslab <= 0 || C <= 0 || count <= 0 || (run_mean == nullptr) != (run_var == nullptr)) return CPC_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slabs, nslab, C, count, eps, momentum, stats,
+                       run_mean, run_var);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool same_shape(const int* a, const int* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[5] == b[5]; }
+
+int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                    int relu, int x_f32, int dtype, hipStream_t st) {
+    if (!grid_ok(gx) || !grid_ok(go) || !same_shape(gx, go) || gx[5] % 4) return CPC_EINVAL;
+    const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && x_f32)
+        hipLaunchKernelGGL((bn_apply_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu),
+                  hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)x, mk(gx), (float*)out, mk(go), stats, gamma, beta, relu));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
+                         int relu, int nblocks, int x_f32, int dtype, hipStream_t st) {
+    if (!grid_ok(gx) || !grid_ok(gy) || !same_shape(gx, gy) || !bn_c_ok(gx[5]) || nblocks <= 0) return CPC_EINVAL;
+    const long long ncol = (long long)gx[0] * gx[1];
+    const long long cpb = (ncol + nblocks - 1) / nblocks;
+    if (dtype == CPC_DTYPE_BF16 && x_f32)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const float*)x, mk(gx), stats, slabs, relu, cpb);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb),
+                  hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nblocks), dim3(256), 0, st, (const float*)dy, (const float*)y, mk(gy), (const float*)x, mk(gx), stats, slabs, relu, cpb));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                        const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
+                        int dtype, hipStream_t st) {
+    if (!grid_ok(gx) || !grid_ok(gy) || !same_shape(gx, gy) || gx[5] % 4 || count <= 0) return CPC_EINVAL;
+    if (train && (!dgamma || !dbeta)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
+    const float inv = (float)(1.0 / count);
+    if (dtype == CPC_DTYPE_BF16 && x_f32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const float*)x, (float*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train),
+                  hipLaunchKernelGGL((bn_bwd_apply_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)dy, (const float*)y, mk(gy), (const float*)x, (float*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool pool_ok(const int* gi, const int* go, int p) {
+    return grid_ok(gi) && grid_ok(go) && p >= 1 && gi[0] == go[0] && gi[5] == go[5] && go[1] == (gi[1] + p - 1) / p &&
+           go[2] == (gi[2] + p - 1) / p;
+}
+
+int launch_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, hipStream_t st) {
+    if (!pool_ok(gi, go, p)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)go[0] * go[1] * go[2] * go[5]);
+    if (in_f32) {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((maxpool2d_fwd_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)in, mk(gi), (bf16_t*)out, mk(go), p),
+                  hipLaunchKernelGGL((maxpool2d_fwd_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, mk(gi), (float*)out, mk(go), p));
+    } else {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((maxpool2d_fwd_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)in, mk(gi), (bf16_t*)out, mk(go), p),
+                  hipLaunchKernelGGL((maxpool2d_fwd_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, mk(gi), (float*)out, mk(go), p));
+    }
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
+                         hipStream_t st) {
+    if (!pool_ok(gi, go, p)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)go[0] * go[1] * go[2] * go[5]);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((maxpool2d_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)din, mk(gi), (const bf16_t*)dout, mk(go), p, accumulate),
+              hipLaunchKernelGGL((maxpool2d_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)in, (float*)din, mk(gi), (const float*)dout, mk(go), p, accumulate));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+static bool crop_ok(const int* ga, const int* gr, const int* go, int oh, int ow) {
+    return grid_ok(ga) && grid_ok(gr) && grid_ok(go) && same_shape(ga, go) && gr[0] == go[0] && gr[5] == go[5] && go[5] % 4 == 0 &&
+           oh >= 0 && ow >= 0 && oh + go[2] <= gr[2] && ow + go[1] <= gr[1];
+}
+
+int launch_residual_add(const void* a, const int* ga, const void* r, const int* gr, void* out, const int* go, int oh, int ow, int relu,
+                        int r_f32, int dtype, hipStream_t st) {
+    if (!crop_ok(ga, gr, go, oh, ow)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && r_f32)
+        hipLaunchKernelGGL((residual_add_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)a, mk(ga), (const float*)r, mk(gr), (bf16_t*)out, mk(go), oh, ow, relu);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((residual_add_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)a, mk(ga), (const bf16_t*)r, mk(gr), (bf16_t*)out, mk(go), oh, ow, relu),
+                  hipLaunchKernelGGL((residual_add_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)a, mk(ga), (const float*)r, mk(gr), (float*)out, mk(go), oh, ow, relu));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
+                            int ow, int relu, int r_f32, int dtype, hipStream_t st) {
+    if (!crop_ok(ga, gr, go, oh, ow)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && r_f32)
+        hipLaunchKernelGGL((residual_add_bwd_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, mk(go), (bf16_t*)da, mk(ga), (float*)dr, mk(gr), oh, ow, relu);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((residual_add_bwd_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, mk(go), (bf16_t*)da, mk(ga), (bf16_t*)dr, mk(gr), oh, ow, relu),
+                  hipLaunchKernelGGL((residual_add_bwd_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out, mk(go), (float*)da, mk(ga), (float*)dr, mk(gr), oh, ow, relu));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t st) {
+    if (n <= 0 || n % 4) return CPC_EINVAL;
+    const int nb = blocks_for(n / 4);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((relu_mask_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (bf16_t*)g, (const bf16_t*)y, n / 4),
+              hipLaunchKernelGGL((relu_mask_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)g, (const float*)y, n / 4));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -111,8 +111,13 @@ class CPCEngine:
         return full, full[guard:guard + rows * cols], guard
 
     def _alloc(self):
-        dev, dt, f32 = self.device, self.dt, torch.float32
-        B, V, H, E, K, n = self.B, self.V, self.H, self.E, self.K, self.n
+        need = self._alloc_encoder()
+        self._alloc_head(need)
+
+    def _alloc_encoder(self):
+        """Activation / gradient buffers and weight operands of the AudioEncoder stack; returns the slab sizes it needs."""
+        dev, dt = self.device, self.dt
+        B, n = self.B, self.n
         La = self.geo.alloc
         self.act, self.dact = [], []
         self._keep = []
@@ -128,20 +133,6 @@ class CPCEngine:
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             self.w_fwd[l] = torch.empty(cout * kw * cin, device=dev, dtype=dt)
             self.w_dgrad[l] = torch.empty(s * cin * self.geo.taps[l] * cout, device=dev, dtype=dt)
-        self.w_p = torch.empty(K * E * H, device=dev, dtype=dt)           # [K*E][H]
-        self.w_p_t = torch.empty(H * K * E, device=dev, dtype=dt)         # [H][K*E]
-        # predictor / loss state
-        self.c = torch.empty(B, H, device=dev, dtype=f32)
-        self.pred = torch.empty(B * K * E, device=dev, dtype=dt)
-        self.ldS = _ceil_div(B, 8) * 8
-        self.S = torch.zeros(K * B * self.ldS, device=dev, dtype=f32)
-        self.dS = torch.zeros(K * B * self.ldS, device=dev, dtype=dt)
-        self.dST = torch.zeros(K * B * self.ldS, device=dev, dtype=dt)
-        self.nce_out = torch.zeros(8, device=dev, dtype=f32)
-        self.nce_ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(B, K)), device=dev, dtype=f32)
-        self.dpred = torch.zeros(B * K * E, device=dev, dtype=dt)
-        self.dc = torch.zeros(B, H, device=dev, dtype=f32)
-        # split-reduction workspace (f32 slabs), sized for the largest user
         need = [1]
         self.nsplit = [1] * n
         for l in range(1, n):
@@ -153,31 +144,49 @@ class CPCEngine:
         need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
         self.colsum_blocks = 1024
         need.append(self.colsum_blocks * max(self.channels))
+        return need
+
+    def _alloc_head(self, need):
+        """Predictor / loss state, the context network's buffers and the shared split-reduction workspace."""
+        dev, dt, f32 = self.device, self.dt, torch.float32
+        B, H, E, K = self.B, self.H, self.E, self.K
+        self.w_p = torch.empty(K * E * H, device=dev, dtype=dt)           # [K*E][H]
+        self.w_p_t = torch.empty(H * K * E, device=dev, dtype=dt)         # [H][K*E]
+        self.c = torch.empty(B, H, device=dev, dtype=f32)
+        self.pred = torch.empty(B * K * E, device=dev, dtype=dt)
+        self.ldS = _ceil_div(B, 8) * 8
+        self.S = torch.zeros(K * B * self.ldS, device=dev, dtype=f32)
+        self.dS = torch.zeros(K * B * self.ldS, device=dev, dtype=dt)
+        self.dST = torch.zeros(K * B * self.ldS, device=dev, dtype=dt)
+        self.nce_out = torch.zeros(8, device=dev, dtype=f32)
+        self.nce_ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(B, K)), device=dev, dtype=f32)
+        self.dpred = torch.zeros(B * K * E, device=dev, dtype=dt)
+        self.dc = torch.zeros(B, H, device=dev, dtype=f32)
+        need = list(need)
         need.append(_ceil_div(max(K * E, 1), 256) * B * H)               # split-K slabs of the dc GEMM
         if self.ctx is not None:
             self.ctx.allocate()
             need.append(self.ctx.slab_floats())
         self.slabs = torch.empty(max(need), device=dev, dtype=f32)
 
-    def _pick_split(self, I, J, M):
-        big = self.dt == torch.bfloat16 and I >= 256 and J >= 256       # 256x256 tiles, one workgroup per CU
+    def _pick_split(self, I, J, M, dt=None):
+        dt = self.dt if dt is None else dt
+        big = dt == torch.bfloat16 and I >= 256 and J >= 256       # 256x256 tiles, one workgroup per CU
         tile = 256 if big else 128
         tiles = _ceil_div(I, tile) * _ceil_div(J, tile)
-        blk = 64 if self.dt == torch.bfloat16 else 32
+        blk = 64 if dt == torch.bfloat16 else 32
         want = _ceil_div(256 if big else 512, tiles)
         return max(1, min(want, _ceil_div(M, 8 * blk), 64))
 
-    def _chunk(self, M, nsplit):
-        blk = 64 if self.dt == torch.bfloat16 else 32
+    def _chunk(self, M, nsplit, dt=None):
+        blk = 64 if (self.dt if dt is None else dt) == torch.bfloat16 else 32
         return _ceil_div(_ceil_div(M, nsplit), blk) * blk
 
     # ---------------------------------------------------------------------------------- weight layouts
     def prepare_weights(self):
         """f32 master parameters (reference state_dict shapes) -> storage-dtype GEMM operand layouts."""
+        self._prepare_encoder_weights()
         p, code = self.model._param, self.code
-        for l in range(1, self.n):
-            _hip.call("cpc_conv_w_prep", _hip.ptr(p[f"encoder.layers.{l}.weight"]), _hip.ptr(self.w_fwd[l]),
-                      _hip.ptr(self.w_dgrad[l]), self.channels[l], self.channels[l - 1], self.kernels[l], self.strides[l], code)
         H, E, K = self.H, self.E, self.K
         if self.ctx is None:          # encoder-only engine (stand-alone AudioEncoder call)
             return
@@ -185,6 +194,12 @@ class CPCEngine:
         w_p = p["prediction_model.weight"]
         _hip.call("cpc_cast2d", _hip.ptr(w_p), _hip.ptr(self.w_p), K * E, H, H, 1, code)
         _hip.call("cpc_cast2d", _hip.ptr(w_p), _hip.ptr(self.w_p_t), H, K * E, 1, H, code)
+
+    def _prepare_encoder_weights(self):
+        p, code = self.model._param, self.code
+        for l in range(1, self.n):
+            _hip.call("cpc_conv_w_prep", _hip.ptr(p[f"encoder.layers.{l}.weight"]), _hip.ptr(self.w_fwd[l]),
+                      _hip.ptr(self.w_dgrad[l]), self.channels[l], self.channels[l - 1], self.kernels[l], self.strides[l], code)
 
     # ------------------------------------------------------------------------------------------ forward
     def _check_input(self, x):
@@ -293,9 +308,9 @@ class CPCEngine:
                      flags=_hip.GEMM_OUT_F32, **kw)
         _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad, grad_offset), I, J, nsplit, I * J, 1, 1, J, 0)
 
-    def _colsum_to_grad(self, X, grad, M, N):
+    def _colsum_to_grad(self, X, grad, M, N, code=None):
         nb = min(self.colsum_blocks, max(1, M // 64))
-        _hip.call("cpc_colsum", X, _hip.ptr(self.slabs), M, N, N, nb, self.code)
+        _hip.call("cpc_colsum", X, _hip.ptr(self.slabs), M, N, N, nb, self.code if code is None else code)
         _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad), 1, N, nb, N, 1, 1, 0, 0)
 
     def backward(self, x, add_dc: Optional[torch.Tensor] = None, add_dz: Optional[torch.Tensor] = None, grad_ready_hook=None):
@@ -330,6 +345,13 @@ class CPCEngine:
         self.ctx.backward(self.dc)      # parameter gradients of the context network + dz into rows [t0, t0+V) of dtop
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
+        self._backward_encoder(x, grad_ready_hook)
+
+    def _backward_encoder(self, x, grad_ready_hook=None):
+        """Encoder part of the backward pass: consumes the top-layer gradient, fills the encoder's parameter gradients."""
+        g, code = self.model._grad, self.code
+        B, n = self.B, self.n
+        La, Lv = self.geo.alloc, self.geo.valid
         # encoder, top layer down to layer 2
         for l in range(n - 1, 0, -1):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]

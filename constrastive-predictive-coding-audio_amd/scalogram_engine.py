@@ -1,0 +1,441 @@
+"""Train-step engine for the scalogram model family (BASELINE configs[2]): ScalogramResidualEncoder in front of the same
+context network / predictor / InfoNCE head as the waveform model.
+
+Activations are channels-last "grids" [B][W = time][H = frequency][C] (csrc/scalogram.hip): the reference's tall (k,1)
+kernels (scalogram_model.py:390-395 with e.g. kernel_size_2 = (64,1)) become overlapped-row GEMMs over the frequency axis,
+every other kernel shape runs as im2col + GEMM + col2im; BatchNorm2d uses batch statistics in train mode, running
+statistics in eval mode.  The encoder's output (one frequency row left) IS the [B][frames][E] buffer the context networks
+read, so everything downstream is shared with engine.CPCEngine.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import _hip
+from .engine import CPCEngine, _ceil_div, make_context
+
+
+class Grid:
+    """Zero-initialised [B][W][Ha][C] buffer with guard rows on both ends; valid rows are [top, top + H) of every column."""
+
+    def __init__(self, B, W, H, C_, device, dtype, top=0, tail=0, guard_rows=96):
+        self.B, self.W, self.H, self.C, self.top = int(B), int(W), int(H), int(C_), int(top)
+        self.Ha = self.top + self.H + int(tail)
+        self.dtype = dtype
+        self.code = _hip.dtype_code(dtype)
+        self.rows = self.B * self.W * self.Ha
+        guard = int(guard_rows) * self.C
+        self.full = torch.zeros(guard + self.rows * self.C + guard, device=device, dtype=dtype)
+        self.t = self.full[guard:guard + self.rows * self.C]
+        self.desc = (C.c_int * 6)(self.B, self.W, self.H, self.Ha, self.top, self.C)
+        # the same memory seen as a grid whose top padding rows are ordinary (zero) data rows
+        self.padded_desc = (C.c_int * 6)(self.B, self.W, self.top + self.H, self.Ha, 0, self.C)
+
+    def ptr(self, offset_elems=0):
+        return _hip.ptr(self.t, offset_elems)
+
+    def like(self, device, dtype=None, guard_rows=96):
+        dtype = self.dtype if dtype is None else dtype
+        return Grid(self.B, self.W, self.H, self.C, device, dtype, top=self.top, tail=self.Ha - self.top - self.H, guard_rows=guard_rows)
+
+    @property
+    def count(self):
+        return self.B * self.W * self.H
+
+
+def _desc(t, desc):
+    return C.cast(desc, C.c_void_p)
+
+
+class _Conv:
+    """One nn.Conv2d of the encoder on grids.  mode 'col': (k,1) kernel, stride 1, no padding -> overlapped-row GEMMs;
+    mode 'win': im2col + GEMM (+ col2im for the data gradient)."""
+
+    def __init__(self, eng, wname, bname, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False):
+        self.eng, self.wname, self.bname, self.gin, self.in_f32, self.need_dgrad, self.relu = eng, wname, bname, gin, in_f32, need_dgrad, relu
+        # a convolution that reads float32 input (the scalogram, or its pooled copy) runs entirely in float32: its output
+        # is normalised / added downstream, and bf16 would quantise away the signal riding on the log-amplitude offset
+        dev, dt = eng.device, (torch.float32 if in_f32 else eng.dt)
+        self.dt, self.code = dt, _hip.dtype_code(dt)
+        self.cin, self.cout = mod.in_channels, mod.out_channels
+        self.kh, self.kw = mod.kernel_size
+        self.sh, self.sw = mod.stride
+        ph, pw = mod.padding
+        if ph != pw:
+            raise NotImplementedError("asymmetric Conv2d padding")
+        self.pad = ph
+        if self.cin != gin.C:
+            raise ValueError(f"{wname}: expects {self.cin} input channels, the incoming activation has {gin.C}")
+        hin = gin.top + gin.H
+        self.Ho = (hin + 2 * self.pad - self.kh) // self.sh + 1
+        self.Wo = (gin.W + 2 * self.pad - self.kw) // self.sw + 1
+        if self.Ho < 1 or self.Wo < 1:
+            raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
+        ch = 8 if dt == torch.bfloat16 else 4
+        col_ok = self.kw == 1 and self.sh == 1 and self.sw == 1 and self.pad == 0 and self.cin % 8 == 0 and not in_f32
+        self.mode = 'col' if col_ok else 'win'
+        B = gin.B
+        if self.cout % 8:
+            raise NotImplementedError("scalogram encoder channel counts must be multiples of 8")
+        if self.mode == 'col':
+            self.y0 = Grid(B, gin.W, self.Ho, self.cout, dev, dt, top=0, tail=gin.Ha - self.Ho, guard_rows=self.kh + 16)
+            self.K = self.kh * self.cin
+            self.w_fwd = torch.empty(self.cout * self.K, device=dev, dtype=dt)
+            self.w_dgrad = torch.empty(self.cin * self.kh * self.cout, device=dev, dtype=dt)
+            self.M = gin.rows
+            self.nsplit = eng._pick_split(self.K, self.cout, self.M)
+            self.slab = self.nsplit * self.K * self.cout
+        else:
+            self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt)
+            self.K = self.kh * self.kw * self.cin
+            self.Kp = _ceil_div(self.K, 8) * 8
+            self.M = B * self.Wo * self.Ho
+            self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
+            self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if need_dgrad else None
+            self.w_fwd = torch.zeros(self.cout, self.Kp, device=dev, dtype=dt)
+            self.w_t = torch.zeros(self.Kp, self.cout, device=dev, dtype=dt)
+            self.nsplit = eng._pick_split(self.Kp, self.cout, self.M, dt)
+            self.slab = self.nsplit * self.Kp * self.cout
+        self.dy0: Optional[Grid] = None        # set by the owner (may alias another gradient grid)
+
+    # ------------------------------------------------------------------
+    def prepare(self):
+        p, code = self.eng.model._param, self.code
+        w = p[self.wname]
+        if self.mode == 'col':
+            _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd), _hip.ptr(self.w_dgrad), self.cout, self.cin, self.kh, 1, code)
+        else:
+            flat = w.detach().permute(0, 2, 3, 1).reshape(self.cout, self.K)         # [co][(dh*kw + dw)*C + c]
+            self.w_fwd[:, :self.K].copy_(flat)
+            self.w_t[:self.K, :].copy_(flat.t())
+
+    def forward(self):
+        e, gin, y0 = self.eng, self.gin, self.y0
+        p, code = e.model._param, self.code
+        bias = _hip.ptr(p.get(self.bname)) if self.bname else None
+        flags = _hip.GEMM_RELU if self.relu else 0
+        if self.mode == 'col':
+            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M, self.cout, self.K, self.cin, self.K, self.cout, code,
+                         bias=bias, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
+        else:
+            _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(self.col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
+                      self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if self.in_f32 else 0, code)
+            _hip.gemm_nt(_hip.ptr(self.col), _hip.ptr(self.w_fwd), y0.ptr(y0.top * self.cout), self.M, self.cout, self.Kp, self.Kp, self.Kp,
+                         self.cout, code, bias=bias, c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
+
+    def backward(self, din: Optional[Grid], accumulate=False, mask_input=False):
+        """dy0 (gradient of the convolution output) -> bias / weight gradients, and the input gradient into ``din``
+        (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
+        e, gin, dy0 = self.eng, self.gin, self.dy0
+        g, code = e.model._grad, self.code
+        if self.bname and self.bname in g:
+            e._colsum_to_grad(dy0.ptr(), g[self.bname], dy0.rows, self.cout, code)
+        if self.mode == 'col':
+            chunk = e._chunk(self.M, self.nsplit)
+            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(e.slabs), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
+                         nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32)
+            _hip.call("cpc_reduce_conv_w", _hip.ptr(e.slabs), _hip.ptr(g[self.wname]), self.cin, self.cout, self.kh, self.nsplit,
+                      self.K * self.cout)
+            if din is not None and self.need_dgrad:
+                D = self.kh
+                dst = din
+                if accumulate:          # the overlapped-row GEMM overwrites: go through a scratch grid of the same layout
+                    if getattr(self, "_din_tmp", None) is None:
+                        self._din_tmp = din.like(e.device, e.dt)
+                    dst = self._din_tmp
+                _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
+                             D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
+                if accumulate:
+                    din.t.add_(dst.t)
+        else:
+            chunk = e._chunk(self.M, self.nsplit, self.dt)
+            _hip.gemm_tn(_hip.ptr(self.col), dy0.ptr(dy0.top * self.cout), _hip.ptr(e.slabs), self.M, self.Kp, self.cout, self.Kp, self.cout,
+                         self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit, m_chunk=chunk,
+                         slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
+            taps = self.kh * self.kw
+            _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[self.wname]), self.K, self.cout, self.nsplit, self.Kp * self.cout,
+                      self.cin, self.cin * taps, 1, taps)
+            if din is not None and self.need_dgrad:
+                _hip.gemm_nt(dy0.ptr(dy0.top * self.cout), _hip.ptr(self.w_t), _hip.ptr(self.dcol), self.M, self.Kp, self.cout, self.cout,
+                             self.cout, self.Kp, code, a_rpi=self.Ho, a_item=dy0.Ha * self.cout)
+                _hip.call("cpc_col2im2d", _hip.ptr(self.dcol), din.ptr(), _desc(din, din.padded_desc), self.kh, self.kw, self.sh, self.sw,
+                          self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if accumulate else 0, code)
+                if mask_input:
+                    _hip.call("cpc_relu_mask", din.ptr(), gin.ptr(), din.rows * din.C, code)
+
+
+class _BatchNorm:
+    """nn.BatchNorm2d + ReLU between a convolution output grid y0 and the activation grid a."""
+
+    def __init__(self, eng, prefix, mod, y0: Grid, a: Grid):
+        self.eng, self.prefix, self.mod, self.y0, self.a = eng, prefix, mod, y0, a
+        self.C = y0.C
+        self.x_f32 = 1 if (y0.dtype == torch.float32 and eng.dt != torch.float32) else 0
+        self.stats = torch.zeros(2, self.C, device=eng.device, dtype=torch.float32)
+        self.nb = max(1, min(512, y0.rows // 512))
+        self.slab = self.nb * 2 * self.C
+        self.dy0: Optional[Grid] = None
+        self.trained = True
+
+    def forward(self):
+        e, mod = self.eng, self.mod
+        p, code = e.model._param, e.code
+        self.trained = bool(mod.training or not mod.track_running_stats)
+        if self.trained:
+            _hip.call("cpc_bn_stats", self.y0.ptr(), _hip.ptr(e.slabs), self.y0.rows, self.C, self.nb, self.y0.code)
+            rm = mod.running_mean if mod.track_running_stats else None
+            rv = mod.running_var if mod.track_running_stats else None
+            momentum = 0.1 if mod.momentum is None else float(mod.momentum)
+            _hip.call("cpc_bn_finalize", _hip.ptr(e.slabs), self.nb, self.C, float(self.y0.count), float(mod.eps), momentum,
+                      _hip.ptr(self.stats), _hip.ptr(rm), _hip.ptr(rv))
+            if mod.track_running_stats and mod.num_batches_tracked is not None:
+                mod.num_batches_tracked += 1
+        else:
+            self.stats[0].copy_(mod.running_mean)
+            self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
+        _hip.call("cpc_bn_apply", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc), _hip.ptr(self.stats),
+                  _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), 1, self.x_f32, code)
+
+    def backward(self, da: Grid):
+        e = self.eng
+        p, g, code = e.model._param, e.model._grad, e.code
+        gw, gb = g[self.prefix + ".weight"], g[self.prefix + ".bias"]
+        _hip.call("cpc_bn_bwd_reduce", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), _desc(self.y0, self.y0.desc),
+                  _hip.ptr(self.stats), _hip.ptr(e.slabs), 1, self.nb, self.x_f32, code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
+                  _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
+                  float(self.y0.count), 1, 1 if self.trained else 0, self.x_f32, code)
+
+
+class _Block:
+    """One ScalogramEncoderBlock (scalogram_model.py:372-479) on grids."""
+
+    def __init__(self, eng, idx, blk, gin: Grid, in_f32, last, next_top):
+        self.eng, self.idx, self.blk, self.gin, self.in_f32, self.last = eng, idx, blk, gin, in_f32, last
+        dev, dt = eng.device, eng.dt
+        cfg = blk.cfg
+        pre = f"encoder.blocks.{idx}."
+        first = idx == 0
+        mm = blk.main_modules
+        has_bn = cfg['batch_norm']
+        bias = cfg['bias']
+        top2 = cfg['top_padding_2'] or 0
+        if in_f32 and not has_bn and dt != torch.float32:
+            raise NotImplementedError("a first scalogram block without batch_norm is supported in fp32 mode only")
+        if (cfg['top_padding_1'] or 0) != gin.top:
+            raise AssertionError("block input grid was not allocated with this block's top_padding_1")
+        # ---- main branch
+        i1, i2 = blk.index['conv_1'], blk.index['conv_2']
+        self.conv_a = _Conv(eng, f"{pre}main_modules.{i1}.weight", f"{pre}main_modules.{i1}.bias" if bias else None, mm[i1], gin,
+                            in_f32=in_f32, need_dgrad=not first, relu=not has_bn)
+        ya = self.conv_a.y0
+        if has_bn:
+            self.a_a = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt, top=top2, guard_rows=cfg['kernel_size_2'][0] + 16)
+            self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya, self.a_a)
+        else:
+            if top2:
+                raise NotImplementedError("top_padding_2 without batch_norm is not part of the HIP path yet")
+            self.a_a, self.bn_a = ya, None
+        self.conv_b = _Conv(eng, f"{pre}main_modules.{i2}.weight", f"{pre}main_modules.{i2}.bias" if bias else None, mm[i2], self.a_a,
+                            relu=not has_bn)
+        yb = self.conv_b.y0
+        if has_bn:
+            self.main = Grid(yb.B, yb.W, yb.H, yb.C, dev, dt)
+            self.bn_b = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_2']}", mm[blk.index['bn_2']], yb, self.main)
+        else:
+            self.main, self.bn_b = yb, None
+        # ---- residual branch
+        self.res_conv = self.rp = None
+        if blk.residual:
+            src, src_f32 = gin, in_f32
+            if gin.top:
+                raise NotImplementedError("residual branch with top_padding_1")
+            if blk.res_pool > 1:
+                p_ = blk.res_pool
+                self.rp = Grid(gin.B, _ceil_div(gin.W, p_), _ceil_div(gin.H, p_), gin.C, dev, torch.float32 if in_f32 else dt)
+                src, src_f32 = self.rp, in_f32
+            if 'res_conv' in blk.index:
+                ri = blk.index['res_conv']
+                self.res_conv = _Conv(eng, f"{pre}residual_modules.{ri}.weight", None, blk.residual_modules[ri], src, in_f32=src_f32,
+                                      need_dgrad=not first)
+                self.res = self.res_conv.y0
+            else:
+                if src_f32:
+                    raise NotImplementedError("identity residual on the float32 scalogram input")
+                self.res = src
+            m = self.main
+            o_h, o_w = (self.res.H - m.H + 1) / 2, (self.res.W - m.W + 1) / 2
+            self.oh = self.res.H - int(o_h + m.H) if int(o_h) > 0 else 0
+            self.ow = self.res.W - int(o_w + m.W) if int(o_w) > 0 else 0
+            if (int(o_h) <= 0 and self.res.H != m.H) or (int(o_w) <= 0 and self.res.W != m.W):
+                raise ValueError(f"block {idx}: residual {self.res.H}x{self.res.W} cannot be cropped onto main {m.H}x{m.W}")
+            self.out = Grid(m.B, m.W, m.H, m.C, dev, dt, top=next_top)
+            self.r_f32 = 1 if (self.res.dtype == torch.float32 and dt != torch.float32) else 0
+        else:
+            if next_top:
+                raise NotImplementedError("top_padding_1 after a block without residual branch")
+            self.out = self.main
+        self.slab = max([c.slab for c in (self.conv_a, self.conv_b, self.res_conv) if c is not None] +
+                        [b.slab for b in (self.bn_a, self.bn_b) if b is not None])
+
+    def allocate_grads(self, d_in: Optional[Grid]):
+        """Gradient grids; ``d_in`` is the gradient grid of the block input (None for the first block)."""
+        dev, dt = self.eng.device, self.eng.dt
+        self.d_in = d_in
+        self.d_out = self.out.like(dev)
+        if self.blk.residual:
+            self.d_main = self.main.like(dev, guard_rows=self.conv_b.kh + 16)
+            self.d_res = self.res.like(dev)
+            self.d_rp = self.rp.like(dev) if (self.rp is not None and self.res_conv is not None) else None
+            if self.res_conv is not None:
+                self.res_conv.dy0 = self.d_res
+        else:
+            self.d_main = self.d_out
+        if self.bn_b is not None:
+            self.bn_b.dy0 = self.conv_b.y0.like(dev, guard_rows=self.conv_b.kh + 16)
+            self.conv_b.dy0 = self.bn_b.dy0
+        else:
+            self.conv_b.dy0 = self.d_main
+        self.d_a = self.a_a.like(dev, guard_rows=self.conv_b.kh + 16)
+        if self.bn_a is not None:
+            self.bn_a.dy0 = self.conv_a.y0.like(dev, guard_rows=self.conv_a.kh + 16)
+            self.conv_a.dy0 = self.bn_a.dy0
+        else:
+            self.conv_a.dy0 = self.d_a
+
+    def prepare(self):
+        for c in (self.conv_a, self.conv_b, self.res_conv):
+            if c is not None:
+                c.prepare()
+
+    def forward(self):
+        e, code = self.eng, self.eng.code
+        self.conv_a.forward()
+        if self.bn_a is not None:
+            self.bn_a.forward()
+        self.conv_b.forward()
+        if self.bn_b is not None:
+            self.bn_b.forward()
+        if self.blk.residual:
+            if self.rp is not None:
+                _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.rp.ptr(), _desc(self.rp, self.rp.desc),
+                          self.blk.res_pool, 1 if self.in_f32 else 0, self.rp.code)
+            if self.res_conv is not None:
+                self.res_conv.forward()
+            _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
+                      self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)
+
+    def backward(self):
+        e, code = self.eng, self.eng.code
+        first = self.idx == 0
+        if self.blk.residual:
+            self.d_res.t.zero_()
+            _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
+                      _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, self.ow,
+                      0 if self.last else 1, self.r_f32, code)
+        # second convolution
+        if self.bn_b is not None:
+            self.bn_b.backward(self.d_main)
+        else:
+            _hip.call("cpc_relu_mask", self.d_main.ptr(), self.main.ptr(), self.d_main.rows * self.d_main.C, code)
+        self.conv_b.backward(self.d_a, mask_input=self.bn_a is None)
+        # first convolution
+        if self.bn_a is not None:
+            self.bn_a.backward(self.d_a)
+        self.conv_a.backward(None if first else self.d_in)
+        # residual branch (adds into the block-input gradient after the main branch wrote it)
+        if self.blk.residual:
+            if self.res_conv is not None:
+                if self.rp is not None:
+                    self.res_conv.backward(None if first else self.d_rp)
+                    if not first:
+                        _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_rp.ptr(),
+                                  _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, code)
+                else:
+                    self.res_conv.backward(None if first else self.d_in, accumulate=True)
+            elif not first:
+                if self.rp is not None:
+                    _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_res.ptr(),
+                              _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, code)
+                else:
+                    self.d_in.t.add_(self.d_res.t)
+
+
+class ScalogramCPCEngine(CPCEngine):
+    """CPCEngine whose encoder is a ScalogramResidualEncoder fed with (B, C, bins, frames) scalograms."""
+
+    def __init__(self, model, in_shape, device, dtype: torch.dtype):
+        enc, ar = model.encoder, model.autoregressive_model
+        self.model = model
+        self.device = torch.device(device)
+        self.dt = dtype
+        self.code = _hip.dtype_code(dtype)
+        B, Cin, Hin, Win = (int(v) for v in in_shape)
+        self.B, self.in_shape = B, (B, Cin, Hin, Win)
+        self.L = Win
+        self.E = int(model.enc_size)
+        self.H = int(model.ar_size)
+        self.K = int(model.prediction_steps)
+        self.V = int(model.visible_steps)
+        self.x_off = 0
+        self.n = 0
+        self.colsum_blocks = 1024
+        model._flatten_parameters(self.device)
+        # ---- encoder graph
+        blocks = list(enc.blocks)
+        top0 = blocks[0].cfg['top_padding_1'] or 0
+        if top0:
+            raise NotImplementedError("top_padding_1 on the first scalogram block")
+        self.x_grid = Grid(B, Win, Hin, Cin, self.device, torch.float32)
+        self.blocks: List[_Block] = []
+        gin, in_f32 = self.x_grid, True
+        for i, blk in enumerate(blocks):
+            last = i == len(blocks) - 1
+            next_top = 0 if last else (blocks[i + 1].cfg['top_padding_1'] or 0)
+            b = _Block(self, i, blk, gin, in_f32, last, next_top)
+            self.blocks.append(b)
+            gin, in_f32 = b.out, False
+        out = self.blocks[-1].out
+        if out.H != 1 or out.Ha != 1 or out.C != self.E:
+            raise NotImplementedError(f"scalogram encoder must end with one frequency row of enc_size channels, got H={out.H}, C={out.C}")
+        self.T = out.W
+        if self.T < self.V + self.K:
+            raise ValueError(f"scalogram gives {self.T} encoder frames, need visible+prediction = {self.V + self.K}")
+        d_in = None
+        for b in self.blocks:
+            b.allocate_grads(d_in)
+            d_in = b.d_out
+        self.geo = SimpleNamespace(alloc=[self.T], valid=[self.T])
+        self.act, self.dact = [out.t], [self.blocks[-1].d_out.t]
+        self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
+        need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)]
+        self._alloc_head(need)
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("the CPC hot path runs on the GPU only (no CPU fallback): move the batch to the device")
+        if tuple(x.shape) != self.in_shape:
+            raise ValueError(f"expected a scalogram batch of shape {self.in_shape}, got {tuple(x.shape)}")
+
+    def _prepare_encoder_weights(self):
+        for b in self.blocks:
+            b.prepare()
+
+    def encoder_forward(self, x):
+        """x (B, C, bins, frames) float32 — typically PreprocessingModule's permuted view, whose memory already is the
+        channels-last grid; any other layout is re-laid out once."""
+        self._check_input(x)
+        cl = x.detach().permute(0, 3, 2, 1)
+        self.x_grid.t.view(cl.shape).copy_(cl)
+        for b in self.blocks:
+            b.forward()
+
+    def _backward_encoder(self, x, grad_ready_hook=None):
+        for b in reversed(self.blocks):
+            b.backward()

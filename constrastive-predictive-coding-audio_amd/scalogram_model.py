@@ -78,3 +78,99 @@ class PreprocessingModule(nn.Module):
         x = out.permute(0, 3, 2, 1)              # (B, channels, bins, frames) view
         self.output = x
         return x
+
+
+default_encoder_block_dict = {'in_channels': 64,
+                              'hidden_channels': None,
+                              'out_channels': 64,
+                              'kernel_size_1': (3, 3),
+                              'kernel_size_2': (3, 3),
+                              'top_padding_1': None,
+                              'top_padding_2': None,
+                              'padding_1': 0,
+                              'padding_2': 0,
+                              'stride_1': 1,
+                              'stride_2': 1,
+                              'pooling_1': 1,
+                              'pooling_2': 1,
+                              'bias': True,
+                              'separable': False,
+                              'residual': True,
+                              'batch_norm': False}
+
+
+class ScalogramEncoderBlock(nn.Module):
+    """conv_a -> [BN] -> ReLU -> [top pad] -> conv_b -> [BN] -> ReLU, plus the pooled / 1x1-projected, cropped residual
+    branch (reference scalogram_model.py:372-479).  Parameter holder: standard torch modules at the reference's
+    ``main_modules`` / ``residual_modules`` indices (so state_dict keys and default initialisation coincide); the
+    arithmetic runs in scalogram_engine.ScalogramCPCEngine."""
+
+    def __init__(self, args_dict=default_encoder_block_dict, name='scalogram_block', activation_register=None):
+        super().__init__()
+        self.name = name
+        if args_dict['hidden_channels'] is None:
+            args_dict['hidden_channels'] = args_dict['out_channels']
+        if args_dict['separable']:
+            raise NotImplementedError("separable scalogram convolutions are not part of the HIP path")
+        if args_dict['pooling_1'] > 1 or args_dict['pooling_2'] > 1:
+            raise NotImplementedError("pooling inside the main branch of a scalogram block is not part of the HIP path yet")
+        a = args_dict
+        self.cfg = {k: a[k] for k in ('in_channels', 'hidden_channels', 'out_channels', 'kernel_size_1', 'kernel_size_2',
+                                      'top_padding_1', 'top_padding_2', 'padding_1', 'padding_2', 'stride_1', 'stride_2',
+                                      'bias', 'residual', 'batch_norm')}
+        self.main_modules = nn.ModuleList()
+        self.index = {}
+        for tag, cin, cout in (('1', a['in_channels'], a['hidden_channels']), ('2', a['hidden_channels'], a['out_channels'])):
+            if a['top_padding_' + tag] is not None:
+                self.main_modules.append(nn.ZeroPad2d((0, 0, a['top_padding_' + tag], 0)))
+            self.index['conv_' + tag] = len(self.main_modules)
+            self.main_modules.append(nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=a['kernel_size_' + tag],
+                                               bias=a['bias'], padding=a['padding_' + tag], stride=a['stride_' + tag]))
+            if a['batch_norm']:
+                self.index['bn_' + tag] = len(self.main_modules)
+                self.main_modules.append(nn.BatchNorm2d(cout))
+            self.main_modules.append(nn.ReLU())
+            self.main_modules.append(ActivationWriter(register=activation_register, name=self.name + '_main_conv_' + tag))
+        self.residual = a['residual']
+        if self.residual:
+            self.residual_modules = nn.ModuleList()
+            self.res_pool = a['stride_1'] * a['stride_2'] * a['pooling_1'] * a['pooling_2']
+            if self.res_pool > 1:
+                self.residual_modules.append(nn.MaxPool2d(kernel_size=self.res_pool, ceil_mode=True))
+            if a['in_channels'] != a['out_channels']:
+                self.index['res_conv'] = len(self.residual_modules)
+                self.residual_modules.append(nn.Conv2d(in_channels=a['in_channels'], out_channels=a['out_channels'], kernel_size=1,
+                                                       padding=a['padding_1'] + a['padding_2'], bias=False))
+        self.output_activation_writer = ActivationWriter(register=activation_register, name=self.name + '_main_conv_2')
+
+    def forward(self, x):
+        raise NotImplementedError("ScalogramEncoderBlock runs inside AudioPredictiveCodingModel.forward on the HIP path")
+
+
+class ScalogramResidualEncoder(nn.Module):
+    """Stack of ScalogramEncoderBlocks with ReLU between blocks; the output is the single remaining frequency row
+    (reference scalogram_model.py:488-529)."""
+
+    def __init__(self, args_dict, preprocessing_module=None, verbose=0):
+        super().__init__()
+        self.verbose = verbose
+        self.phase = args_dict['phase']
+        if self.phase:
+            args_dict['blocks'][0]['in_channels'] = 2
+        if preprocessing_module is None:
+            self.receptive_field = 1
+            self.downsampling_factor = 1
+        else:
+            self.receptive_field = preprocessing_module.receptive_field
+            self.downsampling_factor = preprocessing_module.downsampling_factor
+        self.blocks = nn.ModuleList()
+        for i, block_dict in enumerate(args_dict['blocks']):
+            self.blocks.append(ScalogramEncoderBlock(block_dict, name='scalogram_block_' + str(i),
+                                                     activation_register=args_dict.get('activation_register')))
+            self.receptive_field += (block_dict['kernel_size_1'][1] - 1) * self.downsampling_factor
+            self.downsampling_factor *= block_dict['pooling_1'] * block_dict['stride_1']
+            self.receptive_field += (block_dict['kernel_size_2'][1] - 1) * self.downsampling_factor
+            self.downsampling_factor *= block_dict['pooling_2'] * block_dict['stride_2']
+
+    def forward(self, x):
+        raise NotImplementedError("ScalogramResidualEncoder runs inside AudioPredictiveCodingModel.forward on the HIP path")

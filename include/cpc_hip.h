@@ -155,6 +155,58 @@ int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void
 int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
                             long long ldq, int phase, float offset, float log_offset, float norm, float power, void* stream);
 
+/* ---- 2-D residual encoder on channels-last "grids" (ScalogramEncoderBlock / ScalogramResidualEncoder,
+ * scalogram_model.py:372-529) ----
+ * A grid is described by int[6] = {B, W, H, Ha, top, C}: element (b, w, h, c) at ((b*W + w)*Ha + top + h)*C + c, with
+ * h the frequency axis, w the time axis; Ha >= top + H rows are allocated per (b, w) column and rows outside
+ * [top, top+H) are zero (ZeroPad2d top padding, scalogram_model.py:388-389, is a non-zero `top`).
+ * Convolutions: tall (k,1) stride-1 kernels are cpc_gemm_nt / cpc_gemm_tn over overlapped rows of a grid; every other
+ * kernel shape goes through cpc_im2col2d + plain GEMMs + cpc_col2im2d.
+ *
+ * col T [B*Wo*Ho][Kp], column (dh*kw + dw)*C + c = in(b, wo*sw + dw - pw, ho*sh + dh - ph, c) (zero outside the grid and
+ * for columns >= kh*kw*C); in_f32: the input grid is f32 (the scalogram itself), else T. */
+int cpc_im2col2d(const void* in, void* col, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                 int in_f32, int dtype, void* stream);
+/* The adjoint: din(b,w,h,c) (+= if accumulate) sum of the dcol entries that read it. */
+int cpc_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
+                 int accumulate, int dtype, void* stream);
+/* nn.BatchNorm2d / BatchNorm1d with batch statistics (scalogram_model.py:398-399, audio_model.py:102-103):
+ * cpc_bn_stats: slabs f32 [nblocks][2][C] partial (sum, sum of squares) over the rows of x T [rows][C] (pad rows are zero);
+ * cpc_bn_finalize: stats f32 [2][C] = (mean, 1/sqrt(biased var + eps)) over `count` elements per channel, and, when
+ *   run_mean / run_var are given, torch's running update (momentum, unbiased variance);
+ * cpc_bn_apply: out = act((x - mean) * rstd * gamma + beta) on the valid rows of two grids of equal shape. C in {4,8,..,1024}.
+ * x_f32 (here and in the backward): x / dx are float32 grids although dtype is bf16 — the first convolution of the
+ * encoder reads the float32 scalogram and keeps its pre-normalisation output in float32 (log-amplitudes have a large
+ * common offset that bf16 storage would quantise away before the normalisation removes it). */
+int cpc_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, void* stream);
+int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
+                    float* run_var, void* stream);
+int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                 int relu, int x_f32, int dtype, void* stream);
+/* Backward: g = dy * (y > 0) if relu.  cpc_bn_bwd_reduce: slabs [nblocks][2][C] partials of (sum g*xhat, sum g) = (dgamma,
+ * dbeta) to be summed by cpc_reduce_slabs; cpc_bn_bwd_apply: dx = gamma*rstd*(g - dbeta/count - xhat*dgamma/count) with
+ * train != 0, g*gamma*rstd otherwise (running statistics). */
+int cpc_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
+                      int relu, int nblocks, int x_f32, int dtype, void* stream);
+int cpc_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                     const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
+                     int dtype, void* stream);
+/* nn.MaxPool2d(kernel = stride = p, ceil_mode=True) of the residual branches (scalogram_model.py:434-436); the backward
+ * routes dout to the first maximum of each window (+= if accumulate). */
+int cpc_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, void* stream);
+int cpc_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
+                      void* stream);
+/* out = act(a + r(w + ow, h + oh)) — the cropped residual add (scalogram_model.py:453-472) with the inter-block ReLU
+ * (:525-526) folded in; backward: da = g, dr(w + ow, h + oh) = g with g = dout * (out > 0) if relu (dr is cleared by the caller).
+ * r_f32: the residual grid r / dr is float32 although dtype is bf16 (first block, see x_f32 above). */
+int cpc_residual_add(const void* a, const int* ga, const void* r, const int* gr, void* out, const int* go, int oh, int ow, int relu,
+                     int r_f32, int dtype, void* stream);
+int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
+                         int ow, int relu, int r_f32, int dtype, void* stream);
+
+/* g[i] = y[i] > 0 ? g[i] : 0 for i < n (n % 4 == 0): ReLU backward on whole buffers where no fused epilogue applies. */
+int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream);
+
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);
 /* MFMA fragment order of a [R][Kd] operand (transpose: logical[n][k] = src[k*ld + n]) for the GRU kernels. */

@@ -248,6 +248,56 @@ def preprocessing_forward(cq: torch.Tensor, phase_consts=None, offset_zero: bool
     return (x * norm) ** output_power
 
 
+def scalogram_block_forward(x: torch.Tensor, params: Params, prefix: str, cfg: dict, training: bool, last: bool) -> torch.Tensor:
+    """ScalogramEncoderBlock.forward — scalogram_model.py:381-479 (module order :388-425, residual branch :427-441,
+    cropped add :453-472) followed by the F.relu ScalogramResidualEncoder.forward applies between blocks (:525-526).
+    ``params`` holds weights and BatchNorm buffers under the reference's state_dict keys; running statistics are updated
+    in place when ``training``."""
+    def conv_bn_relu(h, idx, tag):
+        top = cfg.get("top_padding_" + tag)
+        if top is not None:
+            h = F.pad(h, (0, 0, top, 0))
+            idx += 1
+        h = F.conv2d(h, params[f"{prefix}main_modules.{idx}.weight"], params.get(f"{prefix}main_modules.{idx}.bias"),
+                     stride=cfg["stride_" + tag], padding=cfg["padding_" + tag])
+        idx += 1
+        if cfg["batch_norm"]:
+            bn = f"{prefix}main_modules.{idx}."
+            h = F.batch_norm(h, params[bn + "running_mean"], params[bn + "running_var"], params[bn + "weight"], params[bn + "bias"],
+                             training=training, momentum=0.1, eps=1e-5)
+            if training:
+                params[bn + "num_batches_tracked"] += 1
+            idx += 1
+        return torch.relu(h), idx + 2          # ReLU + ActivationWriter
+
+    main, idx = conv_bn_relu(x, 0, "1")
+    main, _ = conv_bn_relu(main, idx, "2")
+    if cfg["residual"]:
+        res, ridx = x, 0
+        pool = cfg["stride_1"] * cfg["stride_2"]
+        if pool > 1:
+            res = F.max_pool2d(res, pool, ceil_mode=True)
+            ridx = 1
+        if cfg["in_channels"] != cfg["out_channels"]:
+            res = F.conv2d(res, params[f"{prefix}residual_modules.{ridx}.weight"], None, padding=cfg["padding_1"] + cfg["padding_2"])
+        m_h, m_w = main.shape[2], main.shape[3]
+        o_h, o_w = (res.shape[2] - m_h + 1) / 2, (res.shape[3] - m_w + 1) / 2
+        if int(o_h) > 0:
+            res = res[:, :, -int(o_h + m_h):-int(o_h), :]
+        if int(o_w) > 0:
+            res = res[:, :, :, -int(o_w + m_w):-int(o_w)]
+        main = main + res
+    return main if last else torch.relu(main)
+
+
+def scalogram_encoder_forward(x: torch.Tensor, params: Params, blocks: Sequence[dict], training: bool = True,
+                              prefix: str = "encoder.") -> torch.Tensor:
+    """ScalogramResidualEncoder.forward — scalogram_model.py:519-529: (B, C, bins, frames) -> (B, E, frames')."""
+    for i, cfg in enumerate(blocks):
+        x = scalogram_block_forward(x, params, f"{prefix}blocks.{i}.", cfg, training, last=i == len(blocks) - 1)
+    return x[:, :, 0, :]
+
+
 # ------------------------------------------------------------------------- CPC model
 def item_length(receptive_field: int, downsampling: int, visible_steps: int, prediction_steps: int) -> int:
     """audio_model.py:187-191."""
@@ -255,13 +305,16 @@ def item_length(receptive_field: int, downsampling: int, visible_steps: int, pre
 
 
 def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_steps: int,
-                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None, attention=None):
+                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None, attention=None, scalogram=None, training: bool = True):
     """AudioPredictiveCodingModel.forward with AudioEncoder + AudioGRUModel — audio_model.py:193-211.
     conv_ar = (kernel_sizes, poolings) selects ConvolutionalArModel, attention = (num_layers, num_heads) AttentionModel.
 
     Returns (predicted_z (B,K,E), targets (B,E,K), z (B,E,V), c (B,H)); targets are NOT detached.
     """
-    enc = encoder_forward(x, params, strides)
+    if scalogram is not None:       # scalogram = list of block dicts; x is the (B, C, bins, frames) scalogram
+        enc = scalogram_encoder_forward(x, params, scalogram, training)
+    else:
+        enc = encoder_forward(x, params, strides)
     K, V = prediction_steps, visible_steps
     targets = enc[:, :, -K:]
     z = enc[:, :, -(V + K):-K]
@@ -360,10 +413,13 @@ class OracleTrainer:
     def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
                  strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
                  all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None,
-                 attention=None):
-        self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+                 attention=None, scalogram=None):
+        is_buffer = lambda k: ("running_" in k) or k.endswith("num_batches_tracked") or k.endswith("positional_encoder.pe")
+        self.buffers = {k: v.detach().clone() for k, v in params.items() if is_buffer(k)}
+        self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if not is_buffer(k)}
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.scalogram = scalogram
         self.V, self.K = visible_steps, prediction_steps
         self.strides = tuple(strides)
         self.score = SCORE_FUNCTIONS[score]
@@ -378,7 +434,9 @@ class OracleTrainer:
         """batch (B, L) -> (loss, max_score, grads dict); does not update parameters."""
         for p in self.params.values():
             p.grad = None
-        pred, targ, _, _ = cpc_forward(batch.unsqueeze(1), self.params, self.V, self.K, self.strides, self.conv_ar, self.attention)
+        x = batch if self.scalogram is not None else batch.unsqueeze(1)
+        pred, targ, _, _ = cpc_forward(x, {**self.params, **self.buffers}, self.V, self.K, self.strides, self.conv_ar, self.attention,
+                                       self.scalogram)
         loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
         loss.backward()
         return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}

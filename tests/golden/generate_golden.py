@@ -21,6 +21,8 @@ Fixtures written (all float32 unless noted):
   conv_ar_model.npz     AudioEncoder + ConvolutionalArModel (k 9/9/9, pooling 1/2/2) forward, losses, gradients
   attention_model.npz   AudioEncoder + AttentionModel (2 layers, 8 heads, dropout 0) forward, losses, gradients
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
+  scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval),
+                        trainer losses, gradients, BatchNorm running statistics
 """
 import io
 import json
@@ -360,6 +362,104 @@ def gen_cqt():
     print("cqt:", meta["kernel_sizes"], meta["index_ranges"], out["cqt"].shape, {k: v.shape for k, v in out.items() if k.startswith("pre/")})
 
 
+def _scalogram_small_blocks():
+    base = {'in_channels': 64, 'hidden_channels': None, 'out_channels': 64, 'kernel_size_1': (3, 3), 'kernel_size_2': (3, 3),
+            'top_padding_1': None, 'top_padding_2': None, 'padding_1': 0, 'padding_2': 0, 'stride_1': 1, 'stride_2': 1,
+            'pooling_1': 1, 'pooling_2': 1, 'bias': True, 'separable': False, 'residual': True, 'batch_norm': False,
+            'ceil_pooling': False}
+    b0 = dict(base, in_channels=1, out_channels=16, stride_1=2, kernel_size_2=(6, 1), top_padding_2=5, batch_norm=True)
+    b1 = dict(base, in_channels=16, out_channels=32, stride_1=2, kernel_size_2=(3, 1), batch_norm=True)
+    b2 = dict(base, in_channels=32, out_channels=64, kernel_size_1=(2, 2), kernel_size_2=(2, 1))
+    return [b0, b1, b2]
+
+
+def gen_scalogram():
+    """A shrunken scalogram_resnet_architecture_7: CQT (24 bins) -> phase scalogram -> 3 residual blocks (strided 3x3 +
+    tall (k,1) kernels with top padding, BatchNorm on the first two, 2x2 + (2,1) on the last) -> GRU context."""
+    _install_librosa_stand_in()
+    import scalogram_model as ref_scal
+    import copy
+    E, H, K, V, B = 64, 32, 3, 10, 4
+    L = 256 + 32 * 60 + 1
+    scale = {"prediction_model.weight": 1.0}
+
+    def build():
+        torch.manual_seed(41)
+        pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, phase=True)
+        enc_dict = {'phase': True, 'blocks': copy.deepcopy(_scalogram_small_blocks()), 'activation_register': None}
+        enc = ref_scal.ScalogramResidualEncoder(args_dict=enc_dict, preprocessing_module=pre)
+        ar = ref_model.AudioGRUModel(input_size=E, hidden_size=H)
+        model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=E, ar_size=H, visible_steps=V, prediction_steps=K)
+        g = torch.Generator().manual_seed(43)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+                if "main_modules" in n and p.dim() == 1 and ".weight" in n:      # BatchNorm gamma away from 1
+                    p.add_(0.3 * torch.randn(p.shape, generator=g))
+            for n, b in model.named_buffers():
+                if n.endswith("running_mean"):
+                    b.add_(0.1 * torch.randn(b.shape, generator=g))
+                if n.endswith("running_var"):
+                    b.mul_(1.0 + 0.5 * torch.rand(b.shape, generator=g))
+        return pre, model
+
+    out = {}
+    pre, model = build()
+    for k, v in np_state(model).items():
+        out["param/" + k] = v
+    g = torch.Generator().manual_seed(9)
+    n_items = 12
+    data = torch.randn(n_items, L, generator=g) * 0.3
+    out["data"] = data.numpy()
+    meta = {"E": E, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "cqt": CQT_SMALL, "blocks": _scalogram_small_blocks(),
+            "receptive_field": int(model.encoder.receptive_field), "downsampling_factor": int(model.encoder.downsampling_factor),
+            "item_length": int(model.item_length), "runs": []}
+    with torch.no_grad():
+        scal = pre(data[:B].unsqueeze(1))
+        out["scalogram"] = scal.numpy()
+        model.eval()
+        pz, tg, z, c = model(scal)
+        out["eval/predicted_z"], out["eval/targets"], out["eval/z"], out["eval/c"] = pz.numpy(), tg.numpy().copy(), z.numpy().copy(), c.numpy()
+        model.train()
+        pz, tg, z, c = model(scal)
+        out["train/predicted_z"], out["train/targets"], out["train/z"], out["train/c"] = pz.numpy(), tg.numpy().copy(), z.numpy().copy(), c.numpy()
+        for k, v in np_state(model).items():
+            if "running_" in k or "num_batches" in k:
+                out["after_train_fwd/" + k] = v
+    rid = 0
+    for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
+                                                ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3),
+                                                ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4)):
+        pre, model = build()
+        ds = TensorDataset(data)
+        logger = Logger()
+        with quiet():
+            tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                                                        score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H,
+                                                        preprocessing=pre)
+            random.seed(91)
+            tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+        tag = f"run{rid}"
+        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+                             "python_seed": 91, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                             "loss": logger.loss_meter.values, "max_score": logger.score_meter.values})
+        if steps == 1:
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    out[f"{tag}/grad/{n}"] = p.grad.numpy().copy()
+        else:
+            for k, v in np_state(model).items():
+                if "running_" in k:
+                    out[f"{tag}/after/{k}"] = v
+        rid += 1
+    np.savez_compressed(os.path.join(OUT, "scalogram_model.npz"), **out)
+    with open(os.path.join(OUT, "scalogram_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("scalogram:", out["scalogram"].shape, out["train/z"].shape, [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]],
+          "rf/ds/item", meta["receptive_field"], meta["downsampling_factor"], meta["item_length"])
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -503,7 +603,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram"]
+    if "scalogram" in which:
+        gen_scalogram()
     if "cqt" in which:
         gen_cqt()
     if "attention" in which:

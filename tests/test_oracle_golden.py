@@ -277,3 +277,72 @@ def test_cqt_and_preprocessing(golden_dir):
             assert bad.float().mean().item() < 1e-3
             got = torch.where(bad, ref, got)
         _close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def _scalogram_blocks(meta):
+    blocks = [dict(b) for b in meta["blocks"]]
+    blocks[0]["in_channels"] = 2          # ScalogramResidualEncoder.__init__ with phase=True (scalogram_model.py:494-495)
+    for b in blocks:
+        for k in ("kernel_size_1", "kernel_size_2"):
+            b[k] = tuple(b[k])
+    return blocks
+
+
+def test_scalogram_model(golden_dir):
+    """PreprocessingModule + ScalogramResidualEncoder (BatchNorm, residual crops, tall kernels with top padding) + GRU:
+    forward in train / eval mode, running statistics, trainer losses and all gradients vs the reference."""
+    g = _load(golden_dir, "scalogram_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+    blocks = _scalogram_blocks(meta)
+    c = meta["cqt"]
+    bank, _ = O.constant_q_filters(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["filter_scale"])
+    sizes, ranges = [256, 128, 64, 32], [(0, 3), (3, 11), (11, 19), (19, 24)]
+    weights = []
+    for size, (lo, hi) in zip(sizes, ranges):
+        off = (bank.shape[1] - size) // 2
+        part = bank[lo:hi, off:bank.shape[1] - off] if off else bank[lo:hi]
+        weights.append(torch.from_numpy(np.concatenate([part.real, part.imag]).astype(np.float32)).unsqueeze(1))
+    consts = O.phase_difference_constants(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["hop_length"])
+
+    def preprocess(wave):
+        return O.preprocessing_forward(O.cqt_forward(wave.unsqueeze(1), weights, c["hop_length"]), consts)
+
+    data = torch.from_numpy(g["data"])
+    B, V, K = meta["B"], meta["V"], meta["K"]
+    scal = preprocess(data[:B])
+    ref_scal = torch.from_numpy(g["scalogram"])
+    bad = (scal - ref_scal).abs() > 1e-4
+    assert bad.float().mean().item() < 1e-3
+    scal = ref_scal
+    p0 = _params(g)
+    for mode in ("eval", "train"):
+        p = {k: v.clone() for k, v in p0.items()}
+        with torch.no_grad():
+            pz, tg, z, cc = O.cpc_forward(scal, p, V, K, scalogram=blocks, training=mode == "train")
+        _close(z, g[mode + "/z"], rtol=1e-4, atol=1e-5)
+        _close(cc, g[mode + "/c"], rtol=1e-4, atol=1e-5)
+        _close(pz, g[mode + "/predicted_z"], rtol=1e-4, atol=1e-5)
+        if mode == "train":
+            for k in [k for k in g if k.startswith("after_train_fwd/")]:
+                _close(p[k.split("/", 1)[1]], g[k], rtol=1e-5, atol=1e-6)
+    for run in meta["runs"]:
+        tr = O.OracleTrainer(p0, V, K, score=run["score"], all_timesteps=run["all_timesteps"], regularization=run["reg"], lr=run["lr"],
+                             scalogram=blocks)
+        for i, idx in enumerate(run["batches"]):
+            batch = preprocess(data[idx])
+            if run["steps"] == 1:
+                saved = {k: v.clone() for k, v in tr.buffers.items()}
+                loss, smax, grads = tr.loss_and_grads(batch)
+                tr.buffers = saved
+                for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                    name = k.split("/grad/")[1]
+                    ref = torch.from_numpy(g[k])
+                    scale = ref.abs().max().item() + 1e-12
+                    if scale < 1e-6:          # conv biases in front of a BatchNorm: mathematically zero gradient
+                        assert grads[name].abs().max().item() < 1e-5
+                        continue
+                    _close(grads[name] / scale, ref / scale, rtol=1e-3, atol=2e-4)
+            loss, smax = tr.step(batch)
+            assert abs(loss - run["loss"][i]) <= 2e-4 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
+        for k in [k for k in g if k.startswith(run["tag"] + "/after/")]:
+            _close(tr.buffers[k.split("/after/")[1]], g[k], rtol=1e-3, atol=2e-4)      # after 4 Adam steps
