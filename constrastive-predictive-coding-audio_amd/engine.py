@@ -799,6 +799,9 @@ def make_context(eng, ar):
     if isinstance(ar, AudioGRUModel):
         return GRUContext(eng, ar)
     if isinstance(ar, ConvolutionalArModel):
+        if ar.batch_norm or ar.residual or any(s != 1 for s in ar.strides):
+            from .scalogram_engine import ConvArGridContext
+            return ConvArGridContext(eng, ar)
         return ConvArContext(eng, ar)
     from .attention_model import AttentionModel
     if isinstance(ar, AttentionModel):

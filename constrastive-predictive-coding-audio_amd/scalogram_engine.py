@@ -99,6 +99,10 @@ class _Conv:
             self.w_fwd = torch.zeros(self.cout, self.Kp, device=dev, dtype=dt)
             self.w_t = torch.zeros(self.Kp, self.cout, device=dev, dtype=dt)
             self.nsplit = eng._pick_split(self.Kp, self.cout, self.M, dt)
+            if self.Kp * self.cout <= 8192:
+                # a tiny weight matrix reduced over millions of rows (first convolution: 18 x 32 over 5 M positions): the
+                # reduction, not the tile, has to fill the chip
+                self.nsplit = max(self.nsplit, min(2048, self.M // 2048))
             self.slab = self.nsplit * self.Kp * self.cout
         self.dy0: Optional[Grid] = None        # set by the owner (may alias another gradient grid)
 
@@ -109,7 +113,8 @@ class _Conv:
         if self.mode == 'col':
             _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd), _hip.ptr(self.w_dgrad), self.cout, self.cin, self.kh, 1, code)
         else:
-            flat = w.detach().permute(0, 2, 3, 1).reshape(self.cout, self.K)         # [co][(dh*kw + dw)*C + c]
+            w4 = w.detach().view(self.cout, self.cin, self.kh, self.kw)
+            flat = w4.permute(0, 2, 3, 1).reshape(self.cout, self.K)                  # [co][(dh*kw + dw)*C + c]
             self.w_fwd[:, :self.K].copy_(flat)
             self.w_t[:self.K, :].copy_(flat.t())
 
@@ -439,3 +444,183 @@ class ScalogramCPCEngine(CPCEngine):
     def _backward_encoder(self, x, grad_ready_hook=None):
         for b in reversed(self.blocks):
             b.backward()
+
+
+# =====================================================================================================================
+# ConvolutionalArModel with BatchNorm1d and / or residual branches (audio_model.py:80-161) on the same grid machinery: a
+# sequence [B][L][C] is a grid with W = 1, Conv1d(k) a tall (k,1) kernel, MaxPool1d(ceil) the p x p pooling restricted to
+# one column, BatchNorm1d the same per-channel statistics.
+class _ArBlock:
+    def __init__(self, eng, idx, blk, gin: Grid, kernel, stride, pool, cin, cout, batch_norm, residual, bias):
+        self.eng, self.idx, self.gin, self.pool, self.stride = eng, idx, gin, pool, stride
+        dev, dt = eng.device, eng.dt
+        pre = f"autoregressive_model.module_list.{idx}."
+        ci = 1 if pool > 1 else 0
+        self.xp = Grid(gin.B, 1, _ceil_div(gin.H, pool), cin, dev, dt) if pool > 1 else gin
+        conv_mod = SimpleNamespace(in_channels=cin, out_channels=cout, kernel_size=(kernel, 1), stride=(stride, 1), padding=(0, 0))
+        self.conv = _Conv(eng, f"{pre}main_modules.{ci}.weight", f"{pre}main_modules.{ci}.bias" if bias else None, conv_mod, self.xp,
+                          relu=not batch_norm)
+        y0 = self.conv.y0
+        if batch_norm:
+            self.main = Grid(y0.B, 1, y0.H, cout, dev, dt)
+            self.bn = _BatchNorm(eng, f"{pre}main_modules.{ci + 1}", blk.main_modules[ci + 1], y0, self.main)
+        else:
+            self.main, self.bn = y0, None
+        self.residual = residual
+        self.res_conv = self.rp = None
+        if residual:
+            rpool = pool * stride
+            if rpool > 1:
+                self.rp = self.xp if stride == 1 else Grid(gin.B, 1, _ceil_div(gin.H, rpool), cin, dev, dt)
+            src = self.rp if self.rp is not None else gin
+            if cin != cout:
+                ri = 1 if rpool > 1 else 0
+                rmod = SimpleNamespace(in_channels=cin, out_channels=cout, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0))
+                self.res_conv = _Conv(eng, f"{pre}residual_modules.{ri}.weight", f"{pre}residual_modules.{ri}.bias", rmod, src)
+                self.res = self.res_conv.y0
+            else:
+                self.res = src
+            self.oh = self.res.H - self.main.H           # right-aligned crop x[:, :, -len:]  (audio_model.py:133)
+            if self.oh < 0:
+                raise ValueError(f"ConvolutionalArBlock {idx}: residual branch shorter than the main branch")
+            self.out = Grid(y0.B, 1, self.main.H, cout, dev, dt)
+        else:
+            self.out = self.main
+        self.slab = max([c.slab for c in (self.conv, self.res_conv) if c is not None] + ([self.bn.slab] if self.bn else [0]))
+
+    def allocate_grads(self, d_in: Grid):
+        dev = self.eng.device
+        self.d_in = d_in
+        self.d_out = self.out.like(dev)
+        self.d_xp = self.xp.like(dev) if self.xp is not self.gin else d_in
+        if self.residual:
+            self.d_main = self.main.like(dev, guard_rows=self.conv.kh + 16)
+            self.d_res = self.res.like(dev)
+            if self.res_conv is not None:
+                self.res_conv.dy0 = self.d_res
+            if self.rp is not None and self.rp is not self.xp:
+                self.d_rp = self.rp.like(dev)
+        else:
+            self.d_main = self.d_out
+        if self.bn is not None:
+            self.bn.dy0 = self.conv.y0.like(dev, guard_rows=self.conv.kh + 16)
+            self.conv.dy0 = self.bn.dy0
+        else:
+            self.conv.dy0 = self.d_main
+
+    def prepare(self):
+        self.conv.prepare()
+        if self.res_conv is not None:
+            self.res_conv.prepare()
+
+    def forward(self):
+        code = self.eng.code
+        if self.pool > 1:
+            _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.xp.ptr(), _desc(self.xp, self.xp.desc),
+                      self.pool, 0, code)
+        self.conv.forward()
+        if self.bn is not None:
+            self.bn.forward()
+        if self.residual:
+            if self.rp is not None and self.rp is not self.xp:
+                _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.rp.ptr(), _desc(self.rp, self.rp.desc),
+                          self.pool * self.stride, 0, code)
+            if self.res_conv is not None:
+                self.res_conv.forward()
+            _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
+                      self.out.ptr(), _desc(self.out, self.out.desc), self.oh, 0, 0, 0, code)
+
+    def backward(self):
+        code = self.eng.code
+        if self.residual:
+            self.d_res.t.zero_()
+            _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
+                      _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, 0, 0, 0, code)
+        if self.bn is not None:
+            self.bn.backward(self.d_main)
+        else:
+            _hip.call("cpc_relu_mask", self.d_main.ptr(), self.main.ptr(), self.d_main.rows * self.d_main.C, code)
+        self.conv.backward(self.d_xp)                                  # writes the gradient of the (pooled) block input
+        shared = self.residual and (self.rp is self.xp or self.rp is None)
+        if self.residual and shared:                                   # residual source is the conv input itself
+            if self.res_conv is not None:
+                self.res_conv.backward(self.d_xp, accumulate=True)
+            else:
+                self.d_xp.t.add_(self.d_res.t)
+        if self.pool > 1:
+            _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_xp.ptr(),
+                      _desc(self.xp, self.xp.desc), self.pool, 0, code)
+        if self.residual and not shared:                               # own pooling (stride > 1)
+            if self.res_conv is not None:
+                self.res_conv.backward(self.d_rp)
+                src = self.d_rp
+            else:
+                src = self.d_res
+            _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), src.ptr(),
+                      _desc(self.rp, self.rp.desc), self.pool * self.stride, 1, code)
+
+
+class ConvArGridContext:
+    """ConvolutionalArModel with batch_norm and / or residual (e.g. ar_conv_architecture_2/3) as the context network."""
+
+    def __init__(self, eng, ar):
+        self.eng, self.ar = eng, ar
+        self.channels = list(ar.channel_count)
+        if self.channels[0] != eng.E or self.channels[-1] != eng.H:
+            raise ValueError("ConvolutionalArModel channel_count does not match enc_size / ar_size")
+        if any(c % 8 for c in self.channels):
+            raise NotImplementedError("ConvolutionalArModel channel counts must be multiples of 8")
+
+    def allocate(self):
+        e, ar = self.eng, self.ar
+        self.x0 = Grid(e.B, 1, e.V, e.E, e.device, e.dt)
+        self.blocks = []
+        gin = self.x0
+        for l in range(len(ar.kernel_sizes)):
+            b = _ArBlock(e, l, ar.module_list[l], gin, ar.kernel_sizes[l], ar.strides[l], ar.poolings[l], self.channels[l],
+                         self.channels[l + 1], ar.batch_norm, ar.residual, ar.module_list[l].main_modules[1 if ar.poolings[l] > 1 else 0].bias is not None)
+            self.blocks.append(b)
+            gin = b.out
+        self.d_x0 = self.x0.like(e.device)
+        d_in = self.d_x0
+        for b in self.blocks:
+            b.allocate_grads(d_in)
+            d_in = b.d_out
+        self.c32 = torch.empty(e.B, self.channels[-1], device=e.device, dtype=torch.float32)
+
+    def slab_floats(self):
+        return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(self.channels)
+
+    def prepare_weights(self):
+        for b in self.blocks:
+            b.prepare()
+
+    def _z_rows(self, buf):
+        e = self.eng
+        t0 = e.T - e.K - e.V
+        return buf.view(e.B, e.geo.alloc[-1], e.E)[:, t0:t0 + e.V, :]
+
+    def forward(self):
+        e = self.eng
+        self.x0.t.view(e.B, e.V, e.E).copy_(self._z_rows(e.act[-1]))
+        for b in self.blocks:
+            b.forward()
+
+    def c_operand(self):
+        out = self.blocks[-1].out
+        return out.t, (out.top + out.H - 1) * out.C, out.Ha * out.C
+
+    def c_float(self):
+        out = self.blocks[-1].out
+        self.c32.copy_(out.t.view(out.B, out.Ha, out.C)[:, out.top + out.H - 1, :])
+        return self.c32
+
+    def backward(self, dc):
+        e = self.eng
+        last = self.blocks[-1]
+        d = last.d_out
+        d.t.zero_()
+        d.t.view(d.B, d.Ha, d.C)[:, d.top + d.H - 1, :] = dc.to(d.t.dtype)
+        for b in reversed(self.blocks):
+            b.backward()
+        self._z_rows(e.dact[-1]).copy_(self.d_x0.t.view(e.B, e.V, e.E))

@@ -174,7 +174,7 @@ int cpc_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, i
  * cpc_bn_stats: slabs f32 [nblocks][2][C] partial (sum, sum of squares) over the rows of x T [rows][C] (pad rows are zero);
  * cpc_bn_finalize: stats f32 [2][C] = (mean, 1/sqrt(biased var + eps)) over `count` elements per channel, and, when
  *   run_mean / run_var are given, torch's running update (momentum, unbiased variance);
- * cpc_bn_apply: out = act((x - mean) * rstd * gamma + beta) on the valid rows of two grids of equal shape. C in {4,8,..,1024}.
+ * cpc_bn_apply: out = act((x - mean) * rstd * gamma + beta) on the valid rows of two grids of equal shape. C a multiple of 4, at most 1024.
  * x_f32 (here and in the backward): x / dx are float32 grids although dtype is bf16 — the first convolution of the
  * encoder reads the float32 scalogram and keeps its pre-normalisation output in float32 (log-amplitudes have a large
  * common offset that bf16 storage would quantise away before the normalisation removes it). */

@@ -107,18 +107,39 @@ def gru_forward(z: torch.Tensor, params: Params, prefix: str = "autoregressive_m
 
 
 def conv_ar_forward(z: torch.Tensor, params: Params, kernel_sizes: Sequence[int], poolings: Sequence[int],
-                    prefix: str = "autoregressive_model.") -> torch.Tensor:
-    """ConvolutionalArModel.forward without batch norm / residual — audio_model.py:98-108 (block), :158-161 (model):
-    per block [MaxPool1d(pool, ceil_mode=True)] -> Conv1d(stride 1) -> ReLU; returns the last position (B, C_out)."""
+                    prefix: str = "autoregressive_model.", strides: Optional[Sequence[int]] = None, batch_norm: bool = False,
+                    residual: bool = False, training: bool = True) -> torch.Tensor:
+    """ConvolutionalArModel.forward — audio_model.py:98-136 (block), :158-161 (model): per block
+    [MaxPool1d(pool, ceil_mode=True)] -> Conv1d -> [BatchNorm1d] -> ReLU, plus the optional residual branch
+    [MaxPool1d(pool*stride, ceil)] -> [Conv1d 1x1 if the channel count changes], right-aligned and added.  The reference
+    adds IN PLACE (``main_x += ...``, :133), which modern autograd rejects in backward; the out-of-place sum below has the
+    same value and is what the gradients of the residual variants are defined by.  Returns the last position (B, C_out)."""
     x = z
-    for l, (k, pool) in enumerate(zip(kernel_sizes, poolings)):
+    strides = [1] * len(kernel_sizes) if strides is None else strides
+    for l, (k, pool, stride) in enumerate(zip(kernel_sizes, poolings, strides)):
+        pre = f"{prefix}module_list.{l}."
+        original = x
         idx = 0
         if pool > 1:
             x = F.max_pool1d(x, pool, ceil_mode=True)
             idx = 1
-        w = params[f"{prefix}module_list.{l}.main_modules.{idx}.weight"]
-        b = params.get(f"{prefix}module_list.{l}.main_modules.{idx}.bias")
-        x = torch.relu(F.conv1d(x, w, b))
+        x = F.conv1d(x, params[f"{pre}main_modules.{idx}.weight"], params.get(f"{pre}main_modules.{idx}.bias"), stride=stride)
+        if batch_norm:
+            bn = f"{pre}main_modules.{idx + 1}."
+            x = F.batch_norm(x, params[bn + "running_mean"], params[bn + "running_var"], params[bn + "weight"], params[bn + "bias"],
+                             training=training, momentum=0.1, eps=1e-5)
+            if training:
+                params[bn + "num_batches_tracked"] += 1
+        x = torch.relu(x)
+        if residual:
+            r, ridx = original, 0
+            if pool * stride > 1:
+                r = F.max_pool1d(r, pool * stride, ceil_mode=True)
+                ridx = 1
+            wname = f"{pre}residual_modules.{ridx}.weight"
+            if wname in params:
+                r = F.conv1d(r, params[wname], params.get(f"{pre}residual_modules.{ridx}.bias"))
+            x = x + r[:, :, -x.shape[2]:]
     return x[:, :, -1]
 
 
@@ -322,7 +343,10 @@ def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_
         c, z = attention_forward(z, params, attention[0], attention[1])
     elif conv_ar is None:
         c = gru_forward(z, params)
-    else:       # conv_ar = (kernel_sizes, poolings) of a ConvolutionalArModel
+    elif isinstance(conv_ar, dict):     # full ConvolutionalArModel args: kernel_sizes, pooling, stride, batch_norm, residual
+        c = conv_ar_forward(z, params, conv_ar["kernel_sizes"], conv_ar["pooling"], strides=conv_ar["stride"],
+                            batch_norm=conv_ar["batch_norm"], residual=conv_ar["residual"], training=training)
+    else:       # conv_ar = (kernel_sizes, poolings) of a plain ConvolutionalArModel
         c = conv_ar_forward(z, params, conv_ar[0], conv_ar[1])
     w_p = params["prediction_model.weight"]
     predicted = (c @ w_p.t()).view(-1, K, enc.shape[1])

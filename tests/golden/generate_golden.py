@@ -21,6 +21,7 @@ Fixtures written (all float32 unless noted):
   conv_ar_model.npz     AudioEncoder + ConvolutionalArModel (k 9/9/9, pooling 1/2/2) forward, losses, gradients
   attention_model.npz   AudioEncoder + AttentionModel (2 layers, 8 heads, dropout 0) forward, losses, gradients
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
+  conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval),
                         trainer losses, gradients, BatchNorm running statistics
 """
@@ -460,6 +461,85 @@ def gen_scalogram():
           "rf/ds/item", meta["receptive_field"], meta["downsampling_factor"], meta["item_length"])
 
 
+def gen_conv_ar_bn():
+    """ConvolutionalArModel with BatchNorm1d / residual branches (the ar_conv_architecture_2/3 family, shrunk).
+    'bn': batch norm only — the reference trains, so losses and gradients are stored.
+    'bn_res': batch norm + residual — the reference's in-place residual add (audio_model.py:133) makes its backward fail on
+    this torch, so only forward outputs (train and eval mode) and the running statistics are stored."""
+    C, H, K, V, B = 64, 48, 4, 60, 6
+    L = 465 + (V + K) * 160 + 7
+    base = {'kernel_sizes': [5, 5, 5, 5], 'channel_count': [C, 64, 96, 48, H], 'stride': [1, 1, 1, 1], 'pooling': [1, 2, 1, 2], 'bias': True,
+            'activation_register': None, 'self_attention': [False] * 4}
+    variants = {"bn": dict(base, batch_norm=True, residual=False), "bn_res": dict(base, batch_norm=True, residual=True)}
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 0.4
+
+    def build(ar_dict):
+        torch.manual_seed(19)
+        enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        ar = ref_model.ConvolutionalArModel(ar_dict)
+        model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K)
+        g = torch.Generator().manual_seed(29)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+                if n.startswith("autoregressive_model.") and p.dim() == 1 and "main_modules" in n and n.endswith("weight"):
+                    p.add_(0.3 * torch.randn(p.shape, generator=g))          # BatchNorm gamma away from 1
+            for n, b in model.named_buffers():
+                if n.endswith("running_mean"):
+                    b.add_(0.1 * torch.randn(b.shape, generator=g))
+                if n.endswith("running_var"):
+                    b.mul_(1.0 + 0.5 * torch.rand(b.shape, generator=g))
+        return model
+
+    g = torch.Generator().manual_seed(12)
+    n_items = 18
+    data = torch.randn(n_items, L, generator=g) * 0.5
+    out = {"data": data.numpy()}
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "variants": {}}
+    for name, ar_dict in variants.items():
+        model = build(ar_dict)
+        for k, v in np_state(model).items():
+            out[f"{name}/param/{k}"] = v
+        info = {"ar": {k: v for k, v in ar_dict.items() if k != 'activation_register'}, "runs": []}
+        with torch.no_grad():
+            for mode in ("eval", "train"):
+                model.train(mode == "train")
+                pz, tg, z, c = model(data[:B].unsqueeze(1))
+                out[f"{name}/{mode}/predicted_z"], out[f"{name}/{mode}/c"] = pz.numpy(), c.numpy()
+            for k, v in np_state(model).items():
+                if "running_" in k:
+                    out[f"{name}/after_train_fwd/{k}"] = v
+        if name == "bn":
+            rid = 0
+            for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
+                                                        ("linear", ref_train.linear_score_function, True, 0.01, 3, 1e-4)):
+                model = build(ar_dict)
+                ds = TensorDataset(data)
+                logger = Logger()
+                with quiet():
+                    tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                                                                score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K,
+                                                                ar_size=H)
+                    random.seed(66)
+                    tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+                tag = f"run{rid}"
+                info["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+                                     "python_seed": 66, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                                     "loss": logger.loss_meter.values})
+                if steps == 1:
+                    for n, p in model.named_parameters():
+                        out[f"{name}/{tag}/grad/{n}"] = p.grad.numpy().copy()
+                rid += 1
+        meta["variants"][name] = info
+    np.savez_compressed(os.path.join(OUT, "conv_ar_bn.npz"), **out)
+    with open(os.path.join(OUT, "conv_ar_bn.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("conv_ar_bn:", {n: [r["loss"] for r in v["runs"]] for n, v in meta["variants"].items()},
+          float(np.abs(out["bn_res/train/c"]).mean()), float(np.abs(out["bn/train/c"]).mean()))
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -603,7 +683,9 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "conv_ar_bn"]
+    if "conv_ar_bn" in which:
+        gen_conv_ar_bn()
     if "scalogram" in which:
         gen_scalogram()
     if "cqt" in which:

@@ -346,3 +346,43 @@ def test_scalogram_model(golden_dir):
             assert abs(loss - run["loss"][i]) <= 2e-4 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
         for k in [k for k in g if k.startswith(run["tag"] + "/after/")]:
             _close(tr.buffers[k.split("/after/")[1]], g[k], rtol=1e-3, atol=2e-4)      # after 4 Adam steps
+
+
+def test_conv_ar_batchnorm_residual(golden_dir):
+    """ConvolutionalArModel with BatchNorm1d (forward, running statistics, trainer losses, gradients vs the reference) and
+    with BatchNorm1d + residual branches (forward in train / eval mode vs the reference; the reference cannot run its own
+    backward for this variant, see conv_ar_forward)."""
+    g = _load(golden_dir, "conv_ar_bn.npz")
+    meta = json.load(open(os.path.join(golden_dir, "conv_ar_bn.json")))
+    data = torch.from_numpy(g["data"])
+    B, V, K = meta["B"], meta["V"], meta["K"]
+    for name, info in meta["variants"].items():
+        p0 = _params(g, prefix=name + "/param/")
+        for mode in ("eval", "train"):
+            p = {k: v.clone() for k, v in p0.items()}
+            with torch.no_grad():
+                pz, tg, z, c = O.cpc_forward(data[:B].unsqueeze(1), p, V, K, conv_ar=info["ar"], training=mode == "train")
+            _close(c, g[f"{name}/{mode}/c"], rtol=1e-4, atol=2e-5)
+            _close(pz, g[f"{name}/{mode}/predicted_z"], rtol=1e-4, atol=2e-5)
+            if mode == "train":
+                for k in [k for k in g if k.startswith(name + "/after_train_fwd/")]:
+                    _close(p[k.split("/after_train_fwd/")[1]], g[k], rtol=1e-5, atol=1e-6)
+        for run in info["runs"]:
+            tr = O.OracleTrainer(p0, V, K, score=run["score"], all_timesteps=run["all_timesteps"], regularization=run["reg"],
+                                 lr=run["lr"], conv_ar=info["ar"])
+            for i, idx in enumerate(run["batches"]):
+                batch = data[idx]
+                if run["steps"] == 1:
+                    saved = {k: v.clone() for k, v in tr.buffers.items()}
+                    loss, smax, grads = tr.loss_and_grads(batch)
+                    tr.buffers = saved
+                    for k in [k for k in g if k.startswith(f"{name}/{run['tag']}/grad/")]:
+                        pname = k.split("/grad/")[1]
+                        ref = torch.from_numpy(g[k])
+                        scale = ref.abs().max().item() + 1e-12
+                        if scale < 1e-6:
+                            assert grads[pname].abs().max().item() < 1e-5
+                            continue
+                        _close(grads[pname] / scale, ref / scale, rtol=1e-3, atol=2e-4)
+                loss, smax = tr.step(batch)
+                assert abs(loss - run["loss"][i]) <= 2e-4 * max(1.0, abs(run["loss"][i])), (name, run["tag"], i, loss)
