@@ -348,6 +348,7 @@ def _standalone_owner(encoder):
         owner.prediction_model = _LinearParams(32, c)
         owner.compute_dtype = getattr(encoder, "compute_dtype", torch.float32)
         owner._engines, owner._flat_param, owner._flat_grad, owner._param, owner._grad = {}, None, None, {}, {}
+        owner._scalogram = False
         object.__setattr__(encoder, "_owner", owner)
     dev = next(encoder.parameters()).device
     if next(owner.autoregressive_model.parameters()).device != dev:
