@@ -478,60 +478,67 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         const unsigned aA0 = lds_u32 + offA[0][0], aA1 = lds_u32 + offA[1][0];
         const unsigned aB0 = lds_u32 + offB[0][0], aB1 = lds_u32 + offB[1][0];
 
+        // Software pipeline over the two k-halves of a stage (fragment register sets 0 and 1):
+        //   wait set 0 -> MFMA(set 0, stage t) | wait set 1, DMA(t+1) landed, barrier | issue DMA(t+2) into the slot of stage
+        //   t (all its fragments are in registers everywhere), issue the set-0 reads of stage t+1 | MFMA(set 1, stage t) |
+        //   issue the set-1 reads of stage t+1.
+        // Every batch of TI+TJ fragment reads is in flight under a block of TI*TJ MFMAs, so after the barrier the matrix
+        // pipe has work while the first reads of the next stage travel (with "read everything, then compute" all eight
+        // waves sat on the LDS pipe right after each barrier with the matrix pipe idle).
+#define NT_READ_SET(fa, fb, aA, aB, cur)                                                                         \
+    do {                                                                                                         \
+        fb[0] = lds_read16_asm<0>(aB + (cur)); fb[1] = lds_read16_asm<2048>(aB + (cur));                         \
+        fb[2] = lds_read16_asm<4096>(aB + (cur)); fb[3] = lds_read16_asm<6144>(aB + (cur));                      \
+        fa[0] = lds_read16_asm<0>(aA + (cur)); fa[1] = lds_read16_asm<2048>(aA + (cur));                         \
+        fa[2] = lds_read16_asm<4096>(aA + (cur)); fa[3] = lds_read16_asm<6144>(aA + (cur));                      \
+        if constexpr (TI == 8) {                                                                                 \
+            fa[4] = lds_read16_asm<8192>(aA + (cur)); fa[5] = lds_read16_asm<10240>(aA + (cur));                 \
+            fa[6] = lds_read16_asm<12288>(aA + (cur)); fa[7] = lds_read16_asm<14336>(aA + (cur));                \
+        }                                                                                                        \
+    } while (0)
+#define NT_WAIT_SET(cnt8, cnt4, fa, fb)                                                                          \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if constexpr (TI == 8)                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(" cnt8 ")"                                                           \
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), \
+                           "+v"(fa[7]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));                    \
+        else                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(" cnt4 ")"                                                           \
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), \
+                           "+v"(fb[3]));                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
         NT_DMA_STAGE(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (nk > 1) NT_DMA_STAGE(1, (long long)BK);
+        u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+        NT_READ_SET(fa0, fb0, aA0, aB0, 0u);
+        NT_READ_SET(fa1, fb1, aA1, aB1, 0u);
         for (int t = 0; t < nk; ++t) {
-            const unsigned cur = (t & 1) * STAGE;
-            if (t + 1 < nk) NT_DMA_STAGE((t + 1) & 1, (long long)(t + 1) * BK);
-            u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
-            // issue every fragment read of this stage, k-half 0 first
-            fb0[0] = lds_read16_asm<0>(aB0 + cur); fb0[1] = lds_read16_asm<2048>(aB0 + cur);
-            fb0[2] = lds_read16_asm<4096>(aB0 + cur); fb0[3] = lds_read16_asm<6144>(aB0 + cur);
-            fa0[0] = lds_read16_asm<0>(aA0 + cur); fa0[1] = lds_read16_asm<2048>(aA0 + cur);
-            fa0[2] = lds_read16_asm<4096>(aA0 + cur); fa0[3] = lds_read16_asm<6144>(aA0 + cur);
-            if constexpr (TI == 8) {
-                fa0[4] = lds_read16_asm<8192>(aA0 + cur); fa0[5] = lds_read16_asm<10240>(aA0 + cur);
-                fa0[6] = lds_read16_asm<12288>(aA0 + cur); fa0[7] = lds_read16_asm<14336>(aA0 + cur);
-            }
-            fb1[0] = lds_read16_asm<0>(aB1 + cur); fb1[1] = lds_read16_asm<2048>(aB1 + cur);
-            fb1[2] = lds_read16_asm<4096>(aB1 + cur); fb1[3] = lds_read16_asm<6144>(aB1 + cur);
-            fa1[0] = lds_read16_asm<0>(aA1 + cur); fa1[1] = lds_read16_asm<2048>(aA1 + cur);
-            fa1[2] = lds_read16_asm<4096>(aA1 + cur); fa1[3] = lds_read16_asm<6144>(aA1 + cur);
-            if constexpr (TI == 8) {
-                fa1[4] = lds_read16_asm<8192>(aA1 + cur); fa1[5] = lds_read16_asm<10240>(aA1 + cur);
-                fa1[6] = lds_read16_asm<12288>(aA1 + cur); fa1[7] = lds_read16_asm<14336>(aA1 + cur);
-            }
-            // k-half 0 has landed once at most the TI+TJ reads of k-half 1 are outstanding
-            if constexpr (TI == 8)
-                asm volatile("s_waitcnt lgkmcnt(12)"
-                             : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa0[4]), "+v"(fa0[5]), "+v"(fa0[6]),
-                               "+v"(fa0[7]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(8)"
-                             : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]),
-                               "+v"(fb0[3]));
-            __builtin_amdgcn_sched_barrier(0);
+            const unsigned nxt = ((t + 1) & 1) * STAGE;
+            // set 0 of stage t has landed once at most the TI+TJ reads of set 1 are outstanding
+            NT_WAIT_SET("12", "8", fa0, fb0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));
-            if constexpr (TI == 8)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fa1[4]), "+v"(fa1[5]), "+v"(fa1[6]),
-                               "+v"(fa1[7]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(fa1[0]), "+v"(fa1[1]), "+v"(fa1[2]), "+v"(fa1[3]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]),
-                               "+v"(fb1[3]));
+            NT_WAIT_SET("0", "0", fa1, fb1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 2 < nk) NT_DMA_STAGE(t & 1, (long long)(t + 2) * BK);
+            if (t + 1 < nk) NT_READ_SET(fa0, fb0, aA0, aB0, nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) mfma_chunk<T>(acc[i][j], as_uint4(fb1[j]), as_uint4(fa1[i]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nk) NT_READ_SET(fa1, fb1, aA1, aB1, nxt);
         }
+#undef NT_READ_SET
+#undef NT_WAIT_SET
 #undef NT_DMA1
 #undef NT_DMA_STAGE
     }
