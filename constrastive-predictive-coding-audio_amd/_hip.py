@@ -67,7 +67,7 @@ _SIGNATURES = {
     "cpc_add_ln_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P], _I),
     "cpc_ln_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P], _I),
     "cpc_mean_time": ([_P, _P, _I, _I, _I, _I, _P], _I),
-    "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _P], _I),
+    "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _I, _I, _P], _I),
     "cpc_im2col2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_col2im2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_bn_stats": ([_P, _P, _L, _I, _I, _I, _P], _I),

@@ -187,9 +187,10 @@ int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void
 }
 
 int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
-                            long long ldq, int phase, float offset, float log_offset, float norm, float power, void* stream) {
+                            long long ldq, int phase, float offset, float log_offset, float norm, float power, int ph, int pw,
+                            void* stream) {
     if (!cq || !out) return CPC_EINVAL;
-    return launch_scalogram_pointwise(cq, fixed_pd, pd_scale, out, B, Tn, bins, ldq, phase, offset, log_offset, norm, power,
+    return launch_scalogram_pointwise(cq, fixed_pd, pd_scale, out, B, Tn, bins, ldq, phase, offset, log_offset, norm, power, ph, pw,
                                       (hipStream_t)stream);
 }
 

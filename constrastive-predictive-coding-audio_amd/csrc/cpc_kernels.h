@@ -96,7 +96,7 @@ int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, h
 
 // scalogram front end / 2-D encoder (scalogram.hip)
 int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
-                               long long ldq, int phase, float offset, float log_offset, float norm, float power,
+                               long long ldq, int phase, float offset, float log_offset, float norm, float power, int ph, int pw,
                                hipStream_t stream);
 int launch_im2col2d(const void* in, void* col, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
                     int in_f32, int dtype, hipStream_t stream);

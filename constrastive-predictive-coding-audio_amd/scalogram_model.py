@@ -61,20 +61,21 @@ class PreprocessingModule(nn.Module):
     def forward(self, x):
         if self.cqt is None:
             return x
-        if self.pooling is not None:
-            raise NotImplementedError("scalogram_pooling is not part of the HIP path yet")
+        ph, pw = (int(self.pooling[0]), int(self.pooling[1])) if self.pooling is not None else (1, 1)
         cq, Tn, ldq = self.cqt.transform(x)
         B, bins = cq.shape[0], self.cqt.n_bins
         phase = self.phase_diff is not None
         W, Cc = (Tn - 1, 2) if phase else (Tn, 1)
         if W < 1:
             raise ValueError("clip too short for a phase-difference scalogram (needs at least two CQT frames)")
-        out = torch.empty(B, W, bins, Cc, device=cq.device, dtype=torch.float32)
+        if W // pw < 1 or bins // ph < 1:
+            raise ValueError("scalogram smaller than the pooling window")
+        out = torch.empty(B, W // pw, bins // ph, Cc, device=cq.device, dtype=torch.float32)
         fixed = self.phase_diff.fixed_phase_diff.detach().to(cq.device).reshape(-1).contiguous() if phase else None
         scale = self.phase_diff.scaling.detach().to(cq.device).reshape(-1).contiguous() if phase else None
         _hip.call("cpc_scalogram_pointwise", _hip.ptr(cq), _hip.ptr(fixed), _hip.ptr(scale), _hip.ptr(out), B, Tn, bins, ldq,
                   1 if phase else 0, float(self.offset), float(self.log_offset), float(self.normalization_factor),
-                  float(self.output_power))
+                  float(self.output_power), ph, pw)
         x = out.permute(0, 3, 2, 1)              # (B, channels, bins, frames) view
         self.output = x
         return x

@@ -151,9 +151,11 @@ int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void
  * (lda = hop) into cq f32 [B][Tn][ldq] with (re, im) interleaved per bin.  This call is the rest of
  * PreprocessingModule.forward: |z|^2 -> log(. + offset) + log_offset, and with phase != 0 the wrapped phase advance
  * (atan2 difference along time + fixed_pd[bin], single wrap into (-pi, pi], * pd_scale[bin]); then * norm and ** power.
- * out f32 channels-last [B][W][bins][Cc]: phase: W = Tn-1, Cc = 2 (amp of frame w+1, phase difference); else W = Tn, Cc = 1. */
+ * out f32 channels-last [B][W/pw][bins/ph][Cc]: phase: W = Tn-1, Cc = 2 (amp of frame w+1, phase difference); else W = Tn,
+ * Cc = 1.  ph, pw: F.max_pool2d(x, [ph, pw]) of scalogram_model.py:90-91 (floor mode), taken before the scaling; 1, 1 = none. */
 int cpc_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
-                            long long ldq, int phase, float offset, float log_offset, float norm, float power, void* stream);
+                            long long ldq, int phase, float offset, float log_offset, float norm, float power, int ph, int pw,
+                            void* stream);
 
 /* ---- 2-D residual encoder on channels-last "grids" (ScalogramEncoderBlock / ScalogramResidualEncoder,
  * scalogram_model.py:372-529) ----

@@ -248,8 +248,8 @@ def phase_difference_constants(sr, fmin, n_bins, bins_per_octave, hop):
 
 
 def preprocessing_forward(cq: torch.Tensor, phase_consts=None, offset_zero: bool = False, output_power: float = 1.0,
-                          scaling: float = 1.0) -> torch.Tensor:
-    """PreprocessingModule.forward after the CQT (no pooling) — scalogram_model.py:77-97 with abs / angle / unwrap /
+                          scaling: float = 1.0, pooling=None) -> torch.Tensor:
+    """PreprocessingModule.forward after the CQT — scalogram_model.py:77-97 with abs / angle / unwrap /
     PhaseDifference.forward of constant_q_transform.py:36-52, :69-72, :281-285.  cq (B, bins, T, 2)."""
     import math
     offset = 1e-9 if offset_zero else 0.0
@@ -266,6 +266,8 @@ def preprocessing_forward(cq: torch.Tensor, phase_consts=None, offset_zero: bool
         x = torch.stack([amp, pd * pscale.view(1, -1, 1)], dim=1)
     else:
         x = (torch.log(mag ** 2 + offset) + log_offset).unsqueeze(1)
+    if pooling is not None:
+        x = F.max_pool2d(x, list(pooling))
     return (x * norm) ** output_power
 
 

@@ -337,7 +337,9 @@ def gen_cqt():
     g = torch.Generator().manual_seed(31)
     B, hop = 3, CQT_SMALL['hop_length']
     variants = {"phase": dict(phase=True), "power": dict(phase=False, offset_zero=True, output_power=2., scaling=10.),
-                "plain": dict(phase=False)}
+                "plain": dict(phase=False),
+                "pooled": dict(phase=False, offset_zero=True, output_power=2., scaling=10., pooling=[1, 2]),
+                "pooled_phase": dict(phase=True, pooling=[2, 2])}
     meta = {"cqt": CQT_SMALL, "variants": variants}
     for name, kw in variants.items():
         pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, **kw)

@@ -269,7 +269,7 @@ def test_cqt_and_preprocessing(golden_dir):
     assert np.array_equal(consts[1].numpy(), g["scaling"].reshape(-1))
     for name, kw in meta["variants"].items():
         got = O.preprocessing_forward(cq, consts if kw.get("phase") else None, kw.get("offset_zero", False),
-                                      kw.get("output_power", 1.0), kw.get("scaling", 1.0))
+                                      kw.get("output_power", 1.0), kw.get("scaling", 1.0), kw.get("pooling"))
         ref = torch.from_numpy(g["pre/" + name])
         if kw.get("phase"):
             # the wrapped phase difference may legitimately flip by 2 pi * scaling where it sits within rounding of +-pi

@@ -34,7 +34,8 @@ def test_cqt_and_preprocessing_match_reference(golden_dir):
         pre = PreprocessingModule(cqt_dict=meta["cqt"], **kw).to(DEV)
         assert [int(k) for k in pre.cqt.conv_kernel_sizes] == meta["kernel_sizes"]
         assert [[r.start, r.stop] for r in pre.cqt.conv_index_ranges] == meta["index_ranges"]
-        assert pre.receptive_field == meta["receptive_field"] and pre.downsampling_factor == meta["downsampling_factor"]
+        pool_w = kw["pooling"][1] if kw.get("pooling") else 1
+        assert pre.receptive_field == meta["receptive_field"] and pre.downsampling_factor == meta["downsampling_factor"] * pool_w
         for i, m in enumerate(pre.cqt.conv_modules):
             assert torch.equal(m.weight.cpu(), torch.from_numpy(g[f"weight/{i}"]))
         cq = pre.cqt(x)
