@@ -376,20 +376,41 @@ def _scalogram_small_blocks():
     return [b0, b1, b2]
 
 
-def gen_scalogram():
-    """A shrunken scalogram_resnet_architecture_7: CQT (24 bins) -> phase scalogram -> 3 residual blocks (strided 3x3 +
-    tall (k,1) kernels with top padding, BatchNorm on the first two, 2x2 + (2,1) on the last) -> GRU context."""
+def _scalogram_small_blocks_b():
+    """Shrunken scalogram_resnet_architecture_8/9 traits: no phase channel, tall first kernel on the raw scalogram, padded
+    3x3 kernels, stride in the SECOND convolution, an identity residual, a padded 1x1 residual projection."""
+    base = {'in_channels': 64, 'hidden_channels': None, 'out_channels': 64, 'kernel_size_1': (3, 3), 'kernel_size_2': (3, 3),
+            'top_padding_1': None, 'top_padding_2': None, 'padding_1': 1, 'padding_2': 1, 'stride_1': 1, 'stride_2': 1,
+            'pooling_1': 1, 'pooling_2': 1, 'bias': True, 'separable': False, 'residual': True, 'batch_norm': True,
+            'ceil_pooling': False}
+    b0 = dict(base, in_channels=1, out_channels=16, kernel_size_1=(5, 1), padding_1=0, stride_2=2)
+    b1 = dict(base, in_channels=16, out_channels=16)
+    b2 = dict(base, in_channels=16, out_channels=32, kernel_size_1=(4, 1), padding_1=0, stride_2=2)
+    b3 = dict(base, in_channels=32, out_channels=64, padding_1=0, padding_2=0, kernel_size_2=(2, 2), batch_norm=False)
+    return [b0, b1, b2, b3]
+
+
+def gen_scalogram(variant="a"):
+    """a: a shrunken scalogram_resnet_architecture_7: CQT (24 bins) -> phase scalogram -> 3 residual blocks (strided 3x3 +
+    tall (k,1) kernels with top padding, BatchNorm on the first two, 2x2 + (2,1) on the last) -> GRU context.
+    b: architecture-8/9 traits (see _scalogram_small_blocks_b) behind a pooled power scalogram."""
     _install_librosa_stand_in()
     import scalogram_model as ref_scal
     import copy
     E, H, K, V, B = 64, 32, 3, 10, 4
-    L = 256 + 32 * 60 + 1
-    scale = {"prediction_model.weight": 1.0}
+    if variant == "a":
+        L = 256 + 32 * 60 + 1
+        pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks, True, "scalogram_model"
+    else:
+        L = 256 + 32 * 127 + 1
+        pre_kw = dict(phase=False, offset_zero=True, output_power=2., scaling=10., pooling=[1, 2])
+        blocks_fn, phase, fname = _scalogram_small_blocks_b, False, "scalogram_model_b"
+    scale = {"prediction_model.weight": 1.0 if variant == "a" else 0.06}
 
     def build():
         torch.manual_seed(41)
-        pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, phase=True)
-        enc_dict = {'phase': True, 'blocks': copy.deepcopy(_scalogram_small_blocks()), 'activation_register': None}
+        pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, **pre_kw)
+        enc_dict = {'phase': phase, 'blocks': copy.deepcopy(blocks_fn()), 'activation_register': None}
         enc = ref_scal.ScalogramResidualEncoder(args_dict=enc_dict, preprocessing_module=pre)
         ar = ref_model.AudioGRUModel(input_size=E, hidden_size=H)
         model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=E, ar_size=H, visible_steps=V, prediction_steps=K)
@@ -415,7 +436,8 @@ def gen_scalogram():
     n_items = 12
     data = torch.randn(n_items, L, generator=g) * 0.3
     out["data"] = data.numpy()
-    meta = {"E": E, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "cqt": CQT_SMALL, "blocks": _scalogram_small_blocks(),
+    meta = {"E": E, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "cqt": CQT_SMALL, "blocks": blocks_fn(),
+            "phase": phase, "pre": pre_kw,
             "receptive_field": int(model.encoder.receptive_field), "downsampling_factor": int(model.encoder.downsampling_factor),
             "item_length": int(model.item_length), "runs": []}
     with torch.no_grad():
@@ -456,8 +478,8 @@ def gen_scalogram():
                 if "running_" in k:
                     out[f"{tag}/after/{k}"] = v
         rid += 1
-    np.savez_compressed(os.path.join(OUT, "scalogram_model.npz"), **out)
-    with open(os.path.join(OUT, "scalogram_model.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, fname + ".npz"), **out)
+    with open(os.path.join(OUT, fname + ".json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("scalogram:", out["scalogram"].shape, out["train/z"].shape, [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]],
           "rf/ds/item", meta["receptive_field"], meta["downsampling_factor"], meta["item_length"])
@@ -685,11 +707,13 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "conv_ar_bn"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "conv_ar_bn"]
     if "conv_ar_bn" in which:
         gen_conv_ar_bn()
     if "scalogram" in which:
-        gen_scalogram()
+        gen_scalogram("a")
+    if "scalogram_b" in which:
+        gen_scalogram("b")
     if "cqt" in which:
         gen_cqt()
     if "attention" in which:

@@ -281,18 +281,22 @@ def test_cqt_and_preprocessing(golden_dir):
 
 def _scalogram_blocks(meta):
     blocks = [dict(b) for b in meta["blocks"]]
-    blocks[0]["in_channels"] = 2          # ScalogramResidualEncoder.__init__ with phase=True (scalogram_model.py:494-495)
+    if meta.get("phase", True):
+        blocks[0]["in_channels"] = 2      # ScalogramResidualEncoder.__init__ with phase=True (scalogram_model.py:494-495)
     for b in blocks:
         for k in ("kernel_size_1", "kernel_size_2"):
             b[k] = tuple(b[k])
     return blocks
 
 
-def test_scalogram_model(golden_dir):
-    """PreprocessingModule + ScalogramResidualEncoder (BatchNorm, residual crops, tall kernels with top padding) + GRU:
-    forward in train / eval mode, running statistics, trainer losses and all gradients vs the reference."""
-    g = _load(golden_dir, "scalogram_model.npz")
-    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b"])
+def test_scalogram_model(golden_dir, fixture):
+    """PreprocessingModule + ScalogramResidualEncoder + GRU: forward in train / eval mode, running statistics, trainer
+    losses and all gradients vs the reference.  Fixture a: architecture-7 traits (phase channel, strided 3x3 + tall kernels
+    with top padding); fixture b: architecture-8/9 traits (pooled power scalogram, tall first kernel, padded kernels,
+    stride in the second convolution, identity and padded-projection residuals)."""
+    g = _load(golden_dir, fixture + ".npz")
+    meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
     blocks = _scalogram_blocks(meta)
     c = meta["cqt"]
     bank, _ = O.constant_q_filters(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["filter_scale"])
@@ -304,8 +308,11 @@ def test_scalogram_model(golden_dir):
         weights.append(torch.from_numpy(np.concatenate([part.real, part.imag]).astype(np.float32)).unsqueeze(1))
     consts = O.phase_difference_constants(c["sample_rate"], c["fmin"], c["n_bins"], c["bins_per_octave"], c["hop_length"])
 
+    pk = meta.get("pre", {"phase": True})
+
     def preprocess(wave):
-        return O.preprocessing_forward(O.cqt_forward(wave.unsqueeze(1), weights, c["hop_length"]), consts)
+        return O.preprocessing_forward(O.cqt_forward(wave.unsqueeze(1), weights, c["hop_length"]), consts if pk.get("phase") else None,
+                                       pk.get("offset_zero", False), pk.get("output_power", 1.0), pk.get("scaling", 1.0), pk.get("pooling"))
 
     data = torch.from_numpy(g["data"])
     B, V, K = meta["B"], meta["V"], meta["K"]
