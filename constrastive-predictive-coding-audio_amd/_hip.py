@@ -43,7 +43,7 @@ class GemmTNArgs(C.Structure):
                 ("flags", C.c_int), ("dtype", C.c_int), ("c_rpi", C.c_int), ("c_item", C.c_longlong)]
 
 
-_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
+_P, _I, _L, _F, _D, _U64, _U32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_ulonglong, C.c_uint
 _SIGNATURES = {
     "cpc_abi_version": ([], _I),
     "cpc_gemm_nt": ([C.POINTER(GemmNTArgs), _P], _I),
@@ -62,10 +62,12 @@ _SIGNATURES = {
     "cpc_relu_row_bwd": ([_P, _P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_pe_scale_fwd": ([_P, _P, _P, _I, _I, _I, _L, _F, _I, _P], _I),
     "cpc_pe_scale_bwd": ([_P, _P, _P, _I, _I, _I, _L, _F, _I, _P], _I),
-    "cpc_attn_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "cpc_attn_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "cpc_add_ln_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P], _I),
-    "cpc_ln_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P], _I),
+    "cpc_dropout": ([_P, _L, _F, _U64, _U32, _I, _P], _I),
+    "cpc_dropout_mask": ([_P, _L, _F, _U64, _U32, _P], _I),
+    "cpc_attn_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _I, _P], _I),
+    "cpc_attn_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _I, _P], _I),
+    "cpc_add_ln_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _I, _P], _I),
+    "cpc_ln_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _F, _U64, _U32, _I, _P], _I),
     "cpc_mean_time": ([_P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _I, _I, _P], _I),
     "cpc_im2col2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),

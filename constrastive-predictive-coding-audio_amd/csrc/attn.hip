@@ -10,6 +10,26 @@ namespace {
 constexpr int ATT_S = 64;       // max sequence length handled by the attention kernels
 constexpr int ATT_D = 64;       // max head dimension
 
+// Dropout masks are a pure function of (seed, site, element index), so the backward pass regenerates them instead of
+// storing them: keep  <=>  hash >= thresh, thresh = p * 2^32.  (The reference draws its masks from torch's generator
+// stream, which no other device or launch geometry can reproduce; only the distribution is shared.)
+struct Drop {
+    unsigned long long seed;
+    unsigned site, thresh;      // thresh == 0: no dropout
+    float inv_keep;             // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)site + 1ull) + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+__device__ __forceinline__ float drop_factor(const Drop& d, unsigned long long idx) {
+    if (d.thresh == 0u) return 1.f;
+    return drop_hash(d.seed, d.site, idx) >= d.thresh ? d.inv_keep : 0.f;
+}
+
 // x0[(b,t)][c] = z[b][t0+t][c] * scale + pe[t][c]      (PositionalEncoder.forward, attention_model.py:28-35)
 template <typename T>
 __global__ __launch_bounds__(256) void pe_scale_fwd_kernel(const T* __restrict__ top, const float* __restrict__ pe, T* __restrict__ x0,
@@ -47,7 +67,7 @@ __global__ __launch_bounds__(256) void pe_scale_bwd_kernel(const T* __restrict__
 //   qkv [(b,t)][3C]: q | k | v column blocks, head h at columns h*d of each;   out [(b,t)][C];   P [(b*heads+h)][S][S]
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ P, int S,
-                                                       int C, int heads, float scale) {
+                                                       int C, int heads, float scale, Drop dr) {
     __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], p[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
     for (int idx = tid; idx < S * d; idx += 256) {
@@ -79,6 +99,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
     __syncthreads();
     for (int idx = tid; idx < S * S; idx += 256) P[(long long)bh * S * S + idx] = from_f32<T>(p[idx / S][idx % S]);
+    if (dr.thresh) {        // nn.MultiheadAttention's dropout on the attention weights (saved P stays undropped)
+        __syncthreads();
+        for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] *= drop_factor(dr, (unsigned long long)bh * S * S + idx);
+        __syncthreads();
+    }
     for (int idx = tid; idx < S * d; idx += 256) {
         const int i = idx / d, c = idx % d;
         float o = 0.f;
@@ -90,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 // Backward: dqkv [(b,t)][3C] from dout [(b,t)][C], the saved P and qkv.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ P, const T* __restrict__ dout,
-                                                       T* __restrict__ dqkv, int S, int C, int heads, float scale) {
+                                                       T* __restrict__ dqkv, int S, int C, int heads, float scale, Drop dr) {
     __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], go[ATT_S][ATT_D + 1];
     __shared__ float p[ATT_S][ATT_S + 1], ds[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
@@ -104,13 +129,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
     for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] = to_f32(P[(long long)bh * S * S + idx]);
     __syncthreads();
-    // dP[i][j] = sum_c dO[i][c] V[j][c]
+    // dP[i][j] = m[i][j] * sum_c dO[i][c] V[j][c]   (m = dropout factor of the attention weights, 1 without dropout)
     for (int idx = tid; idx < S * S; idx += 256) {
         const int i = idx / S, j = idx % S;
         float s = 0.f;
         if (j <= i)
             for (int c = 0; c < d; ++c) s = fmaf(go[i][c], v[j][c], s);
-        ds[i][j] = s;
+        ds[i][j] = s * drop_factor(dr, (unsigned long long)bh * S * S + idx);
     }
     __syncthreads();
     if (tid < S) {
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         for (int j = 0; j <= t; ++j) dq = fmaf(ds[t][j], k[j][c], dq);
         for (int i = t; i < S; ++i) {
             dk = fmaf(ds[i][t], q[i][c], dk);
-            dv = fmaf(p[i][t], go[i][c], dv);
+            dv = fmaf(p[i][t] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + t), go[i][c], dv);
         }
         T* row = dqkv + ((long long)b * S + t) * 3 * C + h * d + c;
         row[0] = from_f32<T>(dq);
@@ -145,30 +170,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <typename T>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b2, const float* __restrict__ w,
                                                          const float* __restrict__ bias, T* __restrict__ r_out, T* __restrict__ y,
-                                                         float* __restrict__ stats, int M, int C, float eps) {
+                                                         float* __restrict__ stats, int M, int C, float eps, Drop dr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4n = C / 4;
+    // r = a + dropout(b): the sum is formed once (dropout factors are per element), kept in r_out when given
+    auto rsum = [&](int m, int c4) {
+        f32x4 v = load4(a + (long long)m * C + c4 * 4);
+        if (b2) {
+            f32x4 w2 = load4(b2 + (long long)m * C + c4 * 4);
+            if (dr.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w2[e] *= drop_factor(dr, (unsigned long long)m * C + c4 * 4 + e);
+            }
+            v += w2;
+        }
+        return v;
+    };
     for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
         float s1 = 0.f;
         for (int c4 = lane; c4 < c4n; c4 += 64) {
-            f32x4 v = load4(a + (long long)m * C + c4 * 4);
-            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+            const f32x4 v = rsum(m, c4);
             if (r_out) store4(r_out + (long long)m * C + c4 * 4, v);
             s1 += v[0] + v[1] + v[2] + v[3];
         }
         const float mean = wave_sum(s1) / (float)C;
         float s2 = 0.f;
         for (int c4 = lane; c4 < c4n; c4 += 64) {
-            f32x4 v = load4(a + (long long)m * C + c4 * 4);
-            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+            const f32x4 v = rsum(m, c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s2 += (v[e] - mean) * (v[e] - mean);
         }
         const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
         if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
         for (int c4 = lane; c4 < c4n; c4 += 64) {
-            f32x4 v = load4(a + (long long)m * C + c4 * 4);
-            if (b2) v += load4(b2 + (long long)m * C + c4 * 4);
+            const f32x4 v = rsum(m, c4);
             const f32x4 wv = *(const f32x4*)(w + c4 * 4), bv = *(const f32x4*)(bias + c4 * 4);
             f32x4 o;
 #pragma unroll
@@ -185,7 +220,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ r,
                                                      const float* __restrict__ stats, const float* __restrict__ w,
                                                      T* __restrict__ dr, float* __restrict__ slabs, int M, int C, int bcast,
-                                                     float gscale) {
+                                                     float gscale, T* __restrict__ dr_b, Drop drp) {
     extern __shared__ __attribute__((aligned(16))) float acc[];      // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4n = C / 4;
@@ -222,6 +257,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, c
                 o[e] = rstd * (dy[e] * wv[e] - m1 - xh * m2);
             }
             store4(dr + (long long)m * C + c4 * 4, o);
+            if (dr_b) {         // gradient of the dropped-out summand b of r = a + dropout(b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= drop_factor(drp, (unsigned long long)m * C + c4 * 4 + e);
+                store4(dr_b + (long long)m * C + c4 * 4, o);
+            }
         }
     }
     __syncthreads();
@@ -241,7 +281,27 @@ __global__ __launch_bounds__(256) void mean_time_kernel(const T* __restrict__ x,
     }
 }
 
+// x[i] *= dropout factor (in place);  mask[i] = factor (f32, for tests)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(T* __restrict__ x, long long n, Drop dr) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        x[i] = from_f32<T>(to_f32(x[i]) * drop_factor(dr, (unsigned long long)i));
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long long n, Drop dr) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        mask[i] = drop_factor(dr, (unsigned long long)i);
+}
+
 }  // namespace
+
+static Drop make_drop(float p, unsigned long long seed, unsigned site) {
+    Drop d;
+    d.seed = seed;
+    d.site = site;
+    d.thresh = p > 0.f ? (unsigned)fmin(4294967295.0, (double)p * 4294967296.0) : 0u;
+    d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    return d;
+}
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32)     \
     do {                                           \
@@ -276,46 +336,52 @@ static bool attn_ok(int B, int S, int C, int heads) {
     return B > 0 && S > 0 && S <= ATT_S && heads > 0 && C % heads == 0 && C / heads <= ATT_D;
 }
 
-int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, hipStream_t st) {
-    if (!attn_ok(B, S, C, heads)) return CPC_EINVAL;
+int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
+                    unsigned site, int dtype, hipStream_t st) {
+    if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
     const float scale = 1.f / sqrtf((float)(C / heads));
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)P, S, C, heads, scale),
-               hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (float*)out, (float*)P, S, C, heads, scale));
+               hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)P, S, C, heads, scale, dr),
+               hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (float*)out, (float*)P, S, C, heads, scale, dr));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
-int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
-                    hipStream_t st) {
-    if (!attn_ok(B, S, C, heads)) return CPC_EINVAL;
+int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, float drop_p,
+                    unsigned long long seed, unsigned site, int dtype, hipStream_t st) {
+    if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
     const float scale = 1.f / sqrtf((float)(C / heads));
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)P, (const bf16_t*)dout, (bf16_t*)dqkv, S, C, heads, scale),
-               hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (const float*)P, (const float*)dout, (float*)dqkv, S, C, heads, scale));
+               hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)P, (const bf16_t*)dout, (bf16_t*)dqkv, S, C, heads, scale, dr),
+               hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (const float*)P, (const float*)dout, (float*)dqkv, S, C, heads, scale, dr));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
 int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
-                      int C, float eps, int dtype, hipStream_t st) {
-    if (M <= 0 || C <= 0 || C % 4 || !w || !bias) return CPC_EINVAL;
+                      int C, float eps, float drop_p, unsigned long long seed, unsigned site, int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C % 4 || !w || !bias || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
     const int blocks = min(2048, (M + 3) / 4);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, w, bias, (bf16_t*)r_out, (bf16_t*)y, stats, M, C, eps),
-               hipLaunchKernelGGL((add_ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, w, bias, (float*)r_out, (float*)y, stats, M, C, eps));
+               hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, w, bias, (bf16_t*)r_out, (bf16_t*)y, stats, M, C, eps, dr),
+               hipLaunchKernelGGL((add_ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, w, bias, (float*)r_out, (float*)y, stats, M, C, eps, dr));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
 int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
-                  int C, int bcast, float gscale, int nblocks, int dtype, hipStream_t st) {
-    if (M <= 0 || C <= 0 || C % 4 || nblocks <= 0) return CPC_EINVAL;
+                  int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
+                  int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C % 4 || nblocks <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop drp = make_drop(drop_p, seed, site);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
     if (shm > 64 * 1024) return CPC_EINVAL;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(nblocks), dim3(256), shm, st, (const bf16_t*)g1, (const bf16_t*)g2, (const bf16_t*)r, stats, w, (bf16_t*)dr, slabs, M, C, bcast, gscale),
-               hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nblocks), dim3(256), shm, st, (const float*)g1, (const float*)g2, (const float*)r, stats, w, (float*)dr, slabs, M, C, bcast, gscale));
+               hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(nblocks), dim3(256), shm, st, (const bf16_t*)g1, (const bf16_t*)g2, (const bf16_t*)r, stats, w, (bf16_t*)dr, slabs, M, C, bcast, gscale, (bf16_t*)dr_b, drp),
+               hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nblocks), dim3(256), shm, st, (const float*)g1, (const float*)g2, (const float*)r, stats, w, (float*)dr, slabs, M, C, bcast, gscale, (float*)dr_b, drp));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
@@ -326,6 +392,26 @@ int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, h
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((mean_time_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, S, C),
                hipLaunchKernelGGL((mean_time_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, B, S, C));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, hipStream_t st) {
+    if (n <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
+    const int blocks = (int)min((long long)4096, (n + 255) / 256);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (bf16_t*)x, n, dr),
+               hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, st, (float*)x, n, dr));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_dropout_mask(float* mask, long long n, float drop_p, unsigned long long seed, unsigned site, hipStream_t st) {
+    if (n <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
+    const int blocks = (int)min((long long)4096, (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, st, mask, n, dr);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -158,27 +158,40 @@ int cpc_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, i
     return launch_pe_scale_bwd(g1, g2, dtop, B, S, C, item_stride, scale, dtype, (hipStream_t)stream);
 }
 
-int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, void* stream) {
+int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
+                 unsigned site, int dtype, void* stream) {
     if (!qkv || !out || !P) return CPC_EINVAL;
-    return launch_attn_fwd(qkv, out, P, B, S, C, heads, dtype, (hipStream_t)stream);
+    return launch_attn_fwd(qkv, out, P, B, S, C, heads, drop_p, seed, site, dtype, (hipStream_t)stream);
 }
 
-int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
-                 void* stream) {
+int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, float drop_p,
+                 unsigned long long seed, unsigned site, int dtype, void* stream) {
     if (!qkv || !P || !dout || !dqkv) return CPC_EINVAL;
-    return launch_attn_bwd(qkv, P, dout, dqkv, B, S, C, heads, dtype, (hipStream_t)stream);
+    return launch_attn_bwd(qkv, P, dout, dqkv, B, S, C, heads, drop_p, seed, site, dtype, (hipStream_t)stream);
 }
 
 int cpc_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
-                   int C, float eps, int dtype, void* stream) {
+                   int C, float eps, float drop_p, unsigned long long seed, unsigned site, int dtype, void* stream) {
     if (!a || !y || !stats) return CPC_EINVAL;
-    return launch_add_ln_fwd(a, b, w, bias, r_out, y, stats, M, C, eps, dtype, (hipStream_t)stream);
+    return launch_add_ln_fwd(a, b, w, bias, r_out, y, stats, M, C, eps, drop_p, seed, site, dtype, (hipStream_t)stream);
 }
 
 int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
-               int C, int bcast, float gscale, int nblocks, int dtype, void* stream) {
+               int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
+               int dtype, void* stream) {
     if (!g1 || !r || !stats || !w || !dr || !slabs) return CPC_EINVAL;
-    return launch_ln_bwd(g1, g2, r, stats, w, dr, slabs, M, C, bcast, gscale, nblocks, dtype, (hipStream_t)stream);
+    return launch_ln_bwd(g1, g2, r, stats, w, dr, slabs, M, C, bcast, gscale, nblocks, dr_b, drop_p, seed, site, dtype,
+                         (hipStream_t)stream);
+}
+
+int cpc_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, void* stream) {
+    if (!x) return CPC_EINVAL;
+    return launch_dropout(x, n, drop_p, seed, site, dtype, (hipStream_t)stream);
+}
+
+int cpc_dropout_mask(float* mask, long long n, float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!mask) return CPC_EINVAL;
+    return launch_dropout_mask(mask, n, drop_p, seed, site, (hipStream_t)stream);
 }
 
 int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream) {

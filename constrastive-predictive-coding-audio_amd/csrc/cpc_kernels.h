@@ -85,13 +85,17 @@ int launch_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S
                         int dtype, hipStream_t stream);
 int launch_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
                         int dtype, hipStream_t stream);
-int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, hipStream_t stream);
-int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
-                    hipStream_t stream);
+int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
+                    unsigned site, int dtype, hipStream_t stream);
+int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, float drop_p,
+                    unsigned long long seed, unsigned site, int dtype, hipStream_t stream);
 int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
-                      int C, float eps, int dtype, hipStream_t stream);
+                      int C, float eps, float drop_p, unsigned long long seed, unsigned site, int dtype, hipStream_t stream);
 int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
-                  int C, int bcast, float gscale, int nblocks, int dtype, hipStream_t stream);
+                  int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
+                  int dtype, hipStream_t stream);
+int launch_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, hipStream_t stream);
+int launch_dropout_mask(float* mask, long long n, float drop_p, unsigned long long seed, unsigned site, hipStream_t stream);
 int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, hipStream_t stream);
 
 // scalogram front end / 2-D encoder (scalogram.hip)

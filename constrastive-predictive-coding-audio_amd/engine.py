@@ -627,9 +627,11 @@ class AttentionContext:
     transformer encoder layers with a causal mask (transformer.py:262-271), a final LayerNorm, the mean over time and
     ``end_layer``.  Rows are (item, step) with C channels; every Linear is a cpc_gemm_nt / cpc_gemm_tn call, the
     per-(item, head) attention, the residual + LayerNorm and the mean are the kernels of csrc/attn.hip.
-    Dropout is not applied (p = 0 or eval mode only)."""
+    Dropout (train mode, p > 0) uses counter-based masks that the backward regenerates (include/cpc_hip.h, cpc_dropout):
+    same distribution as the reference's nn.Dropout, not its random stream."""
 
     LN_EPS = 1e-5
+    SITE_ATTN, SITE_DROP1, SITE_FF, SITE_DROP2 = 0, 1, 2, 3       # dropout sites of layer l: 4*l + ...
 
     def __init__(self, eng, ar):
         self.eng = eng
@@ -648,6 +650,8 @@ class AttentionContext:
             raise NotImplementedError("AttentionModel sizes must be multiples of 8 (channels <= 2048)")
         self.z_scale = math.sqrt(self.C)
         self.prefix = "autoregressive_model."
+        self.drop_p, self.drop_seed, self._drop_counter = 0.0, 0, 0
+        self.fixed_seed = None          # tests pin the mask seed here
 
     def _lname(self, l, what):
         return f"{self.prefix}encoder.layers.{l}.{what}"
@@ -677,6 +681,7 @@ class AttentionContext:
         self.dct = new(B * H)
         # gradient scratch
         self.gA, self.gB, self.gC, self.gD = new(M * C), new(M * C), new(M * C), new(M * C)
+        self.gAd, self.gBd = new(M * C), new(M * C)       # gradients of the dropped-out summands (dropout only)
         self.dqkv, self.df1, self.datt = new(M * 3 * C), new(M * FF), new(M * C)
         # weight operands in the storage dtype: [out][in] for the forward GEMMs, [in][out] for the data gradients
         shapes = {"in": (3 * C, C), "o": (C, C), "l1": (FF, C), "l2": (C, FF)}
@@ -707,11 +712,25 @@ class AttentionContext:
         src = _hip.ptr(p[self.prefix + "end_layer.weight"])
         _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end), H, C, C, 1, code)
         _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end_t), C, H, 1, C, code)
+        # dropout state of this step (prepare_weights runs once per forward, before it)
+        self.drop_p = float(self.ar.dropout) if (self.ar.training and self.ar.dropout > 0.0) else 0.0
+        if self.drop_p > 0.0:
+            if not self.drop_p < 1.0:
+                raise ValueError("dropout probability must be < 1")
+            self._drop_counter += 1
+            base = torch.initial_seed() if self.fixed_seed is None else int(self.fixed_seed)
+            self.drop_seed = (base * 0x9E3779B1 + (0 if self.fixed_seed is not None else self._drop_counter)) & 0x7FFFFFFFFFFFFFFF
+            # d relu(.)·dropout = keep/(1-p): the keep part comes with the ReLU mask of the stored (dropped) activation,
+            # the 1/(1-p) is folded into the operand of the feed-forward data-gradient GEMM
+            for l in range(self.N):
+                self.wt[l]["l2"].mul_(1.0 / (1.0 - self.drop_p))
 
-    def _ln(self, a, b, wname, r_out, y, stats):
+    def _ln(self, a, b, wname, r_out, y, stats, site=None):
         p = self.eng.model._param
+        dp = self.drop_p if site is not None else 0.0
         _hip.call("cpc_add_ln_fwd", _hip.ptr(a), _hip.ptr(b), _hip.ptr(p[wname + ".weight"]), _hip.ptr(p[wname + ".bias"]),
-                  _hip.ptr(r_out), _hip.ptr(y), _hip.ptr(stats), self.eng.B * self.S, self.C, self.LN_EPS, self.eng.code)
+                  _hip.ptr(r_out), _hip.ptr(y), _hip.ptr(stats), self.eng.B * self.S, self.C, self.LN_EPS, dp, self.drop_seed,
+                  site or 0, self.eng.code)
 
     def forward(self):
         e = self.eng
@@ -720,19 +739,21 @@ class AttentionContext:
         M = B * S
         Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
         P = _hip.ptr
-        if self.ar.dropout > 0.0 and self.ar.training:
-            raise NotImplementedError("AttentionModel dropout is not part of the HIP path yet: use dropout 0 or model.eval()")
+        dp, seed = self.drop_p, self.drop_seed
         _hip.call("cpc_pe_scale_fwd", P(e.act[-1], t0 * C), P(self.pe), P(self.X[0]), B, S, C, Ltop * C, self.z_scale, code)
         for l in range(self.N):
             X, w = self.X[l], self.w[l]
             bias = {k: P(p[self._lname(l, n)]) for k, n in self._BNAMES.items()}
             _hip.gemm_nt(P(X), P(w["in"]), P(self.qkv[l]), M, 3 * C, C, C, C, 3 * C, code, bias=bias["in"])
-            _hip.call("cpc_attn_fwd", P(self.qkv[l]), P(self.att[l]), P(self.P[l]), B, S, C, self.heads, code)
+            _hip.call("cpc_attn_fwd", P(self.qkv[l]), P(self.att[l]), P(self.P[l]), B, S, C, self.heads, dp, seed, 4 * l + self.SITE_ATTN,
+                      code)
             _hip.gemm_nt(P(self.att[l]), P(w["o"]), P(self.ytmp), M, C, C, C, C, C, code, bias=bias["o"])
-            self._ln(X, self.ytmp, self._lname(l, "norm1"), self.r1[l], self.x1[l], self.st1[l])
+            self._ln(X, self.ytmp, self._lname(l, "norm1"), self.r1[l], self.x1[l], self.st1[l], site=4 * l + self.SITE_DROP1)
             _hip.gemm_nt(P(self.x1[l]), P(w["l1"]), P(self.f1[l]), M, FF, C, C, C, FF, code, bias=bias["l1"], flags=_hip.GEMM_RELU)
+            if dp > 0.0:
+                _hip.call("cpc_dropout", P(self.f1[l]), M * FF, dp, seed, 4 * l + self.SITE_FF, code)
             _hip.gemm_nt(P(self.f1[l]), P(w["l2"]), P(self.ytmp), M, C, FF, FF, FF, C, code, bias=bias["l2"])
-            self._ln(self.x1[l], self.ytmp, self._lname(l, "norm2"), self.r2[l], self.X[l + 1], self.st2[l])
+            self._ln(self.x1[l], self.ytmp, self._lname(l, "norm2"), self.r2[l], self.X[l + 1], self.st2[l], site=4 * l + self.SITE_DROP2)
         self._ln(self.X[self.N], None, self.prefix + "encoder.norm", None, self.xn, self.stn)
         _hip.call("cpc_mean_time", P(self.xn), P(self.mean), B, S, C, code)
         b_end = P(p[self.prefix + "end_layer.bias"])
@@ -746,12 +767,13 @@ class AttentionContext:
     def c_float(self):
         return self.c32
 
-    def _ln_bwd(self, g1, g2, r, stats, wname, dr, bcast=0, gscale=1.0):
+    def _ln_bwd(self, g1, g2, r, stats, wname, dr, bcast=0, gscale=1.0, dr_b=None, site=0):
         e, C = self.eng, self.C
         g, p = e.model._grad, e.model._param
         nb = self.ln_blocks
         _hip.call("cpc_ln_bwd", _hip.ptr(g1), _hip.ptr(g2), _hip.ptr(r), _hip.ptr(stats), _hip.ptr(p[wname + ".weight"]),
-                  _hip.ptr(dr), _hip.ptr(e.slabs), e.B * self.S, C, bcast, gscale, nb, e.code)
+                  _hip.ptr(dr), _hip.ptr(e.slabs), e.B * self.S, C, bcast, gscale, nb, _hip.ptr(dr_b),
+                  self.drop_p if dr_b is not None else 0.0, self.drop_seed, site, e.code)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[wname + ".weight"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, C), _hip.ptr(g[wname + ".bias"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
 
@@ -772,20 +794,26 @@ class AttentionContext:
         for l in range(self.N - 1, -1, -1):
             wt = self.wt[l]
             gname = lambda k, names: g[self._lname(l, names[k])]
-            # norm2 over r2 = x1 + f2
-            self._ln_bwd(g1, g2, self.r2[l], self.st2[l], self._lname(l, "norm2"), self.gB)
-            e._colsum_to_grad(P(self.gB), gname("l2", self._BNAMES), M, C)
-            e._tn_to_grad(P(self.gB), P(self.f1[l]), gname("l2", self._WNAMES), M, C, FF, C, FF, self.split["l2"])
-            _hip.gemm_nt(P(self.gB), P(wt["l2"]), P(self.df1), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
+            drop = self.drop_p > 0.0
+            # norm2 over r2 = x1 + dropout(f2)
+            gBd = self.gBd if drop else self.gB
+            self._ln_bwd(g1, g2, self.r2[l], self.st2[l], self._lname(l, "norm2"), self.gB, dr_b=self.gBd if drop else None,
+                         site=4 * l + self.SITE_DROP2)
+            e._colsum_to_grad(P(gBd), gname("l2", self._BNAMES), M, C)
+            e._tn_to_grad(P(gBd), P(self.f1[l]), gname("l2", self._WNAMES), M, C, FF, C, FF, self.split["l2"])
+            _hip.gemm_nt(P(gBd), P(wt["l2"]), P(self.df1), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
             e._colsum_to_grad(P(self.df1), gname("l1", self._BNAMES), M, FF)
             e._tn_to_grad(P(self.df1), P(self.x1[l]), gname("l1", self._WNAMES), M, FF, C, FF, C, self.split["l1"])
             _hip.gemm_nt(P(self.df1), P(wt["l1"]), P(self.gC), M, C, FF, FF, FF, C, code)
-            # norm1 over r1 = x + attention output projection
-            self._ln_bwd(self.gB, self.gC, self.r1[l], self.st1[l], self._lname(l, "norm1"), self.gA)
-            e._colsum_to_grad(P(self.gA), gname("o", self._BNAMES), M, C)
-            e._tn_to_grad(P(self.gA), P(self.att[l]), gname("o", self._WNAMES), M, C, C, C, C, self.split["o"])
-            _hip.gemm_nt(P(self.gA), P(wt["o"]), P(self.datt), M, C, C, C, C, C, code)
-            _hip.call("cpc_attn_bwd", P(self.qkv[l]), P(self.P[l]), P(self.datt), P(self.dqkv), B, S, C, self.heads, code)
+            # norm1 over r1 = x + dropout(attention output projection)
+            gAd = self.gAd if drop else self.gA
+            self._ln_bwd(self.gB, self.gC, self.r1[l], self.st1[l], self._lname(l, "norm1"), self.gA, dr_b=self.gAd if drop else None,
+                         site=4 * l + self.SITE_DROP1)
+            e._colsum_to_grad(P(gAd), gname("o", self._BNAMES), M, C)
+            e._tn_to_grad(P(gAd), P(self.att[l]), gname("o", self._WNAMES), M, C, C, C, C, self.split["o"])
+            _hip.gemm_nt(P(gAd), P(wt["o"]), P(self.datt), M, C, C, C, C, C, code)
+            _hip.call("cpc_attn_bwd", P(self.qkv[l]), P(self.P[l]), P(self.datt), P(self.dqkv), B, S, C, self.heads, self.drop_p,
+                      self.drop_seed, 4 * l + self.SITE_ATTN, code)
             e._colsum_to_grad(P(self.dqkv), gname("in", self._BNAMES), M, 3 * C)
             e._tn_to_grad(P(self.dqkv), P(self.X[l]), gname("in", self._WNAMES), M, 3 * C, C, 3 * C, C, self.split["in"])
             _hip.gemm_nt(P(self.dqkv), P(wt["in"]), P(self.gD), M, C, 3 * C, 3 * C, 3 * C, C, code)

@@ -128,21 +128,32 @@ int cpc_pe_scale_fwd(const void* top, const float* pe, void* x0, int B, int S, i
                      int dtype, void* stream);
 int cpc_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S, int C, long long item_stride, float scale,
                      int dtype, void* stream);
+/* Dropout (transformer.py:243-252 modules, active in train mode): every mask is a pure function of (seed, site, element
+ * index) — factor 1/(1-p) where a 64-bit mix of the three is >= p*2^32, else 0 — so the backward entry points regenerate
+ * it from the same (drop_p, seed, site) instead of reading a stored mask.  drop_p = 0 disables it.  The reference draws
+ * its masks from torch's generator stream; only the distribution can be shared, so dropout parity is statistical.
+ * cpc_dropout: x[i] *= factor(i) in place (the feed-forward dropout);  cpc_dropout_mask: mask[i] = factor(i) as f32. */
+int cpc_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, void* stream);
+int cpc_dropout_mask(float* mask, long long n, float drop_p, unsigned long long seed, unsigned site, void* stream);
 /* nn.MultiheadAttention core with the causal mask of attention_model.py:61-63, one (item, head) per workgroup:
- *   qkv T [(b,t)][3C] (q | k | v, head h at columns h*C/heads);  out T [(b,t)][C];  P T [B*heads][S][S] softmax rows (saved).
+ *   qkv T [(b,t)][3C] (q | k | v, head h at columns h*C/heads);  out T [(b,t)][C];  P T [B*heads][S][S] softmax rows (saved,
+ *   before dropout; element index of the dropout mask = its offset in P).
  * Limits: S <= 64, C/heads <= 64 (-EINVAL otherwise).  The backward gives dqkv in the layout of qkv. */
-int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, int dtype, void* stream);
-int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, int dtype,
-                 void* stream);
-/* r = a + b (b may be NULL; r_out may be NULL), y = LayerNorm(r) * w + bias (transformer.py:262-271, eps inside the sqrt);
- * stats f32 [M][2] = (mean, rstd) saved for the backward. */
+int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
+                 unsigned site, int dtype, void* stream);
+int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, float drop_p,
+                 unsigned long long seed, unsigned site, int dtype, void* stream);
+/* r = a + dropout(b) (b may be NULL; r_out may be NULL), y = LayerNorm(r) * w + bias (transformer.py:262-271, eps inside
+ * the sqrt); stats f32 [M][2] = (mean, rstd) saved for the backward; dropout element index = m*C + c. */
 int cpc_add_ln_fwd(const void* a, const void* b, const float* w, const float* bias, void* r_out, void* y, float* stats, int M,
-                   int C, float eps, int dtype, void* stream);
+                   int C, float eps, float drop_p, unsigned long long seed, unsigned site, int dtype, void* stream);
 /* LayerNorm backward: dy = g1 * gscale (+ g2); with bcast > 0 row m reads g1 row m / bcast (the mean over time of
- * attention_model.py:79 folded in, gscale = 1/S).  dr = gradient of r; slabs f32 [nblocks][2][C] hold per-block partial
- * sums of (dw, dbias), to be summed by cpc_reduce_slabs.  C*32 bytes of LDS must fit 64 KB. */
+ * attention_model.py:79 folded in, gscale = 1/S).  dr = gradient of r; dr_b (may be NULL) = dr * dropout factor = gradient of
+ * the summand b; slabs f32 [nblocks][2][C] hold per-block partial sums of (dw, dbias), to be summed by cpc_reduce_slabs.
+ * C*32 bytes of LDS must fit 64 KB. */
 int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
-               int C, int bcast, float gscale, int nblocks, int dtype, void* stream);
+               int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
+               int dtype, void* stream);
 /* out[b][c] = mean_t x[(b,t)][c]  (attention_model.py:79) */
 int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream);
 

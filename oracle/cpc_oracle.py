@@ -163,10 +163,14 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1
 
 
 def attention_forward(z: torch.Tensor, params: Params, num_layers: int, num_heads: int,
-                      prefix: str = "autoregressive_model."):
+                      prefix: str = "autoregressive_model.", dropout_factors=None):
     """AttentionModel.forward in eval mode / dropout 0 — attention_model.py:59-82, with the post-norm encoder layer of
     transformer.py:262-271 (self-attention + residual + LayerNorm, Linear-ReLU-Linear + residual + LayerNorm), the final
     LayerNorm of TransformerEncoder (transformer.py:167-168), the mean over time and end_layer.
+
+    ``dropout_factors`` (train mode with p > 0): {(layer, site): tensor of factors 0 or 1/(1-p)} for the four nn.Dropout
+    sites of a layer — 0: attention weights (B*heads, S, S), 1: attention block output (S, B, C), 2: feed-forward hidden
+    (S, B, FF), 3: feed-forward output (S, B, C) — i.e. nn.Dropout with its mask given instead of drawn.
 
     z (B, C, S).  Returns (c (B, out), z * sqrt(C)): PositionalEncoder multiplies its input IN PLACE
     (attention_model.py:30), and that input is a view of the z the model returns, so the returned z is the scaled one."""
@@ -176,18 +180,20 @@ def attention_forward(z: torch.Tensor, params: Params, num_layers: int, num_head
     z_scaled = z * math.sqrt(C)
     x = z_scaled.permute(2, 0, 1) + positional_encoding(S, C).unsqueeze(1)          # (S, B, C)
     mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
+    df = dropout_factors or {}
+    drop = lambda t, l, site: t * df[(l, site)].to(t.dtype) if (l, site) in df else t
     for l in range(num_layers):
         pl = f"{prefix}encoder.layers.{l}."
         qkv = x @ params[pl + "self_attn.in_proj_weight"].t() + params[pl + "self_attn.in_proj_bias"]
         q, k, v = (t.reshape(S, B * num_heads, d).transpose(0, 1) for t in qkv.split(C, dim=-1))   # (B*h, S, d)
         scores = (q * d ** -0.5) @ k.transpose(1, 2) + mask
-        o = torch.softmax(scores, dim=-1) @ v                                          # (B*h, S, d)
+        o = drop(torch.softmax(scores, dim=-1), l, 0) @ v                              # (B*h, S, d)
         o = o.transpose(0, 1).reshape(S, B, C)
         y = o @ params[pl + "self_attn.out_proj.weight"].t() + params[pl + "self_attn.out_proj.bias"]
-        x = layer_norm(x + y, params[pl + "norm1.weight"], params[pl + "norm1.bias"])
-        f = torch.relu(x @ params[pl + "linear1.weight"].t() + params[pl + "linear1.bias"])
+        x = layer_norm(x + drop(y, l, 1), params[pl + "norm1.weight"], params[pl + "norm1.bias"])
+        f = drop(torch.relu(x @ params[pl + "linear1.weight"].t() + params[pl + "linear1.bias"]), l, 2)
         f = f @ params[pl + "linear2.weight"].t() + params[pl + "linear2.bias"]
-        x = layer_norm(x + f, params[pl + "norm2.weight"], params[pl + "norm2.bias"])
+        x = layer_norm(x + drop(f, l, 3), params[pl + "norm2.weight"], params[pl + "norm2.bias"])
     x = layer_norm(x, params[prefix + "encoder.norm.weight"], params[prefix + "encoder.norm.bias"])
     m = x.sum(0) / S
     c = m @ params[prefix + "end_layer.weight"].t() + params[prefix + "end_layer.bias"]
@@ -341,8 +347,8 @@ def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_
     K, V = prediction_steps, visible_steps
     targets = enc[:, :, -K:]
     z = enc[:, :, -(V + K):-K]
-    if attention is not None:
-        c, z = attention_forward(z, params, attention[0], attention[1])
+    if attention is not None:       # (num_layers, num_heads[, dropout_factors])
+        c, z = attention_forward(z, params, attention[0], attention[1], dropout_factors=attention[2] if len(attention) > 2 else None)
     elif conv_ar is None:
         c = gru_forward(z, params)
     elif isinstance(conv_ar, dict):     # full ConvolutionalArModel args: kernel_sizes, pooling, stride, batch_norm, residual

@@ -460,11 +460,11 @@ def test_attention_fwd_bwd(dt, B, S, C, heads):
     d_qkv, d_dout = dev(qkv.detach().float(), dt), dev(dout.float(), dt)
     o = torch.full((B * S, C), float("nan"), device=DEV, dtype=dt)
     Pd = torch.full((B * heads, S, S), float("nan"), device=DEV, dtype=dt)
-    _hip.call("cpc_attn_fwd", _hip.ptr(d_qkv), _hip.ptr(o), _hip.ptr(Pd), B, S, C, heads, code)
+    _hip.call("cpc_attn_fwd", _hip.ptr(d_qkv), _hip.ptr(o), _hip.ptr(Pd), B, S, C, heads, 0.0, 0, 0, code)
     assert rel_err(o, out) < tol(dt)
     assert rel_err(Pd, P.reshape(B * heads, S, S)) < tol(dt)
     dq = torch.full((B * S, 3 * C), float("nan"), device=DEV, dtype=dt)
-    _hip.call("cpc_attn_bwd", _hip.ptr(d_qkv), _hip.ptr(Pd), _hip.ptr(d_dout), _hip.ptr(dq), B, S, C, heads, code)
+    _hip.call("cpc_attn_bwd", _hip.ptr(d_qkv), _hip.ptr(Pd), _hip.ptr(d_dout), _hip.ptr(dq), B, S, C, heads, 0.0, 0, 0, code)
     assert rel_err(dq, qkv.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
 
 
@@ -473,7 +473,7 @@ def test_attention_unsupported_shapes():
     p = _hip.ptr(x)
     for B, S, C, heads in ((1, 65, 64, 8), (1, 8, 256, 2), (1, 8, 60, 8)):
         with pytest.raises(_hip.HipCallError):
-            _hip.call("cpc_attn_fwd", p, p, p, B, S, C, heads, 0)
+            _hip.call("cpc_attn_fwd", p, p, p, B, S, C, heads, 0.0, 0, 0, 0)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -502,7 +502,7 @@ def test_add_layernorm_fwd_bwd(dt, M, C, bcast):
     y = torch.full((M, C), float("nan"), device=DEV, dtype=dt)
     stats = torch.full((M, 2), float("nan"), device=DEV)
     _hip.call("cpc_add_ln_fwd", _hip.ptr(da), _hip.ptr(db), _hip.ptr(dw), _hip.ptr(dbias), _hip.ptr(r), _hip.ptr(y), _hip.ptr(stats),
-              M, C, 1e-5, code)
+              M, C, 1e-5, 0.0, 0, 0, code)
     assert rel_err(y, y_ref) < tol(dt)
     assert rel_err(r, a.detach() + b) < tol(dt)
     nb = 5
@@ -510,7 +510,7 @@ def test_add_layernorm_fwd_bwd(dt, M, C, bcast):
     dr = torch.full((M, C), float("nan"), device=DEV, dtype=dt)
     dg1, dg2 = dev(g1.float(), dt), (dev(g2.float(), dt) if g2 is not None else None)
     _hip.call("cpc_ln_bwd", _hip.ptr(dg1), _hip.ptr(dg2), _hip.ptr(r), _hip.ptr(stats), _hip.ptr(dw), _hip.ptr(dr), _hip.ptr(slabs),
-              M, C, bcast, (1.0 / bcast) if bcast else 1.0, nb, code)
+              M, C, bcast, (1.0 / bcast) if bcast else 1.0, nb, None, 0.0, 0, 0, code)
     t = 1e-4 if dt == torch.float32 else 2.5e-2
     assert rel_err(dr, a.grad) < t
     assert rel_err(slabs.sum(0)[0], w.grad) < t

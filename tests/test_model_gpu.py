@@ -491,3 +491,59 @@ def test_conv_ar_batchnorm_residual_matches_reference(golden_dir, dtype, variant
                 # storage rounding; fp32 is the parity gate
                 bound = 2e-3 if dtype == "fp32" else 0.35
                 assert l2 < bound, (run["tag"], name, l2)
+
+
+def test_attention_dropout_against_oracle_with_same_masks(golden_dir):
+    """Train-mode dropout (p = 0.2) in the attention context: the device masks are a function of (seed, site, index), so
+    they can be materialised (cpc_dropout_mask) and handed to the oracle; forward, loss and all gradients must then agree
+    (fp32).  Also checks the keep rate and that eval mode ignores dropout."""
+    from cpc_audio_amd import _hip
+    g = _load(golden_dir, "attention_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    C, H, K, V, B = meta["C"], meta["H"], meta["K"], meta["V"], meta["B"]
+    p_drop, layers, heads, FF = 0.2, meta["ar"]["num_layers"], meta["ar"]["num_heads"], meta["ar"]["feedforward_size"]
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, AttentionModel(dict(meta["ar"], dropout=p_drop)), enc_size=C, ar_size=H, visible_steps=V,
+                                       prediction_steps=K, compute_dtype="fp32")
+    model.load_state_dict(state)
+    model = model.to(DEV).train()
+    x = torch.from_numpy(g["data"][:B]).to(DEV)
+    eng = model.engine(B, x.shape[1])
+    eng.ctx.fixed_seed = 1234
+    out = eng.loss_and_grads(x.contiguous(), softplus=True, regularization=1.0)
+    seed, S = eng.ctx.drop_seed, V
+
+    def factors(n, site):
+        m = torch.empty(n, device=DEV)
+        _hip.call("cpc_dropout_mask", _hip.ptr(m), n, p_drop, seed, site)
+        return m.cpu()
+
+    df = {}
+    for l in range(layers):
+        df[(l, 0)] = factors(B * heads * S * S, 4 * l + 0).view(B * heads, S, S)
+        df[(l, 1)] = factors(B * S * C, 4 * l + 1).view(B, S, C).transpose(0, 1)
+        df[(l, 2)] = factors(B * S * FF, 4 * l + 2).view(B, S, FF).transpose(0, 1)
+        df[(l, 3)] = factors(B * S * C, 4 * l + 3).view(B, S, C).transpose(0, 1)
+    keep = torch.cat([v.reshape(-1) for v in df.values()])
+    assert abs((keep > 0).float().mean().item() - (1 - p_drop)) < 5e-3
+    assert torch.all((keep == 0) | ((keep - 1 / (1 - p_drop)).abs() < 1e-6))
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items() if not k.endswith("positional_encoder.pe")}
+    pz, tg, _, _ = O.cpc_forward(x.cpu().unsqueeze(1), params, V, K, attention=(layers, heads, df))
+    loss, _ = O.info_nce_loss(O.softplus_scores(pz, tg), False, 1.0)
+    loss.backward()
+    assert abs(float(out[0]) - float(loss)) < 2e-4 * abs(float(loss))
+    for n in params:
+        ref = params[n].grad.double()
+        l2 = ((model._grad[n].double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+        assert l2 < 2e-3, (n, l2)
+    # a second step draws different masks; eval mode has none
+    eng.ctx.fixed_seed = None
+    a = float(eng.loss_and_grads(x.contiguous(), softplus=True, regularization=1.0)[0])
+    b = float(eng.loss_and_grads(x.contiguous(), softplus=True, regularization=1.0)[0])
+    assert a != b
+    model.eval()
+    with torch.no_grad():
+        c1 = model(x.unsqueeze(1))[3]
+        c2 = model(x.unsqueeze(1))[3]
+    assert torch.equal(c1, c2) and _rel(c1, g["fwd/c"]) < 2e-4
