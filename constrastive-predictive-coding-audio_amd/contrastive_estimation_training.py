@@ -301,7 +301,38 @@ class ContrastiveEstimationTrainer:
         return task_data.numpy(), task_labels.numpy()
 
     def test_task(self, task_data, task_labels, evaluation_ratio=0.2):
-        raise NotImplementedError("the downstream MLP probe (reference :305-350) is outside the hot path (SURVEY.md 8f rank 4)")
+        """Downstream probe of the context vectors (reference :305-350): a 128-64 ReLU MLP classifier trained with Adam
+        (lr 1e-3, batch 64, 10 epochs) on a seeded 80/20 split; returns the evaluation accuracy after the last epoch.
+        This is evaluation tooling outside the train-step hot path: a few thousand 256-vectors through
+        a three-layer MLP, run with stock torch modules on ``self.device``."""
+        num_items = task_data.shape[0]
+        order = list(range(num_items))
+        random.seed(0)
+        random.shuffle(order)
+        n_eval = int(num_items * evaluation_ratio)
+        eval_idx, train_idx = order[:n_eval], order[n_eval:]
+        files = getattr(self.test_task_set, "files", None)
+        n_classes = len(files) if files is not None else int(task_labels.max()) + 1
+        device = self._device()
+        probe = torch.nn.Sequential(torch.nn.Linear(self.ar_size, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64), torch.nn.ReLU(),
+                                    torch.nn.Linear(64, n_classes)).to(device)
+        to_dev = lambda a, idx: torch.from_numpy(a[idx]).to(device)
+        x_train, y_train = to_dev(task_data, train_idx), to_dev(task_labels, train_idx)
+        x_eval, y_eval = to_dev(task_data, eval_idx), to_dev(task_labels, eval_idx)
+        opt = torch.optim.Adam(probe.parameters(), lr=1e-3)
+        accuracy = 0.0
+        for epoch in range(10):
+            for lo in range(0, y_train.shape[0], 64):
+                loss = torch.nn.functional.cross_entropy(probe(x_train[lo:lo + 64]), y_train[lo:lo + 64])
+                probe.zero_grad()
+                loss.backward()
+                opt.step()
+            with torch.no_grad():
+                hits = torch.eq(torch.argmax(probe(x_eval), dim=1), y_eval)
+            accuracy = torch.sum(hits).item() / max(len(eval_idx), 1)
+            if self.verbose:
+                print("task accuracy after epoch", epoch, ":", accuracy)
+        return accuracy
 
 
 class DeterministicSampler(torch.utils.data.Sampler):

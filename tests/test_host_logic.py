@@ -170,3 +170,21 @@ def test_cqt_filter_design_matches_oracle_restatement():
     assert [len(r) for r in m.conv_index_ranges] == [19, 32, 32, 32, 32, 32, 32, 32, 13]
     assert list(m.state_dict().keys()) == [f"conv_modules.{i}.weight" for i in range(9)]
     assert m.frames(97024) == 630
+
+
+def test_downstream_probe_learns_a_separable_task():
+    """ContrastiveEstimationTrainer.test_task (reference :305-350): seeded split, MLP probe; on linearly separable context
+    vectors it must reach high accuracy (CPU; the probe is stock torch, outside the hot path)."""
+    import numpy as np
+    from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer
+    tr = ContrastiveEstimationTrainer.__new__(ContrastiveEstimationTrainer)
+    tr.ar_size, tr.device, tr.verbose = 16, "cpu", False
+    tr.test_task_set = type("S", (), {"files": ["a", "b", "c"]})()
+    tr.model = torch.nn.Linear(1, 1)
+    g = np.random.default_rng(0)
+    labels = g.integers(0, 3, size=600)
+    centers = g.normal(size=(3, 16)) * 3
+    data = (centers[labels] + g.normal(size=(600, 16))).astype(np.float32)
+    torch.manual_seed(0)
+    acc = tr.test_task(data, labels.astype(np.int64))
+    assert acc > 0.9
