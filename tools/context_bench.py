@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--breakdown", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, L, K = args.batch, 20480, 12
@@ -50,12 +51,21 @@ def main():
             out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
             opt.step()
         torch.cuda.synchronize()
+        timer = None
+        if args.breakdown:
+            from cpc_audio_amd import _hip
+            timer = _hip.KernelTimer(only=None, by_shape=False)
+            _hip.set_timer(timer)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
             opt.step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
+        if timer is not None:
+            _hip.set_timer(None)
+            for k, (cnt, kms, w) in sorted(timer.summary().items(), key=lambda kv: -kv[1][1])[:14]:
+                print(f"#   {k:50s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step")
         print(f"{name:28s} V={V:3d} {ms:8.3f} ms/step  {B * 126 / ms * 1e3:12.0f} frames/s  loss {float(out[0]):.5f}  "
               f"mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
         del model, eng, opt
