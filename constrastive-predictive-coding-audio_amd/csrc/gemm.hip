@@ -570,19 +570,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             __syncthreads();
             constexpr int CPR = TBN / 8;                 // 16-byte chunks per tile row
             constexpr int RPP = NTHR / CPR;              // rows per pass
+            constexpr int NPASS = TBM / RPP;
             const int cc = tid % CPR, rr = tid / CPR;
             const int n = n0 + cc * 8;
             if (n < p.N) {
-#pragma unroll 4
-                for (int r = rr; r < TBM; r += RPP) {
+                // ReLU-backward mask: all of a thread's mask chunks are requested before the first is used, so the tile pays
+                // the HBM latency once, not once per group of rows (the accumulators are in LDS by now: registers are free)
+                uint4 mk[NPASS];
+                if (Mb) {
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) {
+                        const int m = min(m0 + rr + q * RPP, p.M - 1);
+                        mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int r = rr + q * RPP;
                     const int m = m0 + r;
                     if (m >= p.M) break;
                     const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
                     uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
                     if (Mb) {
-                        const uint4 mk = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
                         // bf16 > 0  <=>  sign bit clear and not zero
-                        const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                        const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
                         unsigned vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
