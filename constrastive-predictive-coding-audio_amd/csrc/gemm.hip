@@ -878,6 +878,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
+// f32 TN for tiny outputs reduced over very many rows (C[i][j] = sum_m A[m][i] B[m][j] with I <= 32, J <= 64: the weight
+// gradient of the scalogram encoder's first convolution, 18 x 32 over 5 M positions).  A 128-wide MFMA tile would be almost
+// empty; here a workgroup streams its slab of rows through LDS 64 at a time and every thread keeps 4 consecutive j of one
+// i in registers (VALU fma; the kernel is bound by reading A and B once from HBM).
+__global__ __launch_bounds__(256) void gemm_tn_skinny_f32_kernel(GemmTN p) {
+    __shared__ __attribute__((aligned(16))) float sa[64][32 + 4];
+    __shared__ __attribute__((aligned(16))) float sb[64][64 + 4];
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x;
+    const int m_begin = split * p.m_chunk, m_end = min(p.M, m_begin + p.m_chunk);
+    const float* Ab = (const float*)p.A;
+    const float* Bb = (const float*)p.B;
+    const int I4 = (p.I + 3) / 4, J4 = p.J / 4;
+    const int oi = tid / J4, oj4 = tid % J4;                 // output (i = oi, j = 4*oj4 ..) for tid < I * J4
+    const bool owner = oi < p.I;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int mb = m_begin; mb < m_end; mb += 64) {
+        __syncthreads();
+        for (int q = tid; q < 64 * I4; q += 256) {
+            const int r = q / I4, c4 = q % I4, m = mb + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) v = *(const f32x4*)(Ab + row_off(m, p.a_rpi, p.a_item, p.lda) + c4 * 4);      // lda >= 4*I4 (host)
+            *(f32x4*)&sa[r][c4 * 4] = v;
+        }
+        for (int q = tid; q < 64 * J4; q += 256) {
+            const int r = q / J4, c4 = q % J4, m = mb + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) v = *(const f32x4*)(Bb + row_off(m, p.b_rpi, p.b_item, p.ldb) + c4 * 4);
+            *(f32x4*)&sb[r][c4 * 4] = v;
+        }
+        __syncthreads();
+        if (owner) {
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) {
+                const float a = sa[r][oi];
+                const f32x4 b = *(const f32x4*)&sb[r][oj4 * 4];
+                acc += a * b;
+            }
+        }
+    }
+    if (owner) *(f32x4*)((float*)p.C + (long long)split * p.slab_stride + (long long)oi * p.ldc + oj4 * 4) = acc;
+}
+
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
@@ -939,6 +982,14 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     if (p.c_rpi && (p.c_item % 4 || nsplit > 1)) return CPC_EINVAL;
     const bool of32 = p.flags & GEMM_OUT_F32;
     const int eff_chunk = nsplit > 1 ? p.m_chunk : p.M;
+    if (dtype == CPC_DTYPE_F32 && batch == 1 && p.I <= 32 && p.J <= 64 && p.I * (p.J / 4) <= 256 && p.c_rpi == 0 &&
+        p.lda >= (p.I + 3) / 4 * 4 && !(p.flags & GEMM_FORCE_GENERIC)) {
+        GemmTN q = p;
+        q.m_chunk = eff_chunk;
+        hipLaunchKernelGGL(gemm_tn_skinny_f32_kernel, dim3(nsplit), dim3(256), 0, stream, q);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     const bool fast = dtype == CPC_DTYPE_BF16 && !(p.flags & (GEMM_FORCE_GENERIC | GEMM_TN_NO_TR)) && (p.I % 8 == 0) &&
                       p.I >= 8 && p.J >= 8;
     const bool big = fast && p.I >= 256 && p.J >= 256 && eff_chunk >= 1024 && !(p.flags & GEMM_SMALL_TILE);

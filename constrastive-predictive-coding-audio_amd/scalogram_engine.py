@@ -51,6 +51,15 @@ def _desc(t, desc):
     return C.cast(desc, C.c_void_p)
 
 
+def _col_group(cout, kw=1, stride=(1, 1), pad=0):
+    """How many consecutive output rows a tall-kernel GEMM computes per GEMM row: with fewer than 128 output channels the
+    128-wide MFMA tile would be mostly empty, so G = 128 / C_out rows are produced side by side (their windows overlap in
+    all but G-1 input rows; the weight operand holds G shifted copies of the kernel, +(G-1)/k extra FLOPs)."""
+    if kw != 1 or stride != (1, 1) or pad != 0 or cout >= 128 or 128 % cout:
+        return 1
+    return 128 // cout
+
+
 class _Conv:
     """One nn.Conv2d of the encoder on grids.  mode 'col': (k,1) kernel, stride 1, no padding -> overlapped-row GEMMs;
     mode 'win': im2col + GEMM (+ col2im for the data gradient)."""
@@ -84,11 +93,27 @@ class _Conv:
         if self.mode == 'col':
             self.y0 = Grid(B, gin.W, self.Ho, self.cout, dev, dt, top=0, tail=gin.Ha - self.Ho, guard_rows=self.kh + 16)
             self.K = self.kh * self.cin
-            self.w_fwd = torch.empty(self.cout * self.K, device=dev, dtype=dt)
-            self.w_dgrad = torch.empty(self.cin * self.kh * self.cout, device=dev, dtype=dt)
             self.M = gin.rows
-            self.nsplit = eng._pick_split(self.K, self.cout, self.M)
-            self.slab = self.nsplit * self.K * self.cout
+            G = _col_group(self.cout)
+            self.G = G if (G > 1 and gin.Ha % G == 0 and dt == torch.bfloat16) else 1
+            if self.G > 1:
+                G = self.G
+                self.Rw = _ceil_div((self.kh + G - 1) * self.cin, 64) * 64 // self.cin      # window rows incl. K padding to 64
+                self.Rd = _ceil_div((self.kh + G - 1) * self.cout, 64) * 64 // self.cout
+                if (self.Rw * self.cin) % 64 or (self.Rd * self.cout) % 64:
+                    self.G = 1
+            if self.G > 1:
+                G = self.G
+                self.w_fwd = torch.zeros(G, self.cout, self.Rw, self.cin, device=dev, dtype=dt)       # [(dh,co)][(r,c)]
+                self.w_dgrad = torch.zeros(G, self.cin, self.Rd, self.cout, device=dev, dtype=dt)     # [(dr,c)][(q,co)]
+                self.bias_g = torch.zeros(G * self.cout, device=dev, dtype=torch.float32)
+                self.nsplit = eng._pick_split(self.Rw * self.cin, G * self.cout, self.M // G)
+                self.slab = self.nsplit * self.Rw * self.cin * G * self.cout
+            else:
+                self.w_fwd = torch.empty(self.cout * self.K, device=dev, dtype=dt)
+                self.w_dgrad = torch.empty(self.cin * self.kh * self.cout, device=dev, dtype=dt)
+                self.nsplit = eng._pick_split(self.K, self.cout, self.M)
+                self.slab = self.nsplit * self.K * self.cout
         else:
             self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt)
             self.K = self.kh * self.kw * self.cin
@@ -110,7 +135,16 @@ class _Conv:
     def prepare(self):
         p, code = self.eng.model._param, self.code
         w = p[self.wname]
-        if self.mode == 'col':
+        if self.mode == 'col' and self.G > 1:
+            wk = w.detach().view(self.cout, self.cin, self.kh)
+            for dh in range(self.G):
+                # forward: output row 4R+dh uses window rows dh .. dh+kh-1;  data gradient: input row 4R+dr receives tap j from
+                # dY window row q = dr + kh-1 - j
+                self.w_fwd[dh, :, dh:dh + self.kh, :].copy_(wk.permute(0, 2, 1))
+                self.w_dgrad[dh, :, dh:dh + self.kh, :].copy_(wk.permute(1, 2, 0).flip(1))
+            if self.bname:
+                self.bias_g.copy_(p[self.bname].detach().repeat(self.G))
+        elif self.mode == 'col':
             _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd), _hip.ptr(self.w_dgrad), self.cout, self.cin, self.kh, 1, code)
         else:
             w4 = w.detach().view(self.cout, self.cin, self.kh, self.kw)
@@ -123,7 +157,16 @@ class _Conv:
         p, code = e.model._param, self.code
         bias = _hip.ptr(p.get(self.bname)) if self.bname else None
         flags = _hip.GEMM_RELU if self.relu else 0
-        if self.mode == 'col':
+        if self.mode == 'col' and self.G > 1:
+            G = self.G
+            Kg, Ng = self.Rw * self.cin, G * self.cout
+            Hg = _ceil_div(self.Ho, G)
+            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M // G, Ng, Kg, G * self.cin, Kg, Ng, code,
+                         bias=_hip.ptr(self.bias_g) if self.bname else None, c_rpi=gin.Ha // G, c_item=y0.Ha * self.cout,
+                         c_valid=Hg, flags=flags)
+            if Hg * G > self.Ho:          # rows of the last super-row beyond the valid output
+                y0.t.view(-1, y0.Ha, self.cout)[:, self.Ho:Hg * G, :] = 0
+        elif self.mode == 'col':
             _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M, self.cout, self.K, self.cin, self.K, self.cout, code,
                          bias=bias, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
         else:
@@ -139,7 +182,31 @@ class _Conv:
         g, code = e.model._grad, self.code
         if self.bname and self.bname in g:
             e._colsum_to_grad(dy0.ptr(), g[self.bname], dy0.rows, self.cout, code)
-        if self.mode == 'col':
+        if self.mode == 'col' and self.G > 1:
+            G = self.G
+            Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.M // G
+            chunk = e._chunk(Mg, self.nsplit)
+            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(e.slabs), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
+                         m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32)
+            # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
+            S = e.slabs[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
+            gw = g[self.wname].view(self.cout, self.cin, self.kh)
+            acc = S[0:self.kh, :, 0, :]
+            for dh in range(1, G):
+                acc = acc + S[dh:dh + self.kh, :, dh, :]
+            gw.copy_(acc.permute(2, 1, 0))
+            if din is not None and self.need_dgrad:
+                dst = din
+                if accumulate:
+                    if getattr(self, "_din_tmp", None) is None:
+                        self._din_tmp = din.like(e.device, e.dt)
+                    dst = self._din_tmp
+                Kd = self.Rd * self.cout
+                _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
+                             Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
+                if accumulate:
+                    din.t.add_(dst.t)
+        elif self.mode == 'col':
             chunk = e._chunk(self.M, self.nsplit)
             _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(e.slabs), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
                          nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32)
@@ -241,7 +308,9 @@ class _Block:
                             in_f32=in_f32, need_dgrad=not first, relu=not has_bn)
         ya = self.conv_a.y0
         if has_bn:
-            self.a_a = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt, top=top2, guard_rows=cfg['kernel_size_2'][0] + 16)
+            k2 = tuple(cfg['kernel_size_2'])
+            G2 = _col_group(cfg['out_channels'], k2[1], (cfg['stride_2'],) * 2, cfg['padding_2'])
+            self.a_a = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt, top=top2, tail=(-(top2 + ya.H)) % G2, guard_rows=k2[0] + 16)
             self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya, self.a_a)
         else:
             if top2:

@@ -163,6 +163,30 @@ def test_gemm_tn(dt, flags, M, I, J):
     assert rel_err(outT, ref) < tol(dt)
 
 
+@pytest.mark.parametrize("M,I,J,nsplit,ldb_pad", [(5003, 24, 32, 7, 0), (777, 8, 64, 3, 8), (64, 32, 32, 1, 0), (3000, 20, 16, 5, 0)])
+def test_gemm_tn_skinny_f32(M, I, J, nsplit, ldb_pad):
+    """The f32 path for tiny outputs over many rows (first-layer weight gradients of the scalogram encoder) agrees with the
+    generic kernel; A rows may be padded (lda > I), B rows may use item addressing."""
+    g = torch.Generator().manual_seed(M)
+    lda = (I + 3) // 4 * 4 + 4
+    A = torch.randn(M, lda, generator=g)
+    rpi = 11
+    items = -(-M // rpi)
+    Bfull = torch.randn(items, rpi + 2, J + ldb_pad, generator=g)       # item stride (rpi + 2) rows, row stride J + pad
+    Bm = Bfull[:, :rpi, :J].reshape(-1, J)[:M]
+    ref = A[:, :I].double().T @ Bm.double()
+    dA, dB = dev(A), dev(Bfull)
+    chunk = ((M + nsplit - 1) // nsplit + 31) // 32 * 32
+    outs = []
+    for extra in (0, _hip.GEMM_FORCE_GENERIC):
+        slabs = torch.full((nsplit, I, J), float("nan"), device=DEV)
+        _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(slabs), M, I, J, lda, J + ldb_pad, J, _hip.F32, b_rpi=rpi,
+                     b_item=(rpi + 2) * (J + ldb_pad), nsplit=nsplit, m_chunk=chunk if nsplit > 1 else 0, slab_stride=I * J,
+                     flags=_hip.GEMM_OUT_F32 | extra)
+        assert rel_err(slabs.sum(0), ref) < 3e-5
+        outs.append(slabs)
+
+
 @pytest.mark.parametrize("M,I,J,nsplit", [(4096, 264, 256, 2), (2050, 512, 520, 1), (8192, 4096, 512, 4)])
 def test_gemm_tn_tile_variants_agree(M, I, J, nsplit):
     g = torch.Generator().manual_seed(M + I)
