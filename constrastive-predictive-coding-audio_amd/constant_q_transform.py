@@ -92,6 +92,9 @@ class CQT(nn.Module):
             part = cqt_filters[rng, off:total - off] if off > 0 else cqt_filters[rng, :]
             w = torch.cat([torch.from_numpy(np.real(part).copy()), torch.from_numpy(np.imag(part).copy())], dim=0).float()
             self.conv_modules.append(_FilterBank(w.unsqueeze(1), hop_length))
+        # "fp32": exact-f32 MFMA GEMMs;  "bf16x3": waveform and filters split into bf16 (hi, lo) pairs, three bf16 products per
+        # tap accumulated in f32 (error ~2^-16 relative per product) at several times the rate
+        self.precision = "fp32"
         self._trainable = False
         if trainable:
             raise NotImplementedError("trainable CQT filters are not part of the HIP path (every reference config freezes them)")
@@ -106,7 +109,7 @@ class CQT(nn.Module):
 
     # ------------------------------------------------------------------ device operands
     def _prepare(self, device):
-        key = (str(device),) + tuple((m.weight.data_ptr(), m.weight._version) for m in self.conv_modules)
+        key = (str(device), self.precision) + tuple((m.weight.data_ptr(), m.weight._version) for m in self.conv_modules)
         if self._operands is not None and self._operands[0] == key:
             return self._operands[1]
         ops = []
@@ -117,6 +120,13 @@ class CQT(nn.Module):
             inter = torch.zeros(npad, w.shape[1], device=device, dtype=torch.float32)
             inter[0:2 * n:2] = w[:n]
             inter[1:2 * n:2] = w[n:]
+            if self.precision == "bf16x3":
+                npad = (2 * n + 7) // 8 * 8
+                full = torch.zeros(npad, w.shape[1], device=device, dtype=torch.float32)
+                full[:inter.shape[0]] = inter
+                wh = full.to(torch.bfloat16)
+                wl = (full - wh.float()).to(torch.bfloat16)
+                inter = torch.stack([wh, wh, wl], dim=-1).reshape(npad, 3 * w.shape[1])
             ops.append((inter.contiguous(), npad, rng.start))
         self._operands = (key, ops)
         return ops
@@ -129,14 +139,24 @@ class CQT(nn.Module):
             raise RuntimeError("the CQT runs on the GPU only (no CPU fallback)")
         x = x.detach().float().contiguous()
         B, L = x.shape
-        if L % 4:
-            x = torch.nn.functional.pad(x, (0, 4 - L % 4))
+        if L % 8:
+            x = torch.nn.functional.pad(x, (0, 8 - L % 8))
         Tn = self.frames(L)
         if Tn < 1:
             raise ValueError(f"clip of {L} samples is shorter than the longest CQT filter ({self.conv_kernel_sizes[0]})")
         ldq = 2 * self.n_bins + 8
         cq = torch.empty(B, Tn, ldq, device=x.device, dtype=torch.float32)
         k0, hop = self.conv_kernel_sizes[0], self.hop_length
+        if self.precision == "bf16x3":
+            x3 = torch.empty(B, 3 * x.shape[1], device=x.device, dtype=torch.bfloat16)
+            _hip.call("cpc_split3_bf16", _hip.ptr(x), _hip.ptr(x3), x.numel())
+            for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
+                offset = (k0 - size) // 2
+                _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, 3 * size, 3 * hop,
+                             3 * size, ldq, _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], flags=_hip.GEMM_OUT_F32)
+            return cq, Tn, ldq
+        if self.precision != "fp32":
+            raise ValueError("CQT.precision must be 'fp32' or 'bf16x3'")
         for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
             offset = (k0 - size) // 2
             _hip.gemm_nt(_hip.ptr(x, offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, size, hop, size, ldq, _hip.F32,

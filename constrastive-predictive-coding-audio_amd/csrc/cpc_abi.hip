@@ -277,6 +277,11 @@ int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream) 
     return launch_relu_mask(g, y, n, dtype, (hipStream_t)stream);
 }
 
+int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream) {
+    if (!src || !dst) return CPC_EINVAL;
+    return launch_split3_bf16(src, dst, n, (hipStream_t)stream);
+}
+
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);

@@ -124,3 +124,4 @@ int launch_residual_add(const void* a, const int* ga, const void* r, const int* 
 int launch_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
                             int ow, int relu, int r_f32, int dtype, hipStream_t stream);
 int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);
+int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);

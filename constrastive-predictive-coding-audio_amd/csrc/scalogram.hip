@@ -379,6 +379,19 @@ __global__ __launch_bounds__(256) void residual_add_bwd_kernel(const T* __restri
     }
 }
 
+// dst[3 i .. 3 i + 2] = (hi, lo, hi) with hi = bf16(x_i), lo = bf16(x_i - hi): against weights laid out (wh, wh, wl) a bf16
+// MFMA GEMM then accumulates xh wh + xl wh + xh wl = x w up to the dropped lo*lo term (~2^-16 relative) in f32.
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = src[i];
+        const bf16_t hi = (bf16_t)x;
+        const bf16_t lo = (bf16_t)(x - (float)hi);
+        dst[3 * i] = hi;
+        dst[3 * i + 1] = lo;
+        dst[3 * i + 2] = hi;
+    }
+}
+
 // g[i] = y[i] > 0 ? g[i] : 0 over flat buffers (ReLU backward where no fused epilogue applies)
 template <typename T>
 __global__ __launch_bounds__(256) void relu_mask_kernel(T* __restrict__ g, const T* __restrict__ y, long long n4) {
@@ -594,6 +607,13 @@ int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t
     DISPATCH2(dtype,
               hipLaunchKernelGGL((relu_mask_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (bf16_t*)g, (const bf16_t*)y, n / 4),
               hipLaunchKernelGGL((relu_mask_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)g, (const float*)y, n / 4));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t st) {
+    if (n <= 0) return CPC_EINVAL;
+    hipLaunchKernelGGL(split3_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, st, src, (bf16_t*)dst, n);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

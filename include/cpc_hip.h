@@ -217,6 +217,11 @@ int cpc_residual_add(const void* a, const int* ga, const void* r, const int* gr,
 int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
                          int ow, int relu, int r_f32, int dtype, void* stream);
 
+/* dst bf16 [3n]: (hi, lo, hi) per f32 sample, hi = bf16(x), lo = bf16(x - hi).  With filter rows laid out (wh, wh, wl) the CQT
+ * filter bank runs as bf16 MFMA GEMMs with f32-grade accuracy (xh wh + xl wh + xh wl; the dropped lo*lo term is ~2^-16
+ * relative) — the "bf16x3" precision of constant_q_transform.CQT. */
+int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream);
+
 /* g[i] = y[i] > 0 ? g[i] : 0 for i < n (n % 4 == 0): ReLU backward on whole buffers where no fused epilogue applies. */
 int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream);
 

@@ -68,6 +68,13 @@ def test_cqt_full_size_against_oracle():
     oref = O.preprocessing_forward(ref, O.phase_difference_constants(16000, 30, 256, 32, 128))
     bad = (out - oref).abs() > 2e-3 * oref.abs().max()
     assert bad.float().mean().item() < 2e-3
+    # split-bf16 filter bank: three bf16 MFMA products per tap, f32 accumulation
+    pre.cqt.precision = "bf16x3"
+    got3 = pre.cqt(x.to(DEV))
+    assert _rel(got3, ref) < 5e-5
+    out3 = pre(x.to(DEV)).cpu()
+    bad = (out3 - oref).abs() > 2e-3 * oref.abs().max()
+    assert bad.float().mean().item() < 2e-3
 
 
 # ------------------------------------------------------------------------------------------------ grid kernels

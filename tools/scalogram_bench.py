@@ -41,11 +41,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--context", default="gru")
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--cqt", default="bf16x3", choices=["fp32", "bf16x3"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, V, K = args.batch, 60, 16
     torch.manual_seed(0)
     pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True).to(dev)
+    pre.cqt.precision = args.cqt
     enc = ScalogramResidualEncoder(args_dict=copy.deepcopy(architecture_7()), preprocessing_module=pre)
     if args.context == "gru":
         ar = AudioGRUModel(512, 256)
