@@ -69,16 +69,15 @@ __device__ __forceinline__ long long grid_off(const Grid& g, int b, int w, int h
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void im2col2d_kernel(const TI* __restrict__ in, T* __restrict__ col, Grid g, int kh, int kw,
                                                        int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp) {
-    const long long rows = (long long)g.B * Wo * Ho;
-    const long long total = rows * Kp;
+    const unsigned total = (unsigned)((long long)g.B * Wo * Ho * Kp);
     const int K = kh * kw * g.C;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int k = (int)(idx % Kp);
-        const long long row = idx / Kp;
+        const unsigned row = idx / Kp;
         float v = 0.f;
         if (k < K) {
             const int c = k % g.C, tap = k / g.C, dw = tap % kw, dh = tap / kw;
-            const int ho = (int)(row % Ho), wo = (int)((row / Ho) % Wo), b = (int)(row / ((long long)Ho * Wo));
+            const int ho = (int)(row % Ho), wo = (int)((row / Ho) % Wo), b = (int)(row / (unsigned)(Ho * Wo));
             const int h = ho * sh + dh - ph, w = wo * sw + dw - pw;
             if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = to_f32(in[grid_off(g, b, w, h) + c]);
         }
@@ -90,12 +89,12 @@ __global__ __launch_bounds__(256) void im2col2d_kernel(const TI* __restrict__ in
 template <typename T>
 __global__ __launch_bounds__(256) void col2im2d_kernel(const T* __restrict__ dcol, T* __restrict__ din, Grid g, int kh, int kw,
                                                        int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp, int accumulate) {
-    const long long total = (long long)g.B * g.W * g.H * g.C;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)g.B * g.W * g.H * g.C);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c = (int)(idx % g.C);
         const int h = (int)((idx / g.C) % g.H);
-        const int w = (int)((idx / ((long long)g.C * g.H)) % g.W);
-        const int b = (int)(idx / ((long long)g.C * g.H * g.W));
+        const int w = (int)((idx / (unsigned)(g.C * g.H)) % g.W);
+        const int b = (int)(idx / (unsigned)(g.C * g.H * g.W));
         float acc = 0.f;
         for (int dh = 0; dh < kh; ++dh) {
             const int hn = h + ph - dh;
@@ -179,11 +178,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu) {
     const int c4n = gx.C / 4;
-    const long long total = (long long)gx.B * gx.W * gx.H * c4n;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c4n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c4 = (int)(idx % c4n);
         const int h = (int)((idx / c4n) % gx.H);
-        const long long col = idx / ((long long)c4n * gx.H);
+        const unsigned col = idx / (unsigned)(c4n * gx.H);
         const int w = (int)(col % gx.W), b = (int)(col / gx.W);
         const f32x4 v = load4(x + grid_off(gx, b, w, h) + c4 * 4);
         const f32x4 mu = *(const f32x4*)(stats + c4 * 4), rs = *(const f32x4*)(stats + gx.C + c4 * 4);
@@ -210,9 +209,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (rp < nrp) {
         const f32x4 mu = *(const f32x4*)(stats + cg * 4), rs = *(const f32x4*)(stats + C + cg * 4);
-        for (long long r = q0 * gx.H + rp; r < q1 * gx.H; r += nrp) {
-            const long long q = r / gx.H;
-            const int h = (int)(r % gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
+        for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < (unsigned)(q1 * gx.H); r += nrp) {
+            const unsigned q = r / (unsigned)gx.H;
+            const int h = (int)(r - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
             const long long oy = grid_off(gy, b, w, h) + cg * 4;
             f32x4 g = load4(dy + oy);
             if (relu) {
@@ -252,11 +251,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            float inv_count, int relu, int train) {
     const int C = gx.C, c4n = C / 4;
-    const long long total = (long long)gx.B * gx.W * gx.H * c4n;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c4n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c4 = (int)(idx % c4n);
         const int h = (int)((idx / c4n) % gx.H);
-        const long long col = idx / ((long long)c4n * gx.H);
+        const unsigned col = idx / (unsigned)(c4n * gx.H);
         const int w = (int)(col % gx.W), b = (int)(col / gx.W);
         const long long oy = grid_off(gy, b, w, h) + c4 * 4, ox = grid_off(gx, b, w, h) + c4 * 4;
         f32x4 g = load4(dy + oy);
@@ -285,12 +284,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // MaxPool2d(kernel = stride = p, ceil_mode=True, no padding) on grids (residual branches, scalogram_model.py:434-436).
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TI* __restrict__ in, Grid gi, T* __restrict__ out, Grid go, int p) {
-    const long long total = (long long)go.B * go.W * go.H * go.C;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * go.C);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c = (int)(idx % go.C);
         const int ho = (int)((idx / go.C) % go.H);
-        const int wo = (int)((idx / ((long long)go.C * go.H)) % go.W);
-        const int b = (int)(idx / ((long long)go.C * go.H * go.W));
+        const int wo = (int)((idx / (unsigned)(go.C * go.H)) % go.W);
+        const int b = (int)(idx / (unsigned)(go.C * go.H * go.W));
         float m = -INFINITY;
         for (int dh = 0; dh < p; ++dh)
             for (int dw = 0; dw < p; ++dw) {
@@ -305,12 +304,12 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TI* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const T* __restrict__ in, T* __restrict__ din, Grid gi,
                                                             const T* __restrict__ dout, Grid go, int p, int accumulate) {
-    const long long total = (long long)go.B * go.W * go.H * go.C;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * go.C);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c = (int)(idx % go.C);
         const int ho = (int)((idx / go.C) % go.H);
-        const int wo = (int)((idx / ((long long)go.C * go.H)) % go.W);
-        const int b = (int)(idx / ((long long)go.C * go.H * go.W));
+        const int wo = (int)((idx / (unsigned)(go.C * go.H)) % go.W);
+        const int b = (int)(idx / (unsigned)(go.C * go.H * go.W));
         float m = -INFINITY;
         int bh = -1, bw = -1;
         for (int dh = 0; dh < p; ++dh)
@@ -340,11 +339,11 @@ template <typename TR, typename T>
 __global__ __launch_bounds__(256) void residual_add_kernel(const T* __restrict__ a, Grid ga, const TR* __restrict__ r, Grid gr,
                                                            T* __restrict__ out, Grid go, int oh, int ow, int relu) {
     const int c4n = go.C / 4;
-    const long long total = (long long)go.B * go.W * go.H * c4n;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c4n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c4 = (int)(idx % c4n);
         const int h = (int)((idx / c4n) % go.H);
-        const long long col = idx / ((long long)c4n * go.H);
+        const unsigned col = idx / (unsigned)(c4n * go.H);
         const int w = (int)(col % go.W), b = (int)(col / go.W);
         f32x4 v = load4(a + grid_off(ga, b, w, h) + c4 * 4) + load4(r + grid_off(gr, b, w + ow, h + oh) + c4 * 4);
         if (relu) {
@@ -361,11 +360,11 @@ __global__ __launch_bounds__(256) void residual_add_bwd_kernel(const T* __restri
                                                                T* __restrict__ da, Grid ga, TR* __restrict__ dr, Grid gr, int oh,
                                                                int ow, int relu) {
     const int c4n = go.C / 4;
-    const long long total = (long long)go.B * go.W * go.H * c4n;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c4n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c4 = (int)(idx % c4n);
         const int h = (int)((idx / c4n) % go.H);
-        const long long col = idx / ((long long)c4n * go.H);
+        const unsigned col = idx / (unsigned)(c4n * go.H);
         const int w = (int)(col % go.W), b = (int)(col / go.W);
         const long long oo = grid_off(go, b, w, h) + c4 * 4;
         f32x4 g = load4(dout + oo);
@@ -421,8 +420,9 @@ int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const flo
     return CPC_OK;
 }
 
-static bool grid_ok(const int* g) {      // {B, W, H, Ha, top, C}
-    return g && g[0] > 0 && g[1] > 0 && g[2] > 0 && g[4] >= 0 && g[3] >= g[4] + g[2] && g[5] > 0;
+static bool grid_ok(const int* g) {      // {B, W, H, Ha, top, C};  the kernels index elements with 32 bits
+    return g && g[0] > 0 && g[1] > 0 && g[2] > 0 && g[4] >= 0 && g[3] >= g[4] + g[2] && g[5] > 0 &&
+           (long long)g[0] * g[1] * g[2] * g[5] < (1ll << 31);
 }
 static Grid mk(const int* g) { return Grid{g[0], g[1], g[2], g[3], g[4], g[5]}; }
 static int blocks_for(long long total) { return (int)std::min<long long>(8192, (total + 255) / 256); }
@@ -437,7 +437,7 @@ static int blocks_for(long long total) { return (int)std::min<long long>(8192, (
 int launch_im2col2d(const void* in, void* col, const int* g, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
                     int in_f32, int dtype, hipStream_t st) {
     if (!grid_ok(g) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || Ho <= 0 || Wo <= 0) return CPC_EINVAL;
-    if (Kp < kh * kw * g[5]) return CPC_EINVAL;
+    if (Kp < kh * kw * g[5] || (long long)g[0] * Wo * Ho * Kp >= (1ll << 31)) return CPC_EINVAL;
     if ((Ho - 1) * sh + kh - ph > g[2] + ph || (Wo - 1) * sw + kw - pw > g[1] + pw) return CPC_EINVAL;   // windows inside the padded input
     const Grid gg = mk(g);
     const int nb = blocks_for((long long)g[0] * Wo * Ho * Kp);
