@@ -17,7 +17,7 @@ int cpc_abi_version(void) { return 1; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
-    GemmNT p;
+    GemmNT p = {};
     p.A = a->A; p.Bt = a->Bt; p.C = a->C; p.bias = a->bias; p.mask = a->mask;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;

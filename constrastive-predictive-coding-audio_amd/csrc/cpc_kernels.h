@@ -26,6 +26,7 @@ struct GemmNT {
     int c_rpi; long long c_item; int c_valid;   // rows with (m % c_rpi) >= c_valid are written as zeros (c_rpi != 0)
     long long a_batch, b_batch, c_batch;
     int flags;
+    int m_off = 0;        // internal: first row of this launch (fast kernels; a launch may cover rows [m_off, M) only)
 };
 
 struct GemmTN {

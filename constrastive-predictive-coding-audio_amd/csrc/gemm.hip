@@ -361,11 +361,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int numM = (p.M + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
+    const int numM = (p.M - p.m_off + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
     int mt, nt;
     nt_tile_of_block(blockIdx.x, numM, numN, mt, nt);
     if (mt >= numM) return;
-    const int m0 = mt * TBM, n0 = nt * TBN;
+    const int m0 = p.m_off + mt * TBM, n0 = nt * TBN;
 
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
@@ -938,7 +938,33 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
     const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
-    const int numM = (p.M + tbm - 1) / tbm, numN = (p.N + tbn - 1) / tbn;
+    int numM = (p.M - p.m_off + tbm - 1) / tbm;
+    const int numN = (p.N + tbn - 1) / tbn;
+    if (!fast && p.m_off) return CPC_EINVAL;
+    // Tile quantisation: 256 CUs take the 256x256 tiles in rounds; a last round that is mostly empty (e.g. 1824 tiles =
+    // 7 rounds + 32 tiles) costs a full round.  Then the big tiles cover the whole rounds only and the remaining rows go to
+    // a second launch of 128x128 tiles (4x as many, a quarter of the time each) — same arithmetic per output element, so
+    // the result does not depend on where the split falls.
+    int tail_rows = 0;
+    if (big && batch == 1 && p.m_off == 0) {
+        const long long tiles = (long long)numM * numN;
+        const int rem = (int)(tiles % 256);
+        if (tiles > 256 && rem > 0 && rem <= 128) {
+            const int tail_m = (rem + numN - 1) / numN;              // M-tiles handed to the small-tile launch
+            if (tail_m < numM) {
+                tail_rows = p.M - (numM - tail_m) * tbm;
+                numM -= tail_m;
+            }
+        }
+    }
+    if (tail_rows > 0) {
+        q.M = p.M - tail_rows;
+        GemmNT t = p;
+        t.m_off = q.M;
+        t.flags |= GEMM_SMALL_TILE;
+        const int rc = launch_gemm_nt(t, dtype, batch, stream);
+        if (rc != CPC_OK) return rc;
+    }
     const long long blocks = fast ? nt_grid_blocks(numM, numN) : (long long)((numM + 7) / 8) * 8 * numN;
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
