@@ -827,7 +827,11 @@ def make_context(eng, ar):
     if isinstance(ar, AudioGRUModel):
         return GRUContext(eng, ar)
     if isinstance(ar, ConvolutionalArModel):
-        if ar.batch_norm or ar.residual or any(s != 1 for s in ar.strides):
+        # ConvArContext is the lean path for the reference's plain default (no pooling in the first block, pooling in every
+        # later one, stride 1); every other configuration runs on the grid kernels
+        lean = not (ar.batch_norm or ar.residual) and all(s == 1 for s in ar.strides) and ar.poolings[0] == 1 and \
+            all(p > 1 for p in ar.poolings[1:])
+        if not lean:
             from .scalogram_engine import ConvArGridContext
             return ConvArGridContext(eng, ar)
         return ConvArContext(eng, ar)

@@ -547,3 +547,40 @@ def test_attention_dropout_against_oracle_with_same_masks(golden_dir):
         c1 = model(x.unsqueeze(1))[3]
         c2 = model(x.unsqueeze(1))[3]
     assert torch.equal(c1, c2) and _rel(c1, g["fwd/c"]) < 2e-4
+
+
+@pytest.mark.parametrize("variant", ["plain_general", "bn_res_strided"])
+def test_conv_ar_general_configs_against_oracle(variant):
+    """ConvolutionalArModel configurations outside the reference's presets (pooling in the first block, strided
+    convolutions, residual branches with their own pooling) run on the grid kernels; loss and gradients vs the oracle (fp32)."""
+    C, H, K, V, B = 64, 48, 3, 40, 5
+    L = 465 + (V + K) * 160 + 3
+    ar_dict = {'kernel_sizes': [5, 3, 4], 'channel_count': [C, 32, 64, H], 'stride': [1, 2, 1], 'pooling': [2, 1, 2], 'bias': True,
+               'batch_norm': variant == "bn_res_strided", 'residual': variant == "bn_res_strided", 'activation_register': None,
+               'self_attention': [False] * 3}
+    torch.manual_seed(5)
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(ar_dict), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K,
+                                       compute_dtype="fp32")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("encoder.layers") and n.endswith("weight"):
+                p.mul_(2.5)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, L, generator=g) * 0.5
+    eng = model.engine(B, L)
+    assert type(eng.ctx).__name__ == "ConvArGridContext"
+    out = eng.loss_and_grads(x.to(DEV).contiguous(), softplus=True, regularization=1.0)
+    ot = O.OracleTrainer(state, V, K, score="softplus", all_timesteps=False, regularization=1.0, conv_ar=ar_dict)
+    loss, _, grads = ot.loss_and_grads(x)
+    assert abs(float(out[0]) - float(loss)) < 2e-4 * abs(float(loss))
+    for n, ref in grads.items():
+        ref = ref.double()
+        got = model._grad[n].double().cpu()
+        if ref.abs().max().item() < 1e-6:
+            assert got.abs().max().item() < 1e-4
+            continue
+        l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+        assert l2 < 2e-3, (n, l2)
