@@ -68,14 +68,16 @@ __global__ __launch_bounds__(256) void pe_scale_bwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ P, int S,
                                                        int C, int heads, float scale, Drop dr) {
-    __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], p[ATT_S][ATT_S + 1];
+    // operand tiles in the storage type (bf16: half the LDS, so three workgroups share a CU), scores in f32
+    __shared__ T q[ATT_S][ATT_D + 2], k[ATT_S][ATT_D + 2], v[ATT_S][ATT_D + 2];
+    __shared__ float p[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
     for (int idx = tid; idx < S * d; idx += 256) {
         const int t = idx / d, c = idx % d;
         const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
-        q[t][c] = to_f32(row[0]) * scale;
-        k[t][c] = to_f32(row[C]);
-        v[t][c] = to_f32(row[2 * C]);
+        q[t][c] = row[0];
+        k[t][c] = row[C];
+        v[t][c] = row[2 * C];
     }
     __syncthreads();
     for (int idx = tid; idx < S * S; idx += 256) {
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         float s = -INFINITY;
         if (j <= i) {
             s = 0.f;
-            for (int c = 0; c < d; ++c) s = fmaf(q[i][c], k[j][c], s);
+            for (int c = 0; c < d; ++c) s = fmaf(to_f32(q[i][c]), to_f32(k[j][c]), s);
+            s *= scale;
         }
         p[i][j] = s;
     }
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     for (int idx = tid; idx < S * d; idx += 256) {
         const int i = idx / d, c = idx % d;
         float o = 0.f;
-        for (int j = 0; j <= i; ++j) o = fmaf(p[i][j], v[j][c], o);
+        for (int j = 0; j <= i; ++j) o = fmaf(p[i][j], to_f32(v[j][c]), o);
         out[((long long)b * S + i) * C + h * d + c] = from_f32<T>(o);
     }
 }
@@ -116,16 +119,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ P, const T* __restrict__ dout,
                                                        T* __restrict__ dqkv, int S, int C, int heads, float scale, Drop dr) {
-    __shared__ float q[ATT_S][ATT_D + 1], k[ATT_S][ATT_D + 1], v[ATT_S][ATT_D + 1], go[ATT_S][ATT_D + 1];
+    __shared__ T q[ATT_S][ATT_D + 2], k[ATT_S][ATT_D + 2], v[ATT_S][ATT_D + 2], go[ATT_S][ATT_D + 2];
     __shared__ float p[ATT_S][ATT_S + 1], ds[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
     for (int idx = tid; idx < S * d; idx += 256) {
         const int t = idx / d, c = idx % d;
         const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
-        q[t][c] = to_f32(row[0]);
-        k[t][c] = to_f32(row[C]);
-        v[t][c] = to_f32(row[2 * C]);
-        go[t][c] = to_f32(dout[((long long)b * S + t) * C + h * d + c]);
+        q[t][c] = row[0];
+        k[t][c] = row[C];
+        v[t][c] = row[2 * C];
+        go[t][c] = dout[((long long)b * S + t) * C + h * d + c];
     }
     for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] = to_f32(P[(long long)bh * S * S + idx]);
     __syncthreads();
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         const int i = idx / S, j = idx % S;
         float s = 0.f;
         if (j <= i)
-            for (int c = 0; c < d; ++c) s = fmaf(go[i][c], v[j][c], s);
+            for (int c = 0; c < d; ++c) s = fmaf(to_f32(go[i][c]), to_f32(v[j][c]), s);
         ds[i][j] = s * drop_factor(dr, (unsigned long long)bh * S * S + idx);
     }
     __syncthreads();
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     for (int idx = tid; idx < S * d; idx += 256) {
         const int t = idx / d, c = idx % d;
         float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int j = 0; j <= t; ++j) dq = fmaf(ds[t][j], k[j][c], dq);
+        for (int j = 0; j <= t; ++j) dq = fmaf(ds[t][j], to_f32(k[j][c]), dq);
         for (int i = t; i < S; ++i) {
-            dk = fmaf(ds[i][t], q[i][c], dk);
-            dv = fmaf(p[i][t] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + t), go[i][c], dv);
+            dk = fmaf(ds[i][t], to_f32(q[i][c]), dk);
+            dv = fmaf(p[i][t] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + t), to_f32(go[i][c]), dv);
         }
         T* row = dqkv + ((long long)b * S + t) * 3 * C + h * d + c;
         row[0] = from_f32<T>(dq);
