@@ -584,3 +584,26 @@ def test_conv_ar_general_configs_against_oracle(variant):
             continue
         l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
         assert l2 < 2e-3, (n, l2)
+
+
+def test_full_size_attention_context_bf16_vs_fp32():
+    """BASELINE configs[3] (attention_architecture_1 behind the 512-channel AudioEncoder, 60 visible / 12 prediction steps,
+    batch 32, dropout off): bf16 vs exact-f32 — loss within 1e-3 relative, every gradient direction preserved."""
+    from cpc_audio_amd import configs
+    B, V, K, L = 32, 60, 12, 20480
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, L, generator=g).to(DEV)
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        ar = AttentionModel(dict(configs.fresh(configs.attention_architecture_1), dropout=0.0))
+        model = AudioPredictiveCodingModel(AudioEncoder(), ar, enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
+                                           compute_dtype=dtype).to(DEV)
+        out = model.engine(B, L).loss_and_grads(x, softplus=True, regularization=1.0)
+        res[dtype] = (float(out[0]), model)
+    assert abs(res["bf16"][0] - res["fp32"][0]) <= 1e-3 * abs(res["fp32"][0])
+    for n in res["fp32"][1]._grad:
+        a, b = res["fp32"][1]._grad[n].double().flatten(), res["bf16"][1]._grad[n].double().flatten()
+        if a.norm() > 0:
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+            assert cos > 0.97, (n, cos)

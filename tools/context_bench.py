@@ -19,10 +19,9 @@ from cpc_audio_amd.engine import FusedAdam  # noqa: E402
 
 
 def contexts():
-    conv = {'kernel_sizes': [9, 9, 9], 'channel_count': [512, 256, 256, 256], 'stride': [1, 1, 1], 'pooling': [1, 2, 2], 'bias': True,
-            'batch_norm': False, 'residual': False, 'activation_register': None, 'self_attention': [False] * 3}
-    att = {'channels': 512, 'num_layers': 3, 'num_heads': 8, 'feedforward_size': 512, 'dropout': 0.0, 'sequence_length': 60,
-           'output_size': 256}
+    from cpc_audio_amd import configs
+    conv = dict(configs.fresh(configs.ar_conv_default_dict), channel_count=[512, 256, 256, 256])      # enc_size 512 in front
+    att = dict(configs.fresh(configs.attention_architecture_1), dropout=0.0)
     return {"gru_v100": (lambda: AudioGRUModel(512, 256), 100), "gru_v60": (lambda: AudioGRUModel(512, 256), 60),
             "conv_ar_default": (lambda: ConvolutionalArModel(conv), 60), "attention_architecture_1": (lambda: AttentionModel(att), 60)}
 

@@ -18,20 +18,8 @@ sys.path.insert(0, ROOT)
 from cpc_audio_amd import _hip  # noqa: E402
 from cpc_audio_amd.audio_model import AudioGRUModel, AudioPredictiveCodingModel, ConvolutionalArModel  # noqa: E402
 from cpc_audio_amd.engine import FusedAdam  # noqa: E402
+from cpc_audio_amd import configs  # noqa: E402
 from cpc_audio_amd.scalogram_model import PreprocessingModule, ScalogramResidualEncoder, cqt_default_dict  # noqa: E402
-
-
-def architecture_7():
-    """scalogram_resnet_architecture_7 as it is after the reference's config module has been imported."""
-    base = {'in_channels': 64, 'hidden_channels': None, 'out_channels': 64, 'kernel_size_1': (3, 3), 'kernel_size_2': (3, 3),
-            'top_padding_1': None, 'top_padding_2': None, 'padding_1': 0, 'padding_2': 0, 'stride_1': 1, 'stride_2': 1,
-            'pooling_1': 1, 'pooling_2': 1, 'bias': True, 'separable': False, 'residual': True, 'batch_norm': False,
-            'ceil_pooling': False}
-    b0 = dict(base, in_channels=1, out_channels=32, stride_1=2, kernel_size_2=(64, 1), top_padding_2=63, batch_norm=True)
-    b1 = dict(base, in_channels=32, out_channels=128, stride_1=2, kernel_size_2=(30, 1), batch_norm=True)
-    b2 = dict(base, in_channels=128, out_channels=256, stride_1=2, kernel_size_2=(15, 1), batch_norm=True)
-    b3 = dict(base, in_channels=256, out_channels=512, kernel_size_1=(2, 2), kernel_size_2=(1, 1), batch_norm=False)
-    return {'phase': True, 'blocks': [b0, b1, b2, b3], 'activation_register': None}
 
 
 def main():
@@ -48,13 +36,11 @@ def main():
     torch.manual_seed(0)
     pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True).to(dev)
     pre.cqt.precision = args.cqt
-    enc = ScalogramResidualEncoder(args_dict=copy.deepcopy(architecture_7()), preprocessing_module=pre)
+    enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
     if args.context == "gru":
         ar = AudioGRUModel(512, 256)
     else:
-        ar = ConvolutionalArModel({'kernel_sizes': [5] * 6, 'channel_count': [512, 512, 512, 256, 256, 256, 256], 'stride': [1] * 6,
-                                   'pooling': [1, 1, 2, 1, 2, 1], 'bias': True, 'batch_norm': True, 'residual': True,
-                                   'activation_register': None, 'self_attention': [False] * 6})
+        ar = ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3))
     model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
                                        compute_dtype=args.dtype).to(dev)
     L = model.item_length
