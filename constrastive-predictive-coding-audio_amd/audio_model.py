@@ -336,7 +336,7 @@ def _standalone_owner(encoder):
     """A stand-alone AudioEncoder call needs an engine; it is hosted by a private model wrapper cached on the encoder."""
     owner = getattr(encoder, "_owner", None)
     if owner is None:
-        c = encoder.channel_count[-1]
+        c = encoder.channel_count[-1] if hasattr(encoder, "channel_count") else encoder.blocks[-1].cfg['out_channels']
         gru = AudioGRUModel(c, 32)
         object.__setattr__(encoder, "_owner", None)
         owner = AudioPredictiveCodingModel.__new__(AudioPredictiveCodingModel)
@@ -348,7 +348,7 @@ def _standalone_owner(encoder):
         owner.prediction_model = _LinearParams(32, c)
         owner.compute_dtype = getattr(encoder, "compute_dtype", torch.float32)
         owner._engines, owner._flat_param, owner._flat_grad, owner._param, owner._grad = {}, None, None, {}, {}
-        owner._scalogram = False
+        owner._scalogram = not isinstance(encoder, AudioEncoder)
         object.__setattr__(encoder, "_owner", owner)
     dev = next(encoder.parameters()).device
     if next(owner.autoregressive_model.parameters()).device != dev:

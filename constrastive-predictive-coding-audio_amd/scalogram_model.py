@@ -174,4 +174,10 @@ class ScalogramResidualEncoder(nn.Module):
             self.downsampling_factor *= block_dict['pooling_2'] * block_dict['stride_2']
 
     def forward(self, x):
-        raise NotImplementedError("ScalogramResidualEncoder runs inside AudioPredictiveCodingModel.forward on the HIP path")
+        """x (B, C, bins, frames) on the GPU -> (B, E, frames') float32 (the reference's x[:, :, 0, :]).  Inference only when
+        called stand-alone (BatchNorm follows self.training); gradients flow when the encoder is used through
+        AudioPredictiveCodingModel."""
+        from .audio_model import _standalone_owner
+        if x.dim() == 3:
+            x = x.unsqueeze(2)
+        return _standalone_owner(self).encode(x)

@@ -365,3 +365,17 @@ def test_full_size_scalogram_model_bf16_vs_fp32():
     # measured: 0.956 (first BatchNorm scale) ... 0.97 for the first two blocks' BatchNorm parameters and first-layer weights,
     # > 0.98 elsewhere, at random initialisation where the gradient signal itself is small
     assert worst[1] > 0.93, worst
+
+
+def test_scalogram_encoder_standalone_forward(golden_dir):
+    """ScalogramResidualEncoder called on its own (inference): equals the z / targets the full model produces."""
+    g = _load(golden_dir, "scalogram_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+    pre, model = _build_scalogram_model(g, meta, "fp32")
+    scal = torch.from_numpy(g["scalogram"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        enc_out = model.encoder(scal)
+    V, K = meta["V"], meta["K"]
+    assert tuple(enc_out.shape) == (meta["B"], meta["E"], V + K)
+    assert _rel(enc_out[:, :, :V], g["eval/z"]) < 3e-4 and _rel(enc_out[:, :, V:], g["eval/targets"]) < 3e-4
