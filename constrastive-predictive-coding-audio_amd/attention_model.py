@@ -84,4 +84,7 @@ class AttentionModel(nn.Module):
         self.end_layer = nn.Linear(self.channels, self.output_size)
 
     def forward(self, x):
-        raise NotImplementedError("AttentionModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        """(batch, channels, steps) on the GPU -> (batch, output_size).  Inference only when called stand-alone; unlike the
+        reference this does not rescale the caller's tensor in place (attention_model.py:30)."""
+        from .engine import standalone_context_forward
+        return standalone_context_forward(self, x, self.output_size)

@@ -104,7 +104,10 @@ class AudioGRUModel(nn.Module):
         self.reset_hidden = reset_hidden
 
     def forward(self, input):
-        raise NotImplementedError("AudioGRUModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        """(batch, input_size, steps) on the GPU -> last hidden state (batch, hidden_size).  Inference only when called
+        stand-alone; gradients flow when the network is used through AudioPredictiveCodingModel."""
+        from .engine import standalone_context_forward
+        return standalone_context_forward(self, input, self.hidden_size)
 
 
 class ConvolutionalArBlock(nn.Module):
@@ -159,7 +162,10 @@ class ConvolutionalArModel(nn.Module):
         self.ar_size = self.channel_count[-1]
 
     def forward(self, x):
-        raise NotImplementedError("ConvolutionalArModel runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        """(batch, channels, steps) on the GPU -> the last position (batch, ar_size).  Inference only when called
+        stand-alone (BatchNorm follows self.training); gradients flow through AudioPredictiveCodingModel."""
+        from .engine import standalone_context_forward
+        return standalone_context_forward(self, x, self.ar_size)
 
 
 class AudioPredictiveCodingModel(nn.Module):

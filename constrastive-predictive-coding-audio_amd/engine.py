@@ -841,6 +841,75 @@ def make_context(eng, ar):
     raise NotImplementedError(f"no HIP context network for {type(ar).__name__}")
 
 
+class ContextOnlyEngine(CPCEngine):
+    """A context network called on its own (``AudioGRUModel(...)(z)`` etc.): z (B, E, V) -> c (B, H), inference only.
+    Reuses the context classes unchanged by presenting z as the encoder's top buffer."""
+
+    def __init__(self, owner, batch_size, enc_size, steps, device, dtype: torch.dtype):
+        from types import SimpleNamespace
+        self.model = owner
+        self.device = torch.device(device)
+        self.dt = dtype
+        self.code = _hip.dtype_code(dtype)
+        self.B, self.E, self.V, self.K = int(batch_size), int(enc_size), int(steps), 0
+        self.H = int(owner.ar_size)
+        self.T, self.L, self.x_off, self.n = self.V, self.V, 0, 0
+        self.colsum_blocks = 1024
+        owner._flatten_parameters(self.device)
+        self.geo = SimpleNamespace(alloc=[self.V], valid=[self.V])
+        self._keep = []
+        self.act, self.dact = [], []
+        for store in (self.act, self.dact):
+            full, view, _ = self._buf(self.B * self.V, self.E)
+            self._keep.append(full)
+            store.append(view)
+        self.ctx = make_context(self, owner.autoregressive_model)
+        self._alloc_head([1])
+
+    def prepare_weights(self):
+        self.ctx.prepare_weights()
+
+    def run(self, z):
+        if not z.is_cuda:
+            raise RuntimeError("the context networks run on the GPU only (no CPU fallback)")
+        if tuple(z.shape) != (self.B, self.E, self.V):
+            raise ValueError(f"expected input of shape ({self.B}, {self.E}, {self.V}) = (batch, channels, steps), got {tuple(z.shape)}")
+        self.act[-1].view(self.B, self.V, self.E).copy_(z.detach().transpose(1, 2))
+        self.prepare_weights()
+        self.ctx.forward()
+        return self.ctx.c_float().clone()
+
+
+def standalone_context_forward(ar, z, ar_size):
+    """Host side of ``<context network>.forward(z)`` outside an AudioPredictiveCodingModel."""
+    from .audio_model import AudioPredictiveCodingModel, _LinearParams
+    import torch.nn as nn
+    owner = getattr(ar, "_owner", None)
+    if owner is None:
+        object.__setattr__(ar, "_owner", None)
+        owner = AudioPredictiveCodingModel.__new__(AudioPredictiveCodingModel)
+        nn.Module.__init__(owner)
+        owner.enc_size, owner.ar_size = int(z.shape[1]), int(ar_size)
+        owner.visible_steps, owner.prediction_steps = int(z.shape[2]), 0
+        owner.encoder = None
+        owner.autoregressive_model = ar
+        owner.prediction_model = _LinearParams(int(ar_size), 8)
+        owner.compute_dtype = getattr(ar, "compute_dtype", torch.float32)
+        owner._engines, owner._flat_param, owner._flat_grad, owner._param, owner._grad = {}, None, None, {}, {}
+        owner._scalogram = False
+        object.__setattr__(ar, "_owner", owner)
+    dev = z.device
+    if next(owner.prediction_model.parameters()).device != dev:
+        owner.prediction_model.to(dev)
+    key = ("ctx", tuple(z.shape), owner.compute_dtype, str(dev))
+    eng = owner._engines.get(key)
+    if eng is None or owner._flat_param is None or any(p.data_ptr() != owner._param[n].data_ptr() for n, p in owner.named_parameters()):
+        owner._flatten_parameters(dev)
+        eng = ContextOnlyEngine(owner, z.shape[0], z.shape[1], z.shape[2], dev, owner.compute_dtype)
+        owner._engines = {key: eng}
+    return eng.run(z.float())
+
+
 class GradAllReduce:
     """Data-parallel gradient exchange: ONE sum over ranks of the model's flat f32 gradient buffer per step (RCCL over
     xGMI with backend "nccl"), issued in two pieces so that the larger, earlier-finished piece (encoder layers >= 3,

@@ -607,3 +607,37 @@ def test_full_size_attention_context_bf16_vs_fp32():
         if a.norm() > 0:
             cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
             assert cos > 0.97, (n, cos)
+
+
+def test_context_networks_standalone_forward(golden_dir):
+    """AudioGRUModel / ConvolutionalArModel / AttentionModel called on their own (as the reference's tests do,
+    tests/test_audioGRUModel.py, test_convArModel.py, test_attentionModel.py): equal to the oracle's context functions."""
+    # GRU: the reference-generated GRUCell sequence fixture
+    g = _load(golden_dir, "gru.npz")
+    gru = AudioGRUModel(input_size=32, hidden_size=64)
+    gru.load_state_dict({k[len("param/autoregressive_model."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")})
+    x = torch.from_numpy(g["z"])                      # (B, I, steps)
+    out = gru.to(DEV)(x.to(DEV))
+    assert tuple(out.shape) == (7, 64)
+    assert _rel(out, g["h"]) < 1e-4
+    # conv AR with batch norm + residual, attention: against the oracle on the fixture parameters
+    gb = _load(golden_dir, "conv_ar_bn.npz")
+    mb = json.load(open(os.path.join(golden_dir, "conv_ar_bn.json")))
+    info = mb["variants"]["bn_res"]
+    state = {k[len("bn_res/param/"):]: torch.from_numpy(v) for k, v in gb.items() if k.startswith("bn_res/param/")}
+    ar = ConvolutionalArModel(dict(info["ar"], activation_register=None))
+    ar.load_state_dict({k[len("autoregressive_model."):]: v for k, v in state.items() if k.startswith("autoregressive_model.")})
+    ar = ar.to(DEV).eval()
+    z = torch.randn(5, mb["C"], mb["V"], generator=torch.Generator().manual_seed(1))
+    ref = O.conv_ar_forward(z, state, info["ar"]["kernel_sizes"], info["ar"]["pooling"], strides=info["ar"]["stride"], batch_norm=True,
+                            residual=True, training=False)
+    assert _rel(ar(z.to(DEV)), ref) < 2e-4
+    ga = _load(golden_dir, "attention_model.npz")
+    ma = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    sa = {k[len("param/"):]: torch.from_numpy(v) for k, v in ga.items() if k.startswith("param/")}
+    att = AttentionModel(ma["ar"])
+    att.load_state_dict({k[len("autoregressive_model."):]: v for k, v in sa.items() if k.startswith("autoregressive_model.")})
+    att = att.to(DEV).eval()
+    z = torch.randn(4, ma["C"], ma["V"], generator=torch.Generator().manual_seed(2))
+    ref, _ = O.attention_forward(z, sa, ma["ar"]["num_layers"], ma["ar"]["num_heads"])
+    assert _rel(att(z.to(DEV)), ref) < 2e-4
