@@ -86,8 +86,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal knobs (not used by the driver): several ranks on ONE card over gloo, to exercise the multi-rank code path
+        # where only one GPU is available — CPC_BENCH_BACKEND=gloo CPC_BENCH_SHARE_DEVICE=1
+        backend = os.environ.get("CPC_BENCH_BACKEND", "nccl")
+        if os.environ.get("CPC_BENCH_SHARE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     device = torch.device("cuda", local_rank)
