@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
+    ap.add_argument("--all-timesteps", action="store_true",
+                    help="diagnostic: score_over_all_timesteps=True (the full (B*K)^2 score matrix); not the headline configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +116,7 @@ def main():
     sync = GradAllReduce(model) if world > 1 else None
 
     def step(i):
-        out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0,
+        out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
                                  grad_ready_hook=sync.hook if sync is not None else None)
         if sync is not None:
             sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer, two overlapped pieces

@@ -198,11 +198,12 @@ def _variant(dtype, flags, tile=None):
     return f"<bf16,f32{t}>" if flags & GEMM_OUT_F32 else f"<bf16,bf16{t}>"
 
 
-def nt_tile(dtype, M, N, K, flags=0):
+def nt_tile(dtype, M, N, K, flags=0, batch=1):
     """Mirror of the launcher's tile choice for gemm_nt (csrc/gemm.hip launch_gemm_nt)."""
     ch = 8 if dtype == BF16 else 4
     fast = K % (8 * ch) == 0 and not (flags & GEMM_FORCE_GENERIC)
-    return 256 if (fast and dtype == BF16 and M >= 1024 and N >= 256 and not (flags & GEMM_SMALL_TILE)) else 128
+    big_tiles = ((M + 255) // 256) * ((N + 255) // 256) * batch
+    return 256 if (fast and dtype == BF16 and M >= 1024 and N >= 256 and not (flags & GEMM_SMALL_TILE) and big_tiles >= 200) else 128
 
 
 def tn_tile(dtype, M, I, J, nsplit, m_chunk, flags=0):
@@ -219,7 +220,7 @@ def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None,
     args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
                       c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
     if _timer is not None:
-        _timer.run("gemm_nt" + _variant(dtype, flags, nt_tile(dtype, M, N, K, flags)), 2.0 * M * N * K * batch,
+        _timer.run("gemm_nt" + _variant(dtype, flags, nt_tile(dtype, M, N, K, flags, batch)), 2.0 * M * N * K * batch,
                    lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"), shape=(M, N, K, batch))
         return
     _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt")

@@ -932,7 +932,11 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.c_rpi && p.c_item % 4) return CPC_EINVAL;
     const bool of32 = p.flags & GEMM_OUT_F32;
     const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
-    const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE);
+    // 256x256 tiles only where they fill the chip: below ~200 of them (e.g. the 3072 x 3072 all-timesteps score matrix: 144)
+    // four times as many 128x128 tiles keep more CUs busy
+    const long long big_tiles = (long long)((p.M - p.m_off + 255) / 256) * ((p.N + 255) / 256);
+    const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE) &&
+                     (big_tiles >= 200 || big_tiles * batch >= 200);
     GemmNT q = p;
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))

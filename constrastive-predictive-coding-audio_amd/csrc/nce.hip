@@ -22,17 +22,21 @@ __device__ __forceinline__ float score_grad(float x, int softplus) {
     return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
 }
 
-// logsumexp over b of every (k, b') column.  grid (ceil(B/32), K); block 256 = 32 columns x 8 row lanes, each lane keeps an
-// online (max, sum) over its rows, combined through LDS.  Writes lse[k][b'] and one partial sum of lse per block.
+// logsumexp over b of every (k, b') column.  grid (ceil(B/32), K, nsplit); block 256 = 32 columns x 8 row lanes, each lane keeps
+// an online (max, sum) over its rows of the split's row range, combined through LDS.  With nsplit == 1 it writes lse[k][b'] and
+// one partial sum of lse per block; otherwise the per-split (max, sum) pairs go to pm / ps [split][k][b'] for nce_col_merge_kernel
+// (the all-timesteps matrix has 3072 rows but only 96 column blocks: the rows must be split to fill the chip).
 __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
-                                                      float* __restrict__ partial, int B, int K, int ld, int softplus) {
+                                                      float* __restrict__ partial, int B, int K, int ld, int softplus,
+                                                      int rows_per_split, float* __restrict__ pm, float* __restrict__ ps) {
     __shared__ float smx[8][32], ssum[8][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int k = blockIdx.y, bp = blockIdx.x * 32 + tx;
+    const int r0 = blockIdx.z * rows_per_split, r1 = min(B, r0 + rows_per_split);
     float mx = -INFINITY, sum = 0.f;
     if (bp < B) {
         const float* col = S + (long long)k * B * ld + bp;
-        for (int b = ty; b < B; b += 8) {
+        for (int b = r0 + ty; b < r1; b += 8) {
             const float v = score_tf(col[(long long)b * ld], softplus);
             if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
             else sum += expf(v - mx);
@@ -48,6 +52,13 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
         float tot = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) tot += (smx[r][tx] == -INFINITY) ? 0.f : ssum[r][tx] * expf(smx[r][tx] - m);
+        if (gridDim.z > 1) {
+            if (bp < B) {
+                pm[((long long)blockIdx.z * K + k) * B + bp] = m;
+                ps[((long long)blockIdx.z * K + k) * B + bp] = tot;
+            }
+            return;
+        }
         const float l = (bp < B) ? m + logf(tot) : 0.f;
         if (bp < B) lse[k * B + bp] = l;
         // sum the 32 columns of this block (one wave-half): shuffle reduction
@@ -55,6 +66,32 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
         for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
         if (tx == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = acc;
     }
+}
+
+// Merges the per-split (max, sum) pairs of a column in split order: lse[c] and one partial sum of lse per block of 256 columns.
+__global__ __launch_bounds__(256) void nce_col_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps, int nsplit,
+                                                            int ncols, float* __restrict__ lse, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (c < ncols) {
+        float m = -INFINITY;
+        for (int z = 0; z < nsplit; ++z) m = fmaxf(m, pm[(long long)z * ncols + c]);
+        float tot = 0.f;
+        for (int z = 0; z < nsplit; ++z) {
+            const float mz = pm[(long long)z * ncols + c];
+            tot += (mz == -INFINITY) ? 0.f : ps[(long long)z * ncols + c] * expf(mz - m);
+        }
+        l = m + logf(tot);
+        lse[c] = l;
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
 // One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
@@ -193,16 +230,30 @@ __global__ __launch_bounds__(256) void nce_all_grad_kernel(const float* __restri
 }
 
 // all-timesteps finalize: out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term
-__global__ void nce_all_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
+__global__ __launch_bounds__(256) void nce_all_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
                                         int ngrad, float* __restrict__ out, int B, int K, float reg) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // fixed-shape tree reduction: the summation order depends only on (ncol, ngrad), not on timing
+    __shared__ float red[4][256];
     float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
-    for (int i = 0; i < ncol; ++i) lse_sum += col_partial[i];
-    for (int i = 0; i < ngrad; ++i) {
+    for (int i = threadIdx.x; i < ncol; i += 256) lse_sum += col_partial[i];
+    for (int i = threadIdx.x; i < ngrad; i += 256) {
         valid += grad_partial[i * 3 + 0];
         msq += grad_partial[i * 3 + 1];
         mx = fmaxf(mx, grad_partial[i * 3 + 2]);
     }
+    red[0][threadIdx.x] = lse_sum; red[1][threadIdx.x] = valid; red[2][threadIdx.x] = msq; red[3][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s2];
+            red[2][threadIdx.x] += red[2][threadIdx.x + s2];
+            red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    lse_sum = red[0][0]; valid = red[1][0]; msq = red[2][0]; mx = red[3][0];
     const float r = (float)B * (float)K;
     const float t_valid = -valid / r, t_lse = lse_sum / r, t_reg = reg * msq / ((float)B * (float)B * (float)K);
     out[0] = t_valid + t_lse + t_reg;
@@ -213,16 +264,30 @@ __global__ void nce_all_finalize_kernel(const float* __restrict__ col_partial, i
 }
 
 // out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
-__global__ void nce_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
-                                    int ngrad, float* __restrict__ out, int B, int K, float reg) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
+                                        int ngrad, float* __restrict__ out, int B, int K, float reg) {
+    // fixed-shape tree reduction: the summation order depends only on (ncol, ngrad), not on timing
+    __shared__ float red[4][256];
     float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
-    for (int i = 0; i < ncol; ++i) lse_sum += col_partial[i];
-    for (int i = 0; i < ngrad; ++i) {
+    for (int i = threadIdx.x; i < ncol; i += 256) lse_sum += col_partial[i];
+    for (int i = threadIdx.x; i < ngrad; i += 256) {
         valid += grad_partial[i * 3 + 0];
         msq += grad_partial[i * 3 + 1];
         mx = fmaxf(mx, grad_partial[i * 3 + 2]);
     }
+    red[0][threadIdx.x] = lse_sum; red[1][threadIdx.x] = valid; red[2][threadIdx.x] = msq; red[3][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s2];
+            red[2][threadIdx.x] += red[2][threadIdx.x + s2];
+            red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    lse_sum = red[0][0]; valid = red[1][0]; msq = red[2][0]; mx = red[3][0];
     const float bk = (float)B * (float)K;
     const float t_valid = -valid / bk, t_lse = lse_sum / bk, t_reg = reg * msq / ((float)B * (float)B);
     out[0] = t_valid + t_lse + t_reg;
@@ -249,7 +314,8 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
     float* colp = lse + (long long)K * B;
     float* gradp = colp + ncol;
     const int nb = (ld + 31) / 32;
-    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus);
+    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B, (float*)nullptr,
+                       (float*)nullptr);
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
                            gradp, B, K, ld, softplus, reg);
@@ -258,17 +324,18 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
                            B, K, ld, softplus, reg);
     else
         return CPC_EINVAL;
-    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
 // ---- score_over_all_timesteps = True ----
 static const int NCE_ALL_BLOCKS = 1024;
-// workspace: lse [R] + col partials [ceil(R/32)] + grad partials [3 * NCE_ALL_BLOCKS]
+static const int NCE_ALL_SPLITS = 16;
+// workspace: lse [R] + col partials [ceil(R/32)] + grad partials [3 * NCE_ALL_BLOCKS] + per-split (max, sum) [2][NCE_ALL_SPLITS][R]
 long long nce_all_workspace_floats(int B, int K) {
     const long long R = (long long)B * K;
-    return R + (R + 31) / 32 + 3LL * NCE_ALL_BLOCKS;
+    return R + (R + 31) / 32 + 3LL * NCE_ALL_BLOCKS + 2LL * NCE_ALL_SPLITS * R;
 }
 
 int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
@@ -279,7 +346,19 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
     const int ncb = (R + 31) / 32;
     float* colp = lse + R;
     float* gradp = colp + ncb;
-    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus);
+    float* pm = gradp + 3LL * NCE_ALL_BLOCKS;
+    float* ps = pm + (long long)NCE_ALL_SPLITS * R;
+    const int nsplit = R >= 8 * NCE_ALL_SPLITS ? NCE_ALL_SPLITS : 1;
+    int n_colp = ncb;
+    if (nsplit > 1) {
+        const int rps = ((R + nsplit - 1) / nsplit + 7) / 8 * 8;
+        hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1, nsplit), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus, rps, pm, ps);
+        n_colp = (R + 255) / 256;
+        hipLaunchKernelGGL(nce_col_merge_kernel, dim3(n_colp), dim3(256), 0, stream, pm, ps, nsplit, R, lse, colp);
+    } else {
+        hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1, 1), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus, R, (float*)nullptr,
+                           (float*)nullptr);
+    }
     const long long total = (long long)B * R;
     const int blocks = (int)min((long long)NCE_ALL_BLOCKS, (total + 255) / 256);
     if (dtype == CPC_DTYPE_BF16) {
@@ -295,7 +374,7 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
     } else {
         return CPC_EINVAL;
     }
-    hipLaunchKernelGGL(nce_all_finalize_kernel, dim3(1), dim3(64), 0, stream, colp, ncb, gradp, blocks, out, B, K, reg);
+    hipLaunchKernelGGL(nce_all_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, n_colp, gradp, blocks, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -294,10 +294,17 @@ class CPCEngine:
                      a_rpi=K, a_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
         _hip.call("cpc_nce_loss_all", _hip.ptr(self.S_all), _hip.ptr(self.ST_all), _hip.ptr(self.dS_all), _hip.ptr(self.dST_all),
                   _hip.ptr(self.nce_out), _hip.ptr(self.nce_all_ws), B, K, ld, 1 if softplus else 0, C.c_float(regularization), code)
-        # d predicted_z[(b,k)][:] = sum_c dS[(b,k)][c] * targets[c][:]
-        _hip.gemm_tn(_hip.ptr(self.dST_all), _hip.ptr(top, tg), _hip.ptr(self.dpred), R, R, E, ld, E, E, code, b_rpi=K, b_item=Ltop * E)
-        # d targets[c][:] = sum_r dS[r][c] * predicted_z[r][:]   -> rows T-K+k' of item b' of the top-layer gradient
-        _hip.gemm_tn(_hip.ptr(self.dS_all), _hip.ptr(self.pred), _hip.ptr(dtop, tg), R, R, E, ld, E, E, code, c_rpi=K, c_item=Ltop * E)
+        # d predicted_z[(b,k)][:] = sum_c dS[(b,k)][c] * targets[c][:]  and  d targets[c][:] = sum_r dS[r][c] * predicted_z[r][:]
+        # (the latter into rows T-K+k' of item b' of the top-layer gradient).  As NT GEMMs over the long axis — the reduction
+        # form would put a 3072-row reduction on 24 workgroups — with the small right-hand operands transposed once (3 MB each).
+        if getattr(self, "targT", None) is None:
+            self.targT = torch.zeros(E, ld, device=self.device, dtype=self.dt)
+            self.predT = torch.zeros(E, ld, device=self.device, dtype=self.dt)
+        self.targT[:, :R].copy_(top.view(B, Ltop, E)[:, T - K:T, :].reshape(R, E).t())
+        self.predT[:, :R].copy_(self.pred.view(R, E).t())
+        _hip.gemm_nt(_hip.ptr(self.dS_all), _hip.ptr(self.targT), _hip.ptr(self.dpred), R, E, ld, ld, ld, E, code)
+        _hip.gemm_nt(_hip.ptr(self.dST_all), _hip.ptr(self.predT), _hip.ptr(dtop, tg), R, E, ld, ld, ld, E, code,
+                     c_rpi=K, c_item=Ltop * E, c_valid=K)
 
     # ------------------------------------------------------------------------------------------ backward
     def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, grad_offset=0, **kw):
