@@ -115,6 +115,74 @@ __global__ __launch_bounds__(256) void col2im2d_kernel(const T* __restrict__ dco
     }
 }
 
+// 16-byte versions (C and Kp multiples of 16 B / sizeof(T), same element type on both sides): one thread moves a whole
+// chunk of 8 bf16 / 4 f32 channels of one tap.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col2d_vec_kernel(const T* __restrict__ in, T* __restrict__ col, Grid g, int kh, int kw,
+                                                           int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cpr = Kp / V, cpt = g.C / V;                      // chunks per col row, per tap
+    const unsigned total = (unsigned)((long long)g.B * Wo * Ho * cpr);
+    const int K = kh * kw * g.C;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int q = (int)(idx % cpr);
+        const unsigned row = idx / cpr;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q * V < K) {
+            const int tap = q / cpt, c0 = (q - tap * cpt) * V, dw = tap % kw, dh = tap / kw;
+            const int ho = (int)(row % Ho), wo = (int)((row / Ho) % Wo), b = (int)(row / (unsigned)(Ho * Wo));
+            const int h = ho * sh + dh - ph, w = wo * sw + dw - pw;
+            if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = *(const uint4*)(in + grid_off(g, b, w, h) + c0);
+        }
+        *(uint4*)(col + (long long)row * Kp + q * V) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im2d_vec_kernel(const T* __restrict__ dcol, T* __restrict__ din, Grid g, int kh, int kw,
+                                                           int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp, int accumulate) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cv = g.C / V;
+    const unsigned total = (unsigned)((long long)g.B * g.W * g.H * cv);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c0 = (int)(idx % cv) * V;
+        const int h = (int)((idx / cv) % g.H);
+        const int w = (int)((idx / (unsigned)(cv * g.H)) % g.W);
+        const int b = (int)(idx / (unsigned)(cv * g.H * g.W));
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int dh = 0; dh < kh; ++dh) {
+            const int hn = h + ph - dh;
+            if (hn < 0 || hn % sh) continue;
+            const int ho = hn / sh;
+            if (ho >= Ho) continue;
+            for (int dw = 0; dw < kw; ++dw) {
+                const int wn = w + pw - dw;
+                if (wn < 0 || wn % sw) continue;
+                const int wo = wn / sw;
+                if (wo >= Wo) continue;
+                const uint4 raw = *(const uint4*)(dcol + (((long long)b * Wo + wo) * Ho + ho) * Kp + (dh * kw + dw) * g.C + c0);
+                const T* pv = (const T*)&raw;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += to_f32(pv[e]);
+            }
+        }
+        const long long o = grid_off(g, b, w, h) + c0;
+        uint4 outv;
+        T* po = (T*)&outv;
+        if (accumulate) {
+            const uint4 old = *(const uint4*)(din + o);
+            const T* pold = (const T*)&old;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += to_f32(pold[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) po[e] = from_f32<T>(acc[e]);
+        *(uint4*)(din + o) = outv;
+    }
+}
+
 // Per-block partial sums over rows of x[rows][C]: slabs[blk][0][c] = sum x, slabs[blk][1][c] = sum x^2  (BatchNorm statistics;
 // pad rows of a grid are zero and drop out).
 template <typename T>
@@ -440,6 +508,15 @@ int launch_im2col2d(const void* in, void* col, const int* g, int kh, int kw, int
     if (Kp < kh * kw * g[5] || (long long)g[0] * Wo * Ho * Kp >= (1ll << 31)) return CPC_EINVAL;
     if ((Ho - 1) * sh + kh - ph > g[2] + ph || (Wo - 1) * sw + kw - pw > g[1] + pw) return CPC_EINVAL;   // windows inside the padded input
     const Grid gg = mk(g);
+    const int vch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if ((!in_f32 || dtype == CPC_DTYPE_F32) && g[5] % vch == 0 && Kp % vch == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)col % 16 == 0)) {
+        const int nbv = blocks_for((long long)g[0] * Wo * Ho * (Kp / vch));
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((im2col2d_vec_kernel<bf16_t>), dim3(nbv), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp),
+                  hipLaunchKernelGGL((im2col2d_vec_kernel<float>), dim3(nbv), dim3(256), 0, st, (const float*)in, (float*)col, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp));
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     const int nb = blocks_for((long long)g[0] * Wo * Ho * Kp);
     if (in_f32) {
         DISPATCH2(dtype,
@@ -459,6 +536,15 @@ int launch_col2im2d(const void* dcol, void* din, const int* g, int kh, int kw, i
     if (!grid_ok(g) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || Ho <= 0 || Wo <= 0) return CPC_EINVAL;
     if (Kp < kh * kw * g[5]) return CPC_EINVAL;
     const Grid gg = mk(g);
+    const int vch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if (g[5] % vch == 0 && Kp % vch == 0 && ((uintptr_t)dcol % 16 == 0) && ((uintptr_t)din % 16 == 0)) {
+        const int nbv = blocks_for((long long)g[0] * g[1] * g[2] * (g[5] / vch));
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((col2im2d_vec_kernel<bf16_t>), dim3(nbv), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)din, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate),
+                  hipLaunchKernelGGL((col2im2d_vec_kernel<float>), dim3(nbv), dim3(256), 0, st, (const float*)dcol, (float*)din, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate));
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     const int nb = blocks_for((long long)g[0] * g[1] * g[2] * g[5]);
     DISPATCH2(dtype,
               hipLaunchKernelGGL((col2im2d_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)din, gg, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate),

@@ -117,7 +117,9 @@ class _Conv:
         else:
             self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt)
             self.K = self.kh * self.kw * self.cin
-            self.Kp = _ceil_div(self.K, 8) * 8
+            # K padded so that the fast GEMM paths apply (K-stage of 64 bf16 / 32 f32 elements); tiny K stays at a multiple of 8
+            kq = 64 if dt == torch.bfloat16 else 32
+            self.Kp = _ceil_div(self.K, kq) * kq if self.K > kq // 2 else _ceil_div(self.K, 8) * 8
             self.M = B * self.Wo * self.Ho
             self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
             self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if need_dgrad else None
