@@ -942,33 +942,9 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
     const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
-    int numM = (p.M - p.m_off + tbm - 1) / tbm;
+    const int numM = (p.M - p.m_off + tbm - 1) / tbm;
     const int numN = (p.N + tbn - 1) / tbn;
     if (!fast && p.m_off) return CPC_EINVAL;
-    // Tile quantisation: 256 CUs take the 256x256 tiles in rounds; a last round that is mostly empty (e.g. 1824 tiles =
-    // 7 rounds + 32 tiles) costs a full round.  Then the big tiles cover the whole rounds only and the remaining rows go to
-    // a second launch of 128x128 tiles (4x as many, a quarter of the time each) — same arithmetic per output element, so
-    // the result does not depend on where the split falls.
-    int tail_rows = 0;
-    if (big && batch == 1 && p.m_off == 0) {
-        const long long tiles = (long long)numM * numN;
-        const int rem = (int)(tiles % 256);
-        if (tiles > 256 && rem > 0 && rem <= 128) {
-            const int tail_m = (rem + numN - 1) / numN;              // M-tiles handed to the small-tile launch
-            if (tail_m < numM) {
-                tail_rows = p.M - (numM - tail_m) * tbm;
-                numM -= tail_m;
-            }
-        }
-    }
-    if (tail_rows > 0) {
-        q.M = p.M - tail_rows;
-        GemmNT t = p;
-        t.m_off = q.M;
-        t.flags |= GEMM_SMALL_TILE;
-        const int rc = launch_gemm_nt(t, dtype, batch, stream);
-        if (rc != CPC_OK) return rc;
-    }
     const long long blocks = fast ? nt_grid_blocks(numM, numN) : (long long)((numM + 7) / 8) * 8 * numN;
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);

@@ -15,12 +15,17 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: take the most recent run's."""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_bench_b256_bf16.csv"))
 
 
 def per_kernel(counter, sub):
-    f = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = newest(os.path.join(src, sub, "**", "*counter_collection.csv"))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
