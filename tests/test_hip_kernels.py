@@ -564,3 +564,108 @@ def test_positional_scale_and_time_mean(dt):
     m = torch.full((B, C), float("nan"), device=DEV, dtype=dt)
     _hip.call("cpc_mean_time", _hip.ptr(x0), _hip.ptr(m), B, S, C, code)
     assert rel_err(m, x0.double().cpu().reshape(B, S, C).mean(1)) < tol(dt)
+
+
+# --------------------------------------------------------------------------------------- seeded shape fuzzing
+def _rand_shapes(seed, n):
+    import random as _r
+    rng = _r.Random(seed)
+    for _ in range(n):
+        yield rng
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_random_shapes(dt):
+    """40 seeded random problems through cpc_gemm_nt: ragged M / N, K in and out of the fast path's granularity, item
+    addressing on A and C, pad-row zeroing, bias / relu / mask epilogues, f32 or storage-dtype output."""
+    import random as _r
+    rng = _r.Random(1234 + (dt == torch.bfloat16))
+    ch = 8 if dt == torch.bfloat16 else 4
+    code = _hip.dtype_code(dt)
+    for case in range(40):
+        M = rng.choice([1, 7, 64, 130, 257, 513, 1030, 2300])
+        N = rng.choice([4, 8, 36, 64, 128, 200, 260, 520]) // 4 * 4
+        K = rng.choice([ch, 2 * ch, 64, 96, 128, 8 * ch * 3, 320])
+        K = K // ch * ch
+        use_items = rng.random() < 0.5 and M >= 8
+        rpi = rng.choice([3, 5, 16, 40]) if use_items else 0
+        g = torch.Generator().manual_seed(case)
+        lda = K + rng.choice([0, ch, 4 * ch])
+        A = torch.randn(M + 4, lda, generator=g)
+        Bt = torch.randn(N, K, generator=g)
+        bias = torch.randn(N, generator=g)
+        mask = torch.randn(M, N, generator=g)
+        relu, use_bias, use_mask = rng.random() < 0.4, rng.random() < 0.5, rng.random() < 0.4
+        of32 = rng.random() < 0.3 and not use_mask
+        ref = rounded(A[:M, :K], dt) @ rounded(Bt, dt).T
+        if use_bias:
+            ref = ref + bias.double()
+        if relu:
+            ref = torch.relu(ref)
+        if use_mask:
+            ref = torch.where(rounded(mask, dt) > 0, ref, torch.zeros_like(ref))
+        c_valid = 0
+        if rpi:
+            c_valid = rng.randint(1, rpi)
+            rows = torch.arange(M) % rpi
+            ref = torch.where((rows < c_valid).unsqueeze(1), ref, torch.zeros_like(ref))
+        dA, dB, db, dm = dev(A, dt), dev(Bt, dt), dev(bias), dev(mask, dt)
+        items = -(-M // rpi) if rpi else 0
+        item_rows = rpi + 2
+        ldc = N + rng.choice([0, 8])
+        if rpi:
+            out = torch.full((items, item_rows, ldc), float("nan"), device=DEV, dtype=torch.float32 if of32 else dt)
+            dmask = torch.zeros(items, item_rows, ldc, device=DEV, dtype=dt)
+            idx = torch.arange(M, device=DEV)
+            dmask[idx // rpi, idx % rpi, :N] = dm
+        else:
+            out = torch.full((M, ldc), float("nan"), device=DEV, dtype=torch.float32 if of32 else dt)
+            dmask = torch.zeros(M, ldc, device=DEV, dtype=dt)
+            dmask[:, :N] = dm
+        _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(out), M, N, K, lda, K, ldc, code, bias=_hip.ptr(db) if use_bias else None,
+                     mask=_hip.ptr(dmask) if use_mask else None, c_rpi=rpi, c_item=item_rows * ldc if rpi else 0, c_valid=c_valid,
+                     flags=(_hip.GEMM_RELU if relu else 0) | (_hip.GEMM_OUT_F32 if of32 else 0))
+        if rpi:
+            idx = torch.arange(M, device=DEV)
+            got = out[idx // rpi, idx % rpi, :N]
+        else:
+            got = out[:, :N]
+        scale = ref.abs().max().item() + 1e-9
+        err = (got.double().cpu() - ref).abs().max().item() / scale
+        assert err < tol(dt) * 2, (case, M, N, K, rpi, c_valid, relu, use_bias, use_mask, of32, err)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_tn_random_shapes(dt):
+    """30 seeded random problems through cpc_gemm_tn: ragged I (padded A rows), J multiples of the chunk, split reductions,
+    item addressing on B."""
+    import random as _r
+    rng = _r.Random(99 + (dt == torch.bfloat16))
+    ch = 8 if dt == torch.bfloat16 else 4
+    code = _hip.dtype_code(dt)
+    for case in range(30):
+        M = rng.choice([5, 64, 100, 333, 1024, 2500, 4100])
+        I = rng.choice([8, 20, 24, 72, 128, 264, 520])
+        J = rng.choice([ch, 32, 64, 136, 256, 264]) // ch * ch
+        nsplit = rng.choice([1, 1, 2, 3, 7])
+        g = torch.Generator().manual_seed(1000 + case)
+        lda = (I + ch - 1) // ch * ch + rng.choice([0, ch])
+        A = torch.randn(M, lda, generator=g)
+        rpi = rng.choice([0, 0, 9, 32])
+        if rpi:
+            items = -(-M // rpi)
+            Bfull = torch.randn(items, rpi + 1, J, generator=g)
+            Bm = Bfull[:, :rpi].reshape(-1, J)[:M]
+        else:
+            Bfull = torch.randn(M, J, generator=g)
+            Bm = Bfull
+        ref = rounded(A[:, :I], dt).T @ rounded(Bm, dt)
+        dA, dB = dev(A, dt), dev(Bfull, dt)
+        blk = 64 if dt == torch.bfloat16 else 32
+        chunk = ((M + nsplit - 1) // nsplit + blk - 1) // blk * blk
+        slabs = torch.full((nsplit, I, J), float("nan"), device=DEV)
+        _hip.gemm_tn(_hip.ptr(dA), _hip.ptr(dB), _hip.ptr(slabs), M, I, J, lda, J, J, code, b_rpi=rpi, b_item=(rpi + 1) * J if rpi else 0,
+                     nsplit=nsplit, m_chunk=chunk if nsplit > 1 else 0, slab_stride=I * J, flags=_hip.GEMM_OUT_F32)
+        scale = ref.abs().max().item() + 1e-9
+        err = (slabs.sum(0).double().cpu() - ref).abs().max().item() / scale
+        assert err < tol(dt) * 2, (case, M, I, J, nsplit, rpi, err)
