@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
+    ap.add_argument("--graph", action="store_true", help="diagnostic: replay the step from a captured hipGraph (single GPU only)")
     ap.add_argument("--all-timesteps", action="store_true",
                     help="diagnostic: score_over_all_timesteps=True (the full (B*K)^2 score matrix); not the headline configuration")
     args = ap.parse_args()
@@ -104,18 +105,23 @@ def main():
     torch.cuda.set_device(device)
 
     from cpc_audio_amd import _hip
-    from cpc_audio_amd.engine import FusedAdam, GradAllReduce
+    from cpc_audio_amd.engine import FusedAdam, GradAllReduce, GraphedStep
 
     B, L, T = args.batch, 20480, 126
     model = build_model(args.dtype, device, seed=0)                 # identical parameters on every rank
     eng = model.engine(B, L)
-    opt = FusedAdam(model, lr=1e-4)
+    use_graph = args.graph and world == 1 and not args.breakdown
+    opt = FusedAdam(model, lr=1e-4, device_step=use_graph)
     gen = torch.Generator().manual_seed(1000 + rank)                # rank r draws its own clips
     pool = [(torch.randn(B, L, generator=gen)).to(device) for _ in range(4)]
 
     sync = GradAllReduce(model) if world > 1 else None
 
+    graphed = GraphedStep(eng, opt, True, 1.0, args.all_timesteps) if use_graph else None
+
     def step(i):
+        if graphed is not None:
+            return graphed(pool[i % len(pool)])
         out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
                                  grad_ready_hook=sync.hook if sync is not None else None)
         if sync is not None:

@@ -282,6 +282,12 @@ int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream) {
     return launch_split3_bf16(src, dst, n, (hipStream_t)stream);
 }
 
+int cpc_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
+                 float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !state) return CPC_EINVAL;
+    return launch_adam_dev(p, g, m, v, n, lr, b1, b2, eps, state, grad_scale, (hipStream_t)stream);
+}
+
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);

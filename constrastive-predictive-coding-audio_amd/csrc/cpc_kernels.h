@@ -126,3 +126,5 @@ int launch_residual_add_bwd(const void* dout, const void* out, const int* go, vo
                             int ow, int relu, int r_f32, int dtype, hipStream_t stream);
 int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
+                    float grad_scale, hipStream_t stream);

@@ -146,6 +146,40 @@ __global__ __launch_bounds__(256) void relu_row_bwd_kernel(const float* __restri
 
 }  // namespace
 
+// Step counter kept on the device (so that a captured hipGraph can be replayed): state[0] = step count (as float bits of an
+// int), state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t).
+__global__ void adam_tick_kernel(float* __restrict__ state, float lr, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int t = __float_as_int(state[0]) + 1;
+    state[0] = __int_as_float(t);
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    state[1] = (float)((double)lr / bc1);
+    state[2] = (float)(1.0 / sqrt(bc2));
+}
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, const float* __restrict__ state, float b1,
+                                                       float b2, float eps, float grad_scale) {
+    const float step_size = state[1], inv_bc2_sqrt = state[2];
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float ge = g[i] * grad_scale;
+        const float mm = m[i] + (ge - m[i]) * (1.f - b1);
+        const float vv = v[i] * b2 + (1.f - b2) * ge * ge;
+        m[i] = mm; v[i] = vv;
+        p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    }
+}
+
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
+                    float grad_scale, hipStream_t stream) {
+    if (n <= 0 || !state) return CPC_EINVAL;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, state, lr, b1, b2);
+    const int blocks = (int)min((long long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, (const float*)state, b1, b2, eps, grad_scale);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
                 float grad_scale, hipStream_t stream) {
     if (n <= 0 || step < 1) return CPC_EINVAL;

@@ -271,6 +271,11 @@ int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float
  * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first. */
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
              int step, float grad_scale, void* stream);
+/* The same update with the step count kept on the device: state f32[4] = {step count (int bits), lr/(1-b1^t), 1/sqrt(1-b2^t), -},
+ * zero-initialised by the caller; every call advances the count first.  Nothing in the argument list changes from step to
+ * step, so a train step captured in a hipGraph can be replayed. */
+int cpc_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
+                 float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

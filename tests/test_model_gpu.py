@@ -641,3 +641,35 @@ def test_context_networks_standalone_forward(golden_dir):
     z = torch.randn(4, ma["C"], ma["V"], generator=torch.Generator().manual_seed(2))
     ref, _ = O.attention_forward(z, sa, ma["ar"]["num_layers"], ma["ar"]["num_heads"])
     assert _rel(att(z.to(DEV)), ref) < 2e-4
+
+
+def test_graphed_step_matches_eager(golden_dir):
+    """trainer.use_graph: the whole step replayed from a captured hipGraph (device-side Adam step count) follows the
+    reference's recorded training runs exactly as the eager path does — same fixtures, same bounds (fp32)."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"])
+    checked = 0
+    for run in meta["runs"]:
+        if run["steps"] < 2:
+            continue
+        results = []
+        for use_graph in (False, True):
+            model = _small_model(g, meta, "fp32")
+            ds = TensorAudioDataset(data, device=DEV)
+            logger = Logger()
+            tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                              score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                              prediction_steps=meta["K"], ar_size=meta["H"])
+            tr.verbose, tr.use_graph = False, use_graph
+            random.seed(run["python_seed"])
+            tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+            results.append((logger.loss_meter.values, {n: p.detach().clone() for n, p in model.named_parameters()}))
+            for i in range(run["steps"]):
+                assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= 1e-4 * abs(run["loss"][i]) * (1 + 2 * i), (use_graph, i)
+        (l0, p0), (l1, p1) = results
+        assert max(abs(a - b) / abs(a) for a, b in zip(l0, l1)) < 1e-6
+        for n in p0:
+            assert _rel(p1[n], p0[n]) < 1e-5, n
+        checked += 1
+    assert checked >= 1
