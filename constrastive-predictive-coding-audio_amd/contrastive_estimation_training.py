@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import math
 import random
-import time
 
 import torch
 import torch.nn.functional as F

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 

@@ -84,7 +84,6 @@ class _Conv:
         self.Wo = (gin.W + 2 * self.pad - self.kw) // self.sw + 1
         if self.Ho < 1 or self.Wo < 1:
             raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
-        ch = 8 if dt == torch.bfloat16 else 4
         col_ok = self.kw == 1 and self.sh == 1 and self.sw == 1 and self.pad == 0 and self.cin % 8 == 0 and not in_f32
         self.mode = 'col' if col_ok else 'win'
         B = gin.B
