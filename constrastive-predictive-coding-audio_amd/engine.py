@@ -1,10 +1,11 @@
 """Host-side plan of the CPC train step: buffers in HBM + the launch sequence over the C ABI.
 
 One ``CPCEngine`` = one (batch size, clip length, storage dtype) instance of the path
-    AudioEncoder.forward -> AudioGRUModel.forward -> prediction_model -> score/InfoNCE -> backward -> Adam
-for a model built from AudioEncoder + AudioGRUModel (reference: audio_model.py:193-211 and
-contrastive_estimation_training.py:97-162).  PyTorch is used for device memory and streams only; every
-arithmetic step is a HIP kernel behind libcpc_hip.so.
+    AudioEncoder.forward -> context network -> prediction_model -> score/InfoNCE -> backward -> Adam
+(reference: audio_model.py:193-211 and contrastive_estimation_training.py:97-162).  The context network is pluggable:
+GRUContext (AudioGRUModel), ConvArContext / scalogram_engine.ConvArGridContext (ConvolutionalArModel), AttentionContext
+(AttentionModel); scalogram_engine.ScalogramCPCEngine swaps the encoder for the 2-D residual encoder.  PyTorch is used for
+device memory, streams and a few strided copies only; every arithmetic step is a HIP kernel behind libcpc_hip.so.
 
 Data layout (all per GPU, resident for the life of the engine):
   act[l], dact[l]   storage dtype, channels-last [B][L_alloc[l]][C_l], zero pad rows, zero guards front/back
