@@ -673,3 +673,36 @@ def test_graphed_step_matches_eager(golden_dir):
             assert _rel(p1[n], p0[n]) < 1e-5, n
         checked += 1
     assert checked >= 1
+
+
+@pytest.mark.parametrize("B,V,K,extra,all_t", [(1, 2, 1, 0, False), (3, 17, 5, 77, False), (16, 9, 4, 160 * 3 + 1, True), (5, 1, 12, 13, False),
+                                               (2, 30, 2, 0, True)])
+def test_odd_shapes_against_oracle(B, V, K, extra, all_t):
+    """Edge shapes of the waveform model vs the oracle (fp32): single-item and ragged batches, one visible / one predicted
+    step, clips with no spare frame and with several, both loss branches."""
+    C, H = 32, 32
+    L = 465 + (V + K - 1) * 160 + extra
+    torch.manual_seed(B * 100 + V)
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, AudioGRUModel(C, H), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K,
+                                       compute_dtype="fp32")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("weight") and n.startswith("encoder"):
+                p.mul_(3.0)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(V)) * 0.5
+    out = model.engine(B, L).loss_and_grads(x.to(DEV).contiguous(), softplus=True, regularization=0.5, all_timesteps=all_t)
+    ot = O.OracleTrainer(state, V, K, score="softplus", all_timesteps=all_t, regularization=0.5)
+    loss, smax, grads = ot.loss_and_grads(x)
+    assert abs(float(out[0]) - float(loss)) <= 2e-4 * max(1.0, abs(float(loss))), (float(out[0]), float(loss))
+    assert abs(float(out[1]) - float(smax)) <= 2e-4 * max(1.0, abs(float(smax)))
+    for n, ref in grads.items():
+        ref = ref.double()
+        got = model._grad[n].double().cpu()
+        denom = ref.norm().item()
+        if denom < 1e-9:
+            assert got.norm().item() < 1e-6, n
+            continue
+        assert ((got - ref).norm() / denom).item() < 2e-3, (n, ((got - ref).norm() / denom).item())
