@@ -706,3 +706,79 @@ def test_odd_shapes_against_oracle(B, V, K, extra, all_t):
             assert got.norm().item() < 1e-6, n
             continue
         assert ((got - ref).norm() / denom).item() < 2e-3, (n, ((got - ref).norm() / denom).item())
+
+
+_DP_WORKER = r'''
+import os, sys, random, json
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cpc_audio_amd.audio_dataset import TensorAudioDataset
+from cpc_audio_amd.audio_model import AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel
+from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer, softplus_score_function
+from oracle import cpc_oracle as O
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+C, H, K, V, Bloc, steps = 32, 32, 3, 8, 4, 2
+L = 465 + (V + K) * 160
+torch.manual_seed(7)                                     # identical initial parameters on every rank
+enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+model = AudioPredictiveCodingModel(enc, AudioGRUModel(C, H), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+with torch.no_grad():
+    for n, p in model.named_parameters():
+        if n.startswith("encoder") and n.endswith("weight"):
+            p.mul_(3.0)
+state0 = {k: v.clone() for k, v in model.state_dict().items()}
+model = model.to(dev)
+data = torch.randn(24, L, generator=torch.Generator().manual_seed(5)) * 0.5
+ds = TensorAudioDataset(data, device=dev)
+tr = ContrastiveEstimationTrainer(model=model, dataset=ds, device=dev, regularization=1.0, score_function=softplus_score_function,
+                                  prediction_steps=K, ar_size=H)
+tr.verbose = False
+random.seed(100 + rank)                                  # rank 0's sampler lists must win
+tr.train(batch_size=Bloc, epochs=5, lr=1e-3, num_workers=0, max_steps=steps)
+flat = model._flat_param.detach().cpu()
+gathered = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+if rank == 0:
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged"
+    # oracle: per-shard InfoNCE, gradient = mean over shards, one Adam step per global batch
+    random.seed(100)
+    lists = O.file_batch_sampler([len(data)], Bloc * world)
+    ot = O.OracleTrainer(state0, V, K, score="softplus", regularization=1.0, lr=1e-3)
+    for s in range(steps):
+        idx = lists[s]
+        grads = None
+        for r in range(world):
+            _, _, g = ot.loss_and_grads(data[idx[r * Bloc:(r + 1) * Bloc]])
+            g = {k: v.clone() for k, v in g.items()}
+            grads = g if grads is None else {k: grads[k] + g[k] for k in g}
+        ot.t += 1
+        with torch.no_grad():
+            for k, p in ot.params.items():
+                O.adam_update(p, grads[k] / world, ot.m[k], ot.v[k], ot.t, ot.lr)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        ref = ot.params[n].detach()
+        worst = max(worst, ((p.detach().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item())
+    assert worst < 5e-3, worst                           # Adam's sign-like first steps amplify 1e-6 gradient differences
+    print("DP-GPU-OK", worst)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
+    """The trainer's data-parallel path on the GPU with two processes sharing the card (gloo transport, since RCCL refuses two
+    ranks on one device): ranks stay bit-identical, and the parameters after two steps equal the oracle's 'mean of the
+    per-shard gradients' semantics (SURVEY.md 8e)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DP-GPU-OK" in outs[0]
