@@ -91,6 +91,9 @@ class ContrastiveEstimationTrainer:
         # Not in the reference: replay the whole step from a captured hipGraph (single process, fused path, no preprocessing
         # module, no dropout).  Measured neutral on MI355X (launches are already hidden); off by default.
         self.use_graph = False
+        # Not in the reference's signature: under torch.distributed take the InfoNCE loss over the batches of ALL ranks — what
+        # the reference's nn.DataParallel wrap computes — instead of per-GPU negatives (engine.GlobalNegatives).
+        self.global_negatives = False
         self.verbose = True
         if wasserstein_gradient_penalty:
             raise NotImplementedError("the Wasserstein gradient penalty (double backward through the encoder) is not "
@@ -156,11 +159,12 @@ class ContrastiveEstimationTrainer:
         self.model.train()
         fused = self._fused()
         if fused:
-            from .engine import FusedAdam, GradAllReduce, GraphedStep
+            from .engine import FusedAdam, GlobalNegatives, GradAllReduce, GraphedStep
             self.model._flatten_parameters(device)
             graphed = bool(self.use_graph) and world == 1 and self.preprocessing is None
             optimizer = FusedAdam(self.model, lr=lr, device_step=graphed)
             graph_steps = {}
+            glob_neg = {}
             self.model.link_grads()
             sync = GradAllReduce(self.model) if world > 1 else None
         else:
@@ -208,13 +212,19 @@ class ContrastiveEstimationTrainer:
                         else:
                             x_eng = batch.contiguous()
                             eng = self.model.engine(batch.shape[0], batch.shape[1], device)
+                        gneg = None
+                        if self.global_negatives and world > 1:
+                            gneg = glob_neg.get(id(eng))
+                            if gneg is None:
+                                gneg = glob_neg[id(eng)] = GlobalNegatives(eng)
                         out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),
-                                                 grad_ready_hook=sync.hook if sync is not None else None)
+                                                 grad_ready_hook=sync.hook if sync is not None else None, global_negatives=gneg)
                         if sync is not None:
                             sync.finish()
-                        optimizer.step(grad_scale=1.0 / world)
+                        # per-GPU negatives: mean of the shard gradients; global negatives: the shard gradients add up
+                        optimizer.step(grad_scale=1.0 if gneg is not None else 1.0 / world)
                         vals = out[:2].clone()
                     else:
                         vals = self._generic_step(batch, batch.shape[0], optimizer, world)

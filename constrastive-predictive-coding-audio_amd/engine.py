@@ -396,10 +396,14 @@ class CPCEngine:
                       1, 1, 0, 0)
 
     # ------------------------------------------------------------------------------------------ whole step
-    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None):
-        """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg] (no sync)."""
+    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
+                       global_negatives=None):
+        """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg] (no sync).
+        ``global_negatives``: a GlobalNegatives object — the loss is then taken over the batches of ALL ranks."""
         self.forward(x)
-        if all_timesteps:
+        if global_negatives is not None:
+            global_negatives.forward_backward(softplus, regularization, all_timesteps)
+        elif all_timesteps:
             self.nce_all_forward_backward(softplus, regularization)
         else:
             self.nce_forward_backward(softplus, regularization)
@@ -916,6 +920,90 @@ def standalone_context_forward(ar, z, ar_size):
         eng = ContextOnlyEngine(owner, z.shape[0], z.shape[1], z.shape[2], dev, owner.compute_dtype)
         owner._engines = {key: eng}
     return eng.run(z.float())
+
+
+class GlobalNegatives:
+    """InfoNCE over the GLOBAL batch under one process per GPU — the loss the reference's nn.DataParallel wrap computes
+    (setup_functions.py:112-115: outputs gathered to one device, scores and loss over all B x N items; SURVEY.md 8a13 / 8f
+    rank 3).  Every rank all-gathers predicted_z and targets (2 x B K E storage-dtype elements per rank), computes the same
+    global loss and its gradient with respect to all predictions / targets, and back-propagates the slice that belongs to
+    its own clips; the parameter gradients of the ranks then ADD UP to the gradient of the global loss (all-reduce sum, no
+    division).  The default data-parallel mode keeps per-GPU negatives (BASELINE.json's north star); this one is opt-in
+    (``ContrastiveEstimationTrainer.global_negatives``).  Both loss branches."""
+
+    def __init__(self, eng):
+        import torch.distributed as dist
+        self.dist, self.eng = dist, eng
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        B, K, E, dev, dt, f32 = eng.B, eng.K, eng.E, eng.device, eng.dt, torch.float32
+        GB = B * self.world
+        self.GB, self.ld = GB, _ceil_div(GB, 8) * 8
+        self.local_targ = torch.empty(B * K * E, device=dev, dtype=dt)
+        self.pred_all = torch.empty(GB * K * E, device=dev, dtype=dt)
+        self.targ_all = torch.empty(GB * K * E, device=dev, dtype=dt)
+        self.dpred_all = torch.empty(GB * K * E, device=dev, dtype=dt)
+        self.dtarg_all = torch.empty(GB * K * E, device=dev, dtype=dt)
+        self.S = torch.zeros(K * GB * self.ld, device=dev, dtype=f32)
+        self.dS = torch.zeros(K * GB * self.ld, device=dev, dtype=dt)
+        self.dST = torch.zeros(K * GB * self.ld, device=dev, dtype=dt)
+        self.out = torch.zeros(8, device=dev, dtype=f32)
+        self.ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(GB, K)), device=dev, dtype=f32)
+
+    def _all_timesteps(self, softplus: bool, regularization: float):
+        """The full (GB K) x (GB K) score matrix over the gathered predictions / targets (engine.nce_all_forward_backward on
+        the global batch)."""
+        e = self.eng
+        code, E, K, GB = e.code, e.E, e.K, self.GB
+        R = GB * K
+        ld = _ceil_div(R, 8) * 8
+        if getattr(self, "S_all", None) is None:
+            dev, dt, f32 = e.device, e.dt, torch.float32
+            self.S_all = torch.zeros(R * ld, device=dev, dtype=f32)
+            self.ST_all = torch.zeros(R * ld, device=dev, dtype=f32)
+            self.dS_all = torch.zeros(R * ld, device=dev, dtype=dt)
+            self.dST_all = torch.zeros(R * ld, device=dev, dtype=dt)
+            self.ws_all = torch.empty(int(_hip.lib().cpc_nce_all_workspace_floats(GB, K)), device=dev, dtype=f32)
+            self.targT = torch.zeros(E, ld, device=dev, dtype=dt)
+            self.predT = torch.zeros(E, ld, device=dev, dtype=dt)
+        P = _hip.ptr
+        _hip.gemm_nt(P(self.pred_all), P(self.targ_all), P(self.S_all), R, R, E, E, E, ld, code, flags=_hip.GEMM_OUT_F32)
+        _hip.gemm_nt(P(self.targ_all), P(self.pred_all), P(self.ST_all), R, R, E, E, E, ld, code, flags=_hip.GEMM_OUT_F32)
+        _hip.call("cpc_nce_loss_all", P(self.S_all), P(self.ST_all), P(self.dS_all), P(self.dST_all), P(self.out), P(self.ws_all), GB, K,
+                  ld, 1 if softplus else 0, C.c_float(regularization), code)
+        self.targT[:, :R].copy_(self.targ_all.view(R, E).t())
+        self.predT[:, :R].copy_(self.pred_all.view(R, E).t())
+        _hip.gemm_nt(P(self.dS_all), P(self.targT), P(self.dpred_all), R, E, ld, ld, ld, E, code)
+        _hip.gemm_nt(P(self.dST_all), P(self.predT), P(self.dtarg_all), R, E, ld, ld, ld, E, code)
+
+    def forward_backward(self, softplus: bool, regularization: float, all_timesteps: bool = False):
+        e, dist = self.eng, self.dist
+        code, B, E, K, GB, ld = e.code, e.B, e.E, e.K, self.GB, self.ld
+        Ltop, T = e.geo.alloc[-1], e.T
+        top, dtop = e.act[-1].view(B, Ltop, E), e.dact[-1].view(B, Ltop, E)
+        n = B * K * E
+        self.local_targ.view(B, K, E).copy_(top[:, T - K:T, :])
+        dist.all_gather([self.pred_all[r * n:(r + 1) * n] for r in range(self.world)], e.pred)
+        dist.all_gather([self.targ_all[r * n:(r + 1) * n] for r in range(self.world)], self.local_targ)
+        P = _hip.ptr
+        if all_timesteps:
+            self._all_timesteps(softplus, regularization)
+            lo = self.rank * n
+            e.dpred.copy_(self.dpred_all[lo:lo + n])
+            dtop[:, T - K:T, :].copy_(self.dtarg_all[lo:lo + n].view(B, K, E))
+            e.nce_out.copy_(self.out)
+            return
+        _hip.gemm_nt(P(self.pred_all), P(self.targ_all), P(self.S), GB, GB, E, K * E, K * E, ld, code, a_batch=E, b_batch=E,
+                     c_batch=GB * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+        _hip.call("cpc_nce_loss", P(self.S), P(self.dS), P(self.dST), P(self.out), P(self.ws), GB, K, ld, 1 if softplus else 0,
+                  C.c_float(regularization), code)
+        _hip.gemm_tn(P(self.dST), P(self.targ_all), P(self.dpred_all), GB, GB, E, ld, K * E, K * E, code, a_batch=GB * ld, b_batch=E,
+                     c_batch=E, batch=K)
+        _hip.gemm_tn(P(self.dS), P(self.pred_all), P(self.dtarg_all), GB, GB, E, ld, K * E, K * E, code, a_batch=GB * ld, b_batch=E,
+                     c_batch=E, batch=K)
+        lo = self.rank * n
+        e.dpred.copy_(self.dpred_all[lo:lo + n])
+        dtop[:, T - K:T, :].copy_(self.dtarg_all[lo:lo + n].view(B, K, E))
+        e.nce_out.copy_(self.out)
 
 
 class GradAllReduce:

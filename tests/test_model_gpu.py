@@ -782,3 +782,81 @@ def test_data_parallel_two_ranks_on_one_gpu(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "DP-GPU-OK" in outs[0]
+
+
+_GN_WORKER = r'''
+import os, sys, random
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cpc_audio_amd.audio_dataset import TensorAudioDataset
+from cpc_audio_amd.audio_model import AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel
+from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer, softplus_score_function
+from oracle import cpc_oracle as O
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+C, H, K, V, Bloc, steps = 32, 32, 3, 8, 4, 2
+L = 465 + (V + K) * 160
+torch.manual_seed(7)
+enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+model = AudioPredictiveCodingModel(enc, AudioGRUModel(C, H), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+with torch.no_grad():
+    for n, p in model.named_parameters():
+        if n.startswith("encoder") and n.endswith("weight"):
+            p.mul_(3.0)
+state0 = {k: v.clone() for k, v in model.state_dict().items()}
+model = model.to(dev)
+data = torch.randn(24, L, generator=torch.Generator().manual_seed(5)) * 0.5
+ds = TensorAudioDataset(data, device=dev)
+class Log:
+    def __init__(self):
+        self.losses = []
+        self.loss_meter = self.score_meter = self
+    def update(self, v): self.losses.append(float(v))
+    def log(self, step): pass
+log = Log()
+ALL_T = os.environ.get("GN_ALL_TIMESTEPS") == "1"
+tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=log, device=dev, regularization=1.0, score_function=softplus_score_function,
+                                  score_over_all_timesteps=ALL_T, prediction_steps=K, ar_size=H)
+tr.verbose, tr.global_negatives = False, True
+random.seed(100 + rank)
+tr.train(batch_size=Bloc, epochs=5, lr=1e-3, num_workers=0, max_steps=steps)
+flat = model._flat_param.detach().cpu()
+gathered = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+if rank == 0:
+    assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged"
+    # the reference's semantics: ONE process, the whole global batch (rank 0's items first)
+    random.seed(100)
+    lists = O.file_batch_sampler([len(data)], Bloc * world)
+    ot = O.OracleTrainer(state0, V, K, score="softplus", all_timesteps=ALL_T, regularization=1.0, lr=1e-3)
+    ref_losses = [ot.step(data[lists[s]])[0] for s in range(steps)]
+    got_losses = log.losses[0::2]
+    assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(got_losses, ref_losses)), (got_losses, ref_losses)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        ref = ot.params[n].detach()
+        worst = max(worst, ((p.detach().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item())
+    assert worst < 5e-3, worst
+    print("GN-GPU-OK", worst, got_losses, ref_losses)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("all_timesteps", [False, True])
+def test_global_negatives_two_ranks_equal_single_process_reference(tmp_path, all_timesteps):
+    """trainer.global_negatives: two ranks with 4 clips each reproduce the reference's single-process step on the 8-clip batch
+    (losses and parameters after two steps, both loss branches) — the semantics of its nn.DataParallel wrap
+    (setup_functions.py:112-115)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gn_worker.py"
+    script.write_text(_GN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29652" if all_timesteps else "29651", WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", GN_ALL_TIMESTEPS="1" if all_timesteps else "0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GN-GPU-OK" in outs[0]
