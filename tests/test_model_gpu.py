@@ -532,7 +532,7 @@ def test_attention_dropout_against_oracle_with_same_masks(golden_dir):
     pz, tg, _, _ = O.cpc_forward(x.cpu().unsqueeze(1), params, V, K, attention=(layers, heads, df))
     loss, _ = O.info_nce_loss(O.softplus_scores(pz, tg), False, 1.0)
     loss.backward()
-    assert abs(float(out[0]) - float(loss)) < 2e-4 * abs(float(loss))
+    assert abs(float(out[0]) - float(loss.detach())) < 2e-4 * abs(float(loss.detach()))
     for n in params:
         ref = params[n].grad.double()
         l2 = ((model._grad[n].double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
