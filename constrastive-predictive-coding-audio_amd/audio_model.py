@@ -199,7 +199,7 @@ class AudioPredictiveCodingModel(nn.Module):
         from .scalogram_model import ScalogramResidualEncoder
         self._scalogram = isinstance(encoder, ScalogramResidualEncoder)
         if not isinstance(encoder, (AudioEncoder, ScalogramResidualEncoder)) or \
-                not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel, AttentionModel)):
+                not isinstance(autoregressive_model, (AudioGRUModel, ConvolutionalArModel, AttentionModel, ScalogramResidualEncoder)):
             raise NotImplementedError("the HIP path covers AudioEncoder / ScalogramResidualEncoder + AudioGRUModel / "
                                       "ConvolutionalArModel / AttentionModel (SURVEY.md section 8 rows a1-a10)")
 

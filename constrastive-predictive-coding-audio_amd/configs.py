@@ -44,6 +44,19 @@ scalogram_resnet_architecture_7 = {'model': ScalogramResidualEncoder, 'phase': T
                                    'blocks': _arch7_blocks(), 'activation_register': None}
 
 
+# ---- ScalogramResidualEncoder as the context network (reference configs/autoregressive_model_configs.py:66-102; effective
+# values: architecture_2's edits of the shared block dictionaries also reach architecture_1 there — both are given here as
+# the reference's module leaves them after import)
+def _ar_resnet_blocks(first_in, last_out):
+    b = dict(scalogram_block_default_dict, in_channels=256, out_channels=512, kernel_size_1=(1, 9), kernel_size_2=(1, 1),
+             ceil_pooling=True, pooling_1=2, batch_norm=True)
+    return [dict(b, in_channels=first_in), dict(b, in_channels=512), dict(b, in_channels=512, out_channels=last_out, kernel_size_1=(1, 8))]
+
+
+ar_resnet_architecture_2 = {'model': ScalogramResidualEncoder, 'phase': False, 'blocks': _ar_resnet_blocks(512, 256),
+                            'encoding_size': 512, 'ar_code_size': 256, 'activation_register': None}
+
+
 def fresh(config):
     """A deep copy of a preset: the model constructors write into the dictionaries they are given (hidden_channels,
     the first block's in_channels with phase=True), exactly as the reference's do."""

@@ -622,9 +622,12 @@ int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void
     return CPC_OK;
 }
 
+// output extents: ceil mode (windows clipped at the border) or floor mode (the remainder is dropped), per axis
 static bool pool_ok(const int* gi, const int* go, int p) {
-    return grid_ok(gi) && grid_ok(go) && p >= 1 && gi[0] == go[0] && gi[5] == go[5] && go[1] == (gi[1] + p - 1) / p &&
-           go[2] == (gi[2] + p - 1) / p;
+    if (!(grid_ok(gi) && grid_ok(go) && p >= 1 && gi[0] == go[0] && gi[5] == go[5])) return false;
+    const bool w_ok = go[1] == (gi[1] + p - 1) / p || (go[1] == gi[1] / p && go[1] > 0);
+    const bool h_ok = go[2] == (gi[2] + p - 1) / p || (go[2] == gi[2] / p && go[2] > 0);
+    return w_ok && h_ok;
 }
 
 int launch_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, hipStream_t st) {

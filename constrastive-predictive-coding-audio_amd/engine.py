@@ -850,6 +850,10 @@ def make_context(eng, ar):
     from .attention_model import AttentionModel
     if isinstance(ar, AttentionModel):
         return AttentionContext(eng, ar)
+    from .scalogram_model import ScalogramResidualEncoder
+    if isinstance(ar, ScalogramResidualEncoder):
+        from .scalogram_engine import ResNetArContext
+        return ResNetArContext(eng, ar)
     raise NotImplementedError(f"no HIP context network for {type(ar).__name__}")
 
 

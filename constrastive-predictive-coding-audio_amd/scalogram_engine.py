@@ -289,13 +289,17 @@ class _BatchNorm:
 class _Block:
     """One ScalogramEncoderBlock (scalogram_model.py:372-479) on grids."""
 
-    def __init__(self, eng, idx, blk, gin: Grid, in_f32, last, next_top):
+    def __init__(self, eng, idx, blk, gin: Grid, in_f32, last, next_top, prefix="encoder.", need_input_grad=None):
         self.eng, self.idx, self.blk, self.gin, self.in_f32, self.last = eng, idx, blk, gin, in_f32, last
         dev, dt = eng.device, eng.dt
         cfg = blk.cfg
-        pre = f"encoder.blocks.{idx}."
-        first = idx == 0
+        pre = f"{prefix}blocks.{idx}."
+        self.need_input_grad = (idx != 0) if need_input_grad is None else bool(need_input_grad)
+        first = not self.need_input_grad
         mm = blk.main_modules
+        ceil = cfg.get('ceil_pooling', False)
+        pooled = lambda n, p: (_ceil_div(n, p) if ceil else n // p) if p > 1 else n
+        self.pool1, self.pool2 = int(cfg.get('pooling_1', 1)), int(cfg.get('pooling_2', 1))
         has_bn = cfg['batch_norm']
         bias = cfg['bias']
         top2 = cfg['top_padding_2'] or 0
@@ -308,23 +312,49 @@ class _Block:
         self.conv_a = _Conv(eng, f"{pre}main_modules.{i1}.weight", f"{pre}main_modules.{i1}.bias" if bias else None, mm[i1], gin,
                             in_f32=in_f32, need_dgrad=not first, relu=not has_bn)
         ya = self.conv_a.y0
+        # [MaxPool2d(pooling_1)] sits between the BatchNorm and the ReLU in the reference (scalogram_model.py:401-405); max
+        # pooling commutes with the monotone ReLU, so here the fused BatchNorm + ReLU output is pooled
+        Ha1, Wa1 = pooled(ya.H, self.pool1), pooled(ya.W, self.pool1)
+        if Ha1 < 1 or Wa1 < 1:
+            raise ValueError(f"block {idx}: pooling_1 leaves nothing of a {ya.H} x {ya.W} activation")
+        k2 = tuple(cfg['kernel_size_2'])
+        G2 = _col_group(cfg['out_channels'], k2[1], (cfg['stride_2'],) * 2, cfg['padding_2'])
+        self.a_full = None
         if has_bn:
-            k2 = tuple(cfg['kernel_size_2'])
-            G2 = _col_group(cfg['out_channels'], k2[1], (cfg['stride_2'],) * 2, cfg['padding_2'])
-            self.a_a = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt, top=top2, tail=(-(top2 + ya.H)) % G2, guard_rows=k2[0] + 16)
-            self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya, self.a_a)
+            self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, top=top2, tail=(-(top2 + Ha1)) % G2, guard_rows=k2[0] + 16)
+            if self.pool1 > 1:
+                self.a_full = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt)
+            self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya,
+                                   self.a_full if self.pool1 > 1 else self.a_a)
         else:
             if top2:
                 raise NotImplementedError("top_padding_2 without batch_norm is not part of the HIP path yet")
-            self.a_a, self.bn_a = ya, None
+            self.bn_a = None
+            if self.pool1 > 1:
+                self.a_full = ya
+                self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, guard_rows=k2[0] + 16)
+            else:
+                self.a_a = ya
         self.conv_b = _Conv(eng, f"{pre}main_modules.{i2}.weight", f"{pre}main_modules.{i2}.bias" if bias else None, mm[i2], self.a_a,
                             relu=not has_bn)
         yb = self.conv_b.y0
+        Hb2, Wb2 = pooled(yb.H, self.pool2), pooled(yb.W, self.pool2)
+        if Hb2 < 1 or Wb2 < 1:
+            raise ValueError(f"block {idx}: pooling_2 leaves nothing of a {yb.H} x {yb.W} activation")
+        self.main_full = None
         if has_bn:
-            self.main = Grid(yb.B, yb.W, yb.H, yb.C, dev, dt)
-            self.bn_b = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_2']}", mm[blk.index['bn_2']], yb, self.main)
+            self.main = Grid(yb.B, Wb2, Hb2, yb.C, dev, dt)
+            if self.pool2 > 1:
+                self.main_full = Grid(yb.B, yb.W, yb.H, yb.C, dev, dt)
+            self.bn_b = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_2']}", mm[blk.index['bn_2']], yb,
+                                   self.main_full if self.pool2 > 1 else self.main)
         else:
-            self.main, self.bn_b = yb, None
+            self.bn_b = None
+            if self.pool2 > 1:
+                self.main_full = yb
+                self.main = Grid(yb.B, Wb2, Hb2, yb.C, dev, dt)
+            else:
+                self.main = yb
         # ---- residual branch
         self.res_conv = self.rp = None
         if blk.residual:
@@ -372,17 +402,20 @@ class _Block:
                 self.res_conv.dy0 = self.d_res
         else:
             self.d_main = self.d_out
+        # with pooling the gradient first goes back through the pooling to the full-resolution activation
+        self.d_main_full = self.main_full.like(dev, guard_rows=self.conv_b.kh + 16) if self.pool2 > 1 else None
         if self.bn_b is not None:
             self.bn_b.dy0 = self.conv_b.y0.like(dev, guard_rows=self.conv_b.kh + 16)
             self.conv_b.dy0 = self.bn_b.dy0
         else:
-            self.conv_b.dy0 = self.d_main
+            self.conv_b.dy0 = self.d_main_full if self.pool2 > 1 else self.d_main
         self.d_a = self.a_a.like(dev, guard_rows=self.conv_b.kh + 16)
+        self.d_a_full = self.a_full.like(dev, guard_rows=self.conv_a.kh + 16) if self.pool1 > 1 else None
         if self.bn_a is not None:
             self.bn_a.dy0 = self.conv_a.y0.like(dev, guard_rows=self.conv_a.kh + 16)
             self.conv_a.dy0 = self.bn_a.dy0
         else:
-            self.conv_a.dy0 = self.d_a
+            self.conv_a.dy0 = self.d_a_full if self.pool1 > 1 else self.d_a
 
     def prepare(self):
         for c in (self.conv_a, self.conv_b, self.res_conv):
@@ -394,9 +427,15 @@ class _Block:
         self.conv_a.forward()
         if self.bn_a is not None:
             self.bn_a.forward()
+        if self.pool1 > 1:
+            _hip.call("cpc_maxpool2d_fwd", self.a_full.ptr(), _desc(self.a_full, self.a_full.desc), self.a_a.ptr(),
+                      _desc(self.a_a, self.a_a.desc), self.pool1, 0, code)
         self.conv_b.forward()
         if self.bn_b is not None:
             self.bn_b.forward()
+        if self.pool2 > 1:
+            _hip.call("cpc_maxpool2d_fwd", self.main_full.ptr(), _desc(self.main_full, self.main_full.desc), self.main.ptr(),
+                      _desc(self.main, self.main.desc), self.pool2, 0, code)
         if self.blk.residual:
             if self.rp is not None:
                 _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.rp.ptr(), _desc(self.rp, self.rp.desc),
@@ -408,21 +447,37 @@ class _Block:
 
     def backward(self):
         e, code = self.eng, self.eng.code
-        first = self.idx == 0
+        first = not self.need_input_grad
         if self.blk.residual:
             self.d_res.t.zero_()
             _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
                       _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, self.ow,
                       0 if self.last else 1, self.r_f32, code)
+
+        def unpool(full, d_full, pooled, d_pooled, p):
+            """gradient of the pooled activation -> gradient of the full-resolution one (zero outside the windows)"""
+            d_full.t.zero_()
+            _hip.call("cpc_maxpool2d_bwd", full.ptr(), d_full.ptr(), _desc(full, full.desc), d_pooled.ptr(), _desc(pooled, pooled.desc),
+                      p, 1, code)
+            return d_full
+
         # second convolution
+        g_b, act_b = self.d_main, self.main
+        if self.pool2 > 1:
+            g_b, act_b = unpool(self.main_full, self.d_main_full, self.main, self.d_main, self.pool2), self.main_full
         if self.bn_b is not None:
-            self.bn_b.backward(self.d_main)
+            self.bn_b.backward(g_b)
         else:
-            _hip.call("cpc_relu_mask", self.d_main.ptr(), self.main.ptr(), self.d_main.rows * self.d_main.C, code)
-        self.conv_b.backward(self.d_a, mask_input=self.bn_a is None)
+            _hip.call("cpc_relu_mask", g_b.ptr(), act_b.ptr(), g_b.rows * g_b.C, code)
+        self.conv_b.backward(self.d_a, mask_input=self.bn_a is None and self.pool1 == 1)
         # first convolution
+        g_a = self.d_a
+        if self.pool1 > 1:
+            g_a = unpool(self.a_full, self.d_a_full, self.a_a, self.d_a, self.pool1)
+            if self.bn_a is None:
+                _hip.call("cpc_relu_mask", g_a.ptr(), self.a_full.ptr(), g_a.rows * g_a.C, code)
         if self.bn_a is not None:
-            self.bn_a.backward(self.d_a)
+            self.bn_a.backward(g_a)
         self.conv_a.backward(None if first else self.d_in)
         # residual branch (adds into the block-input gradient after the main branch wrote it)
         if self.blk.residual:
@@ -691,6 +746,80 @@ class ConvArGridContext:
         d = last.d_out
         d.t.zero_()
         d.t.view(d.B, d.Ha, d.C)[:, d.top + d.H - 1, :] = dc.to(d.t.dtype)
+        for b in reversed(self.blocks):
+            b.backward()
+        self._z_rows(e.dact[-1]).copy_(self.d_x0.t.view(e.B, e.V, e.E))
+
+
+class ResNetArContext:
+    """ScalogramResidualEncoder used as the autoregressive model (reference configs ar_resnet_architecture_1/2: blocks with
+    (1,k) kernels, pooling_1 = 2 with ceil mode, batch norm, residual branches): z (B, E, V) is the grid [B][W = V][H = 1][E];
+    the model takes the first remaining time step of the (B, C, T') result (audio_model.py:203-204)."""
+
+    def __init__(self, eng, ar):
+        self.eng, self.ar = eng, ar
+        if ar.phase:
+            raise ValueError("a ScalogramResidualEncoder used as context network must have phase=False")
+
+    def allocate(self):
+        e, ar = self.eng, self.ar
+        blocks = list(ar.blocks)
+        if blocks[0].cfg['in_channels'] != e.E or blocks[-1].cfg['out_channels'] != e.H:
+            raise ValueError("context network block channels do not match enc_size / ar_size")
+        if blocks[0].cfg['top_padding_1']:
+            raise NotImplementedError("top_padding_1 on the first block")
+        self.x0 = Grid(e.B, e.V, 1, e.E, e.device, e.dt)
+        self.blocks, gin = [], self.x0
+        for i, blk in enumerate(blocks):
+            last = i == len(blocks) - 1
+            next_top = 0 if last else (blocks[i + 1].cfg['top_padding_1'] or 0)
+            b = _Block(e, i, blk, gin, False, last, next_top, prefix="autoregressive_model.", need_input_grad=True)
+            self.blocks.append(b)
+            gin = b.out
+        out = self.blocks[-1].out
+        if out.H != 1:
+            raise NotImplementedError("the context network must end with one row")
+        self.d_x0 = self.x0.like(e.device)
+        d_in = self.d_x0
+        for b in self.blocks:
+            b.allocate_grads(d_in)
+            d_in = b.d_out
+        self.c32 = torch.empty(e.B, out.C, device=e.device, dtype=torch.float32)
+
+    def slab_floats(self):
+        return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)
+
+    def prepare_weights(self):
+        for b in self.blocks:
+            b.prepare()
+
+    def _z_rows(self, buf):
+        e = self.eng
+        t0 = e.T - e.K - e.V
+        return buf.view(e.B, e.geo.alloc[-1], e.E)[:, t0:t0 + e.V, :]
+
+    def forward(self):
+        e = self.eng
+        self.x0.t.view(e.B, e.V, e.E).copy_(self._z_rows(e.act[-1]))
+        for b in self.blocks:
+            b.forward()
+
+    def _first_step(self, grid):
+        return grid.t.view(grid.B, grid.W, grid.Ha, grid.C)[:, 0, grid.top, :]
+
+    def c_operand(self):
+        out = self.blocks[-1].out
+        return out.t, out.top * out.C, out.W * out.Ha * out.C
+
+    def c_float(self):
+        self.c32.copy_(self._first_step(self.blocks[-1].out))
+        return self.c32
+
+    def backward(self, dc):
+        e = self.eng
+        d = self.blocks[-1].d_out
+        d.t.zero_()
+        self._first_step(d).copy_(dc)
         for b in reversed(self.blocks):
             b.backward()
         self._z_rows(e.dact[-1]).copy_(self.d_x0.t.view(e.B, e.V, e.E))

@@ -113,12 +113,11 @@ class ScalogramEncoderBlock(nn.Module):
             args_dict['hidden_channels'] = args_dict['out_channels']
         if args_dict['separable']:
             raise NotImplementedError("separable scalogram convolutions are not part of the HIP path")
-        if args_dict['pooling_1'] > 1 or args_dict['pooling_2'] > 1:
-            raise NotImplementedError("pooling inside the main branch of a scalogram block is not part of the HIP path yet")
         a = args_dict
         self.cfg = {k: a[k] for k in ('in_channels', 'hidden_channels', 'out_channels', 'kernel_size_1', 'kernel_size_2',
                                       'top_padding_1', 'top_padding_2', 'padding_1', 'padding_2', 'stride_1', 'stride_2',
-                                      'bias', 'residual', 'batch_norm')}
+                                      'pooling_1', 'pooling_2', 'bias', 'residual', 'batch_norm')}
+        self.cfg['ceil_pooling'] = bool(a.get('ceil_pooling', False))
         self.main_modules = nn.ModuleList()
         self.index = {}
         for tag, cin, cout in (('1', a['in_channels'], a['hidden_channels']), ('2', a['hidden_channels'], a['out_channels'])):
@@ -130,6 +129,8 @@ class ScalogramEncoderBlock(nn.Module):
             if a['batch_norm']:
                 self.index['bn_' + tag] = len(self.main_modules)
                 self.main_modules.append(nn.BatchNorm2d(cout))
+            if a['pooling_' + tag] > 1:
+                self.main_modules.append(nn.MaxPool2d(kernel_size=a['pooling_' + tag], ceil_mode=self.cfg['ceil_pooling']))
             self.main_modules.append(nn.ReLU())
             self.main_modules.append(ActivationWriter(register=activation_register, name=self.name + '_main_conv_' + tag))
         self.residual = a['residual']

@@ -204,8 +204,9 @@ int cpc_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* 
 int cpc_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
                      const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
                      int dtype, void* stream);
-/* nn.MaxPool2d(kernel = stride = p, ceil_mode=True) of the residual branches (scalogram_model.py:434-436); the backward
- * routes dout to the first maximum of each window (+= if accumulate). */
+/* nn.MaxPool2d(kernel = stride = p): ceil mode (residual branches, scalogram_model.py:434-436; window clipped at the border)
+ * or floor mode (main-branch pooling, :401-403; remainder dropped) according to the extents of the output grid; the backward
+ * routes dout to the first maximum of each window (+= if accumulate; positions outside every window are not written). */
 int cpc_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, void* stream);
 int cpc_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
                       void* stream);

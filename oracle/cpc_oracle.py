@@ -297,13 +297,16 @@ def scalogram_block_forward(x: torch.Tensor, params: Params, prefix: str, cfg: d
             if training:
                 params[bn + "num_batches_tracked"] += 1
             idx += 1
+        if cfg.get("pooling_" + tag, 1) > 1:
+            h = F.max_pool2d(h, cfg["pooling_" + tag], ceil_mode=bool(cfg.get("ceil_pooling", False)))
+            idx += 1
         return torch.relu(h), idx + 2          # ReLU + ActivationWriter
 
     main, idx = conv_bn_relu(x, 0, "1")
     main, _ = conv_bn_relu(main, idx, "2")
     if cfg["residual"]:
         res, ridx = x, 0
-        pool = cfg["stride_1"] * cfg["stride_2"]
+        pool = cfg["stride_1"] * cfg["stride_2"] * cfg.get("pooling_1", 1) * cfg.get("pooling_2", 1)
         if pool > 1:
             res = F.max_pool2d(res, pool, ceil_mode=True)
             ridx = 1
@@ -334,7 +337,8 @@ def item_length(receptive_field: int, downsampling: int, visible_steps: int, pre
 
 
 def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_steps: int,
-                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None, attention=None, scalogram=None, training: bool = True):
+                strides: Sequence[int] = DEFAULT_STRIDES, conv_ar=None, attention=None, scalogram=None, training: bool = True,
+                ar_resnet=None):
     """AudioPredictiveCodingModel.forward with AudioEncoder + AudioGRUModel — audio_model.py:193-211.
     conv_ar = (kernel_sizes, poolings) selects ConvolutionalArModel, attention = (num_layers, num_heads) AttentionModel.
 
@@ -347,7 +351,10 @@ def cpc_forward(x: torch.Tensor, params: Params, visible_steps: int, prediction_
     K, V = prediction_steps, visible_steps
     targets = enc[:, :, -K:]
     z = enc[:, :, -(V + K):-K]
-    if attention is not None:       # (num_layers, num_heads[, dropout_factors])
+    if ar_resnet is not None:       # ScalogramResidualEncoder as the context network (configs ar_resnet_architecture_*): block dicts
+        c3 = scalogram_encoder_forward(z.unsqueeze(2), params, ar_resnet, training, prefix="autoregressive_model.")
+        c = c3[:, :, 0]             # audio_model.py:203-204
+    elif attention is not None:     # (num_layers, num_heads[, dropout_factors])
         c, z = attention_forward(z, params, attention[0], attention[1], dropout_factors=attention[2] if len(attention) > 2 else None)
     elif conv_ar is None:
         c = gru_forward(z, params)
@@ -445,13 +452,14 @@ class OracleTrainer:
     def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
                  strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
                  all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None,
-                 attention=None, scalogram=None):
+                 attention=None, scalogram=None, ar_resnet=None):
         is_buffer = lambda k: ("running_" in k) or k.endswith("num_batches_tracked") or k.endswith("positional_encoder.pe")
         self.buffers = {k: v.detach().clone() for k, v in params.items() if is_buffer(k)}
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if not is_buffer(k)}
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.scalogram = scalogram
+        self.ar_resnet = ar_resnet
         self.V, self.K = visible_steps, prediction_steps
         self.strides = tuple(strides)
         self.score = SCORE_FUNCTIONS[score]
@@ -468,7 +476,7 @@ class OracleTrainer:
             p.grad = None
         x = batch if self.scalogram is not None else batch.unsqueeze(1)
         pred, targ, _, _ = cpc_forward(x, {**self.params, **self.buffers}, self.V, self.K, self.strides, self.conv_ar, self.attention,
-                                       self.scalogram)
+                                       self.scalogram, ar_resnet=self.ar_resnet)
         loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
         loss.backward()
         return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}

@@ -22,6 +22,7 @@ Fixtures written (all float32 unless noted):
   attention_model.npz   AudioEncoder + AttentionModel (2 layers, 8 heads, dropout 0) forward, losses, gradients
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
+  ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval),
                         trainer losses, gradients, BatchNorm running statistics
 """
@@ -564,6 +565,85 @@ def gen_conv_ar_bn():
           float(np.abs(out["bn_res/train/c"]).mean()), float(np.abs(out["bn/train/c"]).mean()))
 
 
+def _ar_resnet_blocks(E, H):
+    """Shrunken ar_resnet_architecture_1/2 (configs/autoregressive_model_configs.py:66-102): (1,k) kernels, pooling_1 = 2 in
+    ceil mode between BatchNorm and ReLU, (1,1) second convolution, residual branches with pooled 1x1 projections."""
+    base = {'in_channels': E, 'hidden_channels': None, 'out_channels': E, 'kernel_size_1': (1, 5), 'kernel_size_2': (1, 1),
+            'top_padding_1': None, 'top_padding_2': None, 'padding_1': 0, 'padding_2': 0, 'stride_1': 1, 'stride_2': 1,
+            'pooling_1': 2, 'pooling_2': 1, 'bias': True, 'separable': False, 'residual': True, 'batch_norm': True,
+            'ceil_pooling': True}
+    return [dict(base, out_channels=96), dict(base, in_channels=96, out_channels=96), dict(base, in_channels=96, out_channels=H,
+                                                                                           kernel_size_1=(1, 4))]
+
+
+def gen_ar_resnet():
+    import scalogram_model as ref_scal
+    import copy
+    C, H, K, V, B = 64, 48, 4, 30, 6
+    L = 465 + (V + K) * 160 + 5
+    scale = {f"encoder.layers.{l}.weight": s for l, s in enumerate([4.0, 2.5, 2.5, 2.5, 2.5])}
+    scale["prediction_model.weight"] = 0.5
+
+    def build():
+        torch.manual_seed(23)
+        enc = ref_model.AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        ar = ref_scal.ScalogramResidualEncoder(args_dict={'phase': False, 'blocks': copy.deepcopy(_ar_resnet_blocks(C, H)),
+                                                          'activation_register': None})
+        model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K)
+        g = torch.Generator().manual_seed(31)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n in scale:
+                    p.mul_(scale[n])
+                if n.startswith("autoregressive_model.") and p.dim() == 1 and "main_modules" in n and n.endswith("weight"):
+                    p.add_(0.3 * torch.randn(p.shape, generator=g))
+            for n, b in model.named_buffers():
+                if n.endswith("running_mean"):
+                    b.add_(0.1 * torch.randn(b.shape, generator=g))
+                if n.endswith("running_var"):
+                    b.mul_(1.0 + 0.5 * torch.rand(b.shape, generator=g))
+        return model
+
+    out = {}
+    model = build()
+    for k, v in np_state(model).items():
+        out["param/" + k] = v
+    g = torch.Generator().manual_seed(14)
+    n_items = 18
+    data = torch.randn(n_items, L, generator=g) * 0.5
+    out["data"] = data.numpy()
+    meta = {"C": C, "H": H, "K": K, "V": V, "B": B, "L": L, "n_items": n_items, "blocks": _ar_resnet_blocks(C, H), "runs": []}
+    with torch.no_grad():
+        for mode in ("eval", "train"):
+            model.train(mode == "train")
+            pz, tg, z, c = model(data[:B].unsqueeze(1))
+            out[f"{mode}/predicted_z"], out[f"{mode}/c"] = pz.numpy(), c.numpy()
+    rid = 0
+    for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
+                                                ("linear", ref_train.linear_score_function, True, 0.01, 3, 1e-4)):
+        model = build()
+        ds = TensorDataset(data)
+        logger = Logger()
+        with quiet():
+            tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
+                                                        score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H)
+            random.seed(44)
+            tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
+        tag = f"run{rid}"
+        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+                             "python_seed": 44, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
+                             "loss": logger.loss_meter.values})
+        if steps == 1:
+            for n, p in model.named_parameters():
+                out[f"{tag}/grad/{n}"] = p.grad.numpy().copy()
+        rid += 1
+    np.savez_compressed(os.path.join(OUT, "ar_resnet_model.npz"), **out)
+    with open(os.path.join(OUT, "ar_resnet_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("ar_resnet:", [(r["score"], r["all_timesteps"], r["loss"]) for r in meta["runs"]], out["train/c"].shape,
+          float(np.abs(out["train/c"]).mean()))
+
+
 # ------------------------------------------------------------------ encoder reference test
 def gen_encoder_ref_test():
     out = {}
@@ -707,7 +787,10 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "conv_ar_bn"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "conv_ar_bn", "ar_resnet"]
+    if "ar_resnet" in which:
+        _install_librosa_stand_in()
+        gen_ar_resnet()
     if "conv_ar_bn" in which:
         gen_conv_ar_bn()
     if "scalogram" in which:

@@ -860,3 +860,60 @@ def test_global_negatives_two_ranks_equal_single_process_reference(tmp_path, all
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GN-GPU-OK" in outs[0]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ar_resnet_context_matches_reference(golden_dir, dtype):
+    """ScalogramResidualEncoder as the autoregressive model (reference configs ar_resnet_architecture_1/2, shrunk): (1,k)
+    kernels, MaxPool2d(2, ceil) between BatchNorm and ReLU, pooled residual projections — forward (eval / train), losses
+    and gradients vs fixtures from the reference."""
+    from cpc_audio_amd.scalogram_model import ScalogramResidualEncoder
+    g = _load(golden_dir, "ar_resnet_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "ar_resnet_model.json")))
+    C, H, K, V, B = meta["C"], meta["H"], meta["K"], meta["V"], meta["B"]
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+
+    def build():
+        import copy
+        blocks = copy.deepcopy(meta["blocks"])
+        for b in blocks:
+            b["kernel_size_1"], b["kernel_size_2"] = tuple(b["kernel_size_1"]), tuple(b["kernel_size_2"])
+        enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        ar = ScalogramResidualEncoder(args_dict={'phase': False, 'blocks': blocks, 'activation_register': None})
+        model = AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype=dtype)
+        assert list(model.state_dict().keys()) == list(state.keys())
+        model.load_state_dict(state)
+        return model.to(DEV)
+
+    data = torch.from_numpy(g["data"])
+    tol = 3e-4 if dtype == "fp32" else 6e-2
+    model = build()
+    x = data[:B].unsqueeze(1).to(DEV)
+    with torch.no_grad():
+        for mode in ("eval", "train"):
+            model.train(mode == "train")
+            pz, tg, z, c = model(x)
+            assert _rel(c, g[f"{mode}/c"]) < tol and _rel(pz, g[f"{mode}/predicted_z"]) < tol, mode
+    for run in meta["runs"]:
+        model = build()
+        ds = TensorAudioDataset(data, device=DEV)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                          score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                          prediction_steps=K, ar_size=H)
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=B, epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+        ltol = 2e-4 if dtype == "fp32" else 2e-2
+        for i in range(run["steps"]):
+            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= ltol * abs(run["loss"][i]) * (1 + 4 * i), (run["tag"], i)
+        if run["steps"] == 1:
+            for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                name = k.split("/grad/")[1]
+                got = dict(model.named_parameters())[name].grad
+                ref = torch.from_numpy(g[k]).double()
+                if ref.abs().max().item() < 1e-6:
+                    assert got.abs().max().item() < (1e-4 if dtype == "fp32" else 5e-2)
+                    continue
+                l2 = ((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+                assert l2 < (2e-3 if dtype == "fp32" else 0.35), (run["tag"], name, l2)

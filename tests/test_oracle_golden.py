@@ -393,3 +393,39 @@ def test_conv_ar_batchnorm_residual(golden_dir):
                         _close(grads[pname] / scale, ref / scale, rtol=1e-3, atol=2e-4)
                 loss, smax = tr.step(batch)
                 assert abs(loss - run["loss"][i]) <= 2e-4 * max(1.0, abs(run["loss"][i])), (name, run["tag"], i, loss)
+
+
+def test_ar_resnet_context(golden_dir):
+    """ScalogramResidualEncoder as the context network (pooling inside the blocks, ceil mode): forward in train / eval mode,
+    trainer losses and gradients vs the reference."""
+    g = _load(golden_dir, "ar_resnet_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "ar_resnet_model.json")))
+    blocks = [dict(b, kernel_size_1=tuple(b["kernel_size_1"]), kernel_size_2=tuple(b["kernel_size_2"])) for b in meta["blocks"]]
+    data = torch.from_numpy(g["data"])
+    B, V, K = meta["B"], meta["V"], meta["K"]
+    p0 = _params(g)
+    for mode in ("eval", "train"):
+        p = {k: v.clone() for k, v in p0.items()}
+        with torch.no_grad():
+            pz, tg, z, c = O.cpc_forward(data[:B].unsqueeze(1), p, V, K, ar_resnet=blocks, training=mode == "train")
+        _close(c, g[mode + "/c"], rtol=1e-4, atol=2e-5)
+        _close(pz, g[mode + "/predicted_z"], rtol=1e-4, atol=2e-5)
+    for run in meta["runs"]:
+        tr = O.OracleTrainer(p0, V, K, score=run["score"], all_timesteps=run["all_timesteps"], regularization=run["reg"], lr=run["lr"],
+                             ar_resnet=blocks)
+        for i, idx in enumerate(run["batches"]):
+            batch = data[idx]
+            if run["steps"] == 1:
+                saved = {k: v.clone() for k, v in tr.buffers.items()}
+                loss, smax, grads = tr.loss_and_grads(batch)
+                tr.buffers = saved
+                for k in [k for k in g if k.startswith(run["tag"] + "/grad/")]:
+                    name = k.split("/grad/")[1]
+                    ref = torch.from_numpy(g[k])
+                    scale = ref.abs().max().item() + 1e-12
+                    if scale < 1e-6:
+                        assert grads[name].abs().max().item() < 1e-5
+                        continue
+                    _close(grads[name] / scale, ref / scale, rtol=1e-3, atol=2e-4)
+            loss, smax = tr.step(batch)
+            assert abs(loss - run["loss"][i]) <= 2e-4 * max(1.0, abs(run["loss"][i])), (run["tag"], i, loss)
