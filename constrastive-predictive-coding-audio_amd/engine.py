@@ -509,9 +509,9 @@ class ConvArContext:
         self.channels = list(ar.channel_count)
         self.nb = len(self.kernels)
         if ar.batch_norm or ar.residual:
-            raise NotImplementedError("ConvolutionalArModel with batch_norm / residual is not part of the HIP path yet")
+            raise NotImplementedError("ConvArContext is the lean path for plain configurations; make_context() routes batch_norm / residual to ConvArGridContext")
         if any(s != 1 for s in self.strides):
-            raise NotImplementedError("ConvolutionalArModel: only stride-1 convolutions (all reference configs) are supported")
+            raise NotImplementedError("ConvArContext handles stride-1 convolutions; make_context() routes strided ones to ConvArGridContext")
         if self.channels[0] != eng.E or self.channels[-1] != eng.H:
             raise ValueError("ConvolutionalArModel channel_count does not match enc_size / ar_size")
         ch = 8 if eng.dt == torch.bfloat16 else 4
@@ -581,11 +581,11 @@ class ConvArContext:
             if self.pools[l] > 1:
                 if l == 0:
                     t0 = e.T - e.K - e.V
-                    raise NotImplementedError("pooling in the first ConvolutionalArBlock is not supported yet")
+                    raise NotImplementedError("ConvArContext: no pooling in the first block (make_context() routes that to ConvArGridContext)")
                 _hip.call("cpc_maxpool_fwd", _hip.ptr(self.y[l - 1]), _hip.ptr(self.x[l]), B, cin, self.pools[l], self.lo[l - 1],
                           self.la[l - 1], self.lp[l], la, code)
             elif l > 0:
-                raise NotImplementedError("ConvolutionalArBlock without pooling after the first block is not supported yet")
+                raise NotImplementedError("ConvArContext: pooling in every later block (make_context() routes other layouts to ConvArGridContext)")
             a, a_rpi, a_item = self._block_input(l)
             _hip.gemm_nt(a, _hip.ptr(self.w_fwd[l]), _hip.ptr(self.y[l]), B * la, cout, kw * cin, cin, kw * cin, cout, code,
                          bias=_hip.ptr(p.get(self._name(l, "bias"))), a_rpi=a_rpi, a_item=a_item, c_rpi=la, c_item=la * cout,
