@@ -45,7 +45,7 @@ __device__ __forceinline__ void load8<float>(const float* src, float* v) {
 template <typename T, int KW>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int C,
-                                                        int stride, int kw_rt, long long ldx, int L_valid, int L_alloc) {
+                                                        int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu) {
     const int kw = KW > 0 ? KW : kw_rt;
     __shared__ float xs[C1_POS * 8 + C1_MAXK + 8];     // stride <= 8 supported
     const int b = blockIdx.y;
@@ -83,8 +83,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaf(xv, wr[j][e], v[e]);
             }
+            if (relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;      // pad rows are written as zeros
@@ -170,11 +172,11 @@ static bool c1_ok(int C, int stride, int kw) {
 }
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int dtype, hipStream_t stream) {
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream) {
     if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid) return CPC_EINVAL;
     dim3 grid((L_alloc + C1_POS - 1) / C1_POS, B);
 #define LAUNCH(T, KWT) \
-    hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc)
+    hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu)
     if (dtype == CPC_DTYPE_BF16) {
         if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);
     } else if (dtype == CPC_DTYPE_F32) {

@@ -63,10 +63,10 @@ int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nbl
 }
 
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw, long long ldx,
-                  int L_valid, int L_alloc, int dtype, void* stream) {
+                  int L_valid, int L_alloc, int relu, int dtype, void* stream) {
     if (!x || !w || !y) return CPC_EINVAL;
     if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
-    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, dtype, (hipStream_t)stream);
+    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, relu, dtype, (hipStream_t)stream);
 }
 
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx, int L_valid,

@@ -51,7 +51,7 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
 int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int dtype, hipStream_t stream);
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream);
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
 int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,

@@ -214,7 +214,8 @@ class CPCEngine:
         self._check_input(x)
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
         _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
-                  _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0], code)
+                  _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
+                  1 if self.n > 1 else 0, code)
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],

@@ -85,10 +85,11 @@ int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw,
 /* slabs[blk][n] = partial column sums of X[M][N] (T) — bias gradients; reduce with cpc_reduce_slabs(I=1). */
 int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nblocks, int dtype, void* stream);
 
-/* AudioEncoder layer 1 (C_in = 1): y[b][t][co] = relu(bias[co] + sum_j x[b][t*stride+j] * w[co][j])
- * (audio_model.py:38-39 for l == 0).  x: f32 [B][ldx]; w: f32 [C][kw] (reference layout); y: T [B][L_alloc][C]. */
+/* AudioEncoder layer 1 (C_in = 1): y[b][t][co] = act(bias[co] + sum_j x[b][t*stride+j] * w[co][j]), act = relu when
+ * relu != 0 (audio_model.py:38-41 for l == 0: the last layer of the stack has no activation, so a one-layer encoder passes
+ * relu = 0).  x: f32 [B][ldx]; w: f32 [C][kw] (reference layout); y: T [B][L_alloc][C]. */
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                  long long ldx, int L_valid, int L_alloc, int dtype, void* stream);
+                  long long ldx, int L_valid, int L_alloc, int relu, int dtype, void* stream);
 /* Weight/bias gradient of layer 1: slabs[nblk_b*nblk_t][(kw+1)][C] partials (row kw = bias); reduce with
  * cpc_reduce_slabs.  nblk_t blocks split the positions, nblk_b (<= B) blocks stride over the items. */
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,

@@ -235,7 +235,7 @@ def test_conv1_fwd_bwd(dt, C, kw, stride):
     code = _hip.dtype_code(dt)
     dx, dw, db = dev(x), dev(w), dev(bias)
     y = torch.full((B, La, C), float("nan"), device=DEV, dtype=dt)
-    _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(y), B, C, stride, kw, L, Lv, La, code)
+    _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(y), B, C, stride, kw, L, Lv, La, 1, code)
     xr = x.double().unsqueeze(1).requires_grad_(False)
     wr = w.double().requires_grad_(True)
     br = bias.double().requires_grad_(True)

@@ -917,3 +917,33 @@ def test_ar_resnet_context_matches_reference(golden_dir, dtype):
                     continue
                 l2 = ((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
                 assert l2 < (2e-3 if dtype == "fp32" else 0.35), (run["tag"], name, l2)
+
+
+@pytest.mark.parametrize("strides,kernels,channels", [([3, 2, 2], [7, 5, 3], [16, 32, 64]), ([4, 4, 2, 2], [8, 8, 4, 2], [32, 32, 48, 48]),
+                                                      ([2], [6], [64])])
+def test_other_encoder_geometries_against_oracle(strides, kernels, channels):
+    """AudioEncoder configurations other than the default 5-layer stack (different depth, strides, kernel sizes, channel
+    counts per layer, kernel == stride): loss and gradients vs the oracle (fp32)."""
+    E, H, K, V, B = channels[-1], 32, 3, 7, 4
+    ds_, rf = O.encoder_geometry(strides, kernels)
+    L = rf + (V + K) * ds_ + 5
+    torch.manual_seed(len(strides))
+    enc = AudioEncoder({'strides': strides, 'kernel_sizes': kernels, 'channel_count': channels, 'bias': True})
+    assert enc.downsampling_factor == ds_ and enc.receptive_field == rf
+    model = AudioPredictiveCodingModel(enc, AudioGRUModel(E, H), enc_size=E, ar_size=H, visible_steps=V, prediction_steps=K,
+                                       compute_dtype="fp32")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("weight") and n.startswith("encoder"):
+                p.mul_(2.0)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(3)) * 0.5
+    out = model.engine(B, L).loss_and_grads(x.to(DEV).contiguous(), softplus=True, regularization=1.0)
+    ot = O.OracleTrainer(state, V, K, strides=strides, score="softplus", regularization=1.0)
+    loss, smax, grads = ot.loss_and_grads(x)
+    assert abs(float(out[0]) - float(loss)) <= 2e-4 * max(1.0, abs(float(loss)))
+    for n, ref in grads.items():
+        ref = ref.double()
+        got = model._grad[n].double().cpu()
+        assert ((got - ref).norm() / (ref.norm() + 1e-30)).item() < 2e-3, n
