@@ -698,7 +698,7 @@ __device__ __forceinline__ uint4 tn_frag_rb(const unsigned char* tile, int rowb,
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <typename TO, int WI, int WJ, int TI, int TJ>
+template <typename TO, int WI, int WJ, int TI, int TJ, bool PLAIN>
 __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
     typedef bf16_t T;
     constexpr int BKM = 64;
@@ -726,26 +726,49 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
     const int cha = tid % CPRA, chb = tid % CPRB, srow = tid / CPRA;
     const long long acol = min(i0 + cha * 8, p.I - 8);
     const long long bcol = min(j0 + chb * 8, p.J - 8);
-    const bool plain = (p.a_rpi == 0) && (p.b_rpi == 0);
     const int sda = srow * ROWA + cha * 16, sdb = ATILE + srow * ROWB_ + chb * 16;
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-#define TN_LOAD1(RA, RB, mrow)                                                                               \
+    // PLAIN (both operands are ordinary row-major matrices: the conv weight gradients): row m of a stage is a fixed offset
+    // from the stage's first row.  Stages that lie entirely inside [m_begin, m_end) — all but possibly the last — load without
+    // clamping or masking, so their eight global loads stay in flight under the MFMAs of the current stage; only a ragged
+    // last stage clamps the row index and zeroes the rows beyond the split's end (they would otherwise add to the sums).
+    const T* const pa = Ab + acol;
+    const T* const pb = Bb + bcol;
+    const long long a16 = 16LL * p.lda, b16 = 16LL * p.ldb;
+#define TN_LOAD_RAGGED(RA, RB, mrow)                                                                         \
     do {                                                                                                     \
         const int m_ = (mrow);                                                                               \
         const int mc_ = min(m_, p.M - 1);                                                                    \
-        const long long ao_ = plain ? (long long)mc_ * p.lda : row_off(mc_, p.a_rpi, p.a_item, p.lda);       \
-        const long long bo_ = plain ? (long long)mc_ * p.ldb : row_off(mc_, p.b_rpi, p.b_item, p.ldb);       \
-        RA = *(const uint4*)(Ab + ao_ + acol);                                                               \
-        RB = *(const uint4*)(Bb + bo_ + bcol);                                                               \
+        RA = *(const uint4*)(pa + (PLAIN ? (long long)mc_ * p.lda : row_off(mc_, p.a_rpi, p.a_item, p.lda))); \
+        RB = *(const uint4*)(pb + (PLAIN ? (long long)mc_ * p.ldb : row_off(mc_, p.b_rpi, p.b_item, p.ldb))); \
         if (m_ >= m_end) { RA = zero4; RB = zero4; }                                                         \
     } while (0)
-#define TN_GLOAD(mb)                              \
-    do {                                          \
-        TN_LOAD1(ra0, rb0, (mb) + srow);          \
-        TN_LOAD1(ra1, rb1, (mb) + srow + 16);     \
-        TN_LOAD1(ra2, rb2, (mb) + srow + 32);     \
-        TN_LOAD1(ra3, rb3, (mb) + srow + 48);     \
+#define TN_GLOAD(st)                                                                                         \
+    do {                                                                                                     \
+        const int mb_ = m_begin + (st) * BKM + srow;                                                         \
+        if ((st) < nfull) {                                                                                  \
+            if constexpr (PLAIN) {                                                                           \
+                const T* qa = pa + (long long)mb_ * p.lda;                                                   \
+                const T* qb = pb + (long long)mb_ * p.ldb;                                                   \
+                ra0 = *(const uint4*)(qa);           rb0 = *(const uint4*)(qb);                              \
+                ra1 = *(const uint4*)(qa + a16);     rb1 = *(const uint4*)(qb + b16);                        \
+                ra2 = *(const uint4*)(qa + 2 * a16); rb2 = *(const uint4*)(qb + 2 * b16);                    \
+                ra3 = *(const uint4*)(qa + 3 * a16); rb3 = *(const uint4*)(qb + 3 * b16);                    \
+            } else {                                                                                         \
+                ra0 = *(const uint4*)(pa + row_off(mb_, p.a_rpi, p.a_item, p.lda));                          \
+                rb0 = *(const uint4*)(pb + row_off(mb_, p.b_rpi, p.b_item, p.ldb));                          \
+                ra1 = *(const uint4*)(pa + row_off(mb_ + 16, p.a_rpi, p.a_item, p.lda));                     \
+                rb1 = *(const uint4*)(pb + row_off(mb_ + 16, p.b_rpi, p.b_item, p.ldb));                     \
+                ra2 = *(const uint4*)(pa + row_off(mb_ + 32, p.a_rpi, p.a_item, p.lda));                     \
+                rb2 = *(const uint4*)(pb + row_off(mb_ + 32, p.b_rpi, p.b_item, p.ldb));                     \
+                ra3 = *(const uint4*)(pa + row_off(mb_ + 48, p.a_rpi, p.a_item, p.lda));                     \
+                rb3 = *(const uint4*)(pb + row_off(mb_ + 48, p.b_rpi, p.b_item, p.ldb));                     \
+            }                                                                                                \
+        } else {                                                                                             \
+            TN_LOAD_RAGGED(ra0, rb0, mb_);      TN_LOAD_RAGGED(ra1, rb1, mb_ + 16);                          \
+            TN_LOAD_RAGGED(ra2, rb2, mb_ + 32); TN_LOAD_RAGGED(ra3, rb3, mb_ + 48);                          \
+        }                                                                                                    \
     } while (0)
 #define TN_LSTORE(base)                                                                      \
     do {                                                                                     \
@@ -764,8 +787,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nst = (m_end - m_begin + BKM - 1) / BKM;
+    const int nfull = (m_end - m_begin) / BKM;            // stages with all 64 rows inside the split
     if (nst > 0) {
-        TN_GLOAD(m_begin);
+        TN_GLOAD(0);
         TN_LSTORE(lds);
     }
     __syncthreads();
@@ -773,7 +797,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
         const unsigned char* ldsA = lds + (t & 1) * STAGE;
         const unsigned char* ldsB = ldsA + ATILE;
         const bool more = t + 1 < nst;
-        if (more) TN_GLOAD(m_begin + (t + 1) * BKM);
+        if (more) TN_GLOAD(t + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 fa[TI], fb[TJ];
@@ -789,7 +813,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
         if (more) TN_LSTORE(lds + ((t + 1) & 1) * STAGE);
         __syncthreads();
     }
-#undef TN_LOAD1
+#undef TN_LOAD_RAGGED
 #undef TN_GLOAD
 #undef TN_LSTORE
 
@@ -1045,13 +1069,23 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
         GemmTN q = p;
         q.m_chunk = eff_chunk;
         grid = dim3(nsplit, numI * numJ, batch);
+        const bool plain = p.a_rpi == 0 && p.b_rpi == 0;
+#define TN_LAUNCH(WII, WJJ, TII, TJJ, NTH)                                                                               \
+    do {                                                                                                                 \
+        if (plain) {                                                                                                     \
+            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);   \
+            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);      \
+        } else {                                                                                                         \
+            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, WII, WJJ, TII, TJJ, false>), grid, dim3(NTH), 0, stream, q);  \
+            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, WII, WJJ, TII, TJJ, false>), grid, dim3(NTH), 0, stream, q);     \
+        }                                                                                                                \
+    } while (0)
         if (big) {
-            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, 2, 4, 8, 4>), grid, dim3(512), 0, stream, q);
+            TN_LAUNCH(2, 4, 8, 4, 512);
         } else {
-            if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, 2, 2, 4, 4>), grid, dim3(256), 0, stream, q);
+            TN_LAUNCH(2, 2, 4, 4, 256);
         }
+#undef TN_LAUNCH
     } else if (dtype == CPC_DTYPE_BF16) {
         if (of32) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
