@@ -145,6 +145,16 @@ class CPCEngine:
         need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
         self.colsum_blocks = 1024
         need.append(self.colsum_blocks * max(self.channels))
+        # Side stream for the short, latency-bound kernels of the weight-gradient path (bias column sums, slab reductions,
+        # operand-layout preparation): they run beside the large GEMMs of the main stream instead of between them.  The big
+        # GEMMs all stay on the main stream.  Each layer's weight-gradient slabs get their own buffer so that the next layer's
+        # GEMM never waits for the previous reduction.
+        self.aux = torch.cuda.Stream(device=dev, priority=-1)
+        self.wslab = [None] + [torch.empty(need[l], device=dev, dtype=torch.float32) for l in range(1, n)]
+        self.aux_slabs = torch.empty(self.colsum_blocks * max(self.channels), device=dev, dtype=torch.float32)
+        self._ev_d = [torch.cuda.Event() for _ in range(n)]
+        self._ev_w = [torch.cuda.Event() for _ in range(n)]
+        self._ev_prep = (torch.cuda.Event(), torch.cuda.Event())
         return need
 
     def _alloc_head(self, need):
@@ -209,13 +219,15 @@ class CPCEngine:
         if x.dtype != torch.float32 or tuple(x.shape) != (self.B, self.L) or not x.is_contiguous():
             raise ValueError(f"expected a contiguous float32 batch of shape ({self.B}, {self.L}), got {tuple(x.shape)} {x.dtype}")
 
-    def encoder_forward(self, x):
+    def encoder_forward(self, x, after_layer1=None):
         """AudioEncoder.forward (audio_model.py:36-44): relu(conv) x (n-1), then a bare conv."""
         self._check_input(x)
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
         _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
                   1 if self.n > 1 else 0, code)
+        if after_layer1 is not None:
+            after_layer1()
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
@@ -233,8 +245,19 @@ class CPCEngine:
                      a_rpi=1, a_item=cstride)
 
     def forward(self, x):
-        self.prepare_weights()
-        self.encoder_forward(x)
+        if type(self) is CPCEngine and self.n > 1:
+            # the operand-layout kernels (a dozen short launches) run on the side stream under the layer-1 convolution, which
+            # reads the f32 master parameters directly
+            main, aux = torch.cuda.current_stream(), self.aux
+            self._ev_prep[0].record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(self._ev_prep[0])
+                self.prepare_weights()
+                self._ev_prep[1].record(aux)
+            self.encoder_forward(x, after_layer1=lambda: main.wait_event(self._ev_prep[1]))
+        else:
+            self.prepare_weights()
+            self.encoder_forward(x)
         self.context_forward()
 
     # views of the forward results in the reference's shapes (storage dtype, no copies)
@@ -317,10 +340,11 @@ class CPCEngine:
                      flags=_hip.GEMM_OUT_F32, **kw)
         _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad, grad_offset), I, J, nsplit, I * J, 1, 1, J, 0)
 
-    def _colsum_to_grad(self, X, grad, M, N, code=None):
+    def _colsum_to_grad(self, X, grad, M, N, code=None, scratch=None):
         nb = min(self.colsum_blocks, max(1, M // 64))
-        _hip.call("cpc_colsum", X, _hip.ptr(self.slabs), M, N, N, nb, self.code if code is None else code)
-        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad), 1, N, nb, N, 1, 1, 0, 0)
+        scratch = self.slabs if scratch is None else scratch
+        _hip.call("cpc_colsum", X, _hip.ptr(scratch), M, N, N, nb, self.code if code is None else code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(scratch), _hip.ptr(grad), 1, N, nb, N, 1, 1, 0, 0)
 
     def backward(self, x, add_dc: Optional[torch.Tensor] = None, add_dz: Optional[torch.Tensor] = None, grad_ready_hook=None):
         """Gradients of everything upstream of (predicted_z, targets, z, c) into the model's flat gradient buffer.
@@ -361,25 +385,34 @@ class CPCEngine:
         g, code = self.model._grad, self.code
         B, n = self.B, self.n
         La, Lv = self.geo.alloc, self.geo.valid
-        # encoder, top layer down to layer 2
+        # encoder, top layer down to layer 2.  Main stream: weight-gradient GEMM, data-gradient GEMM.  Side stream: the bias
+        # column sum (needs dact[l]) and the slab reduction (needs the weight-gradient GEMM), see _alloc_encoder.
+        main, aux = torch.cuda.current_stream(), self.aux
         for l in range(n - 1, 0, -1):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             bname = f"encoder.layers.{l}.bias"
             if bname in g:
-                self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout)
+                self._ev_d[l].record(main)
+                with torch.cuda.stream(aux):
+                    aux.wait_event(self._ev_d[l])
+                    self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
             flops = 2.0 * B * La[l] * cout * kw * cin
-            _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.slabs), B, cin, cout, kw, s,
+            _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
                       La[l], self.nsplit[l], code,
                       key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32, _hip.tn_tile(code, B * La[l], kw * cin, cout, self.nsplit[l],
                                                                                              self._chunk(B * La[l], self.nsplit[l]))),
                       work=flops,
                       shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
-            _hip.call("cpc_reduce_conv_w", _hip.ptr(self.slabs), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
-                      self.nsplit[l], kw * cin * cout)
-            if grad_ready_hook is not None and l == 2 and n > 2:
-                # everything from encoder layer index 2 upwards (+ GRU, predictor: later in the flat buffer) is final
-                lo = self.model._offset["encoder.layers.2.weight"]
-                grad_ready_hook(lo, self.model._flat_grad.numel())
+            self._ev_w[l].record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(self._ev_w[l])
+                _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
+                          self.nsplit[l], kw * cin * cout)
+                if grad_ready_hook is not None and l == 2 and n > 2:
+                    # everything from encoder layer index 2 upwards (+ GRU, predictor: later in the flat buffer) is final once
+                    # the side stream gets here (its wait on _ev_w covers all earlier main-stream work)
+                    lo = self.model._offset["encoder.layers.2.weight"]
+                    grad_ready_hook(lo, self.model._flat_grad.numel())
             _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
                       _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
                       key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
@@ -395,6 +428,7 @@ class CPCEngine:
         if "encoder.layers.0.bias" in g:
             _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs, k0 * c0), _hip.ptr(g["encoder.layers.0.bias"]), 1, c0, nbb * nblk, stride,
                       1, 1, 0, 0)
+        main.wait_stream(aux)
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
