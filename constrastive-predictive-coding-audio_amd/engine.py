@@ -90,6 +90,8 @@ class CPCEngine:
             raise ValueError("enc_size does not match the encoder's last channel count")
         self._check_supported()
         model._flatten_parameters(self.device)
+        # high-priority side stream for short kernels that need not sit between the large GEMMs (see _alloc_encoder)
+        self.aux = torch.cuda.Stream(device=self.device, priority=-1)
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         self._alloc()
 
@@ -149,7 +151,6 @@ class CPCEngine:
         # operand-layout preparation): they run beside the large GEMMs of the main stream instead of between them.  The big
         # GEMMs all stay on the main stream.  Each layer's weight-gradient slabs get their own buffer so that the next layer's
         # GEMM never waits for the previous reduction.
-        self.aux = torch.cuda.Stream(device=dev, priority=-1)
         self.wslab = [None] + [torch.empty(need[l], device=dev, dtype=torch.float32) for l in range(1, n)]
         self.aux_slabs = torch.empty(self.colsum_blocks * max(self.channels), device=dev, dtype=torch.float32)
         self._ev_d = [torch.cuda.Event() for _ in range(n)]
@@ -332,13 +333,14 @@ class CPCEngine:
                      c_rpi=K, c_item=Ltop * E, c_valid=K)
 
     # ------------------------------------------------------------------------------------------ backward
-    def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, grad_offset=0, **kw):
+    def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, grad_offset=0, scratch=None, **kw):
         """grad[grad_offset + i*J + j] = sum_m A[m][i] B[m][j] via f32 slabs + deterministic reduction."""
         code = self.code
         chunk = self._chunk(M, nsplit)
-        _hip.gemm_tn(A, B_, _hip.ptr(self.slabs), M, I, J, lda, ldb, J, code, nsplit=nsplit, m_chunk=chunk, slab_stride=I * J,
+        scratch = self.slabs if scratch is None else scratch
+        _hip.gemm_tn(A, B_, _hip.ptr(scratch), M, I, J, lda, ldb, J, code, nsplit=nsplit, m_chunk=chunk, slab_stride=I * J,
                      flags=_hip.GEMM_OUT_F32, **kw)
-        _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs), _hip.ptr(grad, grad_offset), I, J, nsplit, I * J, 1, 1, J, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(scratch), _hip.ptr(grad, grad_offset), I, J, nsplit, I * J, 1, 1, J, 0)
 
     def _colsum_to_grad(self, X, grad, M, N, code=None, scratch=None):
         nb = min(self.colsum_blocks, max(1, M // 64))
@@ -379,6 +381,7 @@ class CPCEngine:
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
         self._backward_encoder(x, grad_ready_hook)
+        torch.cuda.current_stream().wait_stream(self.aux)
 
     def _backward_encoder(self, x, grad_ready_hook=None):
         """Encoder part of the backward pass: consumes the top-layer gradient, fills the encoder's parameter gradients."""
@@ -428,7 +431,6 @@ class CPCEngine:
         if "encoder.layers.0.bias" in g:
             _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs, k0 * c0), _hip.ptr(g["encoder.layers.0.bias"]), 1, c0, nbb * nblk, stride,
                       1, 1, 0, 0)
-        main.wait_stream(aux)
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
@@ -473,6 +475,8 @@ class GRUContext:
         self.dG = torch.empty(B * V * 4 * H, device=dev, dtype=dt)       # [dr | du | dn | dn*r] per (item, step)
         self.split_ih = e._pick_split(3 * H, E, B * V)
         self.split_hh = e._pick_split(2 * H, H, B * V)
+        self.scratch = torch.empty(self.slab_floats(), device=dev, dtype=torch.float32)     # side-stream workspace
+        self._ev = torch.cuda.Event()
 
     def slab_floats(self):
         e, H = self.eng, self.H
@@ -511,21 +515,25 @@ class GRUContext:
         # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
         # [3H,4H) that of the recurrent term
         g_ih, g_hh = g[self.prefix + "weight_ih"], g[self.prefix + "weight_hh"]
-        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
-                      b_rpi=V, b_item=Ltop * E)
-        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
-                      b_rpi=V, b_item=(V + 1) * H)
-        e._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
-                      b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H)
-        if (self.prefix + "bias_ih") in g:
-            g_bi, g_bh = g[self.prefix + "bias_ih"], g[self.prefix + "bias_hh"]
-            M = B * V
-            nb = min(e.colsum_blocks, max(1, M // 64))
-            _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(e.slabs), M, 4 * H, 4 * H, nb, code)
-            sl = e.slabs
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
-            _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
+        # the GRU's parameter gradients (ten short launches) are off the critical path dG -> dz -> encoder backward: side stream
+        main, aux, sl = torch.cuda.current_stream(), e.aux, self.scratch
+        self._ev.record(main)
+        with torch.cuda.stream(aux):
+            aux.wait_event(self._ev)
+            e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
+                          b_rpi=V, b_item=Ltop * E, scratch=sl)
+            e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
+                          b_rpi=V, b_item=(V + 1) * H, scratch=sl)
+            e._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
+                          b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H, scratch=sl)
+            if (self.prefix + "bias_ih") in g:
+                g_bi, g_bh = g[self.prefix + "bias_ih"], g[self.prefix + "bias_hh"]
+                M = B * V
+                nb = min(e.colsum_blocks, max(1, M // 64))
+                _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(sl), M, 4 * H, 4 * H, nb, code)
+                _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
+                _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
+                _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
         # dz -> rows [t0, t0+V) of the top-layer gradient
         _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
                      c_rpi=V, c_item=Ltop * E, c_valid=V)
@@ -914,6 +922,7 @@ class ContextOnlyEngine(CPCEngine):
             full, view, _ = self._buf(self.B * self.V, self.E)
             self._keep.append(full)
             store.append(view)
+        self.aux = torch.cuda.Stream(device=self.device, priority=-1)
         self.ctx = make_context(self, owner.autoregressive_model)
         self._alloc_head([1])
 
