@@ -55,6 +55,9 @@ _SIGNATURES = {
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
     "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_dgrad_conv1_floats": ([_I, _I, _I, _I, _I, _I], _L),
+    "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
+    "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -107,6 +107,36 @@ int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void*
     return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
 }
 
+long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what) {
+    const long long numM = ((long long)B * Lout_alloc + 255) / 256, numN = (long long)stride * Cin / 256;
+    if (what == 0) return numM * numN * (kw1 + 1) * 256;      // slabs
+    return 32LL * (kw1 + 1) * Cin;                            // reduction workspace
+}
+
+int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
+                         int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
+                         int dtype, void* stream) {
+    if (!dy || !w_dgrad || !x_act || !x || !slabs || B <= 0 || Lout_alloc <= 0 || dtype != CPC_DTYPE_BF16) return CPC_EINVAL;
+    if (Cin % 256 || kw1 < 1 || kw1 > 15 || stride1 < 1 || L1_valid < 1) return CPC_EINVAL;
+    const int D = (kw + stride - 1) / stride;
+    GemmNT p = {};
+    p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);
+    p.Bt = w_dgrad; p.C = slabs /* not written */; p.bias = nullptr; p.mask = x_act;
+    p.M = B * Lout_alloc; p.N = stride * Cin; p.K = D * Cout;
+    p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
+    p.flags = GEMM_EPI_CONV1;
+    p.c1_x = x; p.c1_ldx = ldx; p.c1_slabs = slabs;
+    p.c1_rpi = Lout_alloc; p.c1_sub = stride; p.c1_stride = stride1; p.c1_kw = kw1; p.c1_valid = L1_valid;
+    return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int B, int Cin, int stride, int Lout_alloc,
+                           int kw1, void* stream) {
+    if (B <= 0 || Lout_alloc <= 0) return CPC_EINVAL;
+    const int numM = (int)(((long long)B * Lout_alloc + 255) / 256);
+    return launch_conv1_fused_reduce(slabs, tmp, dw, db, numM, Cin, stride, kw1, (hipStream_t)stream);
+}
+
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride, int Lout_alloc,
                    int nsplit, int dtype, void* stream) {
     if (!x || !dy || !slabs || B <= 0 || Lout_alloc <= 0 || nsplit <= 0) return CPC_EINVAL;

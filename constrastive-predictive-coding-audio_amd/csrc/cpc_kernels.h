@@ -9,6 +9,7 @@
 #define GEMM_SMALL_TILE 16     // NT: keep the 128x128 tile even where the 256x256 one would be chosen (A-B check)
 #define GEMM_NARROW_EPI 32     // NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A-B check)
 #define GEMM_WIDE_EPI 0x10000  // internal: set by the launcher when the LDS-staged epilogue applies
+#define GEMM_EPI_CONV1 0x20000 // internal: fused layer-1 weight-gradient epilogue (see GemmNT::c1_*)
 #define GEMM_NO_DMA 64         // NT fast path: register-staged global->LDS copies instead of LDS-DMA (A-B check)
 #define GEMM_SKIP_PAD_ROWS 128  // NT: rows with (m % c_rpi) >= c_valid are not stored at all (default: stored as zeros)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
@@ -27,6 +28,12 @@ struct GemmNT {
     long long a_batch, b_batch, c_batch;
     int flags;
     int m_off = 0;        // internal: first row of this launch (fast kernels; a launch may cover rows [m_off, M) only)
+    // internal, GEMM_EPI_CONV1 (data gradient of encoder layer 2 fused with the weight gradient of layer 1): the masked result
+    // tile G[(b,q)][(r,c)] = d loss / d act1[b][q*c1_sub + r][c] is NOT stored; instead
+    //   c1_slabs[tile][j][c] = sum_rows G[row][c] * x[b][t*c1_stride + j]  (j < c1_kw),   [c1_kw][c] = sum_rows G[row][c]
+    // with t = q*c1_sub + r (rows with t >= c1_valid contribute nothing); tile = mt * numN + nt, 256 columns per tile.
+    const float* c1_x = nullptr; long long c1_ldx = 0; float* c1_slabs = nullptr;
+    int c1_rpi = 0, c1_sub = 0, c1_stride = 0, c1_kw = 0, c1_valid = 0;
 };
 
 struct GemmTN {
@@ -54,6 +61,8 @@ int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y,
                      long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream);
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
+int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,
+                              hipStream_t stream);
 int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
                          hipStream_t stream);
 long long gru_tape_elems(int B, int V, int H, int dtype);

@@ -332,7 +332,9 @@ __device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v[
 // can see while an LDS-DMA is in flight, which would serialise load and MFMA; so here the fragment reads are inline-asm
 // ds_read_b128 with hand-counted lgkmcnt waits (each wait statement names the fragments it releases as "+v" operands
 // and is followed by sched_barrier(0), so no MFMA can be scheduled above it).
-template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA>
+__device__ __forceinline__ uint4 tn_frag_rb(const unsigned char* tile, int rowb, int cb, int ks, int lane);
+
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int ATILE = TBM * 128, BTILE = TBN * 128, STAGE = ATILE + BTILE;
     constexpr int NA = TBM * 8 / NTHR, NB = TBN * 8 / NTHR, RSTEP = NTHR / 8;     // staged chunks per thread, row step
     constexpr int EPI_RS = TBN * 2 + 16;                                            // bf16 output tile row stride in LDS
-    constexpr int EPI_BYTES = sizeof(TO) == 2 ? TBM * EPI_RS : 0;
+    constexpr int EPI_BYTES = sizeof(TO) == 2 ? TBM * EPI_RS + (C1 ? 2 * TBM * 32 : 0) : 0;
     constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -612,6 +614,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             constexpr int NPASS = TBM / RPP;
             const int cc = tid % CPR, rr = tid / CPR;
             const int n = n0 + cc * 8;
+            if constexpr (C1) {
+                // ... beside an image of the waveform windows of the tile's rows: xw[2][TBM][16] bf16 = (hi, lo) parts of
+                // x[b][t*stride + j] for slots j < kw, 1.0 in slot kw (bias gradient), 0 elsewhere / for rows that do not count
+                static_assert(NTHR == 2 * TBM, "two threads per tile row");
+                unsigned char* xw = lds + TBM * EPI_RS;
+                const int r = tid >> 1, half = tid & 1;
+                const int m = m0 + r;
+                const int cinN = p.N / p.c1_sub, rsel = n0 / cinN;
+                bool ok = m < p.M;
+                long long xo = 0;
+                if (ok) {
+                    const int b = m / p.c1_rpi, t = (m % p.c1_rpi) * p.c1_sub + rsel;
+                    ok = t < p.c1_valid;
+                    xo = (long long)b * p.c1_ldx + (long long)t * p.c1_stride;
+                }
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    unsigned short h2[2], l2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = half * 8 + e2 * 2 + u;
+                        float xv = 0.f;
+                        if (ok) xv = j < p.c1_kw ? p.c1_x[xo + j] : (j == p.c1_kw ? 1.f : 0.f);
+                        const bf16_t hb = (bf16_t)xv;
+                        const bf16_t lb = (bf16_t)(xv - (float)hb);
+                        h2[u] = __builtin_bit_cast(unsigned short, hb);
+                        l2[u] = __builtin_bit_cast(unsigned short, lb);
+                    }
+                    hw[e2] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
+                    lw[e2] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
+                }
+                *(uint4*)(xw + r * 32 + half * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                *(uint4*)(xw + TBM * 32 + r * 32 + half * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            }
             if (n < p.N) {
                 // ReLU-backward mask: all of a thread's mask chunks are requested before the first is used, so the tile pays
                 // the HBM latency once, not once per group of rows (the accumulators are in LDS by now: registers are free)
@@ -623,6 +660,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n);
                     }
                 }
+                if constexpr (C1) {
+                    // fused layer-1 weight gradient: the masked tile goes back to its LDS image (no global store) ...
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) {
+                        const int r = rr + q * RPP;
+                        uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
+                        const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
+                        unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned lo = mw[e] & 0xffffu, hi = mw[e] >> 16;
+                            const unsigned keep = ((lo != 0u && lo < 0x8000u) ? 0xffffu : 0u) |
+                                                  ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+                            vw[e] &= keep;
+                        }
+                        *(uint4*)(lds + r * EPI_RS + cc * 16) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                    }
+                }
+                if constexpr (!C1) {
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
                     const int r = rr + q * RPP;
@@ -649,6 +705,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         v = make_uint4(0, 0, 0, 0);
                     }
                     *(uint4*)(Cb + coff + n) = v;
+                }
+                }
+            }
+            if constexpr (C1) {
+                // slab[j][c] = sum over the tile's rows of xw[row][j] * G[row][c]: a (16 x TBM) x (TBM x TBN) product on the
+                // matrix pipe with both operands read transposed from their LDS images (the TN kernel's fragment reads);
+                // wave w owns the column blocks 2w and 2w+1, so no sums cross waves.  x = hi + lo keeps ~16 mantissa bits.
+                static_assert(TBN / 16 == 2 * WM * WN, "two 16-column blocks per wave");
+                __syncthreads();
+                const unsigned char* xw = lds + TBM * EPI_RS;
+                f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+                for (int ks = 0; ks < TBM / 32; ++ks) {
+                    const uint4 fh = tn_frag_rb(xw, 32, 0, ks, lane);
+                    const uint4 fl = tn_frag_rb(xw + TBM * 32, 32, 0, ks, lane);
+                    const uint4 g0 = tn_frag_rb(lds, EPI_RS, (wave * 2) * 16, ks, lane);
+                    const uint4 g1 = tn_frag_rb(lds, EPI_RS, (wave * 2 + 1) * 16, ks, lane);
+                    mfma_chunk<bf16_t>(d0, g0, fh);
+                    mfma_chunk<bf16_t>(d0, g0, fl);
+                    mfma_chunk<bf16_t>(d1, g1, fh);
+                    mfma_chunk<bf16_t>(d1, g1, fl);
+                }
+                const int slot = lane & 15, c4 = (lane >> 4) * 4;
+                if (slot <= p.c1_kw) {
+                    float* sl = p.c1_slabs + ((long long)mt * numN + nt) * (p.c1_kw + 1) * TBN + (long long)slot * TBN;
+                    *(f32x4*)(sl + (wave * 2) * 16 + c4) = d0;
+                    *(f32x4*)(sl + (wave * 2 + 1) * 16 + c4) = d1;
                 }
             }
             return;
@@ -1017,6 +1100,15 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         if (dma) hipLaunchKernelGGL((gemm_nt_fast_kernel<TT, TOO, WMM, WNN, TII, TJJ, true>), grid, dim3(NTH), 0, stream, ARG);  \
         else hipLaunchKernelGGL((gemm_nt_fast_kernel<TT, TOO, WMM, WNN, TII, TJJ, false>), grid, dim3(NTH), 0, stream, ARG);     \
     } while (0)
+    if (p.flags & GEMM_EPI_CONV1) {
+        // fused layer-1 weight gradient: only the 256x256 LDS-DMA kernel with the LDS-staged epilogue has that variant
+        if (!(big && dma && (q.flags & GEMM_WIDE_EPI) && p.mask && batch == 1 && p.c1_x && p.c1_slabs && p.c1_sub > 0 &&
+              p.N % p.c1_sub == 0 && (p.N / p.c1_sub) % 256 == 0 && p.c1_kw >= 1 && p.c1_kw <= 15 && p.c1_rpi > 0))
+            return CPC_EINVAL;
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, true>), grid, dim3(512), 0, stream, q);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
             if (of32) NT_LAUNCH(bf16_t, float, 2, 4, 8, 4, 512, q);

@@ -147,6 +147,16 @@ class CPCEngine:
         need.append(self.c1_item_blocks * self.c1_blocks * (self.kernels[0] + 1) * self.channels[0])
         self.colsum_blocks = 1024
         need.append(self.colsum_blocks * max(self.channels))
+        # bf16, wide first layer: the data gradient of layer 2 is fused with the weight / bias gradient of layer 1
+        # (cpc_conv_dgrad_conv1): the 1 GB gradient of layer 1's output is neither written nor read back
+        self.fuse_c1 = False
+        if n >= 2 and dt == torch.bfloat16 and self.channels[0] % 256 == 0 and self.kernels[0] <= 15:
+            s1, c0, c1 = self.strides[1], self.channels[0], self.channels[1]
+            if _hip.nt_tile(self.code, B * La[1], s1 * c0, self.geo.taps[1] * c1) == 256 and (self.geo.taps[1] * c1) % 64 == 0:
+                nf = [int(_hip.lib().cpc_conv_dgrad_conv1_floats(B, c0, s1, La[1], self.kernels[0], w)) for w in (0, 1)]
+                self.c1_slabs = torch.empty(nf[0], device=dev, dtype=torch.float32)
+                self.c1_tmp = torch.empty(nf[1], device=dev, dtype=torch.float32)
+                self.fuse_c1 = True
         # Side stream for the short, latency-bound kernels of the weight-gradient path (bias column sums, slab reductions,
         # operand-layout preparation): they run beside the large GEMMs of the main stream instead of between them.  The big
         # GEMMs all stay on the main stream.  Each layer's weight-gradient slabs get their own buffer so that the next layer's
@@ -416,13 +426,22 @@ class CPCEngine:
                     # the side stream gets here (its wait on _ev_w covers all earlier main-stream work)
                     lo = self.model._offset["encoder.layers.2.weight"]
                     grad_ready_hook(lo, self.model._flat_grad.numel())
-            _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
-                      _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code,
-                      key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
-                      work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
-                      shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
+            tkey = dict(key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
+                        work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
+                        shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
+            if l == 1 and self.fuse_c1:
+                _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
+                          _hip.ptr(x, self.x_off), _hip.ptr(self.c1_slabs), B, cin, cout, kw, s, La[1], self.L, self.kernels[0],
+                          self.strides[0], Lv[0], code, **dict(tkey, key=tkey["key"].replace("gemm_nt", "gemm_nt_conv1")))
+            else:
+                _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
+                          _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code, **tkey)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
+        if self.fuse_c1:
+            _hip.call("cpc_conv1_fused_reduce", _hip.ptr(self.c1_slabs), _hip.ptr(self.c1_tmp), _hip.ptr(g["encoder.layers.0.weight"]),
+                      _hip.ptr(g.get("encoder.layers.0.bias")), B, c0, self.strides[1], La[1], k0)
+            return
         nblk, nbb = self.c1_blocks, self.c1_item_blocks
         _hip.call("cpc_conv1_bwd", _hip.ptr(x, self.x_off), _hip.ptr(self.dact[0]), _hip.ptr(self.slabs), B, c0, s0, k0, self.L, Lv[0], La[0],
                   nblk, nbb, code)

@@ -95,6 +95,20 @@ int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, in
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
                   int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, void* stream);
 
+/* Data gradient of encoder layer 2 FUSED with the weight/bias gradient of layer 1 (audio_model.py:38-39 differentiated, l = 1
+ * and l = 0): the masked gradient tile of layer 1's output never goes to memory; each 256 x 256 tile leaves
+ * slabs[tile][j][c] = sum_rows G[row][c] * x[b][t*stride1 + j] (j < kw1) and [kw1][c] = sum_rows G[row][c].
+ * bf16 only, Cin % 256 == 0, kw1 <= 15; CPC_EINVAL otherwise (callers then use cpc_conv_dgrad + cpc_conv1_bwd).
+ * x: f32 waveform (first sample the encoder reads), ldx samples per item.  Sizes of slabs / tmp (floats):
+ * cpc_conv_dgrad_conv1_floats(..., what = 0 / 1).  cpc_conv1_fused_reduce sums the slabs in a fixed order into
+ * dw [Cin][1][kw1] (reference layout) and db [Cin] (may be NULL). */
+long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what);
+int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
+                         int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
+                         int dtype, void* stream);
+int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int B, int Cin, int stride, int Lout_alloc,
+                           int kw1, void* stream);
+
 /* Conv1d (layers >= 2) in channels-last layout, expressed through the GEMMs above.
  *   fwd  : y[(b,t)][co] = relu?(bias + sum_{j,c} x[(b, t*stride + j)][c] * w[co][c][j])       audio_model.py:38-41
  *   dgrad: dx[(b,p)][c]  = (x_act > 0 ?) sum_{t,co: t*stride + j = p} dy[(b,t)][co] * w[co][c][j]

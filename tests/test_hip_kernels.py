@@ -323,6 +323,54 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     assert rel_err(wg, wr.grad) < tol(dt)
 
 
+@pytest.mark.parametrize("Cin,B,La1", [(256, 8, 1600), (512, 5, 1312)])
+def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
+    """cpc_conv_dgrad_conv1 + cpc_conv1_fused_reduce against cpc_conv_dgrad followed by the plain sums over the stored tile."""
+    dt, code = torch.bfloat16, _hip.BF16
+    g = torch.Generator().manual_seed(Cin + B)
+    Cout, kw, stride, kw1, s1 = 64, 8, 4, 10, 5
+    D = -(-kw // stride)
+    La0 = stride * La1
+    Lv0 = La0 - 7
+    ldx = (La0 - 1) * s1 + kw1 + 3
+    guard = 16 * max(Cin, Cout)
+    xwave = torch.randn(B, ldx, generator=g)
+    act0 = torch.randn(B, La0, Cin, generator=g)                     # layer-1 output (its sign is the ReLU mask)
+    act0[:, Lv0:] = 0
+    dy = torch.randn(B, La1, Cout, generator=g)
+    dy[:, La1 - 3:] = 0
+    w = torch.randn(Cout, Cin, kw, generator=g) * 0.05
+
+    def padded(t):
+        buf = torch.zeros(guard + t.numel() + guard, device=DEV, dtype=dt)
+        buf[guard:guard + t.numel()] = t.reshape(-1).to(DEV).to(dt)
+        return buf
+
+    abuf, dybuf = padded(act0), padded(dy)
+    wf = torch.empty(Cout * kw * Cin, device=DEV, dtype=dt)
+    wd = torch.empty(stride * Cin * D * Cout, device=DEV, dtype=dt)
+    _hip.call("cpc_conv_w_prep", _hip.ptr(w.to(DEV)), _hip.ptr(wf), _hip.ptr(wd), Cout, Cin, kw, stride, code)
+    dxbuf = torch.zeros(guard + B * La0 * Cin + guard, device=DEV, dtype=dt)
+    _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
+              kw, stride, La1, Lv0, code)
+    G = dxbuf[guard:guard + B * La0 * Cin].view(B, La0, Cin).double().cpu()[:, :Lv0]
+    win = xwave.double().unfold(1, kw1, s1)[:, :Lv0]                 # (B, Lv0, kw1)
+    ref_w = torch.einsum("btc,btj->cj", G, win)
+    ref_b = G.sum((0, 1))
+    n_sl = int(_hip.lib().cpc_conv_dgrad_conv1_floats(B, Cin, stride, La1, kw1, 0))
+    n_tmp = int(_hip.lib().cpc_conv_dgrad_conv1_floats(B, Cin, stride, La1, kw1, 1))
+    slabs = torch.full((n_sl,), float("nan"), device=DEV)
+    tmp = torch.full((n_tmp,), float("nan"), device=DEV)
+    xd = xwave.to(DEV)
+    _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(xd), _hip.ptr(slabs), B, Cin,
+              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, code)
+    dw = torch.full((Cin, 1, kw1), float("nan"), device=DEV)
+    db = torch.full((Cin,), float("nan"), device=DEV)
+    _hip.call("cpc_conv1_fused_reduce", _hip.ptr(slabs), _hip.ptr(tmp), _hip.ptr(dw), _hip.ptr(db), B, Cin, stride, La1, kw1)
+    assert rel_err(dw[:, 0, :], ref_w) < 2e-4          # same bf16 tile in both paths; x enters as a (hi, lo) bf16 pair
+    assert rel_err(db, ref_b) < 2e-4
+
+
 # --------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,V,H", [(7, 13, 64), (20, 5, 32), (16, 3, 256)])

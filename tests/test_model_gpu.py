@@ -947,3 +947,29 @@ def test_other_encoder_geometries_against_oracle(strides, kernels, channels):
         ref = ref.double()
         got = model._grad[n].double().cpu()
         assert ((got - ref).norm() / (ref.norm() + 1e-30)).item() < 2e-3, n
+
+
+def test_fused_layer1_weight_gradient_equals_unfused_path():
+    """bf16, default encoder: the data gradient of layer 2 fused with the weight gradient of layer 1 (engine.fuse_c1) against
+    the two-kernel path on the same engine — the same bf16 gradient tile enters both, so only the summation order differs."""
+    B, L = 8, 20480
+    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV)
+    torch.manual_seed(0)
+    model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256, compute_dtype="bf16")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "encoder" in n and n.endswith("weight"):
+                p.mul_(2.0)
+    model.to(DEV)
+    eng = model.engine(B, L)
+    assert eng.fuse_c1, "the headline configuration is expected to take the fused path"
+    got = {}
+    for fused in (True, False):
+        eng.fuse_c1 = fused
+        eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        got[fused] = {n: model._grad[n].detach().double().cpu().clone() for n in ("encoder.layers.0.weight", "encoder.layers.0.bias",
+                                                                                 "encoder.layers.1.weight")}
+    for n in got[True]:
+        a, b = got[True][n], got[False][n]
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), n
