@@ -14,6 +14,7 @@ Data layout (all per GPU, resident for the life of the engine):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import List, Optional, Sequence
@@ -94,6 +95,21 @@ class CPCEngine:
         self.aux = torch.cuda.Stream(device=self.device, priority=-1)
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         self._alloc()
+
+    # ------------------------------------------------------------------------------------------ side stream
+    use_aux = True          # False: everything on the launching stream (GraphedStep captures that way)
+
+    @contextlib.contextmanager
+    def side(self, ev):
+        """Work issued inside runs on the high-priority side stream once everything issued so far on the current stream
+        has finished (event ``ev``); backward() joins the side stream before it returns."""
+        if not self.use_aux:
+            yield
+            return
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(ev)
+            yield
 
     # ------------------------------------------------------------------------------------------ setup
     def _check_supported(self):
@@ -256,15 +272,13 @@ class CPCEngine:
                      a_rpi=1, a_item=cstride)
 
     def forward(self, x):
-        if type(self) is CPCEngine and self.n > 1:
+        if type(self) is CPCEngine and self.n > 1 and self.use_aux:
             # the operand-layout kernels (a dozen short launches) run on the side stream under the layer-1 convolution, which
             # reads the f32 master parameters directly
-            main, aux = torch.cuda.current_stream(), self.aux
-            self._ev_prep[0].record(main)
-            with torch.cuda.stream(aux):
-                aux.wait_event(self._ev_prep[0])
+            main = torch.cuda.current_stream()
+            with self.side(self._ev_prep[0]):
                 self.prepare_weights()
-                self._ev_prep[1].record(aux)
+                self._ev_prep[1].record(self.aux)
             self.encoder_forward(x, after_layer1=lambda: main.wait_event(self._ev_prep[1]))
         else:
             self.prepare_weights()
@@ -391,7 +405,8 @@ class CPCEngine:
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
         self._backward_encoder(x, grad_ready_hook)
-        torch.cuda.current_stream().wait_stream(self.aux)
+        if self.use_aux:
+            torch.cuda.current_stream().wait_stream(self.aux)
 
     def _backward_encoder(self, x, grad_ready_hook=None):
         """Encoder part of the backward pass: consumes the top-layer gradient, fills the encoder's parameter gradients."""
@@ -400,14 +415,11 @@ class CPCEngine:
         La, Lv = self.geo.alloc, self.geo.valid
         # encoder, top layer down to layer 2.  Main stream: weight-gradient GEMM, data-gradient GEMM.  Side stream: the bias
         # column sum (needs dact[l]) and the slab reduction (needs the weight-gradient GEMM), see _alloc_encoder.
-        main, aux = torch.cuda.current_stream(), self.aux
         for l in range(n - 1, 0, -1):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             bname = f"encoder.layers.{l}.bias"
             if bname in g:
-                self._ev_d[l].record(main)
-                with torch.cuda.stream(aux):
-                    aux.wait_event(self._ev_d[l])
+                with self.side(self._ev_d[l]):
                     self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
             flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
@@ -416,9 +428,7 @@ class CPCEngine:
                                                                                              self._chunk(B * La[l], self.nsplit[l]))),
                       work=flops,
                       shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
-            self._ev_w[l].record(main)
-            with torch.cuda.stream(aux):
-                aux.wait_event(self._ev_w[l])
+            with self.side(self._ev_w[l]):
                 _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                           self.nsplit[l], kw * cin * cout)
                 if grad_ready_hook is not None and l == 2 and n > 2:
@@ -535,10 +545,8 @@ class GRUContext:
         # [3H,4H) that of the recurrent term
         g_ih, g_hh = g[self.prefix + "weight_ih"], g[self.prefix + "weight_hh"]
         # the GRU's parameter gradients (ten short launches) are off the critical path dG -> dz -> encoder backward: side stream
-        main, aux, sl = torch.cuda.current_stream(), e.aux, self.scratch
-        self._ev.record(main)
-        with torch.cuda.stream(aux):
-            aux.wait_event(self._ev)
+        sl = self.scratch
+        with e.side(self._ev):
             e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
                           b_rpi=V, b_item=Ltop * E, scratch=sl)
             e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
@@ -1150,6 +1158,7 @@ class GraphedStep:
         args = dict(softplus=softplus, regularization=regularization, all_timesteps=all_timesteps)
         # no warm-up run: nothing here initialises lazily on first use except buffers, which the capture allocates from the
         # graph's own pool — and a real step on a dummy batch would move BatchNorm's running statistics
+        eng.use_aux = False       # a captured graph replays on one stream; the side-stream overlap of the eager step is given up
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = eng.loss_and_grads(self.x, **args)
