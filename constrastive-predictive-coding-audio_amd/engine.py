@@ -431,11 +431,13 @@ class CPCEngine:
             with self.side(self._ev_w[l]):
                 _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                           self.nsplit[l], kw * cin * cout)
-                if grad_ready_hook is not None and l == 2 and n > 2:
-                    # everything from encoder layer index 2 upwards (+ GRU, predictor: later in the flat buffer) is final once
-                    # the side stream gets here (its wait on _ev_w covers all earlier main-stream work)
-                    lo = self.model._offset["encoder.layers.2.weight"]
-                    grad_ready_hook(lo, self.model._flat_grad.numel())
+                if grad_ready_hook is not None and l <= 2:
+                    # everything from this encoder layer upwards (+ context network, predictor: later in the flat buffer) is final
+                    # once the side stream gets here (its wait on _ev_w covers all earlier main-stream work): layers >= 3 and the
+                    # head travel under the backward of layers 2 and 1, layer 2 (index 1) under the last data-gradient GEMM
+                    off = self.model._offset
+                    hi = off[f"encoder.layers.{l + 1}.weight"] if (l == 1 and n > 2) else self.model._flat_grad.numel()
+                    grad_ready_hook(off[f"encoder.layers.{l}.weight"], hi)
             tkey = dict(key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
                         work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
                         shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
@@ -1083,8 +1085,9 @@ class GlobalNegatives:
 
 class GradAllReduce:
     """Data-parallel gradient exchange: ONE sum over ranks of the model's flat f32 gradient buffer per step (RCCL over
-    xGMI with backend "nccl"), issued in two pieces so that the larger, earlier-finished piece (encoder layers >= 3,
-    GRU, predictor: 63 % of the bytes) travels while encoder layers 2 and 1 are still being differentiated.
+    xGMI with backend "nccl"), issued in pieces as the backward pass completes them: encoder layers >= 3 + GRU + predictor
+    (63 % of the bytes) travel while layers 2 and 1 are still being differentiated, layer 2 (28 %) under the last
+    data-gradient GEMM, and only layer 1's 22 KB is left for finish().
     The mean is taken by FusedAdam's ``grad_scale = 1 / world``."""
 
     def __init__(self, model):
@@ -1097,7 +1100,7 @@ class GradAllReduce:
 
     def hook(self, lo, hi):
         """Pass as ``grad_ready_hook``: starts the asynchronous all-reduce of flat_grad[lo:hi]."""
-        self.split = lo
+        self.split = lo if self.split is None else min(self.split, lo)
         self.pending.append(self.dist.all_reduce(self.model._flat_grad[lo:hi], async_op=True))
 
     def finish(self):
