@@ -17,11 +17,26 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _hip
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """ONE high-priority side stream per device for the whole process, shared by every engine: HIP multiplexes its streams
+    onto a few hardware queues, and an engine created late in a process that had made one stream per engine ended up with a
+    side stream sharing a hardware queue with the main stream (measured: the same step 6.9 -> 12.9 ms)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _SIDE_STREAMS[key]
 
 
 def _ceil_div(a, b):
@@ -92,12 +107,12 @@ class CPCEngine:
         self._check_supported()
         model._flatten_parameters(self.device)
         # high-priority side stream for short kernels that need not sit between the large GEMMs (see _alloc_encoder)
-        self.aux = torch.cuda.Stream(device=self.device, priority=-1)
+        self.aux = side_stream(self.device)
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         self._alloc()
 
     # ------------------------------------------------------------------------------------------ side stream
-    use_aux = True          # False: everything on the launching stream (GraphedStep captures that way)
+    use_aux = os.environ.get("CPC_SIDE_STREAM", "1") != "0"     # False: everything on the launching stream (GraphedStep captures that way; CPC_SIDE_STREAM=0 for A/B runs)
 
     @contextlib.contextmanager
     def side(self, ev):
@@ -173,15 +188,13 @@ class CPCEngine:
                 self.c1_slabs = torch.empty(nf[0], device=dev, dtype=torch.float32)
                 self.c1_tmp = torch.empty(nf[1], device=dev, dtype=torch.float32)
                 self.fuse_c1 = True
-        # Side stream for the short, latency-bound kernels of the weight-gradient path (bias column sums, slab reductions,
-        # operand-layout preparation): they run beside the large GEMMs of the main stream instead of between them.  The big
+        # Side stream for the short, latency-bound kernels of the weight-gradient path (bias column sums, slab reductions): they run beside the large GEMMs of the main stream instead of between them.  The big
         # GEMMs all stay on the main stream.  Each layer's weight-gradient slabs get their own buffer so that the next layer's
         # GEMM never waits for the previous reduction.
         self.wslab = [None] + [torch.empty(need[l], device=dev, dtype=torch.float32) for l in range(1, n)]
         self.aux_slabs = torch.empty(self.colsum_blocks * max(self.channels), device=dev, dtype=torch.float32)
         self._ev_d = [torch.cuda.Event() for _ in range(n)]
         self._ev_w = [torch.cuda.Event() for _ in range(n)]
-        self._ev_prep = (torch.cuda.Event(), torch.cuda.Event())
         return need
 
     def _alloc_head(self, need):
@@ -246,15 +259,13 @@ class CPCEngine:
         if x.dtype != torch.float32 or tuple(x.shape) != (self.B, self.L) or not x.is_contiguous():
             raise ValueError(f"expected a contiguous float32 batch of shape ({self.B}, {self.L}), got {tuple(x.shape)} {x.dtype}")
 
-    def encoder_forward(self, x, after_layer1=None):
+    def encoder_forward(self, x):
         """AudioEncoder.forward (audio_model.py:36-44): relu(conv) x (n-1), then a bare conv."""
         self._check_input(x)
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
         _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
                   1 if self.n > 1 else 0, code)
-        if after_layer1 is not None:
-            after_layer1()
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
@@ -272,17 +283,8 @@ class CPCEngine:
                      a_rpi=1, a_item=cstride)
 
     def forward(self, x):
-        if type(self) is CPCEngine and self.n > 1 and self.use_aux:
-            # the operand-layout kernels (a dozen short launches) run on the side stream under the layer-1 convolution, which
-            # reads the f32 master parameters directly
-            main = torch.cuda.current_stream()
-            with self.side(self._ev_prep[0]):
-                self.prepare_weights()
-                self._ev_prep[1].record(self.aux)
-            self.encoder_forward(x, after_layer1=lambda: main.wait_event(self._ev_prep[1]))
-        else:
-            self.prepare_weights()
-            self.encoder_forward(x)
+        self.prepare_weights()
+        self.encoder_forward(x)
         self.context_forward()
 
     # views of the forward results in the reference's shapes (storage dtype, no copies)
@@ -951,7 +953,7 @@ class ContextOnlyEngine(CPCEngine):
             full, view, _ = self._buf(self.B * self.V, self.E)
             self._keep.append(full)
             store.append(view)
-        self.aux = torch.cuda.Stream(device=self.device, priority=-1)
+        self.aux = side_stream(self.device)
         self.ctx = make_context(self, owner.autoregressive_model)
         self._alloc_head([1])
 

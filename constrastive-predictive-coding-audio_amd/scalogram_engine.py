@@ -16,7 +16,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip
-from .engine import CPCEngine, _ceil_div, make_context
+from .engine import CPCEngine, _ceil_div, make_context, side_stream
 
 
 class Grid:
@@ -543,7 +543,7 @@ class ScalogramCPCEngine(CPCEngine):
             d_in = b.d_out
         self.geo = SimpleNamespace(alloc=[self.T], valid=[self.T])
         self.act, self.dact = [out.t], [self.blocks[-1].d_out.t]
-        self.aux = torch.cuda.Stream(device=self.device, priority=-1)      # side stream, see engine.CPCEngine
+        self.aux = side_stream(self.device)      # side stream, see engine.CPCEngine
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)]
         self._alloc_head(need)
