@@ -430,6 +430,13 @@ def validation_terms(scores4: torch.Tensor, all_timesteps: bool = False):
     return prediction_losses, accuracy, s.mean()
 
 
+def gradient_penalty(score_sum: torch.Tensor, batch: torch.Tensor, factor: float) -> torch.Tensor:
+    """Wasserstein gradient penalty — contrastive_estimation_training.py:144-155: the gradient of the summed scores with
+    respect to the (preprocessed) input batch, its 2-norm over dim 1 pushed towards 1; differentiable (create_graph)."""
+    grad, = torch.autograd.grad(outputs=score_sum, inputs=batch, create_graph=True, retain_graph=True, only_inputs=True)
+    return ((grad.norm(2, dim=1) - 1) ** 2).mean() * factor
+
+
 # ------------------------------------------------------------------------------ Adam
 def adam_update(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam defaults (no weight decay / amsgrad), as built at
@@ -445,14 +452,14 @@ def adam_update(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e
 class OracleTrainer:
     """Holds parameters + Adam state and runs the reference train step on CPU.
 
-    Follows the loop body of contrastive_estimation_training.py:97-169 for the
-    AudioEncoder + AudioGRUModel model (no preprocessing, no gradient penalty).
+    Follows the loop body of contrastive_estimation_training.py:97-169 (every model family cpc_forward covers; the optional
+    Wasserstein gradient penalty of :144-155 with ``gradient_penalty_factor``).
     """
 
     def __init__(self, params: Params, visible_steps: int, prediction_steps: int,
                  strides: Sequence[int] = DEFAULT_STRIDES, score: str = "softplus",
                  all_timesteps: bool = False, regularization: float = 1.0, lr: float = 1e-4, conv_ar=None,
-                 attention=None, scalogram=None, ar_resnet=None):
+                 attention=None, scalogram=None, ar_resnet=None, gradient_penalty_factor: Optional[float] = None):
         is_buffer = lambda k: ("running_" in k) or k.endswith("num_batches_tracked") or k.endswith("positional_encoder.pe")
         self.buffers = {k: v.detach().clone() for k, v in params.items() if is_buffer(k)}
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if not is_buffer(k)}
@@ -468,6 +475,7 @@ class OracleTrainer:
         self.lr = lr
         self.conv_ar = conv_ar
         self.attention = attention
+        self.gp_factor = gradient_penalty_factor      # None: wasserstein_gradient_penalty=False
         self.t = 0
 
     def loss_and_grads(self, batch: torch.Tensor):
@@ -475,9 +483,15 @@ class OracleTrainer:
         for p in self.params.values():
             p.grad = None
         x = batch if self.scalogram is not None else batch.unsqueeze(1)
+        if self.gp_factor is not None:
+            x = x.detach().clone().requires_grad_(True)        # :102 (the reference only does this behind a preprocessing module)
         pred, targ, _, _ = cpc_forward(x, {**self.params, **self.buffers}, self.V, self.K, self.strides, self.conv_ar, self.attention,
                                        self.scalogram, ar_resnet=self.ar_resnet)
-        loss, smax = info_nce_loss(self.score(pred, targ), self.all_timesteps, self.regularization)
+        scores = self.score(pred, targ)
+        loss, smax = info_nce_loss(scores, self.all_timesteps, self.regularization)
+        if self.gp_factor is not None:
+            s, _, _ = _loss_terms(scores, self.all_timesteps)      # ``scores`` as rebound at :116 in the default branch
+            loss = loss + gradient_penalty(torch.sum(s), x, self.gp_factor)
         loss.backward()
         return loss.detach(), smax.detach(), {k: p.grad for k, p in self.params.items()}
 

@@ -23,7 +23,7 @@ Fixtures written (all float32 unless noted):
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
-  scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval),
+  scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval), runs with the Wasserstein gradient penalty,
                         trainer losses, gradients, BatchNorm running statistics
 """
 import io
@@ -454,20 +454,28 @@ def gen_scalogram(variant="a"):
             if "running_" in k or "num_batches" in k:
                 out["after_train_fwd/" + k] = v
     rid = 0
-    for fn_name, fn, all_t, reg, steps, lr in (("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3),
-                                                ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3),
-                                                ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4)):
+    runs = [("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3, None),
+            ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3, None),
+            ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4, None)]
+    if variant == "a":
+        # Wasserstein gradient penalty (contrastive_estimation_training.py:144-155), the reference's e11.. experiment settings:
+        # linear scores, both loss branches
+        runs += [("linear", ref_train.linear_score_function, True, 0.0, 1, 1e-3, 10.0),
+                 ("linear", ref_train.linear_score_function, False, 0.01, 1, 1e-3, 1.0),
+                 ("linear", ref_train.linear_score_function, True, 0.0, 3, 1e-4, 10.0)]
+    for fn_name, fn, all_t, reg, steps, lr, gp in runs:
         pre, model = build()
         ds = TensorDataset(data)
         logger = Logger()
         with quiet():
             tr = ref_train.ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=None, regularization=reg,
                                                         score_over_all_timesteps=all_t, score_function=fn, prediction_steps=K, ar_size=H,
-                                                        preprocessing=pre)
+                                                        preprocessing=pre, wasserstein_gradient_penalty=gp is not None,
+                                                        gradient_penalty_factor=10. if gp is None else gp)
             random.seed(91)
             tr.train(batch_size=B, epochs=10, lr=lr, num_workers=0, max_steps=steps)
         tag = f"run{rid}"
-        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr,
+        meta["runs"].append({"tag": tag, "score": fn_name, "all_timesteps": all_t, "reg": reg, "steps": steps, "lr": lr, "gp": gp,
                              "python_seed": 91, "batches": [ds.accessed[i * B:(i + 1) * B] for i in range(steps)],
                              "loss": logger.loss_meter.values, "max_score": logger.score_meter.values})
         if steps == 1:

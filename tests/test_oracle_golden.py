@@ -334,7 +334,7 @@ def test_scalogram_model(golden_dir, fixture):
                 _close(p[k.split("/", 1)[1]], g[k], rtol=1e-5, atol=1e-6)
     for run in meta["runs"]:
         tr = O.OracleTrainer(p0, V, K, score=run["score"], all_timesteps=run["all_timesteps"], regularization=run["reg"], lr=run["lr"],
-                             scalogram=blocks)
+                             scalogram=blocks, gradient_penalty_factor=run.get("gp"))
         for i, idx in enumerate(run["batches"]):
             batch = preprocess(data[idx])
             if run["steps"] == 1:
