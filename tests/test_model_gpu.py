@@ -974,3 +974,29 @@ def test_fused_layer1_weight_gradient_equals_unfused_path():
         a, b = got[True][n], got[False][n]
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), n
+
+
+def test_fused_layer1_weight_gradient_two_layer_encoder_without_bias():
+    """The fused path on a two-layer encoder without biases (no bias-gradient output, layer 2 is also the top layer)."""
+    B, L = 16, 20480
+    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(5)) * 0.5).to(DEV)
+    torch.manual_seed(1)
+    enc = AudioEncoder({'strides': [5, 4], 'kernel_sizes': [10, 8], 'channel_count': [256, 64], 'bias': False})
+    model = AudioPredictiveCodingModel(enc, AudioGRUModel(64, 32), enc_size=64, ar_size=32, visible_steps=1000, prediction_steps=6,
+                                       compute_dtype="bf16")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "encoder" in n and n.endswith("weight"):
+                p.mul_(2.0)
+    model.to(DEV)
+    eng = model.engine(B, L)
+    assert eng.fuse_c1
+    got = {}
+    for fused in (True, False):
+        eng.fuse_c1 = fused
+        eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        got[fused] = {n: model._grad[n].detach().double().cpu().clone() for n in ("encoder.layers.0.weight", "encoder.layers.1.weight")}
+    for n in got[True]:
+        a, b = got[True][n], got[False][n]
+        assert torch.isfinite(a).all() and b.abs().max().item() > 0
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), n
