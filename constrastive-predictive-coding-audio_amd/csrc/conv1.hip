@@ -3,13 +3,14 @@
 //   bwd : dw[co][j] = sum_{b,t} dy[b][t][co] * x[b][t*s + j],  db[co] = sum dy   (dy already relu-masked)
 // A lane owns 8 consecutive output channels (one 16-byte bf16 store per position); the raw waveform window of the
 // workgroup's positions is staged once in LDS and broadcast-read; weights live in registers.
+#include <cstdlib>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
 
 namespace {
 
 constexpr int C1_MAXK = 16;      // max kernel size of layer 1 handled (reference default: 10)
-constexpr int C1_POS = 64;       // output positions per workgroup pass
+constexpr int C1_POS = 64;       // output positions per workgroup pass (backward)
 
 template <typename T>
 __device__ __forceinline__ void store8(T* dst, const float* v);
@@ -40,22 +41,22 @@ __device__ __forceinline__ void load8<float>(const float* src, float* v) {
     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 
-// grid: (ceil(L_alloc / C1_POS), B).  Threads: lanes_per_row = C/8 lanes cover one output row; 256/lanes_per_row rows
+// grid: (ceil(L_alloc / C1_FPOS), B).  Threads: lanes_per_row = C/8 lanes cover one output row; 256/lanes_per_row rows
 // are produced per pass.
-template <typename T, int KW>
+template <typename T, int KW, int C1_FPOS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int C,
                                                         int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu) {
     const int kw = KW > 0 ? KW : kw_rt;
-    __shared__ float xs[C1_POS * 8 + C1_MAXK + 8];     // stride <= 8 supported
+    __shared__ float xs[C1_FPOS * 8 + C1_MAXK + 8];     // stride <= 8 supported
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * C1_POS;
+    const int t0 = blockIdx.x * C1_FPOS;
     const int tid = threadIdx.x;
     const int lpr = C / 8;
     const int cg = tid % lpr, rl = tid / lpr, nrl = 256 / lpr;
 
-    // stage the input window of positions [t0, t0 + C1_POS): samples [t0*stride, (t0+C1_POS-1)*stride + kw)
-    const int npos = min(C1_POS, L_valid - t0);          // valid positions in this block (may be <= 0)
+    // stage the input window of positions [t0, t0 + C1_FPOS): samples [t0*stride, (t0+C1_FPOS-1)*stride + kw)
+    const int npos = min(C1_FPOS, L_valid - t0);          // valid positions in this block (may be <= 0)
     const int nsamp = npos > 0 ? (npos - 1) * stride + kw : 0;
     const float* xb = x + (long long)b * ldx + (long long)t0 * stride;
     for (int i = tid; i < nsamp; i += 256) xs[i] = xb[i];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     __syncthreads();
 
     T* yb = y + ((long long)b * L_alloc + t0) * C + cg * 8;
-    const int nrows = min(C1_POS, L_alloc - t0);
+    const int nrows = min(C1_FPOS, L_alloc - t0);
     for (int r = rl; r < nrows; r += nrl) {
         float v[8];
         if (r < npos) {
@@ -174,9 +175,16 @@ static bool c1_ok(int C, int stride, int kw) {
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
                      long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream) {
     if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid) return CPC_EINVAL;
-    dim3 grid((L_alloc + C1_POS - 1) / C1_POS, B);
+    // output positions per workgroup: the 88 weight / bias registers of a thread are loaded once per workgroup (A/B switch)
+    static const int fpos = getenv("CPC_C1_FPOS") ? atoi(getenv("CPC_C1_FPOS")) : 256;
+    dim3 grid((L_alloc + fpos - 1) / fpos, B);
 #define LAUNCH(T, KWT) \
-    hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu)
+    do { \
+        if (fpos == 64) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 64>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
+        else if (fpos == 128) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 128>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
+        else if (fpos == 256) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 256>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
+        else return CPC_EINVAL; \
+    } while (0)
     if (dtype == CPC_DTYPE_BF16) {
         if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);
     } else if (dtype == CPC_DTYPE_F32) {
