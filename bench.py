@@ -123,7 +123,7 @@ def main():
         if graphed is not None:
             return graphed(pool[i % len(pool)])
         out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
-                                 grad_ready_hook=sync.hook if sync is not None else None)
+                                 grad_ready_hook=sync.hook if sync is not None else opt.hook)
         if sync is not None:
             sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer, two overlapped pieces
         opt.step(grad_scale=1.0 / world)

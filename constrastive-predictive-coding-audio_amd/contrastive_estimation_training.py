@@ -220,7 +220,8 @@ class ContrastiveEstimationTrainer:
                         out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),
-                                                 grad_ready_hook=sync.hook if sync is not None else None, global_negatives=gneg)
+                                                 grad_ready_hook=sync.hook if sync is not None else getattr(optimizer, "hook", None),
+                                                 global_negatives=gneg)
                         if sync is not None:
                             sync.finish()
                         # per-GPU negatives: mean of the shard gradients; global negatives: the shard gradients add up

@@ -224,19 +224,24 @@ int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C,
 // slabs: [numM][numN][(kw+1)][256] with numN = sub * (cin / 256), N-tile nt = r * (cin/256) + chalf.
 // Phase 1: tmp[z][j][c] = sum over the M-panels of chunk z and over r of slab[mt][r*(cin/256) + c/256][j][c % 256];
 // phase 2: dw[c][j] (reference layout [C][1][kw]) / db[c] = sum_z tmp[z][j][c].  Fixed summation order: deterministic.
-#define C1F_CHUNKS 32
+#define C1F_CHUNKS 128
+// block (z, chalf): 256 threads walk the (kw+1) x 256 floats of a slab tile as float4 slots (16 bytes per lane, coalesced)
 __global__ __launch_bounds__(256) void conv1_fused_reduce1_kernel(const float* __restrict__ slabs, float* __restrict__ tmp,
                                                                   int numM, int cin, int sub, int kw) {
     const int nch = cin / 256, numN = sub * nch;
-    const int z = blockIdx.x, j = blockIdx.y, chalf = blockIdx.z;
+    const int z = blockIdx.x, chalf = blockIdx.y;
     const int per = (numM + C1F_CHUNKS - 1) / C1F_CHUNKS;
     const int m_lo = z * per, m_hi = min(numM, m_lo + per);
     const long long tile = (long long)(kw + 1) * 256;
-    float s = 0.f;
-    for (int mt = m_lo; mt < m_hi; ++mt)
-        for (int r = 0; r < sub; ++r)
-            s += slabs[((long long)mt * numN + r * nch + chalf) * tile + (long long)j * 256 + threadIdx.x];
-    tmp[((long long)z * (kw + 1) + j) * cin + chalf * 256 + threadIdx.x] = s;
+    const int nslot = (kw + 1) * 64;                       // float4 slots per tile
+    for (int sl = threadIdx.x; sl < nslot; sl += 256) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = m_lo; mt < m_hi; ++mt)
+            for (int r = 0; r < sub; ++r)
+                s += *(const f32x4*)(slabs + ((long long)mt * numN + r * nch + chalf) * tile + (long long)sl * 4);
+        const int j = sl / 64, c4 = sl % 64;
+        *(f32x4*)(tmp + ((long long)z * (kw + 1) + j) * cin + chalf * 256 + c4 * 4) = s;
+    }
 }
 __global__ __launch_bounds__(256) void conv1_fused_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ dw,
                                                                   float* __restrict__ db, int cin, int kw) {
@@ -251,8 +256,7 @@ __global__ __launch_bounds__(256) void conv1_fused_reduce2_kernel(const float* _
 int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,
                               hipStream_t stream) {
     if (!slabs || !tmp || !dw || numM <= 0 || cin <= 0 || cin % 256 || sub <= 0 || kw <= 0) return CPC_EINVAL;
-    hipLaunchKernelGGL(conv1_fused_reduce1_kernel, dim3(C1F_CHUNKS, kw + 1, cin / 256), dim3(256), 0, stream, slabs, tmp, numM,
-                       cin, sub, kw);
+    hipLaunchKernelGGL(conv1_fused_reduce1_kernel, dim3(C1F_CHUNKS, cin / 256), dim3(256), 0, stream, slabs, tmp, numM, cin, sub, kw);
     hipLaunchKernelGGL(conv1_fused_reduce2_kernel, dim3(cin / 256, kw + 1), dim3(256), 0, stream, tmp, dw, db, cin, kw);
     CPC_CHECK_LAUNCH();
     return CPC_OK;

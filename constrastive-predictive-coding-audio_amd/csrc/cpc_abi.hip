@@ -110,7 +110,7 @@ int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void*
 long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what) {
     const long long numM = ((long long)B * Lout_alloc + 255) / 256, numN = (long long)stride * Cin / 256;
     if (what == 0) return numM * numN * (kw1 + 1) * 256;      // slabs
-    return 32LL * (kw1 + 1) * Cin;                            // reduction workspace
+    return 128LL * (kw1 + 1) * Cin;                           // reduction workspace (C1F_CHUNKS partial sums)
 }
 
 int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,

@@ -1149,13 +1149,39 @@ class FusedAdam:
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
         self.t = 0
+        self._done_lo = None
         # device_step: the step count lives on the device (cpc_adam_dev), so the call's arguments never change and the step
         # can be part of a captured hipGraph
         self.state = torch.zeros(4, device=flat.device, dtype=torch.float32) if device_step else None
 
+    def hook(self, lo, hi):
+        """Single-process use as ``grad_ready_hook``: updates flat_param[lo:hi] as soon as the backward pass reports that range
+        of the gradient final (the engine calls it from its side stream, beside the remaining data-gradient GEMMs); step()
+        then updates what is left.  Nothing the backward pass still runs reads the f32 master parameters of a finished range
+        (the GEMMs use the storage-dtype operand copies made at the start of the step).  Not for data-parallel runs, where the
+        update has to follow the all-reduce."""
+        if self.state is not None:
+            raise ValueError("FusedAdam.hook needs the host-side step count (device_step=False)")
+        self._done_lo = lo if self._done_lo is None else min(self._done_lo, lo)
+        self._launch(lo, hi, self.t + 1, 1.0)
+
+    def _launch(self, lo, hi, t, grad_scale):
+        flat, grad = self.model._flat_param, self.model._flat_grad
+        if hi <= lo:
+            return
+        _hip.call("cpc_adam", _hip.ptr(flat, lo), _hip.ptr(grad, lo), _hip.ptr(self.m, lo), _hip.ptr(self.v, lo), C.c_longlong(hi - lo),
+                  C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), t,
+                  C.c_float(grad_scale))
+
     def step(self, grad_scale: float = 1.0):
         self.t += 1
         flat, grad = self.model._flat_param, self.model._flat_grad
+        if self._done_lo is not None:          # ranges [done_lo, end) were updated by hook() during the backward pass
+            hi, self._done_lo = self._done_lo, None
+            if grad_scale != 1.0:
+                raise ValueError("FusedAdam.hook and grad_scale != 1 do not combine")
+            self._launch(0, hi, self.t, 1.0)
+            return
         if self.state is not None:
             _hip.call("cpc_adam_dev", _hip.ptr(flat), _hip.ptr(grad), _hip.ptr(self.m), _hip.ptr(self.v), C.c_longlong(flat.numel()),
                       C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
