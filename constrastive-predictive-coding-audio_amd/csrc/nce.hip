@@ -36,7 +36,20 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
     float mx = -INFINITY, sum = 0.f;
     if (bp < B) {
         const float* col = S + (long long)k * B * ld + bp;
-        for (int b = r0 + ty; b < r1; b += 8) {
+        // four rows per trip: the loads are independent of the running (max, sum), so they are in flight together
+        int b = r0 + ty;
+        for (; b + 24 < r1; b += 32) {
+            float v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = col[(long long)(b + 8 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = score_tf(v4[u], softplus);
+                if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
+                else sum += expf(v - mx);
+            }
+        }
+        for (; b < r1; b += 8) {
             const float v = score_tf(col[(long long)b * ld], softplus);
             if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
             else sum += expf(v - mx);
@@ -125,8 +138,10 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         }
         mean[r] = m;
     }
-    for (int k = 0; k < K; ++k) {
-        __syncthreads();
+    // grid.z = K: every block recomputes the K-mean of its 32 x 32 pairs (S is 3 MB, L2-resident) and differentiates its own
+    // k; the loss partials are taken from the z == 0 blocks only.  (64 blocks looping over K left three quarters of the chip idle.)
+    {
+        const int k = blockIdx.z;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + ty + 8 * r, bp = bp0 + tx;
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.z == 0) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
         partial[blk * 3 + 0] = red[0][0];
         partial[blk * 3 + 1] = red[1][0];
@@ -317,10 +332,10 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
     hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B, (float*)nullptr,
                        (float*)nullptr);
     if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
+        hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
                            gradp, B, K, ld, softplus, reg);
     else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb), dim3(256), 0, stream, S, lse, (float*)dS, (float*)dST, gradp,
+        hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (float*)dS, (float*)dST, gradp,
                            B, K, ld, softplus, reg);
     else
         return CPC_EINVAL;
