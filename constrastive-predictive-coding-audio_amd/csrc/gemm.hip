@@ -931,23 +931,26 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
-// Same reduction for SMALL outputs and many slabs (bias gradients, layer-1 weights): 256 threads = 16 output float4 x 16
-// slab lanes, lanes combined through LDS in a fixed order, so that the serial chain per thread is nslab / 16.
+// Same reduction for SMALL outputs and many slabs (bias gradients, layer-1 weights, BatchNorm sums): 256 threads =
+// (256 / ZL) output float4 x ZL slab lanes, lanes combined through LDS in a fixed order, so that the serial chain per thread
+// is nslab / ZL  (ZL = 16, or 64 for 512 slabs and more).
+template <int ZL>
 __global__ __launch_bounds__(256) void reduce_slabs_small_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                  int I, int J, int nslab, long long slab_stride, int cdiv,
                                                                  long long s_j, long long s_hi, long long s_lo) {
-    __shared__ float red[16][16][4];
-    const int ol = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    constexpr int OL = 256 / ZL;
+    __shared__ float red[ZL][OL][4];
+    const int ol = threadIdx.x % OL, zl = threadIdx.x / OL;
     const long long total4 = (long long)I * J / 4;
-    const long long o4 = (long long)blockIdx.x * 16 + ol;
+    const long long o4 = (long long)blockIdx.x * OL + ol;
     f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (o4 < total4)
-        for (int z = zl; z < nslab; z += 16) s += *(const f32x4*)(slabs + (long long)z * slab_stride + o4 * 4);
+        for (int z = zl; z < nslab; z += ZL) s += *(const f32x4*)(slabs + (long long)z * slab_stride + o4 * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[zl][ol][q] = s[q];
     __syncthreads();
     if (zl == 0 && o4 < total4) {
-        for (int r = 1; r < 16; ++r)
+        for (int r = 1; r < ZL; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] += red[r][ol][q];
         const long long e = o4 * 4;
@@ -1195,8 +1198,12 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
     if (I <= 0 || J <= 0 || J % 4 || nslab <= 0 || cdiv <= 0) return CPC_EINVAL;
     const long long total4 = (long long)I * J / 4;
     if (total4 <= 16384 && nslab >= 32) {
-        hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, stream, slabs, out, I,
-                           J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo);
+        if (nslab >= 512)
+            hipLaunchKernelGGL(reduce_slabs_small_kernel<64>, dim3((unsigned)((total4 + 3) / 4)), dim3(256), 0, stream, slabs, out, I,
+                               J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo);
+        else
+            hipLaunchKernelGGL(reduce_slabs_small_kernel<16>, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, stream, slabs, out, I,
+                               J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }

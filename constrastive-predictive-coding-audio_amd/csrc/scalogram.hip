@@ -194,12 +194,24 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     // thread t owns column group t % c4n and row phase t / c4n; threads beyond nrp * c4n idle (host guarantees C <= 1024)
     const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n, nrp = 256 / c4n;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    if (rp < nrp)
-        for (long long r = r0 + rp; r < r1; r += nrp) {
-            const f32x4 v = load4(x + r * C + cg * 4);
+    if (rp < nrp) {
+        // four independent row loads per trip (a single 8-byte load per thread in flight leaves the kernel at half the HBM rate)
+        long long r = r0 + rp;
+        const T* px = x + cg * 4;
+        for (; r + 3LL * nrp < r1; r += 4LL * nrp) {
+            const f32x4 v0 = load4(px + r * C), v1 = load4(px + (r + nrp) * C), v2 = load4(px + (r + 2LL * nrp) * C),
+                        v3 = load4(px + (r + 3LL * nrp) * C);
+            s1 += v0; s2 += v0 * v0;
+            s1 += v1; s2 += v1 * v1;
+            s1 += v2; s2 += v2 * v2;
+            s1 += v3; s2 += v3 * v3;
+        }
+        for (; r < r1; r += nrp) {
+            const f32x4 v = load4(px + r * C);
             s1 += v;
             s2 += v * v;
         }
+    }
     __shared__ float red[2048];          // [nrp][2][C]: 256 / (C/4) * 2 * C = 2048 floats for every C
     if (rp < nrp) {
 #pragma unroll
@@ -290,21 +302,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (rp < nrp) {
         const f32x4 mu = *(const f32x4*)(stats + cg * 4), rs = *(const f32x4*)(stats + C + cg * 4);
-        for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < (unsigned)(q1 * gx.H); r += nrp) {
-            const unsigned q = r / (unsigned)gx.H;
-            const int h = (int)(r - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
-            const long long oy = grid_off(gy, b, w, h) + cg * 4;
-            f32x4 g = load4(dy + oy);
-            if (relu) {
-                const f32x4 yy = load4(y + oy);
+        // rows in batches of four: all twelve loads of a batch are issued before the first is used
+        const unsigned rend = (unsigned)(q1 * gx.H);
+        for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < rend; r += 4u * nrp) {
+            f32x4 g4[4], y4[4], x4[4];
+            bool ok[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const unsigned ru = r + (unsigned)(u * nrp);
+                ok[u] = ru < rend;
+                const unsigned rc = ok[u] ? ru : r;
+                const unsigned q = rc / (unsigned)gx.H;
+                const int h = (int)(rc - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
+                const long long oy = grid_off(gy, b, w, h) + cg * 4;
+                g4[u] = load4(dy + oy);
+                y4[u] = relu ? load4(y + oy) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                x4[u] = load4(x + grid_off(gx, b, w, h) + cg * 4);
             }
-            const f32x4 xv = load4(x + grid_off(gx, b, w, h) + cg * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s1[e] += g[e] * (xv[e] - mu[e]) * rs[e];
-                s2[e] += g[e];
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = y4[u][e] > 0.f ? g4[u][e] : 0.f;
+                    s1[e] += g * (x4[u][e] - mu[e]) * rs[e];
+                    s2[e] += g;
+                }
             }
         }
     }
@@ -333,6 +356,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            float inv_count, int relu, int train) {
     const int C = gx.C, c4n = C / 4;
     const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c4n);
+    // When the grid stride is a multiple of C/4 a thread keeps the same four channels for its whole walk: their coefficients
+    // are formed once (dx = k1 * g - k2 - k3 * (x - mean)) instead of sixteen scalar loads per element.
+    const bool fixed = ((gridDim.x * 256u) % (unsigned)c4n) == 0u;
+    f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k3 = k1, mu = k1;
+    auto coeffs = [&](int c4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            const float rs = stats[C + c], ga = gamma[c];
+            mu[e] = stats[c];
+            k1[e] = ga * rs;
+            k2[e] = train ? ga * rs * dbeta[c] * inv_count : 0.f;
+            k3[e] = train ? ga * rs * rs * dgamma[c] * inv_count : 0.f;
+        }
+    };
+    if (fixed) coeffs((int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)c4n));
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int c4 = (int)(idx % c4n);
         const int h = (int)((idx / c4n) % gx.H);
@@ -340,24 +379,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const int w = (int)(col % gx.W), b = (int)(col / gx.W);
         const long long oy = grid_off(gy, b, w, h) + c4 * 4, ox = grid_off(gx, b, w, h) + c4 * 4;
         f32x4 g = load4(dy + oy);
+        const f32x4 xv = load4(x + ox);
         if (relu) {
             const f32x4 yy = load4(y + oy);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 xv = load4(x + ox);
+        if (!fixed) coeffs(c4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c4 * 4 + e;
-            const float rs = stats[C + c], ga = gamma[c];
-            if (train) {
-                const float xh = (xv[e] - stats[c]) * rs;
-                o[e] = ga * rs * (g[e] - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
-            } else {
-                o[e] = g[e] * ga * rs;
-            }
-        }
+        for (int e = 0; e < 4; ++e) o[e] = k1[e] * g[e] - k2[e] - k3[e] * (xv[e] - mu[e]);
         store4(dx + ox, o);
     }
 }

@@ -250,7 +250,10 @@ class _BatchNorm:
         self.x_f32 = 1 if (y0.dtype == torch.float32 and eng.dt != torch.float32) else 0
         self.stats = torch.zeros(2, self.C, device=eng.device, dtype=torch.float32)
         self.nb = max(1, min(512, y0.rows // 512))
-        self.slab = self.nb * 2 * self.C
+        # the backward reduction reads three tensors per element and needs more workgroups in flight to reach the HBM rate; the
+        # forward statistics keep 512 partial sums (their summation order is what the bf16 full-size reference values were taken with)
+        self.nb_bwd = max(1, min(2048, y0.rows // 512))
+        self.slab = self.nb_bwd * 2 * self.C
         self.dy0: Optional[Grid] = None
         self.trained = True
 
@@ -278,9 +281,9 @@ class _BatchNorm:
         p, g, code = e.model._param, e.model._grad, e.code
         gw, gb = g[self.prefix + ".weight"], g[self.prefix + ".bias"]
         _hip.call("cpc_bn_bwd_reduce", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), _desc(self.y0, self.y0.desc),
-                  _hip.ptr(self.stats), _hip.ptr(e.slabs), 1, self.nb, self.x_f32, code)
-        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
-        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
+                  _hip.ptr(self.stats), _hip.ptr(e.slabs), 1, self.nb_bwd, self.x_f32, code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
         _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
                   _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
                   float(self.y0.count), 1, 1 if self.trained else 0, self.x_f32, code)
