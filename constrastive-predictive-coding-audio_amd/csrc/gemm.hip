@@ -13,6 +13,7 @@
 //
 // Storage type T is bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact-f32 parity mode);
 // accumulation is always f32.  128x128 output tile per 256-thread workgroup (4 waves, 64x64 each).
+#include <algorithm>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
 
@@ -1070,6 +1071,59 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_f32_kernel(GemmTN p) {
     if (owner) *(f32x4*)((float*)p.C + (long long)split * p.slab_stride + (long long)oi * p.ldc + oj4 * 4) = acc;
 }
 
+// f32 NT for tiny N and K over very many rows (C[m][n] = bias[n] + sum_k A[m][k] Bt[n][k] with N in {8, 16, 32}, K <= 32: the
+// first convolution and the 1x1 residual projection of the scalogram encoder, 32 outputs from 18 / 2 inputs at 5 M positions).
+// Bound by reading A and writing C once; a 128 x 128 MFMA tile is almost empty there (2.7 TF/s).  N/8 lanes share a row: each
+// reads the row's K floats (L1 broadcast) and owns 8 consecutive outputs; the weights sit transposed in LDS.
+__global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
+    __shared__ __attribute__((aligned(16))) float wt[32][32];
+    const int tid = threadIdx.x, K = p.K, N = p.N, NG = N / 8;
+    const float* Ab = (const float*)p.A;
+    const float* Bb = (const float*)p.Bt;
+    float* Cb = (float*)p.C;
+    for (int i = tid; i < N * K; i += 256) {
+        const int n = i / K, k = i % K;
+        wt[k][n] = Bb[(long long)n * p.ldb + k];
+    }
+    __syncthreads();
+    const int lg = tid % NG, rl = tid / NG, rpp = 256 / NG;
+    float b8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b8[j] = p.bias ? p.bias[lg * 8 + j] : 0.f;
+    const bool relu = p.flags & GEMM_RELU;
+    for (long long m = (long long)blockIdx.x * rpp + rl; m < p.M; m += (long long)gridDim.x * rpp) {
+        const float* ar = Ab + m * p.lda;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = b8[j];
+        for (int k4 = 0; k4 < K / 4; ++k4) {
+            const f32x4 a = *(const f32x4*)(ar + 4 * k4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 w0 = *(const f32x4*)&wt[4 * k4 + e][lg * 8], w1 = *(const f32x4*)&wt[4 * k4 + e][lg * 8 + 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = fmaf(a[e], w0[j], acc[j]);
+                    acc[4 + j] = fmaf(a[e], w1[j], acc[4 + j]);
+                }
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        }
+        const bool row_valid = (p.c_rpi == 0) || ((int)(m % p.c_rpi) < p.c_valid);
+        if (!row_valid) {
+            if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        }
+        float* cr = Cb + row_off((int)m, p.c_rpi, p.c_item, p.ldc) + lg * 8;
+        *(f32x4*)cr = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        *(f32x4*)(cr + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    }
+}
+
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
@@ -1080,6 +1134,15 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.b_rpi && p.b_item % ch) return CPC_EINVAL;
     if (p.c_rpi && p.c_item % 4) return CPC_EINVAL;
     const bool of32 = p.flags & GEMM_OUT_F32;
+    if (dtype == CPC_DTYPE_F32 && batch == 1 && (p.N == 8 || p.N == 16 || p.N == 32) && p.K <= 32 && p.K % 4 == 0 && !p.mask &&
+        p.a_rpi == 0 && p.b_rpi == 0 && p.M >= 4096 && p.ldc % 4 == 0 && (p.c_rpi == 0 || p.c_item % 4 == 0) &&
+        !(p.flags & GEMM_FORCE_GENERIC) && p.m_off == 0 && ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.C % 16 == 0)) {
+        const long long rows_pp = 256 / (p.N / 8);
+        const int blocks = (int)std::min<long long>(256 * 8, (p.M + rows_pp - 1) / rows_pp);
+        hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(blocks), dim3(256), 0, stream, p);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
     // 256x256 tiles only where they fill the chip: below ~200 of them (e.g. the 3072 x 3072 all-timesteps score matrix: 144)
     // four times as many 128x128 tiles keep more CUs busy

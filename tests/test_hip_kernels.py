@@ -371,6 +371,36 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     assert rel_err(db, ref_b) < 2e-4
 
 
+@pytest.mark.parametrize("N,K,relu,rpi", [(32, 8, 0, 0), (32, 32, 1, 0), (16, 20, 0, 0), (32, 20, 1, 37), (8, 4, 0, 0)])
+def test_gemm_nt_skinny_f32(N, K, relu, rpi):
+    """The f32 NT path for tiny N and K over many rows (first scalogram convolutions) against torch, incl. the padded-row
+    output mapping (rows >= c_valid of every item are written as zeros)."""
+    g = torch.Generator().manual_seed(N * 100 + K)
+    M = 37 * 150 if rpi else 6001
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    dA, dW, db = dev(A), dev(W), dev(bias)
+    ref = A.double() @ W.double().t() + bias.double()
+    if relu:
+        ref = torch.relu(ref)
+    if rpi:
+        items, alloc, valid = M // rpi, rpi + 3, rpi - 2
+        out = torch.full((items, alloc, N), float("nan"), device=DEV)
+        _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dW), _hip.ptr(out), M, N, K, K, K, N, _hip.F32, bias=_hip.ptr(db), c_rpi=rpi, c_item=alloc * N,
+                     c_valid=valid, flags=_hip.GEMM_RELU if relu else 0)
+        got = out[:, :rpi].reshape(M, N)
+        refv = ref.view(items, rpi, N).clone()
+        refv[:, valid:] = 0
+        assert rel_err(got, refv.view(M, N)) < 1e-5
+        assert torch.isnan(out[:, rpi:]).all()
+    else:
+        out = torch.full((M, N), float("nan"), device=DEV)
+        _hip.gemm_nt(_hip.ptr(dA), _hip.ptr(dW), _hip.ptr(out), M, N, K, K, K, N, _hip.F32, bias=_hip.ptr(db),
+                     flags=_hip.GEMM_RELU if relu else 0)
+        assert rel_err(out, ref) < 1e-5
+
+
 # --------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,V,H", [(7, 13, 64), (20, 5, 32), (16, 3, 256)])
