@@ -99,6 +99,7 @@ class CQT(nn.Module):
         if trainable:
             raise NotImplementedError("trainable CQT filters are not part of the HIP path (every reference config freezes them)")
         self._operands = None
+        self._split_buf = None
 
     @property
     def trainable(self):
@@ -152,8 +153,21 @@ class CQT(nn.Module):
             _hip.call("cpc_split3_bf16", _hip.ptr(x), _hip.ptr(x3), x.numel())
             for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
                 offset = (k0 - size) // 2
-                _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, 3 * size, 3 * hop,
-                             3 * size, ldq, _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], flags=_hip.GEMM_OUT_F32)
+                M, K = B * Tn, 3 * size
+                tiles = -(-M // 128)
+                if K >= 16384 and tiles % 512 and tiles % 512 <= 256:
+                    # One 128-row tile per workgroup, two workgroups per CU: 630 tiles would run as one full round plus a
+                    # quarter-full one.  The long filters are split in two halves of K (two "batches" into a scratch buffer,
+                    # added afterwards): 1 260 half-length workgroups fill 2.5 rounds instead.
+                    if self._split_buf is None or self._split_buf.shape != (2, M, npad):
+                        self._split_buf = torch.empty(2, M, npad, device=x.device, dtype=torch.float32)
+                    _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(self._split_buf), M, npad, K // 2, 3 * hop, K, npad,
+                                 _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], a_batch=K // 2, b_batch=K // 2, c_batch=M * npad, batch=2,
+                                 flags=_hip.GEMM_OUT_F32)
+                    torch.add(self._split_buf[0], self._split_buf[1], out=cq.view(M, ldq)[:, 2 * start:2 * start + npad])
+                    continue
+                _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), M, npad, K, 3 * hop,
+                             K, ldq, _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], flags=_hip.GEMM_OUT_F32)
             return cq, Tn, ldq
         if self.precision != "fp32":
             raise ValueError("CQT.precision must be 'fp32' or 'bf16x3'")
