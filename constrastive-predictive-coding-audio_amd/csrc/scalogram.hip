@@ -412,6 +412,80 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TI* __restrict
     }
 }
 
+// bf16, C % 8 == 0: eight channels (16 bytes) per thread — the scalar kernels move 2 bytes per lane
+__global__ __launch_bounds__(256) void maxpool2d_fwd_vec8_kernel(const bf16_t* __restrict__ in, Grid gi, bf16_t* __restrict__ out, Grid go,
+                                                                 int p) {
+    const int c8n = go.C / 8;
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c0 = (int)(idx % c8n) * 8;
+        const int ho = (int)((idx / c8n) % go.H);
+        const int wo = (int)((idx / (unsigned)(c8n * go.H)) % go.W);
+        const int b = (int)(idx / (unsigned)(c8n * go.H * go.W));
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const bf16x8 v = *(const bf16x8*)(in + grid_off(gi, b, w, h) + c0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                }
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)m[e];
+        *(bf16x8*)(out + grid_off(go, b, wo, ho) + c0) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2d_bwd_vec8_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ din, Grid gi,
+                                                                 const bf16_t* __restrict__ dout, Grid go, int p, int accumulate) {
+    const int c8n = go.C / 8;
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c0 = (int)(idx % c8n) * 8;
+        const int ho = (int)((idx / c8n) % go.H);
+        const int wo = (int)((idx / (unsigned)(c8n * go.H)) % go.W);
+        const int b = (int)(idx / (unsigned)(c8n * go.H * go.W));
+        float m[8];
+        int best[8];                      // window position dh * p + dw of the first maximum, per channel
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; best[e] = -1; }
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const bf16x8 v = *(const bf16x8*)(in + grid_off(gi, b, w, h) + c0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        if (f > m[e]) { m[e] = f; best[e] = dh * p + dw; }
+                    }
+                }
+            }
+        const bf16x8 g = *(const bf16x8*)(dout + grid_off(go, b, wo, ho) + c0);
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const long long o = grid_off(gi, b, w, h) + c0;
+                    bf16x8 old;
+                    if (accumulate) old = *(const bf16x8*)(din + o);
+                    bf16x8 r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float add = best[e] == dh * p + dw ? (float)g[e] : 0.f;
+                        r[e] = (bf16_t)(accumulate ? (float)old[e] + add : add);
+                    }
+                    *(bf16x8*)(din + o) = r;
+                }
+            }
+    }
+}
+
 // din(window) += dout at the first position holding the window maximum (torch's tie rule: first in (h, w) scan order)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const T* __restrict__ in, T* __restrict__ din, Grid gi,
@@ -677,6 +751,12 @@ static bool pool_ok(const int* gi, const int* go, int p) {
 int launch_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, hipStream_t st) {
     if (!pool_ok(gi, go, p)) return CPC_EINVAL;
     const int nb = blocks_for((long long)go[0] * go[1] * go[2] * go[5]);
+    if (!in_f32 && dtype == CPC_DTYPE_BF16 && go[5] % 8 == 0) {
+        const int nbv = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 8));
+        hipLaunchKernelGGL(maxpool2d_fwd_vec8_kernel, dim3(nbv), dim3(256), 0, st, (const bf16_t*)in, mk(gi), (bf16_t*)out, mk(go), p);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (in_f32) {
         DISPATCH2(dtype,
                   hipLaunchKernelGGL((maxpool2d_fwd_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)in, mk(gi), (bf16_t*)out, mk(go), p),
@@ -694,6 +774,13 @@ int launch_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* d
                          hipStream_t st) {
     if (!pool_ok(gi, go, p)) return CPC_EINVAL;
     const int nb = blocks_for((long long)go[0] * go[1] * go[2] * go[5]);
+    if (dtype == CPC_DTYPE_BF16 && go[5] % 8 == 0) {
+        const int nbv = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 8));
+        hipLaunchKernelGGL(maxpool2d_bwd_vec8_kernel, dim3(nbv), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)din, mk(gi),
+                           (const bf16_t*)dout, mk(go), p, accumulate);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     DISPATCH2(dtype,
               hipLaunchKernelGGL((maxpool2d_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)din, mk(gi), (const bf16_t*)dout, mk(go), p, accumulate),
               hipLaunchKernelGGL((maxpool2d_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)in, (float*)din, mk(gi), (const float*)dout, mk(go), p, accumulate));
