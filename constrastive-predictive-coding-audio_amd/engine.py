@@ -229,7 +229,7 @@ class CPCEngine:
         # as many splits as fit in ONE round of workgroups (256 CUs x one 256-tile or two 128-tile workgroups): rounding the
         # count up instead (30 tiles x 18 splits = 540 workgroups on 512 slots) leaves a second, almost empty round
         want = max(1, (256 if big else 512) // tiles)
-        return max(1, min(want, _ceil_div(M, 8 * blk), 64))
+        return max(1, min(want, _ceil_div(M, 8 * blk), 256))
 
     def _chunk(self, M, nsplit, dt=None):
         blk = 64 if (self.dt if dt is None else dt) == torch.bfloat16 else 32

@@ -29,7 +29,7 @@ def contexts():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default=None)
     ap.add_argument("--breakdown", action="store_true")
@@ -46,7 +46,7 @@ def main():
                                            compute_dtype=args.dtype).to(dev)
         eng = model.engine(B, L)
         opt = FusedAdam(model, lr=1e-4)
-        for _ in range(3):
+        for _ in range(10):          # the first steps after an engine is built run slower (queues, allocator): keep them out
             out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
             opt.step()
         torch.cuda.synchronize()
