@@ -65,28 +65,33 @@ __global__ __launch_bounds__(256) void pe_scale_bwd_kernel(const T* __restrict__
 
 // Causal multi-head self-attention for one (item, head) per workgroup.
 //   qkv [(b,t)][3C]: q | k | v column blocks, head h at columns h*d of each;   out [(b,t)][C];   P [(b*heads+h)][S][S]
+// Every global access and every LDS operand read moves four consecutive elements (d % 4 == 0; the first version moved single
+// 2-byte elements and spent most of its time in the memory instructions, not in the 2 x S x S x d multiply-adds).
+constexpr int ATT_LD = ATT_D + 4;      // LDS row stride of the operand tiles: rows stay 8-byte aligned in bf16
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, T* __restrict__ P, int S,
                                                        int C, int heads, float scale, Drop dr) {
     // operand tiles in the storage type (bf16: half the LDS, so three workgroups share a CU), scores in f32
-    __shared__ T q[ATT_S][ATT_D + 2], k[ATT_S][ATT_D + 2], v[ATT_S][ATT_D + 2];
+    __shared__ __attribute__((aligned(16))) T q[ATT_S][ATT_LD], k[ATT_S][ATT_LD], v[ATT_S][ATT_LD];
     __shared__ float p[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
-    for (int idx = tid; idx < S * d; idx += 256) {
-        const int t = idx / d, c = idx % d;
+    const int d4 = d / 4;
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int t = idx / d4, c = (idx % d4) * 4;
         const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
-        q[t][c] = row[0];
-        k[t][c] = row[C];
-        v[t][c] = row[2 * C];
+        store4(&q[t][c], load4(row));
+        store4(&k[t][c], load4(row + C));
+        store4(&v[t][c], load4(row + 2 * C));
     }
     __syncthreads();
     for (int idx = tid; idx < S * S; idx += 256) {
         const int i = idx / S, j = idx % S;
         float s = -INFINITY;
         if (j <= i) {
-            s = 0.f;
-            for (int c = 0; c < d; ++c) s = fmaf(to_f32(q[i][c]), to_f32(k[j][c]), s);
-            s *= scale;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < d; c += 4) acc += load4(&q[i][c]) * load4(&k[j][c]);
+            s = (acc[0] + acc[1] + acc[2] + acc[3]) * scale;
         }
         p[i][j] = s;
     }
@@ -101,17 +106,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int j = 0; j < S; ++j) p[i][j] = j <= i ? p[i][j] * inv : 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < S * S; idx += 256) P[(long long)bh * S * S + idx] = from_f32<T>(p[idx / S][idx % S]);
+    if (S % 4 == 0) {
+        for (int idx = tid; idx < S * S / 4; idx += 256) {
+            const int i = (idx * 4) / S, j = (idx * 4) % S;
+            store4(P + (long long)bh * S * S + idx * 4, (f32x4){p[i][j], p[i][j + 1], p[i][j + 2], p[i][j + 3]});
+        }
+    } else {
+        for (int idx = tid; idx < S * S; idx += 256) P[(long long)bh * S * S + idx] = from_f32<T>(p[idx / S][idx % S]);
+    }
     if (dr.thresh) {        // nn.MultiheadAttention's dropout on the attention weights (saved P stays undropped)
         __syncthreads();
         for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] *= drop_factor(dr, (unsigned long long)bh * S * S + idx);
         __syncthreads();
     }
-    for (int idx = tid; idx < S * d; idx += 256) {
-        const int i = idx / d, c = idx % d;
-        float o = 0.f;
-        for (int j = 0; j <= i; ++j) o = fmaf(p[i][j], to_f32(v[j][c]), o);
-        out[((long long)b * S + i) * C + h * d + c] = from_f32<T>(o);
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int i = idx / d4, c = (idx % d4) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j <= i; ++j) o += p[i][j] * load4(&v[j][c]);
+        store4(out + ((long long)b * S + i) * C + h * d + c, o);
     }
 }
 
@@ -119,25 +131,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ P, const T* __restrict__ dout,
                                                        T* __restrict__ dqkv, int S, int C, int heads, float scale, Drop dr) {
-    __shared__ T q[ATT_S][ATT_D + 2], k[ATT_S][ATT_D + 2], v[ATT_S][ATT_D + 2], go[ATT_S][ATT_D + 2];
+    __shared__ __attribute__((aligned(16))) T q[ATT_S][ATT_LD], k[ATT_S][ATT_LD], v[ATT_S][ATT_LD], go[ATT_S][ATT_LD];
     __shared__ float p[ATT_S][ATT_S + 1], ds[ATT_S][ATT_S + 1];
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
-    for (int idx = tid; idx < S * d; idx += 256) {
-        const int t = idx / d, c = idx % d;
+    const int d4 = d / 4;
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int t = idx / d4, c = (idx % d4) * 4;
         const T* row = qkv + ((long long)b * S + t) * 3 * C + h * d + c;
-        q[t][c] = row[0];
-        k[t][c] = row[C];
-        v[t][c] = row[2 * C];
-        go[t][c] = dout[((long long)b * S + t) * C + h * d + c];
+        store4(&q[t][c], load4(row));
+        store4(&k[t][c], load4(row + C));
+        store4(&v[t][c], load4(row + 2 * C));
+        store4(&go[t][c], load4(dout + ((long long)b * S + t) * C + h * d + c));
     }
-    for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] = to_f32(P[(long long)bh * S * S + idx]);
+    if (S % 4 == 0) {
+        for (int idx = tid; idx < S * S / 4; idx += 256) {
+            const f32x4 pv = load4(P + (long long)bh * S * S + idx * 4);
+            const int i = (idx * 4) / S, j = (idx * 4) % S;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[i][j + e] = pv[e];
+        }
+    } else {
+        for (int idx = tid; idx < S * S; idx += 256) p[idx / S][idx % S] = to_f32(P[(long long)bh * S * S + idx]);
+    }
     __syncthreads();
     // dP[i][j] = m[i][j] * sum_c dO[i][c] V[j][c]   (m = dropout factor of the attention weights, 1 without dropout)
     for (int idx = tid; idx < S * S; idx += 256) {
         const int i = idx / S, j = idx % S;
         float s = 0.f;
-        if (j <= i)
-            for (int c = 0; c < d; ++c) s = fmaf(to_f32(go[i][c]), to_f32(v[j][c]), s);
+        if (j <= i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < d; c += 4) acc += load4(&go[i][c]) * load4(&v[j][c]);
+            s = acc[0] + acc[1] + acc[2] + acc[3];
+        }
         ds[i][j] = s * drop_factor(dr, (unsigned long long)bh * S * S + idx);
     }
     __syncthreads();
@@ -148,18 +173,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         for (int j = 0; j < S; ++j) ds[i][j] = j <= i ? p[i][j] * (ds[i][j] - dot) * scale : 0.f;    // d (raw q.k score)
     }
     __syncthreads();
-    for (int idx = tid; idx < S * d; idx += 256) {
-        const int t = idx / d, c = idx % d;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int j = 0; j <= t; ++j) dq = fmaf(ds[t][j], to_f32(k[j][c]), dq);
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int t = idx / d4, c = (idx % d4) * 4;
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
+        for (int j = 0; j <= t; ++j) dq += ds[t][j] * load4(&k[j][c]);
         for (int i = t; i < S; ++i) {
-            dk = fmaf(ds[i][t], to_f32(q[i][c]), dk);
-            dv = fmaf(p[i][t] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + t), to_f32(go[i][c]), dv);
+            dk += ds[i][t] * load4(&q[i][c]);
+            dv += (p[i][t] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + t)) * load4(&go[i][c]);
         }
         T* row = dqkv + ((long long)b * S + t) * 3 * C + h * d + c;
-        row[0] = from_f32<T>(dq);
-        row[C] = from_f32<T>(dk);
-        row[2 * C] = from_f32<T>(dv);
+        store4(row, dq);
+        store4(row + C, dk);
+        store4(row + 2 * C, dv);
     }
 }
 
@@ -336,7 +361,7 @@ int launch_pe_scale_bwd(const void* g1, const void* g2, void* dtop, int B, int S
 }
 
 static bool attn_ok(int B, int S, int C, int heads) {
-    return B > 0 && S > 0 && S <= ATT_S && heads > 0 && C % heads == 0 && C / heads <= ATT_D;
+    return B > 0 && S > 0 && S <= ATT_S && heads > 0 && C % heads == 0 && C / heads <= ATT_D && (C / heads) % 4 == 0;
 }
 
 int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
