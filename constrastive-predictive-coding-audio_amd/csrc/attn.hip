@@ -252,44 +252,64 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, c
     extern __shared__ __attribute__((aligned(16))) float acc[];      // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4n = C / 4;
-    float* aw = acc + (long long)wave * 2 * C;
-    for (int i = lane; i < 2 * C; i += 64) aw[i] = 0.f;
+    // A lane owns the column groups lane, lane + 64, ... (at most LN_IT of them: C <= 1024): the weight / bias gradient sums
+    // of its columns stay in registers over all rows of the wave, and a row's operands are loaded once for both passes.
+    constexpr int LN_IT = 4;
+    f32x4 gw[LN_IT], gb[LN_IT], wv[LN_IT];
+#pragma unroll
+    for (int u = 0; u < LN_IT; ++u) {
+        gw[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gb[u] = gw[u];
+        const int c4 = lane + 64 * u;
+        wv[u] = c4 < c4n ? *(const f32x4*)(w + c4 * 4) : gw[u];
+    }
     for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
         const float mean = stats[2 * m], rstd = stats[2 * m + 1];
         const long long grow = bcast > 0 ? (long long)(m / bcast) * C : (long long)m * C;
+        f32x4 dy[LN_IT], xh[LN_IT];
         float s1 = 0.f, s2 = 0.f;
-        for (int c4 = lane; c4 < c4n; c4 += 64) {
-            f32x4 dy = load4(g1 + grow + c4 * 4) * gscale;
-            if (g2) dy += load4(g2 + (long long)m * C + c4 * 4);
-            const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
-            const f32x4 wv = *(const f32x4*)(w + c4 * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (rv[e] - mean) * rstd, dxh = dy[e] * wv[e];
-                s1 += dxh;
-                s2 += dxh * xh;
-                aw[c4 * 4 + e] += dy[e] * xh;
-                aw[C + c4 * 4 + e] += dy[e];
+        for (int u = 0; u < LN_IT; ++u) {
+            const int c4 = lane + 64 * u;
+            if (c4 < c4n) {
+                dy[u] = load4(g1 + grow + c4 * 4) * gscale;
+                if (g2) dy[u] += load4(g2 + (long long)m * C + c4 * 4);
+                const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[u][e] = (rv[e] - mean) * rstd;
+                    const float dxh = dy[u][e] * wv[u][e];
+                    s1 += dxh;
+                    s2 += dxh * xh[u][e];
+                    gw[u][e] += dy[u][e] * xh[u][e];
+                    gb[u][e] += dy[u][e];
+                }
             }
         }
         const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
-        for (int c4 = lane; c4 < c4n; c4 += 64) {
-            f32x4 dy = load4(g1 + grow + c4 * 4) * gscale;
-            if (g2) dy += load4(g2 + (long long)m * C + c4 * 4);
-            const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
-            const f32x4 wv = *(const f32x4*)(w + c4 * 4);
-            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (rv[e] - mean) * rstd;
-                o[e] = rstd * (dy[e] * wv[e] - m1 - xh * m2);
-            }
-            store4(dr + (long long)m * C + c4 * 4, o);
-            if (dr_b) {         // gradient of the dropped-out summand b of r = a + dropout(b)
+        for (int u = 0; u < LN_IT; ++u) {
+            const int c4 = lane + 64 * u;
+            if (c4 < c4n) {
+                f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] *= drop_factor(drp, (unsigned long long)m * C + c4 * 4 + e);
-                store4(dr_b + (long long)m * C + c4 * 4, o);
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (dy[u][e] * wv[u][e] - m1 - xh[u][e] * m2);
+                store4(dr + (long long)m * C + c4 * 4, o);
+                if (dr_b) {         // gradient of the dropped-out summand b of r = a + dropout(b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= drop_factor(drp, (unsigned long long)m * C + c4 * 4 + e);
+                    store4(dr_b + (long long)m * C + c4 * 4, o);
+                }
             }
+        }
+    }
+    float* aw = acc + (long long)wave * 2 * C;
+#pragma unroll
+    for (int u = 0; u < LN_IT; ++u) {
+        const int c4 = lane + 64 * u;
+        if (c4 < c4n) {
+            *(f32x4*)(aw + c4 * 4) = gw[u];
+            *(f32x4*)(aw + C + c4 * 4) = gb[u];
         }
     }
     __syncthreads();
@@ -403,7 +423,7 @@ int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float*
 int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
                   int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
                   int dtype, hipStream_t st) {
-    if (M <= 0 || C <= 0 || C % 4 || nblocks <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    if (M <= 0 || C <= 0 || C % 4 || C > 1024 || nblocks <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
     const Drop drp = make_drop(drop_p, seed, site);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
     if (shm > 64 * 1024) return CPC_EINVAL;
