@@ -87,6 +87,7 @@ _SIGNATURES = {
     "cpc_relu_mask": ([_P, _P, _L, _I, _P], _I),
     "cpc_split3_bf16": ([_P, _P, _L, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
+    "cpc_cast2d_batch": ([_P, _I, _I, _P], _I),
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),

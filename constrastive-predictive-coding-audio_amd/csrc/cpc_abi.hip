@@ -323,6 +323,10 @@ int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long lon
     return launch_cast2d(src, dst, R, C, sr, sc, dtype, (hipStream_t)stream);
 }
 
+int cpc_cast2d_batch(const void* jobs, int njobs, int dtype, void* stream) {
+    return launch_cast2d_batch(jobs, njobs, dtype, (hipStream_t)stream);
+}
+
 int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_prep_frag(src, dst, R, Kd, ld, transpose, dtype, (hipStream_t)stream);

@@ -55,6 +55,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);
 int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream);
+int launch_cast2d_batch(const void* jobs, int njobs, int dtype, hipStream_t stream);
 int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,

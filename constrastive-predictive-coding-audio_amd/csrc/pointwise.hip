@@ -75,6 +75,20 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const float* __restrict__ s
     }
 }
 
+// Many cast2d jobs in one launch (the operand-layout copies of a context network: 26 small matrices for a 3-layer transformer):
+// jobs[y] = {src, dst, R, C, sr, sc}, all 64-bit, in device memory; grid (x, number of jobs).
+struct CastJob { const float* src; void* dst; long long R, C, sr, sc; };
+template <typename T>
+__global__ __launch_bounds__(256) void cast2d_batch_kernel(const CastJob* __restrict__ jobs) {
+    const CastJob j = jobs[blockIdx.y];
+    T* dst = (T*)j.dst;
+    const long long total = j.R * j.C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long c = idx % j.C, r = idx / j.C;
+        dst[idx] = from_f32<T>(j.src[r * j.sr + c * j.sc]);
+    }
+}
+
 // MaxPool1d(pool, ceil_mode=True) over positions of a channels-last activation (ConvolutionalArBlock, audio_model.py:98-99).
 // out[b][p][c] = max_{i < pool, p*pool+i < Lin_valid} in[b][p*pool+i][c];  pad rows (p >= Lout_valid) get zeros.
 template <typename T>
@@ -219,6 +233,18 @@ int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long 
         hipLaunchKernelGGL((cast2d_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, R, C, sr, sc);
     else if (dtype == CPC_DTYPE_F32)
         hipLaunchKernelGGL((cast2d_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, (float*)dst, R, C, sr, sc);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_cast2d_batch(const void* jobs, int njobs, int dtype, hipStream_t stream) {
+    if (!jobs || njobs <= 0 || njobs > 65535) return CPC_EINVAL;
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((cast2d_batch_kernel<bf16_t>), dim3(64, njobs), dim3(256), 0, stream, (const CastJob*)jobs);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((cast2d_batch_kernel<float>), dim3(64, njobs), dim3(256), 0, stream, (const CastJob*)jobs);
     else
         return CPC_EINVAL;
     CPC_CHECK_LAUNCH();

@@ -777,6 +777,7 @@ class AttentionContext:
         self.gAd, self.gBd = [new(M * C), new(M * C)], [new(M * C), new(M * C)]   # dropped-out summands (dropout only)
         self.dqkv, self.df1, self.datt = [new(M * 3 * C), new(M * 3 * C)], [new(M * FF), new(M * FF)], new(M * C)
         self.scratch = None
+        self._cast_jobs = None
         self._ev = [[torch.cuda.Event() for _ in range(5)] for _ in range(self.N + 1)]
         # weight operands in the storage dtype: [out][in] for the forward GEMMs, [in][out] for the data gradients
         shapes = {"in": (3 * C, C), "o": (C, C), "l1": (FF, C), "l2": (C, FF)}
@@ -799,14 +800,20 @@ class AttentionContext:
         e = self.eng
         p, code, C, FF, H = e.model._param, e.code, self.C, self.FF, self.out
         shapes = {"in": (3 * C, C), "o": (C, C), "l1": (FF, C), "l2": (C, FF)}
-        for l in range(self.N):
-            for k, (r, c) in shapes.items():
-                src = _hip.ptr(p[self._lname(l, self._WNAMES[k])])
-                _hip.call("cpc_cast2d", src, _hip.ptr(self.w[l][k]), r, c, c, 1, code)
-                _hip.call("cpc_cast2d", src, _hip.ptr(self.wt[l][k]), c, r, 1, c, code)
-        src = _hip.ptr(p[self.prefix + "end_layer.weight"])
-        _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end), H, C, C, 1, code)
-        _hip.call("cpc_cast2d", src, _hip.ptr(self.w_end_t), C, H, 1, C, code)
+        if self._cast_jobs is None or self._cast_jobs[1] is not e.model._flat_param:
+            # all operand-layout copies (weight and transposed weight of every Linear) as one batched launch; the job table holds
+            # raw addresses, which are stable: parameters are views of the model's flat buffer
+            jobs = []
+            for l in range(self.N):
+                for k, (r, c) in shapes.items():
+                    src = p[self._lname(l, self._WNAMES[k])].data_ptr()
+                    jobs.append((src, self.w[l][k].data_ptr(), r, c, c, 1))
+                    jobs.append((src, self.wt[l][k].data_ptr(), c, r, 1, c))
+            src = p[self.prefix + "end_layer.weight"].data_ptr()
+            jobs.append((src, self.w_end.data_ptr(), H, C, C, 1))
+            jobs.append((src, self.w_end_t.data_ptr(), C, H, 1, C))
+            self._cast_jobs = (torch.tensor(jobs, dtype=torch.int64, device=e.device), e.model._flat_param, len(jobs))
+        _hip.call("cpc_cast2d_batch", _hip.ptr(self._cast_jobs[0]), self._cast_jobs[2], code)
         # dropout state of this step (prepare_weights runs once per forward, before it)
         self.drop_p = float(self.ar.dropout) if (self.ar.training and self.ar.dropout > 0.0) else 0.0
         if self.drop_p > 0.0:

@@ -243,6 +243,11 @@ int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream);
 
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);
+
+/* Many cpc_cast2d jobs in one launch: jobs is a DEVICE array of njobs records {const float* src; void* dst; int64 R, C, sr, sc}
+ * (six 64-bit fields each) with dst[r][c] = (T) src[r*sr + c*sc] — the per-step operand-layout copies of a context network's
+ * nn.Linear weights (attention_model.py:59-66 keeps them f32; the GEMMs read storage-dtype copies). */
+int cpc_cast2d_batch(const void* jobs, int njobs, int dtype, void* stream);
 /* MFMA fragment order of a [R][Kd] operand (transpose: logical[n][k] = src[k*ld + n]) for the GRU kernels. */
 int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, void* stream);
 
