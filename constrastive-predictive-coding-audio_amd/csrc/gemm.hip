@@ -594,6 +594,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             // Storage-dtype output through LDS: the accumulator fragments (4 consecutive columns per lane) are written
             // to a row-major tile image, then every thread moves whole 16-byte chunks of full rows, so the mask read and
             // the store are 512-byte row segments instead of 32-byte ones.  (The K loop ended on a barrier.)
+            constexpr int CPR = TBN / 8;                 // 16-byte chunks per tile row
+            constexpr int RPP = NTHR / CPR;              // rows per pass
+            constexpr int NPASS = TBM / RPP;
+            const int cc = tid % CPR, rr = tid / CPR;
+            const int n = n0 + cc * 8;
+            // ReLU-backward mask: all of a thread's mask chunks are requested here, before the accumulators go to LDS, so the
+            // tile pays the HBM latency once and under the LDS writes (the fragment registers of the K loop are free by now)
+            uint4 mk[NPASS];
+            if (Mb && n < p.N) {
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q) {
+                    const int m = min(m0 + rr + q * RPP, p.M - 1);
+                    mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int ml = (wm * TI + i) * 16 + frow;
@@ -610,11 +625,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 }
             }
             __syncthreads();
-            constexpr int CPR = TBN / 8;                 // 16-byte chunks per tile row
-            constexpr int RPP = NTHR / CPR;              // rows per pass
-            constexpr int NPASS = TBM / RPP;
-            const int cc = tid % CPR, rr = tid / CPR;
-            const int n = n0 + cc * 8;
             if constexpr (C1) {
                 // ... beside an image of the waveform windows of the tile's rows: xw[2][TBM][16] bf16 = (hi, lo) parts of
                 // x[b][t*stride + j] for slots j < kw, 1.0 in slot kw (bias gradient), 0 elsewhere / for rows that do not count
@@ -651,16 +661,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 *(uint4*)(xw + TBM * 32 + r * 32 + half * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
             }
             if (n < p.N) {
-                // ReLU-backward mask: all of a thread's mask chunks are requested before the first is used, so the tile pays
-                // the HBM latency once, not once per group of rows (the accumulators are in LDS by now: registers are free)
-                uint4 mk[NPASS];
-                if (Mb) {
-#pragma unroll
-                    for (int q = 0; q < NPASS; ++q) {
-                        const int m = min(m0 + rr + q * RPP, p.M - 1);
-                        mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n);
-                    }
-                }
                 if constexpr (C1) {
                     // fused layer-1 weight gradient: the masked tile goes back to its LDS image (no global store) ...
 #pragma unroll
