@@ -916,6 +916,205 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_fast_kernel(GemmTN p) {
     }
 }
 
+// TN with LDS-DMA staging (bf16, ordinary row-major operands): the same tile shapes and split layout as gemm_tn_fast_kernel, but
+// the operand stages go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write traffic — the register-
+// staged kernel is bound by its LDS writes) and the transposing fragment reads are inline-asm ds_read_b64_tr_b16 issued between
+// the MFMAs with hand-counted waits, exactly as in gemm_nt_fast_kernel (hipcc would drain vmcnt(0) before every LDS read it sees).
+// LDS rows are unpadded (a DMA piece is 1 KiB of consecutive LDS): the 32-byte column granule g of tile row r sits at granule
+// g ^ (r & 7), applied to the per-lane SOURCE address of the DMA and undone by the fragment reads — the 8 rows x 32 bytes a
+// half-wave touches in one transposed read cover all 64 banks.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr_asm(unsigned addr) {
+    u32x2 d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
+    return d;
+}
+
+template <typename TO, int WI, int WJ, int TI, int TJ>
+__global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_dma_kernel(GemmTN p) {
+    typedef bf16_t T;
+    constexpr int BKM = 64, NW = WI * WJ;
+    constexpr int TBI = WI * TI * 16, TBJ = WJ * TJ * 16;
+    constexpr int RBA = TBI * 2, RBB = TBJ * 2;                         // bytes per LDS row
+    constexpr int ATILE = BKM * RBA, BTILE = BKM * RBB, STAGE = ATILE + BTILE;
+    static_assert(ATILE / 1024 == 4 * NW && BTILE / 1024 == 4 * NW, "four DMA pieces per operand per wave");
+    static_assert(TJ == 4 && (TI == 4 || TI == 8), "read schedule below is written for these tiles");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wi = wave / WJ, wj = wave % WJ;
+    const int numJ = (p.J + TBJ - 1) / TBJ;
+    const int it = blockIdx.y / numJ, jt = blockIdx.y % numJ;
+    const int i0 = it * TBI, j0 = jt * TBJ;
+    const int split = blockIdx.x;
+    const int m_begin = split * p.m_chunk;
+    const int m_end = min(p.M, m_begin + p.m_chunk);
+    const int nst = (m_end - m_begin + BKM - 1) / BKM;
+    const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
+    const T* Bb = (const T*)p.B + (long long)blockIdx.z * p.b_batch;
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) {
+        // ---- DMA sources: wave w fills pieces 4w .. 4w+3 of each operand tile; piece pc = LDS bytes [1024 pc, +1024)
+        constexpr int CPA = RBA / 16, CPB = RBB / 16;                   // 16-byte chunks per row
+        constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;               // rows per piece
+        const int rra = lane / CPA, dca = lane % CPA, rrb = lane / CPB, dcb = lane % CPB;
+        const T* ga[4];
+        const T* gb[4];
+        int rowa[4], rowb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rowa[k] = (wave_u * 4 + k) * RPA + rra;
+            rowb[k] = (wave_u * 4 + k) * RPB + rrb;
+            const int sca = (((dca >> 1) ^ (rowa[k] & 7)) << 1) | (dca & 1);
+            const int scb = (((dcb >> 1) ^ (rowb[k] & 7)) << 1) | (dcb & 1);
+            ga[k] = Ab + min(i0 + sca * 8, p.I - 8);
+            gb[k] = Bb + min(j0 + scb * 8, p.J - 8);
+        }
+        typedef __attribute__((address_space(3))) unsigned char lds_byte;
+        lds_byte* const lds3 = (lds_byte*)lds;
+        const unsigned wdst = wave_u * 4096;
+#define TN_DMA1(g, dst)                                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                         \
+                                     (__attribute__((address_space(3))) void*)(lds3 + (dst)), 16, 0, 0)
+        // piece k of stage st into slot buf (rows beyond the matrix are clamped; rows beyond the split are zeroed after landing)
+#define TN_DMA_PIECE(idx, buf, st)                                                                               \
+    do {                                                                                                         \
+        const int mb_ = m_begin + (st) * BKM;                                                                    \
+        const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
+        switch (idx) {                                                                                           \
+        case 0: TN_DMA1(ga[0] + (long long)min(mb_ + rowa[0], p.M - 1) * p.lda, da); break;                      \
+        case 1: TN_DMA1(gb[0] + (long long)min(mb_ + rowb[0], p.M - 1) * p.ldb, db); break;                      \
+        case 2: TN_DMA1(ga[1] + (long long)min(mb_ + rowa[1], p.M - 1) * p.lda, da + 1024); break;               \
+        case 3: TN_DMA1(gb[1] + (long long)min(mb_ + rowb[1], p.M - 1) * p.ldb, db + 1024); break;               \
+        case 4: TN_DMA1(ga[2] + (long long)min(mb_ + rowa[2], p.M - 1) * p.lda, da + 2048); break;               \
+        case 5: TN_DMA1(gb[2] + (long long)min(mb_ + rowb[2], p.M - 1) * p.ldb, db + 2048); break;               \
+        case 6: TN_DMA1(ga[3] + (long long)min(mb_ + rowa[3], p.M - 1) * p.lda, da + 3072); break;               \
+        case 7: TN_DMA1(gb[3] + (long long)min(mb_ + rowb[3], p.M - 1) * p.ldb, db + 3072); break;               \
+        default: break;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+        // rows of stage st beyond the split's end: zero them in LDS once the stage has landed (they would add to the sums)
+        auto zero_ragged = [&](int buf, int st) {
+            const int valid = m_end - (m_begin + st * BKM);              // rows [valid, 64) are out
+            if (valid >= BKM) return;
+            for (int q = tid; q < BKM * (CPA + CPB); q += 64 * NW) {
+                const bool isa = q < BKM * CPA;
+                const int qq = isa ? q : q - BKM * CPA;
+                const int r = isa ? qq / CPA : qq / CPB, c = isa ? qq % CPA : qq % CPB;
+                if (r >= valid)
+                    *(uint4*)(lds + buf * STAGE + (isa ? 0 : ATILE) + r * (isa ? RBA : RBB) + c * 16) = make_uint4(0, 0, 0, 0);
+            }
+        };
+
+        // ---- fragment read addresses (bytes within a stage)
+        const int g = lane >> 4, idx16 = lane & 15, q4 = idx16 >> 2, pp = idx16 & 3;
+        const int rloc = 4 * g + q4, r7 = rloc & 7;
+        const unsigned lds_u32 = (unsigned)(unsigned long long)(lds3);
+        unsigned adA[TI], adB[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) adA[i] = lds_u32 + rloc * RBA + (((wi * TI + i) ^ r7) << 5) + pp * 8;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) adB[j] = lds_u32 + ATILE + rloc * RBB + (((wj * TJ + j) ^ r7) << 5) + pp * 8;
+        // fragment set of one k-step ks: fb[j] / fa[i] as (low rows, high rows) 8-byte halves
+        u32x2 fbl0[TJ], fbh0[TJ], fal0[TI], fah0[TI], fbl1[TJ], fbh1[TJ], fal1[TI], fah1[TI];
+        constexpr int NRD = 2 * (TI + TJ);                              // reads per fragment set
+#define TN_READ1(idx, KS, fbl, fbh, fal, fah, cur)                                                               \
+    do {                                                                                                         \
+        const int i_ = (idx);                                                                                    \
+        if (i_ >= 0 && i_ < 2 * TJ) {                                                                            \
+            if (i_ & 1) fbh[i_ >> 1] = lds_read_tr_asm<(KS) * 32 * RBB + 16 * RBB>(adB[i_ >> 1] + (cur));        \
+            else fbl[i_ >> 1] = lds_read_tr_asm<(KS) * 32 * RBB>(adB[i_ >> 1] + (cur));                          \
+        } else if (i_ >= 2 * TJ && i_ < NRD) {                                                                   \
+            const int a_ = (i_ - 2 * TJ) >> 1;                                                                   \
+            if (i_ & 1) fah[a_] = lds_read_tr_asm<(KS) * 32 * RBA + 16 * RBA>(adA[a_] + (cur));                  \
+            else fal[a_] = lds_read_tr_asm<(KS) * 32 * RBA>(adA[a_] + (cur));                                    \
+        }                                                                                                        \
+    } while (0)
+#define TN_WAIT_ALL()                                                                                            \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#define TN_FRAG(l, h) make_uint4((l)[0], (l)[1], (h)[0], (h)[1])
+        // one stage: block 0 = MFMAs of k-step 0 with the reads of k-step 1 between them; wait, DMA(t+1) landed, barrier;
+        // block 1 = MFMAs of k-step 1 with the DMA pieces of stage t+2 and the k-step-0 reads of stage t+1 between them
+#define TN_ITER(DO_DMA, DO_READ)                                                                                 \
+    do {                                                                                                         \
+        const unsigned cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;                                       \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
+                mfma_chunk<bf16_t>(acc[i][j], TN_FRAG(fbl0[j], fbh0[j]), TN_FRAG(fal0[i], fah0[i]));             \
+                TN_READ1(i * TJ + j, 1, fbl1, fbh1, fal1, fah1, cur);                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }                                                                                                    \
+        }                                                                                                        \
+        TN_WAIT_ALL();                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+        if (DO_READ) zero_ragged((t + 1) & 1, t + 1);                                                            \
+        __syncthreads();                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
+                mfma_chunk<bf16_t>(acc[i][j], TN_FRAG(fbl1[j], fbh1[j]), TN_FRAG(fal1[i], fah1[i]));             \
+                if (DO_DMA) TN_DMA_PIECE(i * TJ + j, t & 1, t + 2);                                              \
+                if (DO_READ) TN_READ1(TI == 8 ? i * TJ + j - (DO_DMA ? 8 : 0) : i * TJ + j, 0, fbl0, fbh0, fal0, fah0, nxt); \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }                                                                                                    \
+        }                                                                                                        \
+        if (DO_READ) TN_WAIT_ALL();                                                                              \
+    } while (0)
+        static_assert(TI * TJ >= 8 + NRD || TI * TJ == 16, "block 1 must hold 8 DMA pieces and one fragment set");
+        // prologue: stage 0 (and 1) in flight, k-step-0 fragments of stage 0 in registers
+#pragma unroll
+        for (int k = 0; k < 8; ++k) TN_DMA_PIECE(k, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        zero_ragged(0, 0);
+        __syncthreads();
+        if (nst > 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) TN_DMA_PIECE(k, 1, 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) TN_READ1(k, 0, fbl0, fbh0, fal0, fah0, 0u);
+        TN_WAIT_ALL();
+        int t = 0;
+        for (; t + 2 < nst; ++t) TN_ITER(true, true);
+        if (t + 1 < nst) {
+            TN_ITER(false, true);
+            ++t;
+        }
+        TN_ITER(false, false);
+#undef TN_ITER
+#undef TN_FRAG
+#undef TN_WAIT_ALL
+#undef TN_READ1
+#undef TN_DMA_PIECE
+#undef TN_DMA1
+    }
+
+    const int fidx = lane & 15, fg = lane >> 4;
+    TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int ii = i0 + (wi * TI + i) * 16 + fidx;
+        if (ii >= p.I) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int jj = j0 + (wj * TJ + j) * 16 + fg * 4;
+            if (jj >= p.J) continue;
+            store4(Cb + row_off(ii, p.c_rpi, p.c_item, p.ldc) + jj, acc[i][j]);
+        }
+    }
+}
+
 // out[perm(i, j)] = (accumulate ? out : 0) + sum_z slab[z][i][j];   perm(i,j) = j*s_j + (i / cdiv)*s_hi + (i % cdiv)*s_lo
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int I, int J, int nslab, long long slab_stride,
@@ -1228,9 +1427,14 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
         q.m_chunk = eff_chunk;
         grid = dim3(nsplit, numI * numJ, batch);
         const bool plain = p.a_rpi == 0 && p.b_rpi == 0;
+        const bool tdma = plain && !(p.flags & GEMM_NO_DMA) && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.I % 8 == 0 && p.J % 8 == 0 &&
+                          ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.a_batch % 8 == 0 && p.b_batch % 8 == 0;
 #define TN_LAUNCH(WII, WJJ, TII, TJJ, NTH)                                                                               \
     do {                                                                                                                 \
-        if (plain) {                                                                                                     \
+        if (tdma) {                                                                                                      \
+            if (of32) hipLaunchKernelGGL((gemm_tn_dma_kernel<float, WII, WJJ, TII, TJJ>), grid, dim3(NTH), 0, stream, q); \
+            else hipLaunchKernelGGL((gemm_tn_dma_kernel<bf16_t, WII, WJJ, TII, TJJ>), grid, dim3(NTH), 0, stream, q);    \
+        } else if (plain) {                                                                                              \
             if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);   \
             else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);      \
         } else {                                                                                                         \
