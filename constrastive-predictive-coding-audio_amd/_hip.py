@@ -75,6 +75,9 @@ _SIGNATURES = {
     "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _I, _I, _P], _I),
     "cpc_im2col2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_col2im2d": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_dw_fwd": ([_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_dw_bwd_col": ([_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_dw_bwd_w": ([_P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _I, _P], _I),
     "cpc_bn_stats": ([_P, _P, _L, _I, _I, _I, _P], _I),
     "cpc_bn_finalize": ([_P, _I, _I, _D, _F, _F, _P, _P, _P, _P], _I),
     "cpc_bn_apply": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),

@@ -249,6 +249,22 @@ int cpc_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, i
     return launch_col2im2d(dcol, din, grid, kh, kw, sh, sw, ph, pw, Ho, Wo, Kp, accumulate, dtype, (hipStream_t)stream);
 }
 
+int cpc_dw_fwd(const void* col, const float* w, void* y, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+               void* stream) {
+    if (!col || !w || !y) return CPC_EINVAL;
+    return launch_dw_fwd(col, w, y, M, C, taps, Kp, rpi, item, dtype, (hipStream_t)stream);
+}
+int cpc_dw_bwd_col(const void* dy, const float* w, void* dcol, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+                   void* stream) {
+    if (!dy || !w || !dcol) return CPC_EINVAL;
+    return launch_dw_bwd_col(dy, w, dcol, M, C, taps, Kp, rpi, item, dtype, (hipStream_t)stream);
+}
+int cpc_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, int C, int taps, int Kp, int rpi, long long item,
+                 int nblocks, int dtype, void* stream) {
+    if (!col || !dy || !slabs) return CPC_EINVAL;
+    return launch_dw_bwd_w(col, dy, slabs, M, C, taps, Kp, rpi, item, nblocks, dtype, (hipStream_t)stream);
+}
+
 int cpc_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, void* stream) {
     if (!x || !slabs) return CPC_EINVAL;
     return launch_bn_stats(x, slabs, rows, C, nblocks, dtype, (hipStream_t)stream);

@@ -55,6 +55,12 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);
 int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream);
+int launch_dw_fwd(const void* col, const float* w, void* y, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+                  hipStream_t st);
+int launch_dw_bwd_col(const void* dy, const float* w, void* dcol, long long M, int C, int taps, int Kp, int rpi, long long item,
+                      int dtype, hipStream_t st);
+int launch_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, int C, int taps, int Kp, int rpi, long long item,
+                    int nblocks, int dtype, hipStream_t st);
 int launch_cast2d_batch(const void* jobs, int njobs, int dtype, hipStream_t stream);
 int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
 

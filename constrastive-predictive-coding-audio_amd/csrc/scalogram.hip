@@ -183,6 +183,51 @@ __global__ __launch_bounds__(256) void col2im2d_vec_kernel(const T* __restrict__
     }
 }
 
+// Depthwise convolution (Conv2dSeparable's grouped nn.Conv2d, scalogram_model.py:532-544) on the im2col matrix: tap t of
+// channel c of output row m sits at col[m][t*C + c], the weight at w[c*taps + t] (reference layout [C][1][kh][kw]).
+//   fwd   : y[row m][c] = sum_t col[m][t*C + c] * w[c][t]                   y rows at row_off(m, rpi, item, C)
+//   bwd_d : dcol[m][t*C + c] = dy[m][c] * w[c][t]                           (col2im then gives the input gradient)
+//   bwd_w : slabs[blk][c][t] = sum over the block's rows of col[m][t*C + c] * dy[m][c]
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ col, const float* __restrict__ w, T* __restrict__ y,
+                                                     long long M, int C, int taps, int Kp, int rpi, long long item) {
+    const long long total = M * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long m = idx / C;
+        float acc = 0.f;
+        for (int t = 0; t < taps; ++t) acc = fmaf(to_f32(col[m * Kp + (long long)t * C + c]), w[c * taps + t], acc);
+        y[row_off((int)m, rpi, item, C) + c] = from_f32<T>(acc);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_col_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dcol,
+                                                         long long M, int C, int taps, int Kp, int rpi, long long item) {
+    const long long total = M * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long m = idx / C;
+        const float g = to_f32(dy[row_off((int)m, rpi, item, C) + c]);
+        for (int t = 0; t < taps; ++t) dcol[m * Kp + (long long)t * C + c] = from_f32<T>(g * w[c * taps + t]);
+        if (c == 0)
+            for (int k = taps * C; k < Kp; ++k) dcol[m * Kp + k] = from_f32<T>(0.f);          // K padding of the row
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_w_kernel(const T* __restrict__ col, const T* __restrict__ dy, float* __restrict__ slabs,
+                                                       long long M, int C, int taps, int Kp, int rpi, long long item,
+                                                       long long rows_per_block) {
+    // thread -> (c, t) pairs; rows of this block are walked serially (coalesced along c)
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int o = threadIdx.x; o < C * taps; o += 256) {
+        const int t = o / C, c = o % C;
+        float acc = 0.f;
+        for (long long m = r0; m < r1; ++m)
+            acc = fmaf(to_f32(col[m * Kp + (long long)t * C + c]), to_f32(dy[row_off((int)m, rpi, item, C) + c]), acc);
+        slabs[((long long)blockIdx.x * C + c) * taps + t] = acc;
+    }
+}
+
 // Per-block partial sums over rows of x[rows][C]: slabs[blk][0][c] = sum x, slabs[blk][1][c] = sum x^2  (BatchNorm statistics;
 // pad rows of a grid are zero and drop out).
 template <typename T>
@@ -672,6 +717,37 @@ int launch_col2im2d(const void* dcol, void* din, const int* g, int kh, int kw, i
 }
 
 static bool bn_c_ok(int C) { return C > 0 && C % 4 == 0 && C / 4 <= 256; }    // multiples of 4 up to 1024
+
+int launch_dw_fwd(const void* col, const float* w, void* y, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+                  hipStream_t st) {
+    if (M <= 0 || C <= 0 || taps <= 0 || Kp < taps * C || M >= (1ll << 31)) return CPC_EINVAL;
+    const int nb = blocks_for(M * C);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((dw_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)col, w, (bf16_t*)y, M, C, taps, Kp, rpi, item),
+              hipLaunchKernelGGL((dw_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)col, w, (float*)y, M, C, taps, Kp, rpi, item));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+int launch_dw_bwd_col(const void* dy, const float* w, void* dcol, long long M, int C, int taps, int Kp, int rpi, long long item,
+                      int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || taps <= 0 || Kp < taps * C || M >= (1ll << 31)) return CPC_EINVAL;
+    const int nb = blocks_for(M * C);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((dw_bwd_col_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dcol, M, C, taps, Kp, rpi, item),
+              hipLaunchKernelGGL((dw_bwd_col_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dy, w, (float*)dcol, M, C, taps, Kp, rpi, item));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+int launch_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, int C, int taps, int Kp, int rpi, long long item,
+                    int nblocks, int dtype, hipStream_t st) {
+    if (M <= 0 || C <= 0 || taps <= 0 || Kp < taps * C || nblocks <= 0 || M >= (1ll << 31)) return CPC_EINVAL;
+    const long long rpb = (M + nblocks - 1) / nblocks;
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((dw_bwd_w_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)col, (const bf16_t*)dy, slabs, M, C, taps, Kp, rpi, item, rpb),
+              hipLaunchKernelGGL((dw_bwd_w_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const float*)col, (const float*)dy, slabs, M, C, taps, Kp, rpi, item, rpb));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
 
 int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, hipStream_t st) {
     if (rows <= 0 || !bn_c_ok(C) || nblocks <= 0) return CPC_EINVAL;

@@ -241,6 +241,89 @@ class _Conv:
                     _hip.call("cpc_relu_mask", din.ptr(), gin.ptr(), din.rows * din.C, code)
 
 
+class _SepConv:
+    """Conv2dSeparable on grids (scalogram_model.py:532-544): the depthwise k x k convolution runs on the im2col matrix of the
+    input (cpc_im2col2d + cpc_dw_fwd; backward cpc_dw_bwd_col + cpc_col2im2d and cpc_dw_bwd_w), the 1 x 1 convolution is an
+    ordinary _Conv on the depthwise output.  Same interface as _Conv."""
+
+    def __init__(self, eng, prefix, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False, bias=True):
+        self.eng, self.gin, self.in_f32, self.need_dgrad = eng, gin, in_f32, need_dgrad
+        dev, dt = eng.device, (torch.float32 if in_f32 else eng.dt)
+        self.dt, self.code = dt, _hip.dtype_code(dt)
+        dw = mod.conv
+        self.wname = prefix + ".conv.weight"
+        self.C = dw.in_channels
+        self.kh_dw, self.kw = dw.kernel_size
+        self.sh, self.sw = dw.stride
+        ph, pw = dw.padding
+        if ph != pw:
+            raise NotImplementedError("asymmetric Conv2d padding")
+        self.pad = ph
+        if self.C != gin.C:
+            raise ValueError(f"{self.wname}: expects {self.C} input channels, the incoming activation has {gin.C}")
+        hin = gin.top + gin.H
+        self.Ho = (hin + 2 * self.pad - self.kh_dw) // self.sh + 1
+        self.Wo = (gin.W + 2 * self.pad - self.kw) // self.sw + 1
+        if self.Ho < 1 or self.Wo < 1:
+            raise ValueError(f"{self.wname}: input {hin} x {gin.W} is smaller than the kernel")
+        self.taps = self.kh_dw * self.kw
+        self.K = self.taps * self.C
+        self.Kp = _ceil_div(self.K, 8) * 8
+        self.M = gin.B * self.Wo * self.Ho
+        self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
+        self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if need_dgrad else None
+        self.mid = Grid(gin.B, self.Wo, self.Ho, self.C, dev, dt)
+        self.d_mid = self.mid.like(dev)
+        self.pw = _Conv(eng, prefix + ".conv_1x1.weight", prefix + ".conv_1x1.bias" if bias else None, mod.conv_1x1, self.mid,
+                        in_f32=in_f32, need_dgrad=True, relu=relu)
+        self.y0, self.cout, self.kh = self.pw.y0, self.pw.cout, 1
+        self.nb = max(1, min(256, self.M // 256))
+        self.slab = max(self.pw.slab, self.nb * self.C * self.taps)
+
+    @property
+    def dy0(self):
+        return self.pw.dy0
+
+    @dy0.setter
+    def dy0(self, g):
+        self.pw.dy0 = g
+
+    def prepare(self):
+        self.pw.prepare()
+
+    def forward(self):
+        e, gin, mid = self.eng, self.gin, self.mid
+        w = e.model._param[self.wname]
+        _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(self.col), _desc(gin, gin.padded_desc), self.kh_dw, self.kw, self.sh, self.sw,
+                  self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if self.in_f32 else 0, self.code)
+        _hip.call("cpc_dw_fwd", _hip.ptr(self.col), _hip.ptr(w), mid.ptr(mid.top * self.C), C.c_longlong(self.M), self.C, self.taps,
+                  self.Kp, self.Ho, C.c_longlong(mid.Ha * self.C), self.code)
+        self.pw.forward()
+
+    def backward(self, din: Optional[Grid], accumulate=False, mask_input=False):
+        e, gin, d_mid = self.eng, self.gin, self.d_mid
+        w = e.model._param[self.wname]
+        self.pw.backward(d_mid)
+        off = d_mid.top * self.C
+        _hip.call("cpc_dw_bwd_w", _hip.ptr(self.col), d_mid.ptr(off), _hip.ptr(e.slabs), C.c_longlong(self.M), self.C, self.taps, self.Kp,
+                  self.Ho, C.c_longlong(d_mid.Ha * self.C), self.nb, self.code)
+        e.model._grad[self.wname].view(-1).copy_(e.slabs[:self.nb * self.C * self.taps].view(self.nb, -1).sum(0))
+        if din is not None and self.need_dgrad:
+            _hip.call("cpc_dw_bwd_col", d_mid.ptr(off), _hip.ptr(w), _hip.ptr(self.dcol), C.c_longlong(self.M), self.C, self.taps, self.Kp,
+                      self.Ho, C.c_longlong(d_mid.Ha * self.C), self.code)
+            _hip.call("cpc_col2im2d", _hip.ptr(self.dcol), din.ptr(), _desc(din, din.padded_desc), self.kh_dw, self.kw, self.sh, self.sw,
+                      self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if accumulate else 0, self.code)
+            if mask_input:
+                _hip.call("cpc_relu_mask", din.ptr(), gin.ptr(), din.rows * din.C, self.code)
+
+
+def _make_conv(eng, base, mod, gin, bias, **kw):
+    """_Conv for an nn.Conv2d at state_dict prefix ``base``, _SepConv for a Conv2dSeparable."""
+    if hasattr(mod, "conv_1x1"):
+        return _SepConv(eng, base, mod, gin, bias=bias, **kw)
+    return _Conv(eng, base + ".weight", base + ".bias" if bias else None, mod, gin, **kw)
+
+
 class _BatchNorm:
     """nn.BatchNorm2d + ReLU between a convolution output grid y0 and the activation grid a."""
 
@@ -312,8 +395,8 @@ class _Block:
             raise AssertionError("block input grid was not allocated with this block's top_padding_1")
         # ---- main branch
         i1, i2 = blk.index['conv_1'], blk.index['conv_2']
-        self.conv_a = _Conv(eng, f"{pre}main_modules.{i1}.weight", f"{pre}main_modules.{i1}.bias" if bias else None, mm[i1], gin,
-                            in_f32=in_f32, need_dgrad=not first, relu=not has_bn)
+        self.conv_a = _make_conv(eng, f"{pre}main_modules.{i1}", mm[i1], gin, bias, in_f32=in_f32, need_dgrad=not first,
+                                 relu=not has_bn)
         ya = self.conv_a.y0
         # [MaxPool2d(pooling_1)] sits between the BatchNorm and the ReLU in the reference (scalogram_model.py:401-405); max
         # pooling commutes with the monotone ReLU, so here the fused BatchNorm + ReLU output is pooled
@@ -338,8 +421,7 @@ class _Block:
                 self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, guard_rows=k2[0] + 16)
             else:
                 self.a_a = ya
-        self.conv_b = _Conv(eng, f"{pre}main_modules.{i2}.weight", f"{pre}main_modules.{i2}.bias" if bias else None, mm[i2], self.a_a,
-                            relu=not has_bn)
+        self.conv_b = _make_conv(eng, f"{pre}main_modules.{i2}", mm[i2], self.a_a, bias, relu=not has_bn)
         yb = self.conv_b.y0
         Hb2, Wb2 = pooled(yb.H, self.pool2), pooled(yb.W, self.pool2)
         if Hb2 < 1 or Wb2 < 1:

@@ -100,6 +100,27 @@ default_encoder_block_dict = {'in_channels': 64,
                               'batch_norm': False}
 
 
+class Conv2dSeparable(nn.Module):
+    """Depthwise k x k convolution (groups = in_channels, no bias) followed by a 1 x 1 convolution — parameter holder with the
+    reference's sub-module names and construction order (scalogram_model.py:532-544); runs as scalogram_engine._SepConv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        if dilation != 1:
+            raise NotImplementedError("dilated separable convolutions are not part of the HIP path")
+        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=in_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, bias=False, groups=in_channels)
+        self.conv_1x1 = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    @property
+    def weight(self):
+        return self.conv.weight
+
+    def forward(self, x):
+        raise NotImplementedError("Conv2dSeparable runs inside AudioPredictiveCodingModel.forward on the HIP path")
+
+
 class ScalogramEncoderBlock(nn.Module):
     """conv_a -> [BN] -> ReLU -> [top pad] -> conv_b -> [BN] -> ReLU, plus the pooled / 1x1-projected, cropped residual
     branch (reference scalogram_model.py:372-479).  Parameter holder: standard torch modules at the reference's
@@ -111,12 +132,12 @@ class ScalogramEncoderBlock(nn.Module):
         self.name = name
         if args_dict['hidden_channels'] is None:
             args_dict['hidden_channels'] = args_dict['out_channels']
-        if args_dict['separable']:
-            raise NotImplementedError("separable scalogram convolutions are not part of the HIP path")
         a = args_dict
+        conv_module = Conv2dSeparable if a['separable'] else nn.Conv2d
         self.cfg = {k: a[k] for k in ('in_channels', 'hidden_channels', 'out_channels', 'kernel_size_1', 'kernel_size_2',
                                       'top_padding_1', 'top_padding_2', 'padding_1', 'padding_2', 'stride_1', 'stride_2',
                                       'pooling_1', 'pooling_2', 'bias', 'residual', 'batch_norm')}
+        self.cfg['separable'] = bool(a['separable'])
         self.cfg['ceil_pooling'] = bool(a.get('ceil_pooling', False))
         self.main_modules = nn.ModuleList()
         self.index = {}
@@ -124,8 +145,8 @@ class ScalogramEncoderBlock(nn.Module):
             if a['top_padding_' + tag] is not None:
                 self.main_modules.append(nn.ZeroPad2d((0, 0, a['top_padding_' + tag], 0)))
             self.index['conv_' + tag] = len(self.main_modules)
-            self.main_modules.append(nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=a['kernel_size_' + tag],
-                                               bias=a['bias'], padding=a['padding_' + tag], stride=a['stride_' + tag]))
+            self.main_modules.append(conv_module(in_channels=cin, out_channels=cout, kernel_size=a['kernel_size_' + tag],
+                                                 bias=a['bias'], padding=a['padding_' + tag], stride=a['stride_' + tag]))
             if a['batch_norm']:
                 self.index['bn_' + tag] = len(self.main_modules)
                 self.main_modules.append(nn.BatchNorm2d(cout))

@@ -198,6 +198,18 @@ int cpc_im2col2d(const void* in, void* col, const int* grid, int kh, int kw, int
 /* The adjoint: din(b,w,h,c) (+= if accumulate) sum of the dcol entries that read it. */
 int cpc_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo, int Kp,
                  int accumulate, int dtype, void* stream);
+/* Depthwise (groups = channels) convolution of Conv2dSeparable (scalogram_model.py:532-544) on the im2col matrix of its input
+ * (cpc_im2col2d: tap t of channel c of output row m at col[m][t*C + c]); w f32 [C][taps] is the reference's [C][1][kh][kw].
+ * Output / gradient rows m live at (m / rpi) * item + (m % rpi) * C (rpi == 0: m * C), i.e. inside a grid.
+ *   cpc_dw_fwd     : y[m][c] = sum_t col[m][t*C + c] * w[c][t]
+ *   cpc_dw_bwd_col : dcol[m][t*C + c] = dy[m][c] * w[c][t]      (cpc_col2im2d then gives the input gradient)
+ *   cpc_dw_bwd_w   : slabs[blk][c][t] = partial sums over rows of col[m][t*C + c] * dy[m][c]  (reduce with cpc_reduce_slabs) */
+int cpc_dw_fwd(const void* col, const float* w, void* y, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+               void* stream);
+int cpc_dw_bwd_col(const void* dy, const float* w, void* dcol, long long M, int C, int taps, int Kp, int rpi, long long item, int dtype,
+                   void* stream);
+int cpc_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, int C, int taps, int Kp, int rpi, long long item,
+                 int nblocks, int dtype, void* stream);
 /* nn.BatchNorm2d / BatchNorm1d with batch statistics (scalogram_model.py:398-399, audio_model.py:102-103):
  * cpc_bn_stats: slabs f32 [nblocks][2][C] partial (sum, sum of squares) over the rows of x T [rows][C] (pad rows are zero);
  * cpc_bn_finalize: stats f32 [2][C] = (mean, 1/sqrt(biased var + eps)) over `count` elements per channel, and, when

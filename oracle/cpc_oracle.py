@@ -287,8 +287,14 @@ def scalogram_block_forward(x: torch.Tensor, params: Params, prefix: str, cfg: d
         if top is not None:
             h = F.pad(h, (0, 0, top, 0))
             idx += 1
-        h = F.conv2d(h, params[f"{prefix}main_modules.{idx}.weight"], params.get(f"{prefix}main_modules.{idx}.bias"),
-                     stride=cfg["stride_" + tag], padding=cfg["padding_" + tag])
+        if cfg.get("separable"):
+            # Conv2dSeparable (scalogram_model.py:532-544): depthwise k x k (groups = channels, no bias), then 1 x 1 with bias
+            wd = params[f"{prefix}main_modules.{idx}.conv.weight"]
+            h = F.conv2d(h, wd, None, stride=cfg["stride_" + tag], padding=cfg["padding_" + tag], groups=wd.shape[0])
+            h = F.conv2d(h, params[f"{prefix}main_modules.{idx}.conv_1x1.weight"], params.get(f"{prefix}main_modules.{idx}.conv_1x1.bias"))
+        else:
+            h = F.conv2d(h, params[f"{prefix}main_modules.{idx}.weight"], params.get(f"{prefix}main_modules.{idx}.bias"),
+                         stride=cfg["stride_" + tag], padding=cfg["padding_" + tag])
         idx += 1
         if cfg["batch_norm"]:
             bn = f"{prefix}main_modules.{idx}."

@@ -23,6 +23,7 @@ Fixtures written (all float32 unless noted):
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
+  scalogram_model_sep.npz  the same model with Conv2dSeparable convolutions (depthwise + 1x1)
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval), runs with the Wasserstein gradient penalty,
                         trainer losses, gradients, BatchNorm running statistics
 """
@@ -377,6 +378,11 @@ def _scalogram_small_blocks():
     return [b0, b1, b2]
 
 
+def _scalogram_small_blocks_sep():
+    """The blocks of fixture a with Conv2dSeparable convolutions (depthwise k x k + 1 x 1), scalogram_model.py:532-544."""
+    return [dict(b, separable=True) for b in _scalogram_small_blocks()]
+
+
 def _scalogram_small_blocks_b():
     """Shrunken scalogram_resnet_architecture_8/9 traits: no phase channel, tall first kernel on the raw scalogram, padded
     3x3 kernels, stride in the SECOND convolution, an identity residual, a padded 1x1 residual projection."""
@@ -402,11 +408,14 @@ def gen_scalogram(variant="a"):
     if variant == "a":
         L = 256 + 32 * 60 + 1
         pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks, True, "scalogram_model"
+    elif variant == "sep":
+        L = 256 + 32 * 60 + 1
+        pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks_sep, True, "scalogram_model_sep"
     else:
         L = 256 + 32 * 127 + 1
         pre_kw = dict(phase=False, offset_zero=True, output_power=2., scaling=10., pooling=[1, 2])
         blocks_fn, phase, fname = _scalogram_small_blocks_b, False, "scalogram_model_b"
-    scale = {"prediction_model.weight": 1.0 if variant == "a" else 0.06}
+    scale = {"prediction_model.weight": 0.06 if variant == "b" else 1.0}
 
     def build():
         torch.manual_seed(41)
@@ -795,7 +804,7 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "conv_ar_bn", "ar_resnet"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "conv_ar_bn", "ar_resnet"]
     if "ar_resnet" in which:
         _install_librosa_stand_in()
         gen_ar_resnet()
@@ -805,6 +814,8 @@ if __name__ == "__main__":
         gen_scalogram("a")
     if "scalogram_b" in which:
         gen_scalogram("b")
+    if "scalogram_sep" in which:
+        gen_scalogram("sep")
     if "cqt" in which:
         gen_cqt()
     if "attention" in which:
