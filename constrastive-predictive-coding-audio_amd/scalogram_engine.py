@@ -181,21 +181,30 @@ class _Conv:
         (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
         e, gin, dy0 = self.eng, self.gin, self.dy0
         g, code = e.model._grad, self.code
+        # The short reductions of the weight-gradient path (bias column sum, slab sums) run on the engine's side stream beside
+        # the next GEMMs of the main stream; the slabs of this convolution therefore live in a buffer of their own.
+        if getattr(self, "_wslab", None) is None:
+            self._wslab = torch.empty(max(self.slab, 1), device=e.device, dtype=torch.float32)
+            self._bscratch = torch.empty(e.colsum_blocks * self.cout, device=e.device, dtype=torch.float32)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+        wslab = self._wslab
         if self.bname and self.bname in g:
-            e._colsum_to_grad(dy0.ptr(), g[self.bname], dy0.rows, self.cout, code)
+            with e.side(self._ev[0]):
+                e._colsum_to_grad(dy0.ptr(), g[self.bname], dy0.rows, self.cout, code, scratch=self._bscratch)
         if self.mode == 'col' and self.G > 1:
             G = self.G
             Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.M // G
             chunk = e._chunk(Mg, self.nsplit)
-            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(e.slabs), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
+            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
                          m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32)
-            # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
-            S = e.slabs[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
-            gw = g[self.wname].view(self.cout, self.cin, self.kh)
-            acc = S[0:self.kh, :, 0, :]
-            for dh in range(1, G):
-                acc = acc + S[dh:dh + self.kh, :, dh, :]
-            gw.copy_(acc.permute(2, 1, 0))
+            with e.side(self._ev[1]):
+                # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
+                S = wslab[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
+                gw = g[self.wname].view(self.cout, self.cin, self.kh)
+                acc = S[0:self.kh, :, 0, :]
+                for dh in range(1, G):
+                    acc = acc + S[dh:dh + self.kh, :, dh, :]
+                gw.copy_(acc.permute(2, 1, 0))
             if din is not None and self.need_dgrad:
                 dst = din
                 if accumulate:
@@ -209,10 +218,11 @@ class _Conv:
                     din.t.add_(dst.t)
         elif self.mode == 'col':
             chunk = e._chunk(self.M, self.nsplit)
-            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(e.slabs), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
+            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
                          nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32)
-            _hip.call("cpc_reduce_conv_w", _hip.ptr(e.slabs), _hip.ptr(g[self.wname]), self.cin, self.cout, self.kh, self.nsplit,
-                      self.K * self.cout)
+            with e.side(self._ev[1]):
+                _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(g[self.wname]), self.cin, self.cout, self.kh, self.nsplit,
+                          self.K * self.cout)
             if din is not None and self.need_dgrad:
                 D = self.kh
                 dst = din
@@ -226,12 +236,13 @@ class _Conv:
                     din.t.add_(dst.t)
         else:
             chunk = e._chunk(self.M, self.nsplit, self.dt)
-            _hip.gemm_tn(_hip.ptr(self.col), dy0.ptr(dy0.top * self.cout), _hip.ptr(e.slabs), self.M, self.Kp, self.cout, self.Kp, self.cout,
+            _hip.gemm_tn(_hip.ptr(self.col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp, self.cout,
                          self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit, m_chunk=chunk,
                          slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
             taps = self.kh * self.kw
-            _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[self.wname]), self.K, self.cout, self.nsplit, self.Kp * self.cout,
-                      self.cin, self.cin * taps, 1, taps)
+            with e.side(self._ev[1]):
+                _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(g[self.wname]), self.K, self.cout, self.nsplit, self.Kp * self.cout,
+                          self.cin, self.cin * taps, 1, taps)
             if din is not None and self.need_dgrad:
                 _hip.gemm_nt(dy0.ptr(dy0.top * self.cout), _hip.ptr(self.w_t), _hip.ptr(self.dcol), self.M, self.Kp, self.cout, self.cout,
                              self.cout, self.Kp, code, a_rpi=self.Ho, a_item=dy0.Ha * self.cout)
