@@ -24,6 +24,7 @@ Fixtures written (all float32 unless noted):
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
   scalogram_model_sep.npz  the same model with Conv2dSeparable convolutions (depthwise + 1x1)
+  scalogram_model_gp.npz   scalogram encoder + BatchNorm ConvolutionalArModel, linear scores, Wasserstein gradient penalty runs
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval), runs with the Wasserstein gradient penalty,
                         trainer losses, gradients, BatchNorm running statistics
 """
@@ -397,6 +398,10 @@ def _scalogram_small_blocks_b():
     return [b0, b1, b2, b3]
 
 
+GP_AR = {'kernel_sizes': [3, 3], 'channel_count': [64, 48, 32], 'stride': [1, 1], 'pooling': [1, 2], 'bias': True, 'batch_norm': True,
+         'residual': False, 'self_attention': [False, False]}
+
+
 def gen_scalogram(variant="a"):
     """a: a shrunken scalogram_resnet_architecture_7: CQT (24 bins) -> phase scalogram -> 3 residual blocks (strided 3x3 +
     tall (k,1) kernels with top padding, BatchNorm on the first two, 2x2 + (2,1) on the last) -> GRU context.
@@ -411,6 +416,11 @@ def gen_scalogram(variant="a"):
     elif variant == "sep":
         L = 256 + 32 * 60 + 1
         pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks_sep, True, "scalogram_model_sep"
+    elif variant == "gp":
+        # the shape of the reference's gradient-penalty experiments (e22..): scalogram encoder, convolutional context network with
+        # BatchNorm, linear scores, Wasserstein gradient penalty
+        L = 256 + 32 * 60 + 1
+        pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks, True, "scalogram_model_gp"
     else:
         L = 256 + 32 * 127 + 1
         pre_kw = dict(phase=False, offset_zero=True, output_power=2., scaling=10., pooling=[1, 2])
@@ -422,7 +432,10 @@ def gen_scalogram(variant="a"):
         pre = ref_scal.PreprocessingModule(cqt_dict=CQT_SMALL, **pre_kw)
         enc_dict = {'phase': phase, 'blocks': copy.deepcopy(blocks_fn()), 'activation_register': None}
         enc = ref_scal.ScalogramResidualEncoder(args_dict=enc_dict, preprocessing_module=pre)
-        ar = ref_model.AudioGRUModel(input_size=E, hidden_size=H)
+        if variant == "gp":
+            ar = ref_model.ConvolutionalArModel(dict(GP_AR, activation_register=None))
+        else:
+            ar = ref_model.AudioGRUModel(input_size=E, hidden_size=H)
         model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=E, ar_size=H, visible_steps=V, prediction_steps=K)
         g = torch.Generator().manual_seed(43)
         with torch.no_grad():
@@ -463,10 +476,14 @@ def gen_scalogram(variant="a"):
             if "running_" in k or "num_batches" in k:
                 out["after_train_fwd/" + k] = v
     rid = 0
+    if variant == "gp":
+        meta["ar"] = GP_AR
     runs = [("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3, None),
             ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3, None),
             ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4, None)]
-    if variant == "a":
+    if variant == "gp":
+        runs = []
+    if variant in ("a", "gp"):
         # Wasserstein gradient penalty (contrastive_estimation_training.py:144-155), the reference's e11.. experiment settings:
         # linear scores, both loss branches
         runs += [("linear", ref_train.linear_score_function, True, 0.0, 1, 1e-3, 10.0),
@@ -804,7 +821,7 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "conv_ar_bn", "ar_resnet"]
+    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "conv_ar_bn", "ar_resnet"]
     if "ar_resnet" in which:
         _install_librosa_stand_in()
         gen_ar_resnet()
@@ -816,6 +833,8 @@ if __name__ == "__main__":
         gen_scalogram("b")
     if "scalogram_sep" in which:
         gen_scalogram("sep")
+    if "scalogram_gp" in which:
+        gen_scalogram("gp")
     if "cqt" in which:
         gen_cqt()
     if "attention" in which:
