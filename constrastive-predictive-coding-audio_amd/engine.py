@@ -629,6 +629,11 @@ class ConvArContext:
             self.w_dgrad.append(torch.empty(cin * kw * cout, device=dev, dtype=dt))
             self.nsplit.append(e._pick_split(kw * cin, cout, B * self.la[l]))
         self.c32 = torch.empty(B, self.channels[-1], device=dev, dtype=torch.float32)
+        # side-stream reductions: per-layer weight-gradient slabs, one bias scratch, events
+        self.wslab = [torch.empty(self.nsplit[l] * self.kernels[l] * self.channels[l] * self.channels[l + 1], device=dev, dtype=torch.float32)
+                      for l in range(self.nb)]
+        self.bscratch = torch.empty(e.colsum_blocks * max(self.channels), device=dev, dtype=torch.float32)
+        self._ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(self.nb)]
 
     def slab_floats(self):
         return max(self.nsplit[l] * self.kernels[l] * self.channels[l] * self.channels[l + 1] for l in range(self.nb)) + \
@@ -689,15 +694,17 @@ class ConvArContext:
             cin, cout, kw, la = self.channels[l], self.channels[l + 1], self.kernels[l], self.la[l]
             bname = self._name(l, "bias")
             if bname in g:
-                e._colsum_to_grad(_hip.ptr(self.dy[l]), g[bname], B * la, cout)
+                with e.side(self._ev[l][0]):
+                    e._colsum_to_grad(_hip.ptr(self.dy[l]), g[bname], B * la, cout, scratch=self.bscratch)
             a, a_rpi, a_item = self._block_input(l)
             chunk = e._chunk(B * la, self.nsplit[l])
-            # (on the main stream: moved to the high-priority side stream these weight-gradient GEMMs take the CUs from the
-            # short data-gradient chain they run beside — measured 3.9 -> 5.3 ms per step)
-            _hip.gemm_tn(a, _hip.ptr(self.dy[l]), _hip.ptr(e.slabs), B * la, kw * cin, cout, cin, cout, cout, code, a_rpi=a_rpi,
+            # The weight-gradient GEMM stays on the main stream (on the high-priority side stream it takes the CUs from the short
+            # data-gradient chain it runs beside: measured 3.9 -> 5.3 ms per step); only the short reductions go to the side stream.
+            _hip.gemm_tn(a, _hip.ptr(self.dy[l]), _hip.ptr(self.wslab[l]), B * la, kw * cin, cout, cin, cout, cout, code, a_rpi=a_rpi,
                          a_item=a_item, nsplit=self.nsplit[l], m_chunk=chunk, slab_stride=kw * cin * cout, flags=_hip.GEMM_OUT_F32)
-            _hip.call("cpc_reduce_conv_w", _hip.ptr(e.slabs), _hip.ptr(g[self._name(l, "weight")]), cin, cout, kw, self.nsplit[l],
-                      kw * cin * cout)
+            with e.side(self._ev[l][1]):
+                _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[self._name(l, "weight")]), cin, cout, kw,
+                          self.nsplit[l], kw * cin * cout)
             D = kw                                   # stride 1: every input position is touched by kw output rows
             dy_shift = _hip.ptr(self.dy[l], -(D - 1) * cout)
             if self.x[l] is None:
