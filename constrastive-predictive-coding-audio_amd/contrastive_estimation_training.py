@@ -145,8 +145,33 @@ class ContrastiveEstimationTrainer:
             return
         loader = torch.utils.data.DataLoader(dataset, batch_sampler=index_lists if index_lists is not None else sampler,
                                              num_workers=num_workers, pin_memory=pin_memory)
-        for batch in iter(loader):
-            yield batch.to(device=device, non_blocking=True)
+        if torch.device(device).type != "cuda":
+            for batch in iter(loader):
+                yield batch.to(device=device, non_blocking=True)
+            return
+        # Host dataset: double-buffered upload.  Batch i + 1 travels pinned host -> HBM on a copy stream while step i computes
+        # (21 MB per step at B = 256: 0.3-0.4 ms of PCIe time that would otherwise sit in front of every step).
+        copy = torch.cuda.Stream(device=device)
+        it = iter(loader)
+
+        def fetch():
+            batch = next(it, None)
+            if batch is None:
+                return None
+            with torch.cuda.stream(copy):
+                dev_batch = batch.to(device=device, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy)
+            return dev_batch, done, batch          # the pinned source stays referenced until its copy has been waited for
+
+        nxt = fetch()
+        while nxt is not None:
+            dev_batch, done, _src = nxt
+            nxt = fetch()
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(done)
+            dev_batch.record_stream(cur)
+            yield dev_batch
 
     # ------------------------------------------------------------------------------------------ train
     def train(self, batch_size=32, epochs=10, lr=0.0001, continue_training_at_step=0, num_workers=1, max_steps=None,

@@ -1000,3 +1000,27 @@ def test_fused_layer1_weight_gradient_two_layer_encoder_without_bias():
         a, b = got[True][n], got[False][n]
         assert torch.isfinite(a).all() and b.abs().max().item() > 0
         assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), n
+
+
+def test_host_dataset_double_buffered_upload_equals_resident_dataset(golden_dir):
+    """A dataset kept in host memory goes through the DataLoader and the trainer's copy-stream prefetch; the losses and the
+    parameters after the steps equal those of the same run on a device-resident dataset."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"])
+    run = [r for r in meta["runs"] if r["steps"] > 1][0]
+    results = []
+    for resident in (True, False):
+        model = _small_model(g, meta, "fp32")
+        ds = TensorAudioDataset(data, device=DEV if resident else None)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
+                                          score_over_all_timesteps=run["all_timesteps"], score_function=SCORE[run["score"]],
+                                          prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+        results.append((list(logger.loss_meter.values), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
