@@ -23,6 +23,7 @@ Fixtures written (all float32 unless noted):
   cqt_small.npz         CQT (24 bins, 3 octave groups) and PreprocessingModule outputs (phase / power / plain variants)
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
+  reference_snapshot_small.pt  a whole-module pickle as the reference's SnapshotManager writes (+ .npz of the same tensors)
   scalogram_model_sep.npz  the same model with Conv2dSeparable convolutions (depthwise + 1x1)
   scalogram_model_gp.npz   scalogram encoder + BatchNorm ConvolutionalArModel, linear scores, Wasserstein gradient penalty runs
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval), runs with the Wasserstein gradient penalty,
@@ -679,6 +680,17 @@ def gen_ar_resnet():
 
 
 # ------------------------------------------------------------------ encoder reference test
+def gen_snapshot():
+    """A whole-module pickle as the reference's SnapshotManager writes them (torch.save(model, path)) + the same tensors as npz:
+    data for the snapshot reader of the HIP package (no reference code travels: the pickle holds tensors and class NAMES)."""
+    model = build_model(16, 16, 3, 8, seed=5)
+    torch.save(model, os.path.join(OUT, "reference_snapshot_small.pt"))
+    np.savez_compressed(os.path.join(OUT, "reference_snapshot_small.npz"), **np_state(model))
+    with open(os.path.join(OUT, "reference_snapshot_small.json"), "w") as f:
+        json.dump({"channels": 16, "ar_size": 16, "K": 3, "V": 8}, f)
+    print("snapshot:", os.path.getsize(os.path.join(OUT, "reference_snapshot_small.pt")), "bytes")
+
+
 def gen_encoder_ref_test():
     out = {}
     torch.manual_seed(3)
@@ -821,7 +833,7 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "conv_ar_bn", "ar_resnet"]
+    which = sys.argv[1:] or ["snapshot", "small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "conv_ar_bn", "ar_resnet"]
     if "ar_resnet" in which:
         _install_librosa_stand_in()
         gen_ar_resnet()
@@ -851,5 +863,7 @@ if __name__ == "__main__":
         gen_validate()
     if "samplers" in which:
         gen_samplers()
+    if "snapshot" in which:
+        gen_snapshot()
     if "cfg1" in which:
         gen_cfg1()

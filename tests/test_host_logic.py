@@ -1,6 +1,7 @@
 """CPU-side tests: host logic of the product package, the C-ABI surface (symbols only — no compute without a GPU),
 and the multi-process (gloo, world size 2) data-parallel plumbing."""
 import json
+import numpy as np
 import os
 import random
 import re
@@ -188,3 +189,26 @@ def test_downstream_probe_learns_a_separable_task():
     torch.manual_seed(0)
     acc = tr.test_task(data, labels.astype(np.int64))
     assert acc > 0.9
+
+
+def test_reference_whole_module_snapshot_loads_without_the_reference(golden_dir):
+    """The reference's snapshots are whole-module pickles naming its classes (setup_functions.py:134-164); the reader replaces
+    classes of modules that are not importable by stand-ins and returns the state_dict, which loads strictly into this package's
+    model of the same configuration."""
+    import sys
+    from cpc_audio_amd.checkpoint import load_reference_snapshot, reference_state_dict
+    assert "audio_model" not in sys.modules or "reference" not in (getattr(sys.modules["audio_model"], "__file__", "") or "")
+    path = os.path.join(golden_dir, "reference_snapshot_small.pt")
+    meta = json.load(open(os.path.join(golden_dir, "reference_snapshot_small.json")))
+    ref = np.load(os.path.join(golden_dir, "reference_snapshot_small.npz"))
+    sd = reference_state_dict(path)
+    assert set(sd.keys()) == set(ref.files)
+    for k in ref.files:
+        assert torch.equal(sd[k], torch.from_numpy(ref[k])), k
+    c = meta["channels"]
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [c] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, AudioGRUModel(c, meta["ar_size"]), enc_size=c, ar_size=meta["ar_size"],
+                                       visible_steps=meta["V"], prediction_steps=meta["K"], compute_dtype="fp32")
+    load_reference_snapshot(model, path)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), torch.from_numpy(ref[k])), k
