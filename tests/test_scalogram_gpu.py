@@ -252,7 +252,12 @@ def _build_scalogram_model(g, meta, dtype):
     enc = ScalogramResidualEncoder(args_dict={'phase': meta.get("phase", True), 'blocks': blocks, 'activation_register': None},
                                    preprocessing_module=pre)
     assert enc.receptive_field == meta["receptive_field"] and enc.downsampling_factor == meta["downsampling_factor"]
-    model = AudioPredictiveCodingModel(enc, AudioGRUModel(input_size=meta["E"], hidden_size=meta["H"]), enc_size=meta["E"],
+    if "ar" in meta:
+        from cpc_audio_amd.audio_model import ConvolutionalArModel
+        ar = ConvolutionalArModel(dict(meta["ar"], activation_register=None))
+    else:
+        ar = AudioGRUModel(input_size=meta["E"], hidden_size=meta["H"])
+    model = AudioPredictiveCodingModel(enc, ar, enc_size=meta["E"],
                                        ar_size=meta["H"], visible_steps=meta["V"], prediction_steps=meta["K"], compute_dtype=dtype)
     assert model.item_length == meta["item_length"]
     state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
@@ -368,6 +373,22 @@ def test_full_size_scalogram_model_bf16_vs_fp32():
     # measured: 0.956 (first BatchNorm scale) ... 0.97 for the first two blocks' BatchNorm parameters and first-layer weights,
     # > 0.98 elsewhere, at random initialisation where the gradient signal itself is small
     assert worst[1] > 0.93, worst
+
+
+def test_scalogram_encoder_with_batchnorm_conv_context_forward(golden_dir):
+    """The model shape of the reference's gradient-penalty experiments (scalogram encoder + BatchNorm ConvolutionalArModel):
+    forward in eval and train mode against the reference (the fixture's training runs all carry the gradient penalty, which
+    only the oracle has so far)."""
+    g = _load(golden_dir, "scalogram_model_gp.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model_gp.json")))
+    pre, model = _build_scalogram_model(g, meta, "fp32")
+    scal = torch.from_numpy(g["scalogram"]).to(DEV)
+    with torch.no_grad():
+        for mode in ("eval", "train"):
+            model.train(mode == "train")
+            pz, tg, z, c = model(scal)
+            for name, got in (("predicted_z", pz), ("targets", tg), ("z", z), ("c", c)):
+                assert _rel(got, g[mode + "/" + name]) < 3e-4, (mode, name)
 
 
 def test_scalogram_encoder_standalone_forward(golden_dir):
