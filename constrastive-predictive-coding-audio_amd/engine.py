@@ -1210,10 +1210,10 @@ class FusedAdam:
 
 class GraphedStep:
     """One whole train step — forward, loss, backward, fused Adam — captured once into a hipGraph and replayed with one call.
-    Measured on MI355X it is neutral: 1.30 ms per step at B = 8, 1.81 at B = 32, 6.31 vs 6.37 at B = 256, with or without the
-    graph — the ~90 launches of a step are already issued ahead of the GPU, and the small-batch step is bound by
-    latency-bound kernels (the GRU's 100 sequential steps each way), not by launch overhead.  Kept as an option for hosts with
-    slower launch paths.  Requirements: single process (no collective inside the graph), no host-side per-step state
+    Measured on MI355X at B = 256: 5.04 ms per step replayed (single stream) against 4.9-5.0 ms for the eager step with its side
+    stream and 5.5 ms for the eager step on one stream — the graph closes the same gaps between short kernels that the side
+    stream hides.  The small-batch step is bound by latency-bound kernels (the GRU's 100 sequential steps each way), not by
+    launch overhead.  Kept as an option for hosts with slower launch paths.  Requirements: single process (no collective inside the graph), no host-side per-step state
     (dropout seeds)."""
 
     def __init__(self, eng, opt, softplus: bool, regularization: float, all_timesteps: bool = False):
@@ -1228,7 +1228,9 @@ class GraphedStep:
         args = dict(softplus=softplus, regularization=regularization, all_timesteps=all_timesteps)
         # no warm-up run: nothing here initialises lazily on first use except buffers, which the capture allocates from the
         # graph's own pool — and a real step on a dummy batch would move BatchNorm's running statistics
-        eng.use_aux = False       # a captured graph replays on one stream; the side-stream overlap of the eager step is given up
+        # captured on ONE stream: a capture with the side-stream forks replays slower (6.4 vs 5.0 ms at B = 256), and the graph
+        # itself closes the launch gaps the side stream hides in the eager step
+        eng.use_aux = False
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = eng.loss_and_grads(self.x, **args)
