@@ -242,6 +242,9 @@ class ContrastiveEstimationTrainer:
                             gneg = glob_neg.get(id(eng))
                             if gneg is None:
                                 gneg = glob_neg[id(eng)] = GlobalNegatives(eng)
+                        # single process: the operand copies of the next step are rebuilt as soon as Adam has updated their
+                        # parameters (engine.CPCEngine.prepare_ahead)
+                        optimizer.after_update = eng.prepare_ahead if sync is None else None
                         out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),

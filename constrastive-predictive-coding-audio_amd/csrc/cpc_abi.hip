@@ -154,7 +154,7 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
 }
 
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype, void* stream) {
-    if (!w || !w_fwd) return CPC_EINVAL;
+    if (!w || (!w_fwd && !w_dgrad)) return CPC_EINVAL;
     return launch_conv_w_prep(w, w_fwd, w_dgrad, Cout, Cin, kw, stride, dtype, (hipStream_t)stream);
 }
 

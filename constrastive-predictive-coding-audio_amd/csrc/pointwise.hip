@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restric
     const long long nf = (long long)Cout * kw * Cin;
     const long long nd = (long long)stride * Cin * D * Cout;
     const long long gstride = (long long)gridDim.x * 256;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nf; idx += gstride) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; fwd && idx < nf; idx += gstride) {
         const int c = (int)(idx % Cin);
         const int j = (int)((idx / Cin) % kw);
         const int co = (int)(idx / ((long long)Cin * kw));

@@ -237,8 +237,16 @@ class CPCEngine:
 
     # ---------------------------------------------------------------------------------- weight layouts
     def prepare_weights(self):
-        """f32 master parameters (reference state_dict shapes) -> storage-dtype GEMM operand layouts."""
+        """f32 master parameters (reference state_dict shapes) -> storage-dtype GEMM operand layouts.  Skipped when
+        prepare_ahead() already rebuilt every operand copy after the last parameter update and nothing has touched the
+        parameters since."""
+        token, self._ahead_token = getattr(self, "_ahead_token", None), None
+        if token is not None and token == self._param_state():
+            return
         self._prepare_encoder_weights()
+        self._prepare_head_weights()
+
+    def _prepare_head_weights(self):
         p, code = self.model._param, self.code
         H, E, K = self.H, self.E, self.K
         if self.ctx is None:          # encoder-only engine (stand-alone AudioEncoder call)
@@ -249,10 +257,59 @@ class CPCEngine:
         _hip.call("cpc_cast2d", _hip.ptr(w_p), _hip.ptr(self.w_p_t), H, K * E, 1, H, code)
 
     def _prepare_encoder_weights(self):
-        p, code = self.model._param, self.code
         for l in range(1, self.n):
-            _hip.call("cpc_conv_w_prep", _hip.ptr(p[f"encoder.layers.{l}.weight"]), _hip.ptr(self.w_fwd[l]),
-                      _hip.ptr(self.w_dgrad[l]), self.channels[l], self.channels[l - 1], self.kernels[l], self.strides[l], code)
+            self._prepare_conv(l, True, True)
+
+    def _prepare_conv(self, l, fwd, dgrad):
+        w = self.model._param[f"encoder.layers.{l}.weight"]
+        _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd[l]) if fwd else None,
+                  _hip.ptr(self.w_dgrad[l]) if dgrad else None, self.channels[l], self.channels[l - 1], self.kernels[l],
+                  self.strides[l], self.code)
+
+    # Operand copies for the NEXT step, rebuilt as soon as the optimizer has updated their parameters (single-process training):
+    # the ten layout kernels (0.1 ms at B = 256) then run on the side stream beside the remaining backward GEMMs instead of in
+    # front of the next step's first convolution.
+    supports_prepare_ahead = True
+
+    def _param_state(self):
+        """Changes whenever the parameters may have changed: torch's version counters catch in-place torch ops on the
+        parameters (load_state_dict, torch optimizers), model._raw_updates counts the fused optimizer's raw-pointer updates."""
+        m = self.model
+        return (sum(p._version for p in m.parameters()) + m._flat_param._version, getattr(m, "_raw_updates", 0),
+                m._flat_param.data_ptr())
+
+    def prepare_ahead(self, lo, hi, final):
+        """FusedAdam calls this right after it updated flat_param[lo:hi): from the backward pass's grad_ready_hook (on the
+        side stream; ``final`` False) and from step() for the head of the buffer (``final`` True, main stream, backward
+        complete).  In the hook call the lowest updated encoder layer's data-gradient operand is still being read by that
+        layer's data-gradient GEMM on the main stream, so that one piece waits for the next call."""
+        if not self.supports_prepare_ahead or not getattr(self.ctx, "ahead_ok", False):
+            return
+        st = getattr(self, "_ahead", None)
+        if st is None:
+            st = self._ahead = {"fwd": set(), "dgrad": set(), "head": False, "deferred": []}
+        off = self.model._offset
+        for l in st["deferred"]:            # their data-gradient GEMMs were issued before the event this call waited for
+            self._prepare_conv(l, False, True)
+            st["dgrad"].add(l)
+        st["deferred"] = []
+        updated = [l for l in range(1, self.n) if lo <= off[f"encoder.layers.{l}.weight"] < hi]
+        for l in updated:
+            busy = (not final) and l == min(updated)
+            self._prepare_conv(l, True, not busy)
+            st["fwd"].add(l)
+            if busy:
+                st["deferred"].append(l)
+            else:
+                st["dgrad"].add(l)
+        if lo <= off["prediction_model.weight"] < hi:
+            self._prepare_head_weights()
+            st["head"] = True
+        if final:
+            every = set(range(1, self.n))
+            complete = st["head"] and st["fwd"] == every and st["dgrad"] == every and not st["deferred"]
+            self._ahead = None
+            self._ahead_token = self._param_state() if complete else None
 
     # ------------------------------------------------------------------------------------------ forward
     def _check_input(self, x):
@@ -487,6 +544,8 @@ class GRUContext:
     """AudioGRUModel as the context network (audio_model.py:47-77): one batched input-projection GEMM for all V steps, the
     persistent GRU kernels for the recurrence, GEMMs for the weight gradients and for dz."""
 
+    ahead_ok = True       # prepare_weights is a pure function of the parameters (CPCEngine.prepare_ahead)
+
     def __init__(self, eng, ar):
         self.eng = eng
         self.H = int(ar.hidden_size)
@@ -576,6 +635,8 @@ class ConvArContext:
     """ConvolutionalArModel as the context network (audio_model.py:80-161) for the plain configuration (no batch norm, no
     residual branch; e.g. ``ar_conv_default_dict``): per block [MaxPool1d(pool, ceil)] -> Conv1d(k, stride 1) -> ReLU on
     channels-last buffers; the convolutions are the same overlapped-row GEMMs as the encoder's; c = the last position."""
+
+    ahead_ok = True       # prepare_weights is a pure function of the parameters (CPCEngine.prepare_ahead)
 
     def __init__(self, eng, ar):
         self.eng = eng
@@ -1166,6 +1227,9 @@ class FusedAdam:
         self.v = torch.zeros_like(flat)
         self.t = 0
         self._done_lo = None
+        # after_update(lo, hi, final): called right after flat_param[lo:hi) was updated; set it to the engine's prepare_ahead in
+        # single-process training so that the operand copies of the next step are rebuilt off the critical path
+        self.after_update = None
         # device_step: the step count lives on the device (cpc_adam_dev), so the call's arguments never change and the step
         # can be part of a captured hipGraph
         self.state = torch.zeros(4, device=flat.device, dtype=torch.float32) if device_step else None
@@ -1180,11 +1244,14 @@ class FusedAdam:
             raise ValueError("FusedAdam.hook needs the host-side step count (device_step=False)")
         self._done_lo = lo if self._done_lo is None else min(self._done_lo, lo)
         self._launch(lo, hi, self.t + 1, 1.0)
+        if self.after_update is not None:
+            self.after_update(lo, hi, False)
 
     def _launch(self, lo, hi, t, grad_scale):
         flat, grad = self.model._flat_param, self.model._flat_grad
         if hi <= lo:
             return
+        self.model._raw_updates = getattr(self.model, "_raw_updates", 0) + 1
         _hip.call("cpc_adam", _hip.ptr(flat, lo), _hip.ptr(grad, lo), _hip.ptr(self.m, lo), _hip.ptr(self.v, lo), C.c_longlong(hi - lo),
                   C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), t,
                   C.c_float(grad_scale))
@@ -1197,7 +1264,10 @@ class FusedAdam:
             if grad_scale != 1.0:
                 raise ValueError("FusedAdam.hook and grad_scale != 1 do not combine")
             self._launch(0, hi, self.t, 1.0)
+            if self.after_update is not None:
+                self.after_update(0, hi, True)
             return
+        self.model._raw_updates = getattr(self.model, "_raw_updates", 0) + 1
         if self.state is not None:
             _hip.call("cpc_adam_dev", _hip.ptr(flat), _hip.ptr(grad), _hip.ptr(self.m), _hip.ptr(self.v), C.c_longlong(flat.numel()),
                       C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
@@ -1231,6 +1301,7 @@ class GraphedStep:
         # captured on ONE stream: a capture with the side-stream forks replays slower (6.4 vs 5.0 ms at B = 256), and the graph
         # itself closes the launch gaps the side stream hides in the eager step
         eng.use_aux = False
+        eng._ahead_token = None            # the captured step always rebuilds its operand copies
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = eng.loss_and_grads(self.x, **args)
@@ -1241,6 +1312,7 @@ class GraphedStep:
         self.x.copy_(batch, non_blocking=True)
         self.graph.replay()
         self.opt.t += 1
+        self.eng.model._raw_updates = getattr(self.eng.model, "_raw_updates", 0) + 1
         return self.out
 
 

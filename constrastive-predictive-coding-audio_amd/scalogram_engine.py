@@ -644,6 +644,8 @@ class ScalogramCPCEngine(CPCEngine):
         need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)]
         self._alloc_head(need)
 
+    supports_prepare_ahead = False     # operand copies are rebuilt at the start of every step (engine.CPCEngine.prepare_ahead)
+
     def _check_input(self, x):
         if not x.is_cuda:
             raise RuntimeError("the CPC hot path runs on the GPU only (no CPU fallback): move the batch to the device")

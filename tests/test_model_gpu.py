@@ -1024,3 +1024,61 @@ def test_host_dataset_double_buffered_upload_equals_resident_dataset(golden_dir)
     assert results[0][0] == results[1][0]
     for k in results[0][1]:
         assert torch.equal(results[0][1][k], results[1][1][k]), k
+
+
+@pytest.mark.parametrize("context", ["gru", "conv"])
+def test_operand_copies_prepared_ahead_equal_prepared_at_step_start(context):
+    """Single-process training rebuilds the storage-dtype operand copies right after Adam updated their parameters (on the side
+    stream, CPCEngine.prepare_ahead) instead of at the start of the next step: same kernels on the same values, so parameters
+    after several steps must be bit-identical; a parameter change by anything else (load_state_dict) must invalidate the copies."""
+    from cpc_audio_amd.engine import FusedAdam
+    B, V, K, C, H = 8, 20, 4, 64, 64
+    L = 465 + (V + K) * 160
+    data = [(torch.randn(B, L, generator=torch.Generator().manual_seed(10 + i)) * 0.5).to(DEV) for i in range(3)]
+
+    def build():
+        torch.manual_seed(5)
+        enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
+        if context == "gru":
+            ar = AudioGRUModel(input_size=C, hidden_size=H)
+        else:
+            ar = ConvolutionalArModel({'kernel_sizes': [5, 3, 2], 'channel_count': [C, C, C, H], 'pooling': [1, 2, 2], 'stride': [1, 1, 1],
+                                       'bias': True, 'batch_norm': False, 'residual': False})
+        m = AudioPredictiveCodingModel(enc, ar, enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype="bf16")
+        return m.to(DEV)
+
+    results = {}
+    for ahead in (False, True):
+        model = build()
+        eng = model.engine(B, L)
+        opt = FusedAdam(model, lr=1e-3)
+        if ahead:
+            opt.after_update = eng.prepare_ahead
+        for x in data:
+            eng.loss_and_grads(x, softplus=True, regularization=1.0, grad_ready_hook=opt.hook)
+            opt.step()
+            assert (eng._ahead_token is not None) == ahead
+        results[ahead] = (model, eng, model._flat_param.detach().clone())
+    assert torch.equal(results[False][2], results[True][2])
+    # a state_dict load between steps: the prepared copies are stale and must be rebuilt
+    model, eng, _ = results[True]
+    other = build()
+    model.load_state_dict(other.state_dict())
+    ref_eng = other.engine(B, L)
+    ref_eng.forward(data[0])
+    eng.forward(data[0])
+    for got, ref in zip(eng.outputs(), ref_eng.outputs()):
+        assert torch.equal(got, ref)
+    # ... and raw-pointer updates by another optimizer object are seen as well
+    opt_a, opt_b = FusedAdam(model, lr=1e-3), FusedAdam(other, lr=1e-3)
+    opt_a.after_update = eng.prepare_ahead
+    for e_, o_ in ((eng, opt_a), (ref_eng, opt_b)):
+        e_.loss_and_grads(data[1], softplus=True, regularization=1.0, grad_ready_hook=o_.hook)
+        o_.step()
+    assert eng._ahead_token is not None and ref_eng._ahead_token is None
+    for m_ in (model, other):
+        FusedAdam(m_, lr=1e-2).step()           # a second update from the gradients still in the buffers
+    eng.forward(data[2])
+    ref_eng.forward(data[2])
+    for got, ref in zip(eng.outputs(), ref_eng.outputs()):
+        assert torch.equal(got, ref)
