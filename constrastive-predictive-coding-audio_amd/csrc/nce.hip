@@ -109,11 +109,13 @@ __global__ __launch_bounds__(256) void nce_col_merge_kernel(const float* __restr
 
 // One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
 // Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T) and per-block partials {sum valid, sum m^2, max sp}.
-template <typename T>
+// KT > 0: the number of prediction steps as a compile-time constant (the K loads of a pair's mean are then all in flight).
+template <typename T, int KT>
 __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
                                                        T* __restrict__ dS, T* __restrict__ dST,
-                                                       float* __restrict__ partial, int B, int K, int ld, int softplus,
+                                                       float* __restrict__ partial, int B, int K_rt, int ld, int softplus,
                                                        float reg) {
+    const int K = KT > 0 ? KT : K_rt;
     __shared__ float tile[32][33];
     __shared__ float red[3][256];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
@@ -127,8 +129,21 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         const int b = b0 + ty + 8 * r, bp = bp0 + tx;
         float m = 0.f;
         if (b < B && bp < B) {
+            const float* sp0 = S + (long long)b * ld + bp;
+            if (KT > 0) {
+                float raw[KT > 0 ? KT : 1];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) raw[k] = sp0[(long long)k * B * ld];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const float sp = score_tf(raw[k], softplus);
+                    m += sp;
+                    mx = fmaxf(mx, sp);
+                    if (b == bp) valid += sp;
+                }
+            } else
             for (int k = 0; k < K; ++k) {
-                const float sp = score_tf(S[((long long)k * B + b) * ld + bp], softplus);
+                const float sp = score_tf(sp0[(long long)k * B * ld], softplus);
                 m += sp;
                 mx = fmaxf(mx, sp);
                 if (b == bp) valid += sp;
@@ -331,14 +346,16 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
     const int nb = (ld + 31) / 32;
     hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B, (float*)nullptr,
                        (float*)nullptr);
-    if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (bf16_t*)dS, (bf16_t*)dST,
-                           gradp, B, K, ld, softplus, reg);
-    else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (float*)dS, (float*)dST, gradp,
-                           B, K, ld, softplus, reg);
-    else
+#define NCE_GRAD(T, KT) hipLaunchKernelGGL((nce_grad_kernel<T, KT>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (T*)dS, (T*)dST, \
+                                           gradp, B, K, ld, softplus, reg)
+    if (dtype == CPC_DTYPE_BF16) {
+        if (K == 12) NCE_GRAD(bf16_t, 12); else if (K == 16) NCE_GRAD(bf16_t, 16); else NCE_GRAD(bf16_t, 0);
+    } else if (dtype == CPC_DTYPE_F32) {
+        if (K == 12) NCE_GRAD(float, 12); else if (K == 16) NCE_GRAD(float, 16); else NCE_GRAD(float, 0);
+    } else {
         return CPC_EINVAL;
+    }
+#undef NCE_GRAD
     hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;

@@ -163,6 +163,7 @@ class CPCEngine:
         # weight operand layouts (storage dtype)
         self.w_fwd: List[Optional[torch.Tensor]] = [None] * n
         self.w_dgrad: List[Optional[torch.Tensor]] = [None] * n
+        self._w_dgrad_alt: List[Optional[torch.Tensor]] = [None] * n      # see prepare_ahead
         for l in range(1, n):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             self.w_fwd[l] = torch.empty(cout * kw * cin, device=dev, dtype=dt)
@@ -260,11 +261,17 @@ class CPCEngine:
         for l in range(1, self.n):
             self._prepare_conv(l, True, True)
 
-    def _prepare_conv(self, l, fwd, dgrad):
+    def _prepare_conv(self, l, fwd, dgrad, alt=False):
         w = self.model._param[f"encoder.layers.{l}.weight"]
-        _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd[l]) if fwd else None,
-                  _hip.ptr(self.w_dgrad[l]) if dgrad else None, self.channels[l], self.channels[l - 1], self.kernels[l],
-                  self.strides[l], self.code)
+        wd = None
+        if dgrad:
+            wd = self.w_dgrad[l]
+            if alt:          # the current copy is still being read: build the next one in a second buffer (swapped in later)
+                if self._w_dgrad_alt[l] is None:
+                    self._w_dgrad_alt[l] = torch.empty_like(self.w_dgrad[l])
+                wd = self._w_dgrad_alt[l]
+        _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd[l]) if fwd else None, _hip.ptr(wd), self.channels[l],
+                  self.channels[l - 1], self.kernels[l], self.strides[l], self.code)
 
     # Operand copies for the NEXT step, rebuilt as soon as the optimizer has updated their parameters (single-process training):
     # the ten layout kernels (0.1 ms at B = 256) then run on the side stream beside the remaining backward GEMMs instead of in
@@ -281,33 +288,28 @@ class CPCEngine:
     def prepare_ahead(self, lo, hi, final):
         """FusedAdam calls this right after it updated flat_param[lo:hi): from the backward pass's grad_ready_hook (on the
         side stream; ``final`` False) and from step() for the head of the buffer (``final`` True, main stream, backward
-        complete).  In the hook call the lowest updated encoder layer's data-gradient operand is still being read by that
-        layer's data-gradient GEMM on the main stream, so that one piece waits for the next call."""
+        complete).  In a hook call the lowest updated encoder layer's data-gradient operand is still being read by that
+        layer's data-gradient GEMM on the main stream: its next copy is built in a second buffer, swapped in by the final call."""
         if not self.supports_prepare_ahead or not getattr(self.ctx, "ahead_ok", False):
             return
         st = getattr(self, "_ahead", None)
         if st is None:
-            st = self._ahead = {"fwd": set(), "dgrad": set(), "head": False, "deferred": []}
+            st = self._ahead = {"conv": set(), "head": False, "swap": []}
         off = self.model._offset
-        for l in st["deferred"]:            # their data-gradient GEMMs were issued before the event this call waited for
-            self._prepare_conv(l, False, True)
-            st["dgrad"].add(l)
-        st["deferred"] = []
         updated = [l for l in range(1, self.n) if lo <= off[f"encoder.layers.{l}.weight"] < hi]
         for l in updated:
             busy = (not final) and l == min(updated)
-            self._prepare_conv(l, True, not busy)
-            st["fwd"].add(l)
+            self._prepare_conv(l, True, True, alt=busy)
+            st["conv"].add(l)
             if busy:
-                st["deferred"].append(l)
-            else:
-                st["dgrad"].add(l)
+                st["swap"].append(l)
         if lo <= off["prediction_model.weight"] < hi:
             self._prepare_head_weights()
             st["head"] = True
         if final:
-            every = set(range(1, self.n))
-            complete = st["head"] and st["fwd"] == every and st["dgrad"] == every and not st["deferred"]
+            for l in st["swap"]:
+                self.w_dgrad[l], self._w_dgrad_alt[l] = self._w_dgrad_alt[l], self.w_dgrad[l]
+            complete = st["head"] and st["conv"] == set(range(1, self.n))
             self._ahead = None
             self._ahead_token = self._param_state() if complete else None
 
@@ -474,14 +476,11 @@ class CPCEngine:
         g, code = self.model._grad, self.code
         B, n = self.B, self.n
         La, Lv = self.geo.alloc, self.geo.valid
-        # encoder, top layer down to layer 2.  Main stream: weight-gradient GEMM, data-gradient GEMM.  Side stream: the bias
-        # column sum (needs dact[l]) and the slab reduction (needs the weight-gradient GEMM), see _alloc_encoder.
+        # encoder, top layer down to layer 2.  Main stream: weight-gradient GEMM, data-gradient GEMM.  Side stream, after the
+        # weight-gradient GEMM: the bias column sum (needs dact[l]) and the slab reduction, see _alloc_encoder.
         for l in range(n - 1, 0, -1):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             bname = f"encoder.layers.{l}.bias"
-            if bname in g:
-                with self.side(self._ev_d[l]):
-                    self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
             flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
                       La[l], self.nsplit[l], code,
@@ -490,6 +489,9 @@ class CPCEngine:
                       work=flops,
                       shape=("wgrad", B * La[l], kw * cin, cout, self.nsplit[l]))
             with self.side(self._ev_w[l]):
+                # (ONE event per layer on the main stream: a recorded event between two GEMMs costs ~6 us of idle queue)
+                if bname in g:
+                    self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
                 _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                           self.nsplit[l], kw * cin * cout)
                 if grad_ready_hook is not None and l <= 2:
