@@ -234,14 +234,24 @@ __global__ __launch_bounds__(256) void conv1_fused_reduce1_kernel(const float* _
     const int m_lo = z * per, m_hi = min(numM, m_lo + per);
     const long long tile = (long long)(kw + 1) * 256;
     const int nslot = (kw + 1) * 64;                       // float4 slots per tile
-    for (int sl = threadIdx.x; sl < nslot; sl += 256) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int mt = m_lo; mt < m_hi; ++mt)
-            for (int r = 0; r < sub; ++r)
-                s += *(const f32x4*)(slabs + ((long long)mt * numN + r * nch + chalf) * tile + (long long)sl * 4);
-        const int j = sl / 64, c4 = sl % 64;
-        *(f32x4*)(tmp + ((long long)z * (kw + 1) + j) * cin + chalf * 256 + c4 * 4) = s;
+    // grid.z walks the slots (one slot per thread): three times the workgroups in flight, the same summation order per slot
+    const int sl = blockIdx.z * 256 + threadIdx.x;
+    if (sl >= nslot) return;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* base = slabs + (long long)chalf * tile + (long long)sl * 4;
+    for (int mt = m_lo; mt < m_hi; ++mt) {
+        if (sub == 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = *(const f32x4*)(base + ((long long)mt * numN + r * nch) * tile);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += v[r];
+        } else {
+            for (int r = 0; r < sub; ++r) s += *(const f32x4*)(base + ((long long)mt * numN + r * nch) * tile);
+        }
     }
+    const int j = sl / 64, c4 = sl % 64;
+    *(f32x4*)(tmp + ((long long)z * (kw + 1) + j) * cin + chalf * 256 + c4 * 4) = s;
 }
 __global__ __launch_bounds__(256) void conv1_fused_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ dw,
                                                                   float* __restrict__ db, int cin, int kw) {
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256) void conv1_fused_reduce2_kernel(const float* _
 int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,
                               hipStream_t stream) {
     if (!slabs || !tmp || !dw || numM <= 0 || cin <= 0 || cin % 256 || sub <= 0 || kw <= 0) return CPC_EINVAL;
-    hipLaunchKernelGGL(conv1_fused_reduce1_kernel, dim3(C1F_CHUNKS, cin / 256), dim3(256), 0, stream, slabs, tmp, numM, cin, sub, kw);
+    hipLaunchKernelGGL(conv1_fused_reduce1_kernel, dim3(C1F_CHUNKS, cin / 256, ((kw + 1) * 64 + 255) / 256), dim3(256), 0, stream, slabs, tmp, numM, cin, sub, kw);
     hipLaunchKernelGGL(conv1_fused_reduce2_kernel, dim3(cin / 256, kw + 1), dim3(256), 0, stream, tmp, dw, db, cin, kw);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
