@@ -12,7 +12,8 @@ own in-batch negatives; gradients are averaged with one RCCL all-reduce per step
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
-                FLOPs of its launches / their HIP-event durations measured inside the timed region.
+                FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
+                (every tenth: an event pair around a launch leaves ~12 us of idle queue).
   cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host on a bounded sample.
 """
 import argparse
