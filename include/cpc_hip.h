@@ -113,7 +113,8 @@ int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db,
  *   fwd  : y[(b,t)][co] = relu?(bias + sum_{j,c} x[(b, t*stride + j)][c] * w[co][c][j])       audio_model.py:38-41
  *   dgrad: dx[(b,p)][c]  = (x_act > 0 ?) sum_{t,co: t*stride + j = p} dy[(b,t)][co] * w[co][c][j]
  *   wgrad: slabs of dw[(j,c)][co] = sum_{b,t} x[(b, t*stride+j)][c] * dy[(b,t)][co]
- * w_fwd / w_dgrad are the operand layouts cpc_conv_w_prep produces.  Lout_alloc * stride == Lin_alloc is required. */
+ * w_fwd / w_dgrad are the operand layouts cpc_conv_w_prep produces (either output pointer may be NULL: that layout is then
+ * not written).  Lout_alloc * stride == Lin_alloc is required. */
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw,
                  int stride, int Lout_alloc, int Lout_valid, int relu, int dtype, void* stream);
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
