@@ -856,7 +856,7 @@ class AttentionContext:
         self.w_end, self.w_end_t = new(H * C), new(C * H)
         # LayerNorm backward: a wave walks its rows one at a time (load -> two wave reductions -> store), so the row loop is latency-
         # bound; 512 workgroups = 2 waves per SIMD overlap the rows (attention_architecture_1 at B = 256: 5.60 ms per step with 256 workgroups, 5.45 with 512 or 1024, 5.57 with 2048)
-        self.ln_blocks = max(1, min(int(os.environ.get("CPC_LN_BLOCKS", "1024")), M // 4))
+        self.ln_blocks = max(1, min(int(os.environ.get("CPC_LN_BLOCKS", "512")), M // 4))
         self.split = {k: e._pick_split(r, c, M) for k, (r, c) in shapes.items()}
 
     def slab_floats(self):
