@@ -116,7 +116,7 @@ def main():
     gen = torch.Generator().manual_seed(1000 + rank)                # rank r draws its own clips
     pool = [(torch.randn(B, L, generator=gen)).to(device) for _ in range(4)]
 
-    sync = GradAllReduce(model) if world > 1 else None
+    sync = GradAllReduce(model, optimizer=opt) if world > 1 else None      # Adam follows each reduced piece of the gradient
 
     graphed = GraphedStep(eng, opt, True, 1.0, args.all_timesteps) if use_graph else None
 
@@ -126,7 +126,7 @@ def main():
         out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
                                  grad_ready_hook=sync.hook if sync is not None else opt.hook)
         if sync is not None:
-            sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer, two overlapped pieces
+            sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer: overlapped pieces + the head
         opt.step(grad_scale=1.0 / world)
         return out
 
@@ -144,7 +144,7 @@ def main():
     # the dominant kernel's launches are event-timed in every `every`-th step of the timed region (about ten sampled steps):
     # an event pair costs ~12 us of idle queue per launch, 0.15 ms per step if every launch of every step were bracketed
     every = 1 if args.breakdown else max(1, args.steps // 10)
-    if sync is None and graphed is None and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
+    if graphed is None and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
         opt.after_update = eng.prepare_ahead      # next step's operand copies rebuilt beside the rest of the backward pass
     t0 = time.perf_counter()
     for i in range(args.steps):

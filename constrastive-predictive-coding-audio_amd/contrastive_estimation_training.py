@@ -191,7 +191,7 @@ class ContrastiveEstimationTrainer:
             graph_steps = {}
             glob_neg = {}
             self.model.link_grads()
-            sync = GradAllReduce(self.model) if world > 1 else None
+            sync = GradAllReduce(self.model, optimizer=optimizer) if world > 1 else None
         else:
             self.model._flatten_parameters(device)
             optimizer = self.optimizer(self.model.parameters(), lr=lr)
@@ -242,9 +242,11 @@ class ContrastiveEstimationTrainer:
                             gneg = glob_neg.get(id(eng))
                             if gneg is None:
                                 gneg = glob_neg[id(eng)] = GlobalNegatives(eng)
-                        # single process: the operand copies of the next step are rebuilt as soon as Adam has updated their
-                        # parameters (engine.CPCEngine.prepare_ahead)
-                        optimizer.after_update = eng.prepare_ahead if sync is None else None
+                        # the operand copies of the next step are rebuilt as soon as Adam has updated their parameters
+                        # (engine.CPCEngine.prepare_ahead; under data parallelism Adam follows each reduced gradient piece)
+                        optimizer.after_update = eng.prepare_ahead
+                        if sync is not None:      # per-GPU negatives: mean of the shard gradients; global negatives: they add up
+                            sync.grad_scale = 1.0 if gneg is not None else 1.0 / world
                         out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),

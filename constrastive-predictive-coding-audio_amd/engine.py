@@ -1196,28 +1196,44 @@ class GradAllReduce:
     data-gradient GEMM, and only layer 1's 22 KB is left for finish().
     The mean is taken by FusedAdam's ``grad_scale = 1 / world``."""
 
-    def __init__(self, model):
+    def __init__(self, model, optimizer=None, grad_scale=None):
         import torch.distributed as dist
         self.dist = dist
         self.model = model
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.pending = []
         self.split = None
+        # With a FusedAdam given, a piece's parameters are updated (and their operand copies for the next step rebuilt, see
+        # CPCEngine.prepare_ahead) as soon as its reduction has finished: at the next hook call, on the side stream beside the
+        # remaining backward GEMMs, instead of after the whole backward pass.  grad_scale: 1 / world for the mean of the shard
+        # gradients (default), 1 where the shard gradients add up (global negatives).
+        self.optimizer = optimizer
+        self.grad_scale = (1.0 / self.world) if grad_scale is None else float(grad_scale)
+
+    def _apply_finished(self):
+        """Adam on every piece whose all-reduce has been issued: the current stream waits for the reduction first."""
+        for work, lo, hi in self.pending:
+            work.wait()
+            if self.optimizer is not None:
+                self.optimizer.update_range(lo, hi, self.grad_scale)
+        self.pending = []
 
     def hook(self, lo, hi):
         """Pass as ``grad_ready_hook``: starts the asynchronous all-reduce of flat_grad[lo:hi]."""
+        if self.optimizer is not None:
+            self._apply_finished()          # pieces issued at earlier hook calls (reduced while the backward pass went on)
         self.split = lo if self.split is None else min(self.split, lo)
-        self.pending.append(self.dist.all_reduce(self.model._flat_grad[lo:hi], async_op=True))
+        self.pending.append((self.dist.all_reduce(self.model._flat_grad[lo:hi], async_op=True), lo, hi))
 
     def finish(self):
-        """Reduces what the hook has not covered and makes the current stream wait for all pieces."""
+        """Reduces what the hook has not covered and makes the current stream wait for all pieces.  With an optimizer attached
+        the caller still calls ``optimizer.step(grad_scale)`` afterwards: it updates what is left (the head of the buffer)."""
         flat = self.model._flat_grad
         rest = flat if self.split is None else flat[:self.split]
+        self._apply_finished()
         if rest.numel():
-            self.pending.append(self.dist.all_reduce(rest, async_op=True))
-        for work in self.pending:
-            work.wait()
-        self.pending, self.split = [], None
+            self.dist.all_reduce(rest, async_op=True).wait()
+        self.split = None
 
 
 class FusedAdam:
@@ -1231,6 +1247,7 @@ class FusedAdam:
         self.v = torch.zeros_like(flat)
         self.t = 0
         self._done_lo = None
+        self._piece_scale = 1.0
         # after_update(lo, hi, final): called right after flat_param[lo:hi) was updated; set it to the engine's prepare_ahead in
         # single-process training so that the operand copies of the next step are rebuilt off the critical path
         self.after_update = None
@@ -1246,8 +1263,16 @@ class FusedAdam:
         update has to follow the all-reduce."""
         if self.state is not None:
             raise ValueError("FusedAdam.hook needs the host-side step count (device_step=False)")
+        self.update_range(lo, hi, 1.0)
+
+    def update_range(self, lo, hi, grad_scale=1.0):
+        """Data-parallel use (GradAllReduce): Adam on flat_param[lo:hi) once that range of the gradient has been reduced over
+        the ranks, with the step count of the step in progress; step(grad_scale) then updates the head of the buffer."""
+        if self.state is not None:
+            raise ValueError("piecewise updates need the host-side step count (device_step=False)")
         self._done_lo = lo if self._done_lo is None else min(self._done_lo, lo)
-        self._launch(lo, hi, self.t + 1, 1.0)
+        self._piece_scale = float(grad_scale)
+        self._launch(lo, hi, self.t + 1, grad_scale)
         if self.after_update is not None:
             self.after_update(lo, hi, False)
 
@@ -1265,9 +1290,9 @@ class FusedAdam:
         flat, grad = self.model._flat_param, self.model._flat_grad
         if self._done_lo is not None:          # ranges [done_lo, end) were updated by hook() during the backward pass
             hi, self._done_lo = self._done_lo, None
-            if grad_scale != 1.0:
-                raise ValueError("FusedAdam.hook and grad_scale != 1 do not combine")
-            self._launch(0, hi, self.t, 1.0)
+            if float(grad_scale) != self._piece_scale:
+                raise ValueError(f"the pieces of this step were updated with grad_scale {self._piece_scale}, step() got {grad_scale}")
+            self._launch(0, hi, self.t, grad_scale)
             if self.after_update is not None:
                 self.after_update(0, hi, True)
             return
