@@ -157,6 +157,66 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     assert "DP-OK" in outs[0]
 
 
+WORKER_PIECES = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cpc_audio_amd.engine import GradAllReduce
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+
+class Model:
+    pass
+
+class Opt:
+    """Stands in for FusedAdam: records the pieces and checks that a piece is REDUCED when its update is issued."""
+    def __init__(self, model):
+        self.model, self.calls = model, []
+    def update_range(self, lo, hi, scale):
+        g = self.model._flat_grad[lo:hi]
+        assert torch.equal(g, torch.full_like(g, 3.0)), (lo, hi, g)       # ranks hold 1 and 2
+        self.calls.append((lo, hi, scale))
+
+m = Model()
+for step in range(2):
+    m._flat_grad = torch.full((100,), float(rank + 1))
+    opt = Opt(m)
+    sync = GradAllReduce(m, optimizer=opt)
+    assert sync.world == 2 and sync.grad_scale == 0.5
+    sync.hook(60, 100)
+    assert opt.calls == []                       # nothing is applied before a later hook / finish
+    sync.hook(20, 60)
+    assert opt.calls == [(60, 100, 0.5)]
+    sync.finish()
+    assert opt.calls == [(60, 100, 0.5), (20, 60, 0.5)]
+    assert torch.equal(m._flat_grad, torch.full((100,), 3.0))          # head [0, 20) reduced by finish(); step() updates it
+    assert sync.pending == [] and sync.split is None
+# without an optimizer: plain overlapped reduction
+m._flat_grad = torch.full((100,), float(rank + 1))
+sync = GradAllReduce(m)
+sync.hook(50, 100)
+sync.finish()
+assert torch.equal(m._flat_grad, torch.full((100,), 3.0))
+if rank == 0:
+    print("PIECES-OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_pieces_are_updated_only_after_their_reduction_gloo_world2(tmp_path):
+    """engine.GradAllReduce with an optimizer attached (the data-parallel train step): Adam on a piece of the flat gradient is
+    issued at the NEXT hook call / in finish(), after that piece's all-reduce, never before."""
+    script = tmp_path / "worker_pieces.py"
+    script.write_text(WORKER_PIECES)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "PIECES-OK" in outs[0]
+
+
 def test_cqt_filter_design_matches_oracle_restatement():
     """Product and oracle hold independent restatements of the (absent, unpinned) librosa filter design; they must agree
     bit for bit, and the octave grouping must be the one the reference derives for its default bank (SURVEY.md 8a7)."""
