@@ -274,7 +274,7 @@ def test_gradient_allreduce_path_single_rank_nccl():
         started = True
     try:
         results = []
-        for use_sync in (False, True):
+        for use_sync in (False, True, "pieces"):
             torch.manual_seed(3)
             enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [64] * 5, 'bias': True})
             model = AudioPredictiveCodingModel(enc, AudioGRUModel(64, 64), enc_size=64, ar_size=64, visible_steps=10,
@@ -282,17 +282,25 @@ def test_gradient_allreduce_path_single_rank_nccl():
             x = (torch.randn(8, 465 + 14 * 160, generator=torch.Generator().manual_seed(4)) * 0.5).to(DEV)
             eng = model.engine(8, x.shape[1])
             opt = FusedAdam(model, lr=1e-3)
-            sync = GradAllReduce(model) if use_sync else None
+            # "pieces": the train step's form — Adam and the next step's operand copies follow each reduced piece (side stream)
+            sync = (GradAllReduce(model, optimizer=opt) if use_sync == "pieces" else GradAllReduce(model)) if use_sync else None
+            if use_sync == "pieces":
+                opt.after_update = eng.prepare_ahead
             out = eng.loss_and_grads(x, softplus=True, regularization=1.0, grad_ready_hook=sync.hook if sync else None)
             if sync:
                 # pieces issued during backward: [layer index 2 .. end) and [layer index 1, layer index 2); layer 0 is left
-                assert sync.split == model._offset["encoder.layers.1.weight"] and len(sync.pending) == 2
+                assert sync.split == model._offset["encoder.layers.1.weight"]
+                assert len(sync.pending) == (1 if use_sync == "pieces" else 2)       # the first piece was updated at the second hook
                 sync.finish()
             opt.step(grad_scale=1.0)
+            assert (eng._ahead_token is not None) == (use_sync == "pieces")
+            # a second step: the operand copies prepared ahead must equal those prepared at the start of the step
+            out2 = eng.loss_and_grads(x, softplus=True, regularization=1.0)
             torch.cuda.synchronize()
-            results.append((float(out[0]), model._flat_grad.clone(), model._flat_param.clone()))
-        assert results[0][0] == results[1][0]
-        assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+            results.append((float(out[0]), model._flat_param.clone(), float(out2[0]), model._flat_grad.clone()))
+        for other in results[1:]:
+            assert results[0][0] == other[0] and results[0][2] == other[2]
+            assert torch.equal(results[0][1], other[1]) and torch.equal(results[0][3], other[3])
     finally:
         if started:
             dist.destroy_process_group()
