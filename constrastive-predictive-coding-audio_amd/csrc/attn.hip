@@ -96,14 +96,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         p[i][j] = s;
     }
     __syncthreads();
-    if (tid < S) {
-        const int i = tid;
-        float mx = -INFINITY;
-        for (int j = 0; j <= i; ++j) mx = fmaxf(mx, p[i][j]);
-        float sum = 0.f;
-        for (int j = 0; j <= i; ++j) { const float e = expf(p[i][j] - mx); p[i][j] = e; sum += e; }
-        const float inv = 1.f / sum;
-        for (int j = 0; j < S; ++j) p[i][j] = j <= i ? p[i][j] * inv : 0.f;
+    {
+        // row softmax: four neighbouring lanes share a row (columns part, part + 4, ...) and combine by lane exchange — with
+        // one thread per row a single wave walked 3 x S dependent LDS reads while the other three waited at the barrier
+        const int i = tid >> 2, part = tid & 3;          // 256 threads = ATT_S rows x 4
+        if (i < S) {
+            float mx = -INFINITY;
+            for (int j = part; j <= i; j += 4) mx = fmaxf(mx, p[i][j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            float sum = 0.f;
+            for (int j = part; j <= i; j += 4) { const float e = expf(p[i][j] - mx); p[i][j] = e; sum += e; }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float inv = 1.f / sum;
+            for (int j = part; j < S; j += 4) p[i][j] = j <= i ? p[i][j] * inv : 0.f;
+        }
     }
     __syncthreads();
     if (S % 4 == 0) {
@@ -166,11 +174,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         ds[i][j] = s * drop_factor(dr, (unsigned long long)bh * S * S + idx);
     }
     __syncthreads();
-    if (tid < S) {
-        const int i = tid;
-        float dot = 0.f;
-        for (int j = 0; j <= i; ++j) dot = fmaf(ds[i][j], p[i][j], dot);
-        for (int j = 0; j < S; ++j) ds[i][j] = j <= i ? p[i][j] * (ds[i][j] - dot) * scale : 0.f;    // d (raw q.k score)
+    {
+        const int i = tid >> 2, part = tid & 3;          // four lanes per row, as in the forward softmax
+        if (i < S) {
+            float dot = 0.f;
+            for (int j = part; j <= i; j += 4) dot = fmaf(ds[i][j], p[i][j], dot);
+            dot += __shfl_xor(dot, 1, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            for (int j = part; j < S; j += 4) ds[i][j] = j <= i ? p[i][j] * (ds[i][j] - dot) * scale : 0.f;    // d (raw q.k score)
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < S * d4; idx += 256) {
