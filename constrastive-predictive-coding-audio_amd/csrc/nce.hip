@@ -205,12 +205,15 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
 // The kernel is element-wise given lse, so it runs once on S (writing dS) and once on S^T (writing dS^T) with the
 // roles of the two strides swapped — no transposes.  Element (r=(b,k), c) of the input sits at c*sc + (b*K+k)*sr.
 // FAST_C: consecutive threads walk c (S, sc = 1) or b (S^T, sr = 1; a thread then owns K contiguous elements).
-template <typename T, bool FAST_C>
+// KT > 0: K as a compile-time constant — the K scores of a pair are loaded once, all loads in flight (with a run-time K the
+// pair's 2 K dependent-latency loads made the launch latency-bound: 85 us for 38 MB at B = 256, K = 12).
+template <typename T, bool FAST_C, int KT>
 __global__ __launch_bounds__(256) void nce_all_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
-                                                           T* __restrict__ dS, float* __restrict__ partial, int B, int K,
+                                                           T* __restrict__ dS, float* __restrict__ partial, int B, int K_rt,
                                                            long long sc, long long sr, int softplus, float reg,
                                                            int want_partials) {
     __shared__ float red[3][256];
+    const int K = KT > 0 ? KT : K_rt;
     const int R = B * K;
     const long long total = (long long)B * R;                 // (b, c) pairs
     const float inv_r = 1.f / (float)R;
@@ -221,6 +224,29 @@ __global__ __launch_bounds__(256) void nce_all_grad_kernel(const float* __restri
         const int c = FAST_C ? (int)(idx % R) : (int)(idx / B);
         const float* base = S + (long long)c * sc + (long long)b * K * sr;
         float m = 0.f;
+        const float l = lse[c];
+        T* obase = dS + (long long)c * sc + (long long)b * K * sr;
+        if (KT > 0) {
+            float raw[KT > 0 ? KT : 1], spv[KT > 0 ? KT : 1];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) raw[k] = base[(long long)k * sr];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                spv[k] = score_tf(raw[k], softplus);
+                m += spv[k];
+                mx = fmaxf(mx, spv[k]);
+                if (b * K + k == c) valid += spv[k];
+            }
+            m /= (float)K;
+            msq += m * m;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float dsp = expf(spv[k] - l) * inv_r + reg_c * m;
+                if (b * K + k == c) dsp -= inv_r;
+                obase[(long long)k * sr] = from_f32<T>(dsp * score_grad(raw[k], softplus));
+            }
+            continue;
+        }
         for (int k = 0; k < K; ++k) {
             const float sp = score_tf(base[(long long)k * sr], softplus);
             m += sp;
@@ -229,8 +255,6 @@ __global__ __launch_bounds__(256) void nce_all_grad_kernel(const float* __restri
         }
         m /= (float)K;
         msq += m * m;
-        const float l = lse[c];
-        T* obase = dS + (long long)c * sc + (long long)b * K * sr;
         for (int k = 0; k < K; ++k) {
             const float x = base[(long long)k * sr];
             const float sp = score_tf(x, softplus);
@@ -362,7 +386,7 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
 }
 
 // ---- score_over_all_timesteps = True ----
-static const int NCE_ALL_BLOCKS = 1024;
+static const int NCE_ALL_BLOCKS = 3072;
 static const int NCE_ALL_SPLITS = 16;
 // workspace: lse [R] + col partials [ceil(R/32)] + grad partials [3 * NCE_ALL_BLOCKS] + per-split (max, sum) [2][NCE_ALL_SPLITS][R]
 long long nce_all_workspace_floats(int B, int K) {
@@ -393,19 +417,21 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
     }
     const long long total = (long long)B * R;
     const int blocks = (int)min((long long)NCE_ALL_BLOCKS, (total + 255) / 256);
+#define NCE_ALL_GRAD(T, KT) \
+    do { \
+        hipLaunchKernelGGL((nce_all_grad_kernel<T, true, KT>), dim3(blocks), dim3(256), 0, stream, S, lse, (T*)dS, gradp, B, K, 1LL, \
+                           (long long)ld, softplus, reg, 1); \
+        hipLaunchKernelGGL((nce_all_grad_kernel<T, false, KT>), dim3(blocks), dim3(256), 0, stream, ST, lse, (T*)dST, gradp, B, K, \
+                           (long long)ld, 1LL, softplus, reg, 0); \
+    } while (0)
     if (dtype == CPC_DTYPE_BF16) {
-        hipLaunchKernelGGL((nce_all_grad_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, S, lse, (bf16_t*)dS, gradp, B, K,
-                           1LL, (long long)ld, softplus, reg, 1);
-        hipLaunchKernelGGL((nce_all_grad_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, ST, lse, (bf16_t*)dST, gradp, B,
-                           K, (long long)ld, 1LL, softplus, reg, 0);
+        if (K == 12) NCE_ALL_GRAD(bf16_t, 12); else if (K == 16) NCE_ALL_GRAD(bf16_t, 16); else NCE_ALL_GRAD(bf16_t, 0);
     } else if (dtype == CPC_DTYPE_F32) {
-        hipLaunchKernelGGL((nce_all_grad_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, S, lse, (float*)dS, gradp, B, K,
-                           1LL, (long long)ld, softplus, reg, 1);
-        hipLaunchKernelGGL((nce_all_grad_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, ST, lse, (float*)dST, gradp, B, K,
-                           (long long)ld, 1LL, softplus, reg, 0);
+        if (K == 12) NCE_ALL_GRAD(float, 12); else if (K == 16) NCE_ALL_GRAD(float, 16); else NCE_ALL_GRAD(float, 0);
     } else {
         return CPC_EINVAL;
     }
+#undef NCE_ALL_GRAD
     hipLaunchKernelGGL(nce_all_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, n_colp, gradp, blocks, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
