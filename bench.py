@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
                 FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
                 (every tenth: an event pair around a launch leaves ~12 us of idle queue).
+  hbm_kernel    the HBM-bound piece of the conv stack (encoder layer 1, C_in = 1): algorithmic bytes / HIP-event duration vs 8 TB/s.
   cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host on a bounded sample.
 """
 import argparse
@@ -138,7 +139,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"],
+    # event-timed kernels: the dominant MFMA kernel (`roofline`) and the HBM-bound layer-1 forward (`hbm_kernel`)
+    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>",
+                                                              "cpc_conv1_fwd"],
                              by_shape=args.breakdown)
     _hip.set_timer(timer)
     # the dominant kernel's launches are event-timed in every `every`-th step of the timed region (about ten sampled steps):
@@ -199,6 +202,16 @@ def main():
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
         }
+        c1 = [v for k, v in summary.items() if k.startswith("cpc_conv1_fwd")]
+        if c1 and sum(v[1] for v in c1) > 0:
+            # encoder layer 1 (C_in = 1): writes its [B][L_alloc][512] output once, reads 4 B per input sample
+            esz = 2 if args.dtype == "bf16" else 4
+            nbytes = float(B) * eng.geo.alloc[0] * eng.channels[0] * esz + float(B) * eng.L_eff * 4
+            cn, cms = sum(v[0] for v in c1), sum(v[1] for v in c1)
+            gbs = nbytes * cn / (cms * 1e-3) / 1e9
+            line["hbm_kernel"] = {"kernel": "conv1_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "launches": cn,
+                                  "avg_launch_ms": round(cms / cn, 4), "algorithmic_bytes_per_launch": nbytes}
         if args.breakdown:
             rows = sorted(summary.items(), key=lambda kv: -kv[1][1])
             tot = sum(v[1] for _, v in rows)
