@@ -107,76 +107,42 @@ __global__ __launch_bounds__(256) void nce_col_merge_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
-// Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T) and per-block partials {sum valid, sum m^2, max sp}.
-// KT > 0: the number of prediction steps as a compile-time constant (the K loads of a pair's mean are then all in flight).
-template <typename T, int KT>
-__global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
-                                                       T* __restrict__ dS, T* __restrict__ dST,
-                                                       float* __restrict__ partial, int B, int K_rt, int ld, int softplus,
-                                                       float reg) {
-    const int K = KT > 0 ? KT : K_rt;
-    __shared__ float tile[32][33];
+// m[b][b'] = mean_k sp[k][b][b'] (the regulariser's mean over the prediction steps, contrastive_estimation_training.py:141)
+// for every pair once, plus per-block partials {sum of the valid scores sp[k][b][b], sum m^2, max sp}.  (The gradient kernel
+// used to recompute this mean in each of its K blocks per tile: 12 x the softplus work, 42 of the loss's 65 us.)
+template <int KT>
+__global__ __launch_bounds__(256) void nce_mean_kernel(const float* __restrict__ S, float* __restrict__ mean,
+                                                       float* __restrict__ partial, int B, int K_rt, int ld, int softplus) {
     __shared__ float red[3][256];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
-    const int bp0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const float inv_bk = 1.f / ((float)B * (float)K);
-    const float reg_c = 2.f * reg / ((float)B * (float)B * (float)K);
+    const int K = KT > 0 ? KT : K_rt;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     float valid = 0.f, msq = 0.f, mx = -INFINITY;
-    float mean[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = b0 + ty + 8 * r, bp = bp0 + tx;
+    if (idx < (long long)B * B) {
+        const int b = (int)(idx / B), bp = (int)(idx % B);
+        const float* sp0 = S + (long long)b * ld + bp;
         float m = 0.f;
-        if (b < B && bp < B) {
-            const float* sp0 = S + (long long)b * ld + bp;
-            if (KT > 0) {
-                float raw[KT > 0 ? KT : 1];
+        if (KT > 0) {
+            float raw[KT > 0 ? KT : 1];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) raw[k] = sp0[(long long)k * B * ld];
+            for (int k = 0; k < KT; ++k) raw[k] = sp0[(long long)k * B * ld];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    const float sp = score_tf(raw[k], softplus);
-                    m += sp;
-                    mx = fmaxf(mx, sp);
-                    if (b == bp) valid += sp;
-                }
-            } else
+            for (int k = 0; k < KT; ++k) {
+                const float sp = score_tf(raw[k], softplus);
+                m += sp;
+                mx = fmaxf(mx, sp);
+                if (b == bp) valid += sp;
+            }
+        } else {
             for (int k = 0; k < K; ++k) {
                 const float sp = score_tf(sp0[(long long)k * B * ld], softplus);
                 m += sp;
                 mx = fmaxf(mx, sp);
                 if (b == bp) valid += sp;
             }
-            m /= (float)K;
-            msq += m * m;
         }
-        mean[r] = m;
-    }
-    // grid.z = K: every block recomputes the K-mean of its 32 x 32 pairs (S is 3 MB, L2-resident) and differentiates its own
-    // k; the loss partials are taken from the z == 0 blocks only.  (64 blocks looping over K left three quarters of the chip idle.)
-    {
-        const int k = blockIdx.z;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = b0 + ty + 8 * r, bp = bp0 + tx;
-            float g = 0.f;
-            if (b < B && bp < B) {
-                const float x = S[((long long)k * B + b) * ld + bp];
-                const float sp = score_tf(x, softplus);
-                float dsp = expf(sp - lse[k * B + bp]) * inv_bk + reg_c * mean[r];
-                if (b == bp) dsp -= inv_bk;
-                g = dsp * score_grad(x, softplus);
-            }
-            if (b < B && bp < ld) dS[((long long)k * B + b) * ld + bp] = from_f32<T>(g);
-            tile[ty + 8 * r][tx] = g;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int bp = bp0 + ty + 8 * r, b = b0 + tx;
-            if (b < ld && bp < B) dST[((long long)k * B + bp) * ld + b] = from_f32<T>(tile[tx][ty + 8 * r]);
-        }
+        m /= (float)K;
+        msq = m * m;
+        mean[(long long)b * ld + bp] = m;
     }
     red[0][threadIdx.x] = valid;
     red[1][threadIdx.x] = msq;
@@ -190,11 +156,45 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && blockIdx.z == 0) {
-        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-        partial[blk * 3 + 0] = red[0][0];
-        partial[blk * 3 + 1] = red[1][0];
-        partial[blk * 3 + 2] = red[2][0];
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 3 + 0] = red[0][0];
+        partial[blockIdx.x * 3 + 1] = red[1][0];
+        partial[blockIdx.x * 3 + 2] = red[2][0];
+    }
+}
+
+// One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
+// Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T) and per-block partials {sum valid, sum m^2, max sp}.
+// Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T); grid (tiles, tiles, K).
+template <typename T>
+__global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
+                                                       const float* __restrict__ mean, T* __restrict__ dS, T* __restrict__ dST,
+                                                       int B, int K, int ld, int softplus, float reg) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
+    const int bp0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const float inv_bk = 1.f / ((float)B * (float)K);
+    const float reg_c = 2.f * reg / ((float)B * (float)B * (float)K);
+    const int k = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + ty + 8 * r, bp = bp0 + tx;
+        float g = 0.f;
+        if (b < B && bp < B) {
+            const float x = S[((long long)k * B + b) * ld + bp];
+            const float sp = score_tf(x, softplus);
+            float dsp = expf(sp - lse[k * B + bp]) * inv_bk + reg_c * mean[(long long)b * ld + bp];
+            if (b == bp) dsp -= inv_bk;
+            g = dsp * score_grad(x, softplus);
+        }
+        if (b < B && bp < ld) dS[((long long)k * B + b) * ld + bp] = from_f32<T>(g);
+        tile[ty + 8 * r][tx] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bp = bp0 + ty + 8 * r, b = b0 + tx;
+        if (b < ld && bp < B) dST[((long long)k * B + bp) * ld + b] = from_f32<T>(tile[tx][ty + 8 * r]);
     }
 }
 
@@ -354,33 +354,37 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
 }  // namespace
 
 // workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
+// workspace: lse [K][B] + column partials [K * ceil(B/32)] + pair partials [3 * ceil(B*B/256)] + pair means [B][ld <= B + 7]
 long long nce_workspace_floats(int B, int K) {
-    const long long nb = (B + 8 + 31) / 32;     // room for a leading dimension padded up to a multiple of 8
-    return (long long)K * B + (long long)K * ((B + 31) / 32) + 3 * nb * nb;
+    const long long nmb = ((long long)B * B + 255) / 256;
+    return (long long)K * B + (long long)K * ((B + 31) / 32) + 3 * nmb + (long long)B * (B + 8);
 }
 
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream) {
-    if (B <= 0 || K <= 0 || ld < B) return CPC_EINVAL;
+    if (B <= 0 || K <= 0 || ld < B || ld > B + 7) return CPC_EINVAL;
     float* lse = workspace;
     const int ncb = (B + 31) / 32;
     const int ncol = K * ncb;
     float* colp = lse + (long long)K * B;
     float* gradp = colp + ncol;
+    const int nmb = (int)(((long long)B * B + 255) / 256);
+    float* mean = gradp + 3LL * nmb;
     const int nb = (ld + 31) / 32;
     hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B, (float*)nullptr,
                        (float*)nullptr);
-#define NCE_GRAD(T, KT) hipLaunchKernelGGL((nce_grad_kernel<T, KT>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, (T*)dS, (T*)dST, \
-                                           gradp, B, K, ld, softplus, reg)
-    if (dtype == CPC_DTYPE_BF16) {
-        if (K == 12) NCE_GRAD(bf16_t, 12); else if (K == 16) NCE_GRAD(bf16_t, 16); else NCE_GRAD(bf16_t, 0);
-    } else if (dtype == CPC_DTYPE_F32) {
-        if (K == 12) NCE_GRAD(float, 12); else if (K == 16) NCE_GRAD(float, 16); else NCE_GRAD(float, 0);
-    } else {
+    if (K == 12) hipLaunchKernelGGL(nce_mean_kernel<12>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
+    else if (K == 16) hipLaunchKernelGGL(nce_mean_kernel<16>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
+    else hipLaunchKernelGGL(nce_mean_kernel<0>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, mean, (bf16_t*)dS, (bf16_t*)dST,
+                           B, K, ld, softplus, reg);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, mean, (float*)dS, (float*)dST, B, K,
+                           ld, softplus, reg);
+    else
         return CPC_EINVAL;
-    }
-#undef NCE_GRAD
-    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncol, gradp, nb * nb, out, B, K, reg);
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncol, gradp, nmb, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
