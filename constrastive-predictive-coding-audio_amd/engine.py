@@ -447,6 +447,7 @@ class CPCEngine:
         La, Lv = self.geo.alloc, self.geo.valid
         Ltop, T = La[-1], self.T
         t0 = T - K - V
+        self._ahead = None          # prepare_ahead state of a step whose optimizer step never came (nothing was swapped in yet)
         top, dtop = self.act[-1], self.dact[-1]
         # predictor: dW_p = dpred^T c ;  dc = dpred W_p
         ct, coff, cstride = self.ctx.c_operand()

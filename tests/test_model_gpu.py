@@ -1068,8 +1068,22 @@ def test_operand_copies_prepared_ahead_equal_prepared_at_step_start(context):
             assert (eng._ahead_token is not None) == ahead
         results[ahead] = (model, eng, model._flat_param.detach().clone())
     assert torch.equal(results[False][2], results[True][2])
+    # a backward pass whose optimizer step never comes (the pieces were updated from the hook, the head was not): whatever was
+    # prepared ahead for it must not leak into the next, complete step
+    for ahead in (False, True):
+        model, eng, _ = results[ahead]
+        opt = FusedAdam(model, lr=1e-3)
+        if ahead:
+            opt.after_update = eng.prepare_ahead
+        eng.loss_and_grads(data[0], softplus=True, regularization=1.0, grad_ready_hook=opt.hook)
+        opt._done_lo = None                                     # abandon the step
+        eng.loss_and_grads(data[1], softplus=True, regularization=1.0, grad_ready_hook=opt.hook)
+        opt.step()
+        eng.loss_and_grads(data[2], softplus=True, regularization=1.0)
+        results[ahead] = (model, eng, model._flat_param.detach().clone(), model._flat_grad.detach().clone())
+    assert torch.equal(results[False][2], results[True][2]) and torch.equal(results[False][3], results[True][3])
     # a state_dict load between steps: the prepared copies are stale and must be rebuilt
-    model, eng, _ = results[True]
+    model, eng = results[True][:2]
     other = build()
     model.load_state_dict(other.state_dict())
     ref_eng = other.engine(B, L)
