@@ -12,6 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA, GEMM_SKIP_PAD_ROWS = 1, 2, 4, 8, 16, 32, 64, 128
+GEMM_LINEAR_K = 256
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")
@@ -96,6 +97,7 @@ _SIGNATURES = {
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_set_streaming": ([_I], _I),
+    "cpc_debug_set": ([_I, _I], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_nce_all_workspace_floats": ([_I, _I], _L),

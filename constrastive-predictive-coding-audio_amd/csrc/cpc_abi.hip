@@ -7,6 +7,7 @@
 static_assert(CPC_GEMM_FORCE_GENERIC == GEMM_FORCE_GENERIC && CPC_GEMM_SMALL_TILE == GEMM_SMALL_TILE, "flag mismatch");
 static_assert(CPC_GEMM_SKIP_PAD_ROWS == GEMM_SKIP_PAD_ROWS && CPC_GEMM_NO_DMA == GEMM_NO_DMA, "flag mismatch");
 static_assert(CPC_GEMM_RELU == GEMM_RELU && CPC_GEMM_OUT_F32 == GEMM_OUT_F32 && CPC_GEMM_TN_NO_TR == GEMM_TN_NO_TR, "flag mismatch");
+static_assert(CPC_GEMM_LINEAR_K == GEMM_LINEAR_K, "flag mismatch");
 static_assert(CPC_F32 == CPC_DTYPE_F32 && CPC_BF16 == CPC_DTYPE_BF16, "dtype mismatch");
 
 static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
@@ -370,6 +371,11 @@ int cpc_gru_set_streaming(int on) {
     if (on >= 100 && on < 108) { g_gru_debug = on - 100; return old; } // 100 + bits: timing experiments (see gru.hip)
     g_gru_force_streaming = on ? 1 : 0;
     return old;
+}
+
+int cpc_debug_set(int key, int value) {
+    if (key == 1) { const int old = g_nt_stagger64; g_nt_stagger64 = value; return old; }
+    return CPC_EINVAL;
 }
 
 long long cpc_nce_workspace_floats(int B, int K) { return nce_workspace_floats(B, K); }

@@ -12,6 +12,7 @@
 #define GEMM_EPI_CONV1 0x20000 // internal: fused layer-1 weight-gradient epilogue (see GemmNT::c1_*)
 #define GEMM_NO_DMA 64         // NT fast path: register-staged global->LDS copies instead of LDS-DMA (A-B check)
 #define GEMM_SKIP_PAD_ROWS 128  // NT: rows with (m % c_rpi) >= c_valid are not stored at all (default: stored as zeros)
+#define GEMM_LINEAR_K 256       // NT fast path: visit K in storage order even for overlapped-row operands (A-B check, see GemmNT::k_taps)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {
@@ -28,6 +29,17 @@ struct GemmNT {
     long long a_batch, b_batch, c_batch;
     int flags;
     int m_off = 0;        // internal: first row of this launch (fast kernels; a launch may cover rows [m_off, M) only)
+    // internal, fast kernels: order in which the K axis is visited.  Stage s (BK elements) covers the K offsets
+    //   (s / k_taps) * BK + (s % k_taps) * k_tap_stride ... + BK        (k_taps <= 1: plain s * BK)
+    // for BOTH operands — a permutation of the reduction index, invisible in the sum.  The launcher sets it for overlapped-row
+    // A operands (lda < K, K % lda == 0: the strided-conv views) to k_tap_stride = lda, k_taps = K / lda: row m+1 at tap j then
+    // reads the bytes row m read at tap j+1 ONE stage earlier (an L2 hit) instead of lda / BK stages earlier (by then evicted:
+    // every activation byte crossed the fabric K / lda times; profiles/r01h_traffic.json, conv forward 2.16x).
+    int k_taps = 0; long long k_tap_stride = 0;
+    // internal, 256x256 LDS-DMA kernel: start stagger.  The workgroups of the first round (one per CU) start (phase * stagger)
+    // sleeps of 4096 cycles late, phase = (block / 8) % 8, so that the CUs do not all sit in their epilogues (a 32 MB store
+    // burst per round of tiles) and prologues at the same time; 0 = off.  Set by the launcher from the tile's K extent.
+    int stagger = 0;
     // internal, GEMM_EPI_CONV1 (data gradient of encoder layer 2 fused with the weight gradient of layer 1): the masked result
     // tile G[(b,q)][(r,c)] = d loss / d act1[b][q*c1_sub + r][c] is NOT stored; instead
     //   c1_slabs[tile][j][c] = sum_rows G[row][c] * x[b][t*c1_stride + j]  (j < c1_kw),   [c1_kw][c] = sum_rows G[row][c]
@@ -51,6 +63,8 @@ struct GemmTN {
     int flags;
 };
 
+// tuning knobs (cpc_debug_set): key 1 = stagger of the 256x256 NT kernel in 1/64 of a tile time (default see gemm.hip)
+extern int g_nt_stagger64;
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);
 int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,

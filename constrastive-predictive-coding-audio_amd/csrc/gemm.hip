@@ -357,6 +357,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
+    if constexpr (DMA && TI == 8) {
+        // start stagger of the first round of workgroups (GemmNT::stagger)
+        if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.z == 0) {
+            const int nsleep = ((blockIdx.x >> 3) & 7) * p.stagger;
+            for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(64);
+        }
+    }
 
     f32x4 acc[TI][TJ];
 #pragma unroll
@@ -374,6 +381,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         for (int j = 0; j < TJ; ++j) offB[kk][j] = ATILE + lds_off(wn * TJ * 16 + j * 16 + frow, kk * 4 + fg);
     }
     const int nk = p.K / BK;
+    // K visiting order (GemmNT::k_taps): element offset of stage 1, and of the stage the loop fetches next (kb + kj * tstride)
+    const int taps = p.k_taps > 1 ? p.k_taps : 1;
+    const long long tstride = p.k_taps > 1 ? p.k_tap_stride : 0;
+    const long long koff1 = taps > 1 ? tstride : (long long)BK;
     if constexpr (!DMA) {
         // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
         // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
@@ -410,10 +421,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         NT_GLOAD(0);
         NT_LSTORE(lds);
         __syncthreads();
+        int kj = 1 % taps;
+        long long kb = (long long)(1 / taps) * BK;
         for (int t = 0; t < nk; ++t) {
             const unsigned char* cur = lds + (t & 1) * STAGE;
             const bool more = t + 1 < nk;
-            if (more) NT_GLOAD((long long)(t + 1) * BK);
+            if (more) {
+                NT_GLOAD(kb + kj * tstride);
+                if (++kj == taps) { kj = 0; kb += BK; }
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 fa[TI], fb[TJ];
@@ -540,7 +556,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #define NT_ITER(DO_DMA, DO_READ)                                                                                 \
     do {                                                                                                         \
         const unsigned cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;                                       \
-        const long long k2 = (long long)(t + 2) * BK;                                                            \
+        const long long k2 = kb + kj * tstride;                                                                  \
+        if (DO_DMA) { if (++kj == taps) { kj = 0; kb += BK; } }                                                  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
                 mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));                                    \
@@ -565,7 +582,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         NT_DMA_STAGE(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (nk > 1) NT_DMA_STAGE(1, (long long)BK);
+        if (nk > 1) NT_DMA_STAGE(1, koff1);
+        int kj = 2 % taps;
+        long long kb = (long long)(2 / taps) * BK;
         u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
         NT_READ_SET(fa0, fb0, aA0, aB0, 0u);
         NT_WAIT_SET(fa0, fb0);
@@ -1323,6 +1342,8 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
     }
 }
 
+int g_nt_stagger64 = 0;
+
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
@@ -1349,9 +1370,21 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE) &&
                      (big_tiles >= 200 || big_tiles * batch >= 200);
     GemmNT q = p;
+    // overlapped-row A operand (strided-conv view): visit K tap-innermost, see GemmNT::k_taps
+    const int bk = 8 * ch;
+    if (fast && p.k_taps == 0 && p.lda > 0 && p.lda < p.K && p.K % p.lda == 0 && p.lda % bk == 0 && !(p.flags & GEMM_LINEAR_K)) {
+        q.k_taps = (int)(p.K / p.lda);
+        q.k_tap_stride = p.lda;
+    }
+    if (q.k_taps > 1 && (!fast || (long long)q.k_taps * q.k_tap_stride != p.K || q.k_tap_stride % bk)) return CPC_EINVAL;
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
+    if (big && g_nt_stagger64 > 0 && big_tiles * batch >= 3 * 256) {
+        // a tile takes about nk * 3600 + 20000 cycles; the largest phase (7) starts g_nt_stagger64 / 64 of that late
+        const long long tile_cycles = (long long)(p.K / bk) * 3600 + 20000;
+        q.stagger = (int)std::max<long long>(1, tile_cycles * g_nt_stagger64 / 64 / 7 / 4096);
+    }
     const int tbm = big ? 256 : BM, tbn = big ? 256 : BN;
     const int numM = (p.M - p.m_off + tbm - 1) / tbm;
     const int numN = (p.N + tbn - 1) / tbn;
@@ -1386,7 +1419,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
             else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
         }
     } else if (dtype == CPC_DTYPE_F32) {
-        if (fast) NT_LAUNCH(float, float, 2, 2, 4, 4, 256, p);
+        if (fast) NT_LAUNCH(float, float, 2, 2, 4, 4, 256, q);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else {
         return CPC_EINVAL;

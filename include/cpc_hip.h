@@ -30,6 +30,8 @@ extern "C" {
 #define CPC_GEMM_NARROW_EPI 32   /* NT/bf16: per-lane 8-byte stores instead of the LDS-staged full-row epilogue (A/B check) */
 #define CPC_GEMM_NO_DMA 64       /* NT fast path: register-staged global->LDS copies instead of LDS-DMA (A/B check) */
 #define CPC_GEMM_SKIP_PAD_ROWS 128 /* NT: rows with (m % c_rpi) >= c_valid are left untouched instead of zeroed */
+#define CPC_GEMM_LINEAR_K 256     /* NT: visit K in storage order even for overlapped-row A operands (A/B check; default for lda < K,
+                                    K % lda == 0 is tap-innermost: identical sums in a different order, each input byte fetched once) */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
 int cpc_abi_version(void);
@@ -283,6 +285,9 @@ int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG,
 /* A/B switch: on != 0 forces the weight-streaming GRU kernels where the weight-resident bf16 ones would be used
  * (H in {32,64,128,256}); returns the previous setting.  Not stream-ordered (host-side flag). */
 int cpc_gru_set_streaming(int on);
+/* Tuning knobs for A/B measurements (tools/): key 1 = start stagger of the 256x256 NT GEMM in 1/64 of a tile time (0 = off).
+ * Returns the previous value, CPC_EINVAL for an unknown key.  Not part of the product path. */
+int cpc_debug_set(int key, int value);
 
 /* InfoNCE loss of ContrastiveEstimationTrainer.train, default branch score_over_all_timesteps=False
  * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32, rows of ld >= B
