@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA, GEMM_SKIP_PAD_ROWS = 1, 2, 4, 8, 16, 32, 64, 128
-GEMM_LINEAR_K = 256
+GEMM_LINEAR_K, GEMM_NO_PERS, GEMM_DIRECT_MASK = 256, 512, 1024
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")

@@ -7,7 +7,7 @@
 static_assert(CPC_GEMM_FORCE_GENERIC == GEMM_FORCE_GENERIC && CPC_GEMM_SMALL_TILE == GEMM_SMALL_TILE, "flag mismatch");
 static_assert(CPC_GEMM_SKIP_PAD_ROWS == GEMM_SKIP_PAD_ROWS && CPC_GEMM_NO_DMA == GEMM_NO_DMA, "flag mismatch");
 static_assert(CPC_GEMM_RELU == GEMM_RELU && CPC_GEMM_OUT_F32 == GEMM_OUT_F32 && CPC_GEMM_TN_NO_TR == GEMM_TN_NO_TR, "flag mismatch");
-static_assert(CPC_GEMM_LINEAR_K == GEMM_LINEAR_K, "flag mismatch");
+static_assert(CPC_GEMM_LINEAR_K == GEMM_LINEAR_K && CPC_GEMM_NO_PERS == GEMM_NO_PERS && CPC_GEMM_DIRECT_MASK == GEMM_DIRECT_MASK, "flag mismatch");
 static_assert(CPC_F32 == CPC_DTYPE_F32 && CPC_BF16 == CPC_DTYPE_BF16, "dtype mismatch");
 
 static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }

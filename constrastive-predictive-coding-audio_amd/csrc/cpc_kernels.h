@@ -12,6 +12,8 @@
 #define GEMM_EPI_CONV1 0x20000 // internal: fused layer-1 weight-gradient epilogue (see GemmNT::c1_*)
 #define GEMM_NO_DMA 64         // NT fast path: register-staged global->LDS copies instead of LDS-DMA (A-B check)
 #define GEMM_SKIP_PAD_ROWS 128  // NT: rows with (m % c_rpi) >= c_valid are not stored at all (default: stored as zeros)
+#define GEMM_NO_PERS 512        // NT/bf16: LDS-staged epilogue instead of the register epilogue (A-B check; see DIRECT in gemm.hip)
+#define GEMM_DIRECT_MASK 1024   // NT/bf16: register epilogue also for masked launches (A-B check)
 #define GEMM_LINEAR_K 256       // NT fast path: visit K in storage order even for overlapped-row operands (A-B check, see GemmNT::k_taps)
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 

@@ -335,8 +335,22 @@ __device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v[
 // and is followed by sched_barrier(0), so no MFMA can be scheduled above it).
 __device__ __forceinline__ uint4 tn_frag_rb(const unsigned char* tile, int rowb, int cb, int ks, int lane);
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false>
+// DIRECT = true (bf16 in / out, LDS-DMA): the epilogue goes from the accumulator registers straight to memory — no LDS image,
+// no barrier, and the workgroup ends with its stores in flight, so the CU's next workgroup starts its first loads while they
+// drain (the LDS-staged epilogue holds the CU until a 32 MB-per-round store burst has been accepted).  The B rows are dealt to
+// the MFMA rows in a permuted order — applied to the SOURCE rows of the LDS-DMA, so the LDS image and the fragment reads are
+// unchanged — such that a lane holds 8 consecutive output columns of a row in the accumulators of the tile pair (2p, 2p+1):
+// 16-byte stores, 64 contiguous bytes per row and instruction.  Same sums in the same order as the other variants.
+// tile row r of the B operand (consumed by wave column r / 64 as MFMA tile j = (r / 16) % 4, MFMA row q = r % 16) holds output
+// column 64 (r / 64) + 32 (j / 2) + 8 (q / 4) + 4 (j % 2) + q % 4 of the tile
+__device__ __forceinline__ int direct_b_col(int r) {
+    const int j = (r >> 4) & 3, q = r & 15;
+    return (r & ~63) + 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3);
+}
+
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
+    static_assert(!DIRECT || (DMA && !C1 && sizeof(T) == 2 && sizeof(TO) == 2 && TJ == 4), "direct epilogue: bf16 LDS-DMA variants");
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
     constexpr int TBM = WM * TI * 16, TBN = WN * TJ * 16, NTHR = 64 * WM * WN;
@@ -459,10 +473,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         const T* ga1 = Ab + row_off(min(m0 + r0 + 8, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
         const T* ga2 = Ab + row_off(min(m0 + r0 + 16, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
         const T* ga3 = Ab + row_off(min(m0 + r0 + 24, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
-        const T* gb0 = Bb + row_off(min(n0 + r0, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
-        const T* gb1 = Bb + row_off(min(n0 + r0 + 8, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
-        const T* gb2 = Bb + row_off(min(n0 + r0 + 16, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
-        const T* gb3 = Bb + row_off(min(n0 + r0 + 24, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const int br0 = DIRECT ? direct_b_col(r0) : r0, br1 = DIRECT ? direct_b_col(r0 + 8) : r0 + 8;
+        const int br2 = DIRECT ? direct_b_col(r0 + 16) : r0 + 16, br3 = DIRECT ? direct_b_col(r0 + 24) : r0 + 24;
+        const T* gb0 = Bb + row_off(min(n0 + br0, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb1 = Bb + row_off(min(n0 + br1, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb2 = Bb + row_off(min(n0 + br2, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        const T* gb3 = Bb + row_off(min(n0 + br3, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
         typedef __attribute__((address_space(3))) unsigned char lds_byte;
         lds_byte* const lds3 = (lds_byte*)lds;
         const unsigned wdst = wave_u * 4096;                   // this wave's 4 KiB slice of an operand tile
@@ -608,6 +624,69 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     TO* Cb = (TO*)p.C + (long long)blockIdx.z * p.c_batch;
     const T* Mb = (const T*)p.mask;
     const bool relu = p.flags & GEMM_RELU;
+    if constexpr (DIRECT) {
+        // lane: rows m0 + (wm*TI + i)*16 + frow, columns n0 + wn*64 + 32 pr + 8 fg + (0..7) from acc[i][2 pr] | acc[i][2 pr + 1]
+        const int nb = n0 + wn * 64 + 8 * fg;
+        const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
+        const T* Mz = Mb ? Mb + (long long)blockIdx.z * p.c_batch : nullptr;
+        long long off[TI];
+        bool rv[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int m = min(m0 + (wm * TI + i) * 16 + frow, p.M - 1);
+            off[i] = row_off(m, p.c_rpi, p.c_item, p.ldc) + min(nb, p.N - 8);
+            rv[i] = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
+        }
+        const long long o1 = (nb + 32 < p.N) ? 32 : 0;                  // pair 1 beyond N: any valid address (value unused)
+        uint4 mk[TI][2];
+        if (Mz) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                mk[i][0] = *(const uint4*)(Mz + off[i]);
+                mk[i][1] = *(const uint4*)(Mz + off[i] + o1);
+            }
+        }
+        f32x4 bs[4];
+        if (p.bias) {
+            const int c0 = min(nb, p.N - 8), c1 = min(nb + 32, p.N - 8);
+            bs[0] = *(const f32x4*)(p.bias + c0); bs[1] = *(const f32x4*)(p.bias + c0 + 4);
+            bs[2] = *(const f32x4*)(p.bias + c1); bs[3] = *(const f32x4*)(p.bias + c1 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 lo = acc[i][2 * pr], hi = acc[i][2 * pr + 1];
+                if (p.bias) { lo += bs[2 * pr]; hi += bs[2 * pr + 1]; }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+                }
+                bf16x4 pl, ph;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pl[e] = (bf16_t)lo[e]; ph[e] = (bf16_t)hi[e]; }
+                const uint2 ul = __builtin_bit_cast(uint2, pl), uh = __builtin_bit_cast(uint2, ph);
+                unsigned vw[4] = {ul.x, ul.y, uh.x, uh.y};
+                if (Mz) {
+                    // bf16 > 0  <=>  sign bit clear and not zero
+                    const unsigned mw4[4] = {mk[i][pr].x, mk[i][pr].y, mk[i][pr].z, mk[i][pr].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned l16 = mw4[e] & 0xffffu, h16 = mw4[e] >> 16;
+                        const unsigned keep = ((l16 != 0u && l16 < 0x8000u) ? 0xffffu : 0u) | ((h16 != 0u && h16 < 0x8000u) ? 0xffff0000u : 0u);
+                        vw[e] &= keep;
+                    }
+                }
+                if (!rv[i]) {
+                    if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+                    vw[0] = 0u; vw[1] = 0u; vw[2] = 0u; vw[3] = 0u;
+                }
+                uint4* dst = (uint4*)(Cb + off[i] + 32 * pr);
+                if (full || (m0 + (wm * TI + i) * 16 + frow < p.M && nb + 32 * pr < p.N)) *dst = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(TO) == 2) {
         if (p.flags & GEMM_WIDE_EPI) {
             // Storage-dtype output through LDS: the accumulator fragments (4 consecutive columns per lane) are written
@@ -1407,12 +1486,19 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
+    // register epilogue (see DIRECT above): bf16 in / out, LDS-DMA staging, whole 16-byte column groups
+    // (measured, tools/nt_ab.py: conv forward launches +4.5 ... 9 %; with a ReLU-backward mask the 64-byte row segments of the
+    // mask reads cost what the missing LDS round trip saves, so masked launches keep the LDS-staged epilogue)
+    const bool direct = fast && dma && dtype == CPC_DTYPE_BF16 && (q.flags & GEMM_WIDE_EPI) && !(p.flags & GEMM_NO_PERS) &&
+                        (!p.bias || (uintptr_t)p.bias % 16 == 0) && (!p.mask || (p.flags & GEMM_DIRECT_MASK));
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
             if (of32) NT_LAUNCH(bf16_t, float, 2, 4, 8, 4, 512, q);
+            else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true>), grid, dim3(512), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {
             if (of32) NT_LAUNCH(bf16_t, float, 2, 2, 4, 4, 256, q);
+            else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 2, 4, 4, true, false, true>), grid, dim3(256), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 2, 4, 4, 256, q);
         } else {
             if (of32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);

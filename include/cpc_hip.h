@@ -32,6 +32,8 @@ extern "C" {
 #define CPC_GEMM_SKIP_PAD_ROWS 128 /* NT: rows with (m % c_rpi) >= c_valid are left untouched instead of zeroed */
 #define CPC_GEMM_LINEAR_K 256     /* NT: visit K in storage order even for overlapped-row A operands (A/B check; default for lda < K,
                                     K % lda == 0 is tap-innermost: identical sums in a different order, each input byte fetched once) */
+#define CPC_GEMM_NO_PERS 512      /* NT/bf16: LDS-staged epilogue instead of the register epilogue (A/B check) */
+#define CPC_GEMM_DIRECT_MASK 1024 /* NT/bf16: register epilogue also for launches with a mask (A/B check; default: LDS-staged there) */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
 int cpc_abi_version(void);

@@ -85,6 +85,46 @@ def test_gemm_nt_tile_variants_agree(M, N, K):
         assert torch.equal(outs[0], o)
 
 
+@pytest.mark.parametrize("M,N,K,lda,rpi", [(256 * 80, 1024, 256, 256, 0), (256 * 79 + 100, 1000, 512, 256, 0),
+                                             (256 * 60 + 8, 1024, 512, 128, 97), (256 * 130, 512, 1024, 512, 640)])
+def test_gemm_nt_register_epilogue_agrees(M, N, K, lda, rpi):
+    """The register epilogue of the 256x256 kernel (16-byte stores straight from the accumulators, permuted B rows) against
+    the LDS-staged epilogue (CPC_GEMM_NO_PERS) and the f64 reference: bias + relu, relu-backward mask, pad-row zeroing /
+    skipping, ragged M and N, overlapped rows (lda < K: tap-innermost K order).  Bitwise equal: same sums in the same order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    X = torch.randn((M - 1) * lda + K + 64, generator=g)
+    Bt = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    dX, dB, db = dev(X, bf), dev(Bt, bf), dev(bias)
+    Xr = rounded(X, bf)
+    A = Xr.as_strided((M, K), (lda, 1))
+    ref0 = A @ rounded(Bt, bf).T
+    ldc = N
+    valid = rpi - 3 if rpi else 0
+    rowsel = (torch.arange(M) % rpi < valid) if rpi else torch.ones(M, dtype=torch.bool)
+    mask = torch.randn(M, N, generator=g)
+    dM = dev(mask, bf)
+    cases = [("bias_relu", dict(bias=_hip.ptr(db), flags=_hip.GEMM_RELU), torch.relu(ref0 + bias.double())),
+             ("mask", dict(mask=_hip.ptr(dM)), torch.where(rounded(mask, bf) > 0, ref0, torch.zeros_like(ref0))),
+             ("plain", dict(), ref0)]
+    for name, kw, ref in cases:
+        for skip in ((0, _hip.GEMM_SKIP_PAD_ROWS) if rpi else (0,)):
+            outs = []
+            for extra in (_hip.GEMM_DIRECT_MASK, _hip.GEMM_NO_PERS):
+                out = torch.full((M, N), 7.0, device=DEV, dtype=bf)
+                k2 = dict(kw)
+                k2["flags"] = k2.get("flags", 0) | extra | skip
+                _hip.gemm_nt(_hip.ptr(dX), _hip.ptr(dB), _hip.ptr(out), M, N, K, lda, K, ldc, _hip.BF16, c_rpi=rpi, c_item=rpi * ldc,
+                             c_valid=valid, **k2)
+                outs.append(out)
+            r = ref.clone()
+            if rpi:
+                r[~rowsel] = 7.0 if skip else 0.0
+            assert rel_err(outs[0], r) < tol(bf), (name, skip)
+            assert torch.equal(outs[0], outs[1]), (name, skip)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_nt_addressing_mask_batch(dt):
     """Overlapping rows (strided-conv view), item addressing on A and C, pad-row zeroing, relu mask, batch strides."""

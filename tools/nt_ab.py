@@ -3,7 +3,8 @@
 
     python tools/nt_ab.py [--rounds 5] [--iters 10] [--fit]
 
-Variants: default (tap-innermost K order for overlapped rows) vs CPC_GEMM_LINEAR_K (storage order).  Operands are post-ReLU
+Variants: default (register epilogue, tap-innermost K order for overlapped rows) vs CPC_GEMM_NO_PERS (LDS-staged epilogue)
+vs additionally CPC_GEMM_LINEAR_K (storage order).  Operands are post-ReLU
 like the real activations (half zeros) for the forward shapes and dense random for the gradients."""
 import argparse, os, sys
 import torch
@@ -80,8 +81,8 @@ for name, Lo, kw, s in LAYERS:
             _hip.lib().cpc_debug_set(1, 0)
         return run
 
-    fv = {"tap": lambda: fwd(0), "lin": lambda: fwd(_hip.GEMM_LINEAR_K)}
-    dv = {"tap": lambda: dgrad(0), "lin": lambda: dgrad(_hip.GEMM_LINEAR_K)}
+    fv = {"direct": lambda: fwd(0), "lds": lambda: fwd(_hip.GEMM_NO_PERS), "lds-lin": lambda: fwd(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
+    dv = {"direct": lambda: dgrad(0), "lds": lambda: dgrad(_hip.GEMM_NO_PERS), "lds-lin": lambda: dgrad(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
     for v in a.stagger:
         fv[f"st{v}"] = stag(fwd, v)
         dv[f"st{v}"] = stag(dgrad, v)
@@ -99,16 +100,17 @@ if a.fit:
     for K in (512, 1024, 2048, 4096, 8192):
         A = torch.randn(M * K, device=dev).to(bf)
         Bt = torch.randn(N * K, device=dev).to(bf)
-        for label, kw_ in (("plain", {}), ("mask", {"mask": P(msk)})):
+        for label, kw_ in (("plain", {}), ("mask", {"mask": P(msk)}), ("plain-lds", {"flags": _hip.GEMM_NO_PERS}),
+                           ("mask-lds", {"mask": P(msk), "flags": _hip.GEMM_NO_PERS})):
             f = lambda: _hip.gemm_nt(P(A), P(Bt), P(out), M, N, K, K, K, N, 1, **kw_)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
             t = sorted(timed(f, a.iters) for _ in range(a.rounds))[a.rounds // 2]
             pts.append((label, K, t))
-            print(f"fit {label:5s} K={K:5d}: {t * 1e3:8.1f} us = {t * 1e3 / 7:7.2f} us per round, {2.0 * M * N * K / t / 1e9:7.1f} TF/s", flush=True)
+            print(f"fit {label:10s} K={K:5d}: {t * 1e3:8.1f} us = {t * 1e3 / 7:7.2f} us per round, {2.0 * M * N * K / t / 1e9:7.1f} TF/s", flush=True)
         del A, Bt
-    for label in ("plain", "mask"):
+    for label in ("plain", "mask", "plain-lds", "mask-lds"):
         p = [(k, t * 1e3 / 7) for l, k, t in pts if l == label]
         (k0, t0), (k1, t1) = p[0], p[-1]
         slope = (t1 - t0) / ((k1 - k0) / 64)
