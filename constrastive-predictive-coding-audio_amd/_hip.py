@@ -30,7 +30,7 @@ class GemmNTArgs(C.Structure):
                 ("b_rpi", C.c_int), ("b_item", C.c_longlong),
                 ("c_rpi", C.c_int), ("c_item", C.c_longlong), ("c_valid", C.c_int),
                 ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
-                ("flags", C.c_int), ("dtype", C.c_int)]
+                ("flags", C.c_int), ("dtype", C.c_int), ("a_extent", C.c_longlong), ("b_extent", C.c_longlong)]
 
 
 class GemmTNArgs(C.Structure):
@@ -54,12 +54,12 @@ _SIGNATURES = {
     "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
     "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
-    "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
-    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_dgrad_conv1_floats": ([_I, _I, _I, _I, _I, _I], _L),
-    "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
@@ -123,7 +123,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 1:
+        if handle.cpc_abi_version() != 2:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib
@@ -228,10 +228,11 @@ def tn_tile(dtype, M, I, J, nsplit, m_chunk, flags=0):
 
 # ----------------------------------------------------------------------------- thin call wrappers
 def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None, a_rpi=0, a_item=0, b_rpi=0, b_item=0,
-            c_rpi=0, c_item=0, c_valid=0, a_batch=0, b_batch=0, c_batch=0, batch=1, flags=0):
-    """A, Bt, Cout, bias, mask are ctypes void pointers (see ptr())."""
+            c_rpi=0, c_item=0, c_valid=0, a_batch=0, b_batch=0, c_batch=0, batch=1, flags=0, a_extent=0, b_extent=0):
+    """A, Bt, Cout, bias, mask are ctypes void pointers (see ptr()).  a_extent / b_extent: elements readable from A / Bt
+    (0 = unchecked), see the over-read contract in include/cpc_hip.h."""
     args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
-                      c_valid, a_batch, b_batch, c_batch, batch, flags, dtype)
+                      c_valid, a_batch, b_batch, c_batch, batch, flags, dtype, a_extent, b_extent)
     if _timer is not None:
         _timer.run("gemm_nt" + _variant(dtype, flags, nt_tile(dtype, M, N, K, flags, batch)), 2.0 * M * N * K * batch,
                    lambda: _check(lib().cpc_gemm_nt(C.byref(args), stream_ptr()), "cpc_gemm_nt"), shape=(M, N, K, batch))

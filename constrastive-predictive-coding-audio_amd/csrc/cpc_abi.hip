@@ -1,5 +1,6 @@
 // extern "C" boundary of libcpc_hip.so: argument checking + translation of the domain-level calls (conv / GRU / NCE /
 // Adam) onto the kernel launchers.  See include/cpc_hip.h for the contract.
+#include <algorithm>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
 #include "../../include/cpc_hip.h"
@@ -14,7 +15,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 1; }
+int cpc_abi_version(void) { return 2; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -29,7 +30,19 @@ int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     p.flags = a->flags;
     if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
     if (a->mask && (p.flags & GEMM_OUT_F32) && a->dtype != CPC_DTYPE_F32) return CPC_EINVAL;
-    return launch_gemm_nt(p, a->dtype, a->batch > 0 ? a->batch : 1, (hipStream_t)stream);
+    // Optional extent check (see the over-read contract in cpc_hip.h): the last row of the last batch ends at ..._end elements.
+    const int nb = a->batch > 0 ? a->batch : 1;
+    if (a->a_extent > 0 && a->M > 0) {
+        const long long last = a->a_rpi ? (long long)((a->M - 1) / a->a_rpi) * a->a_item + (long long)((a->M - 1) % a->a_rpi) * a->lda
+                                        : (long long)(a->M - 1) * a->lda;
+        if (last + a->K + (long long)(nb - 1) * a->a_batch > a->a_extent) return CPC_EINVAL;
+    }
+    if (a->b_extent > 0 && a->N > 0) {
+        const long long last = a->b_rpi ? (long long)((a->N - 1) / a->b_rpi) * a->b_item + (long long)((a->N - 1) % a->b_rpi) * a->ldb
+                                        : (long long)(a->N - 1) * a->ldb;
+        if (last + a->K + (long long)(nb - 1) * a->b_batch > a->b_extent) return CPC_EINVAL;
+    }
+    return launch_gemm_nt(p, a->dtype, nb, (hipStream_t)stream);
 }
 
 int cpc_gemm_tn(const cpc_gemm_tn_args* a, void* stream) {
@@ -83,8 +96,9 @@ int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw,
 }
 
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw, int stride,
-                 int Lout_alloc, int Lout_valid, int relu, int dtype, void* stream) {
-    if (!x || !w_fwd || !y || B <= 0 || Lout_alloc <= 0 || Lout_valid > Lout_alloc) return CPC_EINVAL;
+                 int Lout_alloc, int Lout_valid, int relu, long long x_tail, int dtype, void* stream) {
+    if (!x || !w_fwd || !y || B <= 0 || Lout_alloc <= 0 || Lout_valid > Lout_alloc || kw <= 0 || stride <= 0) return CPC_EINVAL;
+    if (x_tail < (long long)std::max(0, kw - stride) * Cin) return CPC_EINVAL;    // the last row reads kw - stride positions past the end
     GemmNT p = {};
     p.A = x; p.Bt = w_fwd; p.C = y; p.bias = bias; p.mask = nullptr;
     p.M = B * Lout_alloc; p.N = Cout; p.K = kw * Cin;
@@ -95,10 +109,11 @@ int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, i
 }
 
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
-                   int stride, int Lout_alloc, int Lin_valid, int dtype, void* stream) {
-    if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0) return CPC_EINVAL;
+                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, void* stream) {
+    if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;
     (void)Lin_valid;   // positions >= Lin_valid receive zeros because the pad rows of dy are zero
     const int D = (kw + stride - 1) / stride;
+    if (dy_head < (long long)(D - 1) * Cout) return CPC_EINVAL;                   // the first row starts D - 1 positions before dy
     GemmNT p = {};
     p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);   // D-1 zero guard rows precede the buffer
     p.Bt = w_dgrad; p.C = dx; p.bias = nullptr; p.mask = x_act;
@@ -116,10 +131,11 @@ long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc
 
 int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
                          int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
-                         int dtype, void* stream) {
+                         long long dy_head, int dtype, void* stream) {
     if (!dy || !w_dgrad || !x_act || !x || !slabs || B <= 0 || Lout_alloc <= 0 || dtype != CPC_DTYPE_BF16) return CPC_EINVAL;
-    if (Cin % 256 || kw1 < 1 || kw1 > 15 || stride1 < 1 || L1_valid < 1) return CPC_EINVAL;
+    if (Cin % 256 || kw1 < 1 || kw1 > 15 || stride1 < 1 || L1_valid < 1 || kw <= 0 || stride <= 0) return CPC_EINVAL;
     const int D = (kw + stride - 1) / stride;
+    if (dy_head < (long long)(D - 1) * Cout) return CPC_EINVAL;
     GemmNT p = {};
     p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);
     p.Bt = w_dgrad; p.C = slabs /* not written */; p.bias = nullptr; p.mask = x_act;
@@ -139,8 +155,9 @@ int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db,
 }
 
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride, int Lout_alloc,
-                   int nsplit, int dtype, void* stream) {
-    if (!x || !dy || !slabs || B <= 0 || Lout_alloc <= 0 || nsplit <= 0) return CPC_EINVAL;
+                   int nsplit, long long x_tail, int dtype, void* stream) {
+    if (!x || !dy || !slabs || B <= 0 || Lout_alloc <= 0 || nsplit <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;
+    if (x_tail < (long long)std::max(0, kw - stride) * Cin) return CPC_EINVAL;
     GemmTN p = {};
     p.A = x; p.B = dy; p.C = slabs;
     p.M = B * Lout_alloc; p.I = kw * Cin; p.J = Cout;

@@ -138,9 +138,11 @@ class CPCEngine:
         if self.E % ch:
             raise NotImplementedError("enc_size must be a multiple of 8")
 
-    def _buf(self, rows: int, cols: int):
-        """Zeroed [rows][cols] storage-dtype buffer with 16 guard rows on both sides; returns (full, view, guard_elems)."""
-        guard = 16 * cols
+    def _buf(self, rows: int, cols: int, guard_rows: int = 16):
+        """Zeroed [rows][cols] storage-dtype buffer with ``guard_rows`` (>= 16) zero rows on both sides; returns (full, view,
+        guard_elems).  The guards are what the overlapped-row GEMMs read beyond the array (include/cpc_hip.h, guard contract):
+        kernel - stride rows after a convolution input, ceil(kernel / stride) - 1 rows before an output gradient."""
+        guard = max(16, int(guard_rows)) * cols
         full = torch.zeros(guard + rows * cols + guard, device=self.device, dtype=self.dt)
         return full, full[guard:guard + rows * cols], guard
 
@@ -155,11 +157,16 @@ class CPCEngine:
         La = self.geo.alloc
         self.act, self.dact = [], []
         self._keep = []
+        # guard rows: act[l] is read (kernel - stride) rows past its end by layer l+1's forward / weight gradient, dact[l] is
+        # read (taps - 1) rows before its start by layer l's data gradient
+        self.guard_rows = max([16] + [self.kernels[l] - self.strides[l] for l in range(1, n)] + [t - 1 for t in self.geo.taps[1:]])
+        self.guard = []
         for l in range(n):
             for store in (self.act, self.dact):
-                full, view, _ = self._buf(B * La[l], self.channels[l])
+                full, view, g_el = self._buf(B * La[l], self.channels[l], self.guard_rows)
                 self._keep.append(full)
                 store.append(view)
+            self.guard.append(g_el)
         # weight operand layouts (storage dtype)
         self.w_fwd: List[Optional[torch.Tensor]] = [None] * n
         self.w_dgrad: List[Optional[torch.Tensor]] = [None] * n
@@ -330,7 +337,7 @@ class CPCEngine:
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
-                      La[l], Lv[l], 1 if l < self.n - 1 else 0, code,
+                      La[l], Lv[l], 1 if l < self.n - 1 else 0, C.c_longlong(self.guard[l - 1]), code,
                       key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1])),
                       work=2.0 * B * La[l] * self.channels[l] * self.kernels[l] * self.channels[l - 1],
                       shape=("fwd", B * La[l], self.channels[l], self.kernels[l] * self.channels[l - 1]))
@@ -484,7 +491,7 @@ class CPCEngine:
             bname = f"encoder.layers.{l}.bias"
             flops = 2.0 * B * La[l] * cout * kw * cin
             _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
-                      La[l], self.nsplit[l], code,
+                      La[l], self.nsplit[l], C.c_longlong(self.guard[l - 1]), code,
                       key="gemm_tn" + _hip._variant(code, _hip.GEMM_OUT_F32, _hip.tn_tile(code, B * La[l], kw * cin, cout, self.nsplit[l],
                                                                                              self._chunk(B * La[l], self.nsplit[l]))),
                       work=flops,
@@ -508,10 +515,11 @@ class CPCEngine:
             if l == 1 and self.fuse_c1:
                 _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
                           _hip.ptr(x, self.x_off), _hip.ptr(self.c1_slabs), B, cin, cout, kw, s, La[1], self.L, self.kernels[0],
-                          self.strides[0], Lv[0], code, **dict(tkey, key=tkey["key"].replace("gemm_nt", "gemm_nt_conv1")))
+                          self.strides[0], Lv[0], C.c_longlong(self.guard[1]), code,
+                          **dict(tkey, key=tkey["key"].replace("gemm_nt", "gemm_nt_conv1")))
             else:
                 _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
-                          _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], code, **tkey)
+                          _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], C.c_longlong(self.guard[l]), code, **tkey)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
         if self.fuse_c1:
@@ -686,7 +694,7 @@ class ConvArContext:
                 if l == 0 and self.pools[0] == 1 and store in (self.x, self.dx):
                     store.append(None)        # block 0 without pooling reads z straight out of the encoder's top buffer
                     continue
-                full, view, _ = e._buf(B * self.la[l], cols)
+                full, view, _ = e._buf(B * self.la[l], cols, max(self.kernels))
                 self._keep.append(full)
                 store.append(view)
             self.w_fwd.append(torch.empty(cout * kw * cin, device=dev, dtype=dt))

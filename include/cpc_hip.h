@@ -58,6 +58,14 @@ typedef struct cpc_gemm_nt_args {
     int c_rpi; long long c_item; int c_valid;   /* rows with (m % c_rpi) >= c_valid are stored as zeros */
     long long a_batch, b_batch, c_batch; int batch;
     int flags; int dtype;
+    /* OVER-READ CONTRACT.  Row m of A is read as the K elements starting at its row address, whatever lda is: with
+     * overlapped rows (lda < K, the strided-convolution view) the last row therefore reads (K - lda) elements beyond the end
+     * of an [M][lda] array, and rows are clamped to M - 1 but never shortened.  ALL of [A, A + last_row_offset + K) (and the
+     * same for Bt) must be readable device memory: an allocation that ends exactly at M*lda elements may end at the end of a
+     * mapped segment, and the over-read then faults (this happened once).  a_extent / b_extent:
+     * number of elements readable from A / Bt (all batches); when > 0 the call returns CPC_EINVAL if any row would end beyond
+     * it; 0 = not checked, the caller vouches. */
+    long long a_extent, b_extent;
 } cpc_gemm_nt_args;
 int cpc_gemm_nt(const cpc_gemm_nt_args* args, void* stream);
 
@@ -109,7 +117,7 @@ int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, in
 long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what);
 int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
                          int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
-                         int dtype, void* stream);
+                         long long dy_head, int dtype, void* stream);
 int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int B, int Cin, int stride, int Lout_alloc,
                            int kw1, void* stream);
 
@@ -118,13 +126,18 @@ int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db,
  *   dgrad: dx[(b,p)][c]  = (x_act > 0 ?) sum_{t,co: t*stride + j = p} dy[(b,t)][co] * w[co][c][j]
  *   wgrad: slabs of dw[(j,c)][co] = sum_{b,t} x[(b, t*stride+j)][c] * dy[(b,t)][co]
  * w_fwd / w_dgrad are the operand layouts cpc_conv_w_prep produces (either output pointer may be NULL: that layout is then
- * not written).  Lout_alloc * stride == Lin_alloc is required. */
+ * not written).  Lout_alloc * stride == Lin_alloc is required.
+ * GUARD CONTRACT (the over-read contract of cpc_gemm_nt_args for these views): the forward and the weight gradient read
+ * max(0, kw - stride) * Cin elements BEYOND the B * Lin_alloc * Cin elements of x (the window of the last row); the data
+ * gradient reads (ceil(kw / stride) - 1) * Cout elements BEFORE dy.  The caller states how many elements are readable there
+ * (x_tail after the end of x, dy_head in front of dy; zeros expected in dy_head, values in x_tail only ever meet pad rows);
+ * CPC_EINVAL when that is less than the call needs. */
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw,
-                 int stride, int Lout_alloc, int Lout_valid, int relu, int dtype, void* stream);
+                 int stride, int Lout_alloc, int Lout_valid, int relu, long long x_tail, int dtype, void* stream);
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
-                   int stride, int Lout_alloc, int Lin_valid, int dtype, void* stream);
+                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, void* stream);
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride,
-                   int Lout_alloc, int nsplit, int dtype, void* stream);
+                   int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
                     void* stream);
 

@@ -329,7 +329,7 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     ybuf = torch.full((guard + B * Lout_alloc * Cout + guard,), float("nan"), device=DEV, dtype=dt)
     for relu in (1, 0):
         _hip.call("cpc_conv_fwd", _hip.ptr(xbuf, guard), _hip.ptr(wf), _hip.ptr(db_), _hip.ptr(ybuf, guard), B, Cin, Cout, kw,
-                  stride, Lout_alloc, Lout_valid, relu, code)
+                  stride, Lout_alloc, Lout_valid, relu, C.c_longlong(guard), code)
         y = ybuf[guard:guard + B * Lout_alloc * Cout].view(B, Lout_alloc, Cout)
         xr = rounded(x, dt)[:, :Lin_valid].transpose(1, 2)
         ref = F.conv1d(xr, rounded(w, dt), bias.double(), stride=stride)
@@ -343,7 +343,7 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     dybuf = padded(dy)
     dxbuf = torch.full((guard + B * Lin_alloc * Cin + guard,), float("nan"), device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(xbuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, Lout_alloc, Lin_valid, code)
+              kw, stride, Lout_alloc, Lin_valid, C.c_longlong(guard), code)
     xin = rounded(x, dt)[:, :Lin_valid].transpose(1, 2).clone().requires_grad_(True)
     wr = rounded(w, dt).clone().requires_grad_(True)
     out = F.conv1d(xin, wr, None, stride=stride)
@@ -355,7 +355,7 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     nsplit = 2
     slabs = torch.full((nsplit, kw * Cin, Cout), float("nan"), device=DEV)
     _hip.call("cpc_conv_wgrad", _hip.ptr(xbuf, guard), _hip.ptr(dybuf, guard), _hip.ptr(slabs), B, Cin, Cout, kw, stride, Lout_alloc,
-              nsplit, code)
+              nsplit, C.c_longlong(guard), code)
     got = slabs.sum(0).view(kw, Cin, Cout).permute(2, 1, 0)
     assert rel_err(got, wr.grad) < tol(dt)
     wg = torch.full((Cout, Cin, kw), float("nan"), device=DEV)
@@ -392,7 +392,7 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     _hip.call("cpc_conv_w_prep", _hip.ptr(w.to(DEV)), _hip.ptr(wf), _hip.ptr(wd), Cout, Cin, kw, stride, code)
     dxbuf = torch.zeros(guard + B * La0 * Cin + guard, device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, La1, Lv0, code)
+              kw, stride, La1, Lv0, C.c_longlong(guard), code)
     G = dxbuf[guard:guard + B * La0 * Cin].view(B, La0, Cin).double().cpu()[:, :Lv0]
     win = xwave.double().unfold(1, kw1, s1)[:, :Lv0]                 # (B, Lv0, kw1)
     ref_w = torch.einsum("btc,btj->cj", G, win)
@@ -403,7 +403,7 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     tmp = torch.full((n_tmp,), float("nan"), device=DEV)
     xd = xwave.to(DEV)
     _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(xd), _hip.ptr(slabs), B, Cin,
-              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, code)
+              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, C.c_longlong(guard), code)
     dw = torch.full((Cin, 1, kw1), float("nan"), device=DEV)
     db = torch.full((Cin,), float("nan"), device=DEV)
     _hip.call("cpc_conv1_fused_reduce", _hip.ptr(slabs), _hip.ptr(tmp), _hip.ptr(dw), _hip.ptr(db), B, Cin, stride, La1, kw1)

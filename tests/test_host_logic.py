@@ -86,10 +86,42 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert handle.cpc_abi_version() == 1
+    assert handle.cpc_abi_version() == 2
     nm = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cpc_\w+)", nm))
     assert exported == declared
+
+
+def test_over_read_contract_is_checked_before_any_launch():
+    """include/cpc_hip.h, over-read / guard contract: calls whose overlapped-row views would read beyond what the caller says
+    is readable return CPC_EINVAL (-22) from the argument check — no kernel is launched, so this runs without a GPU."""
+    import ctypes as C
+    lib = _hip.lib()
+    P = C.c_void_p(0x1000)        # never dereferenced: the calls below are refused before any launch
+    B, Cin, Cout, kw, stride, La = 2, 64, 64, 8, 4, 10
+    need_tail, need_head = (kw - stride) * Cin, (-(-kw // stride) - 1) * Cout
+    s = C.c_void_p(0)
+    assert lib.cpc_conv_fwd(P, P, None, P, B, Cin, Cout, kw, stride, La, La - 1, 1, C.c_longlong(need_tail - 1), _hip.BF16, s) == -22
+    assert lib.cpc_conv_wgrad(P, P, P, B, Cin, Cout, kw, stride, La, 1, C.c_longlong(0), _hip.BF16, s) == -22
+    assert lib.cpc_conv_dgrad(P, P, None, P, B, Cin, Cout, kw, stride, La, La * stride, C.c_longlong(need_head - 1), _hip.BF16, s) == -22
+    assert lib.cpc_conv_dgrad_conv1(P, P, P, P, P, B, 256, Cout, kw, stride, La, 100, 10, 5, 10, C.c_longlong(need_head - 1), _hip.BF16, s) == -22
+    # cpc_gemm_nt with stated extents: M rows of K = 512 at lda = 256 need (M - 1) * 256 + 512 readable elements
+    M, N, K, lda = 40, 64, 512, 256
+    args = _hip.GemmNTArgs(P, P, P, None, None, M, N, K, lda, K, N, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, _hip.BF16, M * lda, 0)
+    assert lib.cpc_gemm_nt(C.byref(args), s) == -22            # an [M][lda] array is (K - lda) elements short
+    args = _hip.GemmNTArgs(P, P, P, None, None, M, N, K, lda, K, N, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, _hip.BF16, 0, N * K - 1)
+    assert lib.cpc_gemm_nt(C.byref(args), s) == -22
+
+
+def test_engine_guard_rows_cover_every_over_read():
+    """EncoderGeometry / CPCEngine._buf: the guard in front of and behind every activation buffer is at least what the
+    overlapped-row GEMMs of its consumers read there, also for kernels much wider than their stride."""
+    from cpc_audio_amd.engine import EncoderGeometry
+    for strides, kernels in (([5, 4, 2, 2, 2], [10, 8, 4, 4, 4]), ([5, 2, 1], [10, 40, 33])):
+        geo = EncoderGeometry(4000, strides, kernels)
+        need = max([16] + [kernels[l] - strides[l] for l in range(1, len(strides))] + [t - 1 for t in geo.taps[1:]])
+        assert need >= max(k - s for k, s in zip(kernels[1:], strides[1:]))
+        assert need >= max(-(-k // s) - 1 for k, s in zip(kernels[1:], strides[1:]))
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
