@@ -118,6 +118,7 @@ def main():
     pool = [(torch.randn(B, L, generator=gen)).to(device) for _ in range(4)]
 
     sync = GradAllReduce(model, optimizer=opt) if world > 1 else None      # Adam follows each reduced piece of the gradient
+    opt.skip_flag = eng.nan_flag()          # the trainer's device-side NaN guard is part of the measured step
 
     graphed = GraphedStep(eng, opt, True, 1.0, args.all_timesteps) if use_graph else None
 
@@ -125,7 +126,8 @@ def main():
         if graphed is not None:
             return graphed(pool[i % len(pool)])
         out = eng.loss_and_grads(pool[i % len(pool)], softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
-                                 grad_ready_hook=sync.hook if sync is not None else opt.hook)
+                                 grad_ready_hook=sync.hook if sync is not None else opt.hook,
+                                 after_loss=sync.reduce_flag if sync is not None else None)
         if sync is not None:
             sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer: overlapped pieces + the head
         opt.step(grad_scale=1.0 / world)

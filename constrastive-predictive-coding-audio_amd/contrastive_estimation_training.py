@@ -201,6 +201,7 @@ class ContrastiveEstimationTrainer:
                                    verbose=self.verbose)
         self.training_step = continue_training_at_step
         pending = []          # (step, device scalars) not yet read back
+        guarded = set()       # engines whose sticky NaN flag was cleared for this run
 
         on_gpu = torch.device(device).type == "cuda"
         ring, ring_pos = [], [0]
@@ -210,14 +211,14 @@ class ContrastiveEstimationTrainer:
             step's own kernels and an event marks their arrival: reading them later does not wait for LATER steps' work, which a
             synchronous read of a device tensor — queued behind everything launched since — would."""
             if not on_gpu:
-                pending.append((step, vals.detach()[:2].clone(), None))
+                pending.append((step, vals.detach()[:6].clone(), None))
                 return
             need = self.host_sync_interval + self.host_sync_lag + 2
             while len(ring) < need:
-                ring.append(torch.empty(2, dtype=torch.float32, pin_memory=True))
+                ring.append(torch.empty(6, dtype=torch.float32, pin_memory=True))
             buf = ring[ring_pos[0] % len(ring)]
             ring_pos[0] += 1
-            buf.copy_(vals.detach()[:2].float(), non_blocking=True)
+            buf.copy_(vals.detach()[:6].float(), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             pending.append((step, buf, ev))
@@ -228,20 +229,23 @@ class ContrastiveEstimationTrainer:
             for step, vals, ev in pending[:n]:
                 if ev is not None:
                     ev.synchronize()
-                loss_v, score_v = (float(v) for v in vals.tolist()[:2])
+                row = vals.tolist()
+                loss_v, score_v, nan_v = float(row[0]), float(row[1]), float(row[5])        # cpc_nce_loss: out[0], out[1], out[5]
+                # reference order (:124-133 before :164-169): a NaN loss ends the run before anything is logged for that step
+                if nan_v != 0.0 or math.isnan(loss_v):
+                    pending.clear()
+                    return step
                 if self.logger is not None:
                     self.logger.loss_meter.update(loss_v)
                     self.logger.score_meter.update(score_v)
                     self.logger.log(step)
                 elif self.verbose:
                     print("loss at step step " + str(step) + ":", loss_v)
-                if math.isnan(loss_v):
-                    pending.clear()
-                    return step
             del pending[:n]
             return None
 
         def nan_return(step):
+            self.training_step = step          # the reference leaves train() inside step `step`, before its update (:124-133)
             print("nan loss")
             print("returned with nan loss at step", step)
             return None
@@ -259,6 +263,9 @@ class ContrastiveEstimationTrainer:
                         if key not in graph_steps:
                             graph_steps[key] = GraphedStep(eng, optimizer, self.score_function is softplus_score_function,
                                                            float(self.regularization), bool(self.score_over_all_timesteps))
+                        if id(eng) not in guarded:
+                            eng.nan_flag().zero_()
+                            guarded.add(id(eng))
                         vals = graph_steps[key](batch)
                     elif fused:
                         if self.preprocessing is not None:
@@ -275,13 +282,20 @@ class ContrastiveEstimationTrainer:
                         # the operand copies of the next step are rebuilt as soon as Adam has updated their parameters
                         # (engine.CPCEngine.prepare_ahead; under data parallelism Adam follows each reduced gradient piece)
                         optimizer.after_update = eng.prepare_ahead
+                        # NaN guard on the device (reference :124-133 returns before backward() / optimizer.step()): the loss
+                        # kernel raises the engine's sticky flag, every Adam launch of this and of later steps is a no-op while it
+                        # is up, and the host leaves train() when the step's indicator arrives (host_sync_lag steps later)
+                        if id(eng) not in guarded:
+                            eng.nan_flag().zero_()
+                            guarded.add(id(eng))
+                        optimizer.skip_flag = eng.nan_flag()
                         if sync is not None:      # per-GPU negatives: mean of the shard gradients; global negatives: they add up
                             sync.grad_scale = 1.0 if gneg is not None else 1.0 / world
                         out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
                                                  regularization=float(self.regularization),
                                                  all_timesteps=bool(self.score_over_all_timesteps),
                                                  grad_ready_hook=sync.hook if sync is not None else getattr(optimizer, "hook", None),
-                                                 global_negatives=gneg)
+                                                 global_negatives=gneg, after_loss=sync.reduce_flag if sync is not None else None)
                         if sync is not None:
                             sync.finish()
                         # per-GPU negatives: mean of the shard gradients; global negatives: the shard gradients add up
@@ -290,6 +304,10 @@ class ContrastiveEstimationTrainer:
                     else:
                         vals = self._generic_step(batch, batch.shape[0], optimizer, world)
                     stash(self.training_step, vals)
+                    if not fused:            # this route has already read the loss (NaN check in front of backward(), as the reference)
+                        nan_step = flush()
+                        if nan_step is not None:
+                            return nan_return(nan_step)
                     # the readback trails the launches by host_sync_lag steps: the host waits for step i - 1's loss while step i
                     # already runs (reading step i's loss right away left the GPU idle for 0.3 ms of every 5.1 ms step while the
                     # host prepared the next one); every step is still logged, in order, and a NaN loss still ends the run
@@ -316,6 +334,14 @@ class ContrastiveEstimationTrainer:
                                                           self.score_over_all_timesteps)
         prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=1)
         loss = torch.mean(prediction_losses)
+        nan = torch.isnan(loss)
+        if world > 1:          # every rank has its own loss: all ranks leave at the same step
+            import torch.distributed as dist
+            nan = nan.float()
+            dist.all_reduce(nan, op=dist.ReduceOp.MAX)
+        if bool(nan.item()):   # reference :124-133: return before backward() / optimizer.step() (this route reads the loss every step)
+            z = torch.zeros_like(loss.detach())
+            return torch.stack([loss.detach(), torch.max(scores).detach(), z, z, z, z + 1])
         loss = loss + self.regularization * torch.mean(torch.mean(scores, dim=1) ** 2)
         self.model.zero_grad()
         loss.backward()
@@ -325,7 +351,8 @@ class ContrastiveEstimationTrainer:
                 dist.all_reduce(p.grad)
                 p.grad.div_(world)
         optimizer.step()
-        return torch.stack([loss.detach(), torch.max(scores).detach()])
+        z = torch.zeros_like(loss.detach())
+        return torch.stack([loss.detach(), torch.max(scores).detach(), z, z, z, z])
 
     # ------------------------------------------------------------------------------------------ validate
     def validate(self, batch_size=64, num_workers=1, max_steps=None):

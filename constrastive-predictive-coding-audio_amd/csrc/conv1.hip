@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             }
             if (relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
             }
         } else {
 #pragma unroll

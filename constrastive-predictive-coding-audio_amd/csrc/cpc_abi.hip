@@ -347,9 +347,9 @@ int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream) {
 }
 
 int cpc_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
-                 float grad_scale, void* stream) {
+                 float grad_scale, const float* skip, void* stream) {
     if (!p || !g || !m || !v || !state) return CPC_EINVAL;
-    return launch_adam_dev(p, g, m, v, n, lr, b1, b2, eps, state, grad_scale, (hipStream_t)stream);
+    return launch_adam_dev(p, g, m, v, n, lr, b1, b2, eps, state, grad_scale, skip, (hipStream_t)stream);
 }
 
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream) {
@@ -412,9 +412,9 @@ int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float
 }
 
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
-             float grad_scale, void* stream) {
+             float grad_scale, const float* skip, void* stream) {
     if (!p || !g || !m || !v) return CPC_EINVAL;
-    return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+    return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, skip, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -28,6 +28,10 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
 
+// relu as torch computes it: a NaN stays a NaN (fmaxf(NaN, 0) = 0 would swallow it, and with it the trainer's NaN guard,
+// contrastive_estimation_training.py:124-133)
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
 // Store 4 consecutive values held as f32 into a T* (8 B for bf16, 16 B for f32). dst must be aligned to that size.
 __device__ __forceinline__ void store4(float* dst, f32x4 v) { *(f32x4*)dst = v; }
 __device__ __forceinline__ void store4(bf16_t* dst, f32x4 v) {

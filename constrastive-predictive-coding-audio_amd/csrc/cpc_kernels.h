@@ -101,7 +101,7 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
-                float grad_scale, hipStream_t stream);
+                float grad_scale, const float* skip, hipStream_t stream);
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,
                        hipStream_t stream);
 int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, hipStream_t stream);
@@ -159,4 +159,4 @@ int launch_residual_add_bwd(const void* dout, const void* out, const int* go, vo
 int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
-                    float grad_scale, hipStream_t stream);
+                    float grad_scale, const float* skip, hipStream_t stream);

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             }
             if (relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
             }
             if (Mb) {
                 const f32x4 mk = load4(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 if (p.bias) { lo += bs[2 * pr]; hi += bs[2 * pr + 1]; }
                 if (relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+                    for (int e = 0; e < 4; ++e) { lo[e] = relu_f(lo[e]); hi[e] = relu_f(hi[e]); }
                 }
                 bf16x4 pl, ph;
 #pragma unroll
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     if (p.bias) v += *(const f32x4*)(p.bias + min(n0 + nl, p.N - 4));
                     if (relu) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                     }
                     store4((TO*)(lds + ml * EPI_RS) + nl, v);
                 }
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             if (p.bias) v += *(const f32x4*)(p.bias + n);
             if (relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
             }
             if (Mb) {
                 const f32x4 mk = load4(Mb + (long long)blockIdx.z * p.c_batch + coff + n);
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
         }
         if (relu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+            for (int j = 0; j < 8; ++j) acc[j] = relu_f(acc[j]);
         }
         const bool row_valid = (p.c_rpi == 0) || ((int)(m % p.c_rpi) < p.c_valid);
         if (!row_valid) {

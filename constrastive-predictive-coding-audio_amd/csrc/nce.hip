@@ -315,6 +315,13 @@ __global__ __launch_bounds__(256) void nce_all_finalize_kernel(const float* __re
     out[2] = t_valid;
     out[3] = t_lse;
     out[4] = t_reg;
+    // NaN guard of the reference (contrastive_estimation_training.py:124-133: isnan of the loss BEFORE the regulariser, then
+    // `return` before backward() / optimizer.step()): out[5] = this step's indicator, out[6] = sticky (stays raised until the host
+    // clears it) — cpc_adam / cpc_adam_dev skip their update while it is raised
+    const float lb = t_valid + t_lse;
+    const float bad = (lb != lb) ? 1.f : 0.f;
+    out[5] = bad;
+    if (bad != 0.f) out[6] = 1.f;
 }
 
 // out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
@@ -349,6 +356,13 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
     out[2] = t_valid;
     out[3] = t_lse;
     out[4] = t_reg;
+    // NaN guard of the reference (contrastive_estimation_training.py:124-133: isnan of the loss BEFORE the regulariser, then
+    // `return` before backward() / optimizer.step()): out[5] = this step's indicator, out[6] = sticky (stays raised until the host
+    // clears it) — cpc_adam / cpc_adam_dev skip their update while it is raised
+    const float lb = t_valid + t_lse;
+    const float bad = (lb != lb) ? 1.f : 0.f;
+    out[5] = bad;
+    if (bad != 0.f) out[6] = 1.f;
 }
 
 }  // namespace

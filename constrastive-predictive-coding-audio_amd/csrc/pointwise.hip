@@ -9,7 +9,10 @@ namespace {
 // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).   g is pre-multiplied by grad_scale (1 / world size for DP means).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float b1, float b2,
-                                                   float eps, float inv_bc2_sqrt, float grad_scale) {
+                                                   float eps, float inv_bc2_sqrt, float grad_scale, const float* __restrict__ skip) {
+    // NaN guard (contrastive_estimation_training.py:124-133 returns BEFORE backward() / optimizer.step()): the loss kernel raises
+    // *skip when the loss is NaN and this update becomes a no-op — parameters and moments keep their last good values
+    if (skip && skip[0] != 0.f) return;
     const long long n4 = n / 4;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -162,8 +165,9 @@ __global__ __launch_bounds__(256) void relu_row_bwd_kernel(const float* __restri
 
 // Step counter kept on the device (so that a captured hipGraph can be replayed): state[0] = step count (as float bits of an
 // int), state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t).
-__global__ void adam_tick_kernel(float* __restrict__ state, float lr, float b1, float b2) {
+__global__ void adam_tick_kernel(float* __restrict__ state, float lr, float b1, float b2, const float* __restrict__ skip) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (skip && skip[0] != 0.f) return;
     int t = __float_as_int(state[0]) + 1;
     state[0] = __int_as_float(t);
     const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
@@ -172,7 +176,8 @@ __global__ void adam_tick_kernel(float* __restrict__ state, float lr, float b1, 
 }
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long long n, const float* __restrict__ state, float b1,
-                                                       float b2, float eps, float grad_scale) {
+                                                       float b2, float eps, float grad_scale, const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;
     const float step_size = state[1], inv_bc2_sqrt = state[2];
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -185,24 +190,25 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
-                    float grad_scale, hipStream_t stream) {
+                    float grad_scale, const float* skip, hipStream_t stream) {
     if (n <= 0 || !state) return CPC_EINVAL;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, state, lr, b1, b2);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, state, lr, b1, b2, skip);
     const int blocks = (int)min((long long)2048, (n + 255) / 256);
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, (const float*)state, b1, b2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, (const float*)state, b1, b2, eps, grad_scale,
+                       skip);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
-                float grad_scale, hipStream_t stream) {
+                float grad_scale, const float* skip, hipStream_t stream) {
     if (n <= 0 || step < 1) return CPC_EINVAL;
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const int blocks = (int)min((long long)2048, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, step_size, b1, b2, eps, inv_bc2_sqrt,
-                       grad_scale);
+                       grad_scale, skip);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
-            if (relu) o[e] = fmaxf(o[e], 0.f);
+            if (relu) o[e] = relu_f(o[e]);
         }
         store4(out + grid_off(go, b, w, h) + c4 * 4, o);
     }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void residual_add_kernel(const T* __restrict__
         f32x4 v = load4(a + grid_off(ga, b, w, h) + c4 * 4) + load4(r + grid_off(gr, b, w + ow, h + oh) + c4 * 4);
         if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
         }
         store4(out + grid_off(go, b, w, h) + c4 * 4, v);
     }

@@ -537,9 +537,12 @@ class CPCEngine:
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
-                       global_negatives=None):
-        """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg] (no sync).
-        ``global_negatives``: a GlobalNegatives object — the loss is then taken over the batches of ALL ranks."""
+                       global_negatives=None, after_loss=None):
+        """Forward + loss + backward; returns the device tensor [loss, max_score, -mean valid, mean lse, reg, NaN indicator of
+        this step, sticky NaN flag, -] (no sync; include/cpc_hip.h, cpc_nce_loss).
+        ``global_negatives``: a GlobalNegatives object — the loss is then taken over the batches of ALL ranks.
+        ``after_loss(nce_out)`` is called once the loss kernels are queued and before the backward pass is: data-parallel runs
+        start the reduction of the NaN flag over the ranks there (GradAllReduce.reduce_flag)."""
         self.forward(x)
         if global_negatives is not None:
             global_negatives.forward_backward(softplus, regularization, all_timesteps)
@@ -547,8 +550,14 @@ class CPCEngine:
             self.nce_all_forward_backward(softplus, regularization)
         else:
             self.nce_forward_backward(softplus, regularization)
+        if after_loss is not None:
+            after_loss(self.nce_out)
         self.backward(x, grad_ready_hook=grad_ready_hook)
         return self.nce_out
+
+    def nan_flag(self):
+        """One-element view of the sticky NaN flag (nce_out[6]): FusedAdam.skip_flag; zero it when a run starts."""
+        return self.nce_out[6:7]
 
 
 class GRUContext:
@@ -1138,7 +1147,7 @@ class GlobalNegatives:
         self.S = torch.zeros(K * GB * self.ld, device=dev, dtype=f32)
         self.dS = torch.zeros(K * GB * self.ld, device=dev, dtype=dt)
         self.dST = torch.zeros(K * GB * self.ld, device=dev, dtype=dt)
-        self.out = torch.zeros(8, device=dev, dtype=f32)
+        self.out = eng.nce_out          # loss values and NaN flags go straight to the engine's result cell
         self.ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(GB, K)), device=dev, dtype=f32)
 
     def _all_timesteps(self, softplus: bool, regularization: float):
@@ -1182,7 +1191,6 @@ class GlobalNegatives:
             lo = self.rank * n
             e.dpred.copy_(self.dpred_all[lo:lo + n])
             dtop[:, T - K:T, :].copy_(self.dtarg_all[lo:lo + n].view(B, K, E))
-            e.nce_out.copy_(self.out)
             return
         _hip.gemm_nt(P(self.pred_all), P(self.targ_all), P(self.S), GB, GB, E, K * E, K * E, ld, code, a_batch=E, b_batch=E,
                      c_batch=GB * ld, batch=K, flags=_hip.GEMM_OUT_F32)
@@ -1195,7 +1203,6 @@ class GlobalNegatives:
         lo = self.rank * n
         e.dpred.copy_(self.dpred_all[lo:lo + n])
         dtop[:, T - K:T, :].copy_(self.dtarg_all[lo:lo + n].view(B, K, E))
-        e.nce_out.copy_(self.out)
 
 
 class GradAllReduce:
@@ -1219,8 +1226,19 @@ class GradAllReduce:
         self.optimizer = optimizer
         self.grad_scale = (1.0 / self.world) if grad_scale is None else float(grad_scale)
 
+    def reduce_flag(self, nce_out):
+        """Pass as ``after_loss``: the sticky NaN flag (nce_out[6]) becomes the MAXIMUM over the ranks (and the step's indicator
+        nce_out[5] with it), asynchronously, before any Adam piece of this step reads it — so that with per-GPU negatives, where
+        every rank has its own loss, all ranks skip the same update and all of them leave train() at the same step."""
+        if self.world > 1:
+            self.flag_work = self.dist.all_reduce(nce_out[5:7], op=self.dist.ReduceOp.MAX, async_op=True)
+
     def _apply_finished(self):
         """Adam on every piece whose all-reduce has been issued: the current stream waits for the reduction first."""
+        work = getattr(self, "flag_work", None)
+        if work is not None:
+            work.wait()
+            self.flag_work = None
         for work, lo, hi in self.pending:
             work.wait()
             if self.optimizer is not None:
@@ -1260,6 +1278,9 @@ class FusedAdam:
         # after_update(lo, hi, final): called right after flat_param[lo:hi) was updated; set it to the engine's prepare_ahead in
         # single-process training so that the operand copies of the next step are rebuilt off the critical path
         self.after_update = None
+        # skip_flag: one-element device tensor (CPCEngine.nan_flag()); while it is non-zero every update is a no-op on the device
+        # — the reference's NaN guard returns before backward() / optimizer.step() (contrastive_estimation_training.py:124-133)
+        self.skip_flag = None
         # device_step: the step count lives on the device (cpc_adam_dev), so the call's arguments never change and the step
         # can be part of a captured hipGraph
         self.state = torch.zeros(4, device=flat.device, dtype=torch.float32) if device_step else None
@@ -1292,7 +1313,7 @@ class FusedAdam:
         self.model._raw_updates = getattr(self.model, "_raw_updates", 0) + 1
         _hip.call("cpc_adam", _hip.ptr(flat, lo), _hip.ptr(grad, lo), _hip.ptr(self.m, lo), _hip.ptr(self.v, lo), C.c_longlong(hi - lo),
                   C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), t,
-                  C.c_float(grad_scale))
+                  C.c_float(grad_scale), _hip.ptr(self.skip_flag))
 
     def step(self, grad_scale: float = 1.0):
         self.t += 1
@@ -1309,11 +1330,11 @@ class FusedAdam:
         if self.state is not None:
             _hip.call("cpc_adam_dev", _hip.ptr(flat), _hip.ptr(grad), _hip.ptr(self.m), _hip.ptr(self.v), C.c_longlong(flat.numel()),
                       C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                      _hip.ptr(self.state), C.c_float(grad_scale))
+                      _hip.ptr(self.state), C.c_float(grad_scale), _hip.ptr(self.skip_flag))
             return
         _hip.call("cpc_adam", _hip.ptr(flat), _hip.ptr(grad), _hip.ptr(self.m), _hip.ptr(self.v), C.c_longlong(flat.numel()),
                   C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.t,
-                  C.c_float(grad_scale))
+                  C.c_float(grad_scale), _hip.ptr(self.skip_flag))
 
 
 class GraphedStep:
@@ -1340,6 +1361,7 @@ class GraphedStep:
         # itself closes the launch gaps the side stream hides in the eager step
         eng.use_aux = False
         eng._ahead_token = None            # the captured step always rebuilds its operand copies
+        opt.skip_flag = eng.nan_flag()     # NaN guard: part of the captured update
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = eng.loss_and_grads(self.x, **args)

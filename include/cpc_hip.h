@@ -308,7 +308,10 @@ int cpc_debug_set(int key, int value);
  * (contrastive_estimation_training.py:116-122, :141) on the equal-step scores S[k][b][b'] (f32, rows of ld >= B
  * floats; dS / dST use the same ld and get zeros in the pad columns), with the score
  * function folded in (softplus != 0: softplus_score_function :12-16, else linear_score_function :19-22).
- *   out[0] = loss (incl. regulariser), out[1] = max score (logger value, :166), out[2..4] = -mean valid, mean lse, reg
+ *   out f32[8]: out[0] = loss (incl. regulariser), out[1] = max score (logger value, :166), out[2..4] = -mean valid, mean lse,
+ *   reg; out[5] = 1 if the loss before the regulariser (out[2] + out[3]) is NaN — the value the reference's NaN guard tests
+ *   (:124) — else 0; out[6] = sticky NaN flag: set to 1 together with out[5], never cleared by the library (the caller zeroes it
+ *   when a run starts; cpc_adam's `skip` argument).  cpc_nce_loss_all writes the same eight values.
  *   dS[k][b][b'], dST[k][b'][b] (T): d loss / d linear score.  workspace: cpc_nce_workspace_floats(B,K) f32. */
 long long cpc_nce_workspace_floats(int B, int K);
 int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus,
@@ -322,14 +325,18 @@ int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float
                      int softplus, float regularization, int dtype, void* stream);
 
 /* torch.optim.Adam.step with default betas/eps semantics over one flat f32 buffer
- * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first. */
+ * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first.
+ * skip (device pointer to one float, or NULL): the reference's NaN guard returns BEFORE backward() / optimizer.step()
+ * (contrastive_estimation_training.py:124-133), so a NaN loss leaves the parameters at their last good values.  Here the update
+ * is issued without waiting for the host to read the loss: while *skip != 0 — pass out + 6 of cpc_nce_loss / cpc_nce_loss_all,
+ * the sticky NaN flag — the call changes nothing (p, m, v and the device-side step count keep their values). */
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-             int step, float grad_scale, void* stream);
+             int step, float grad_scale, const float* skip, void* stream);
 /* The same update with the step count kept on the device: state f32[4] = {step count (int bits), lr/(1-b1^t), 1/sqrt(1-b2^t), -},
  * zero-initialised by the caller; every call advances the count first.  Nothing in the argument list changes from step to
  * step, so a train step captured in a hipGraph can be replayed. */
 int cpc_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
-                 float grad_scale, void* stream);
+                 float grad_scale, const float* skip, void* stream);
 
 #ifdef __cplusplus
 }

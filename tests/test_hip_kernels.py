@@ -574,8 +574,21 @@ def test_adam_matches_torch():
         opt.step()
         dg = dev(grad * 2.0)
         _hip.call("cpc_adam", _hip.ptr(p), _hip.ptr(dg), _hip.ptr(m), _hip.ptr(v), C.c_longlong(n), C.c_float(1e-3),
-                  C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), step, C.c_float(0.5))
+                  C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), step, C.c_float(0.5), None)
         assert (p.cpu() - ref_p.detach()).abs().max().item() < 2e-6
+    # skip flag (the NaN guard): raised -> parameters and both moments keep their bits; lowered -> the update happens
+    flag = torch.ones(1, device=DEV)
+    before = [t.clone() for t in (p, m, v)]
+    state = torch.zeros(4, device=DEV)
+    for name, extra in (("cpc_adam", (4, C.c_float(1.0))), ("cpc_adam_dev", (_hip.ptr(state), C.c_float(1.0)))):
+        _hip.call(name, _hip.ptr(p), _hip.ptr(dg), _hip.ptr(m), _hip.ptr(v), C.c_longlong(n), C.c_float(1e-3),
+                  C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), *extra, _hip.ptr(flag))
+        assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v))), name
+    assert torch.equal(state, torch.zeros(4, device=DEV))          # the device-side step count did not advance either
+    flag.zero_()
+    _hip.call("cpc_adam", _hip.ptr(p), _hip.ptr(dg), _hip.ptr(m), _hip.ptr(v), C.c_longlong(n), C.c_float(1e-3),
+              C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), 4, C.c_float(1.0), _hip.ptr(flag))
+    assert not torch.equal(before[0], p)
 
 
 def test_unsupported_shapes_fail_loudly():

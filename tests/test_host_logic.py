@@ -199,49 +199,65 @@ rank, world = dist.get_rank(), dist.get_world_size()
 class Model:
     pass
 
+import time
+total = float(sum(range(1, world + 1)))           # rank r holds r + 1 everywhere
 class Opt:
-    """Stands in for FusedAdam: records the pieces and checks that a piece is REDUCED when its update is issued."""
-    def __init__(self, model):
-        self.model, self.calls = model, []
+    """Stands in for FusedAdam: records the pieces and checks that a piece is REDUCED when its update is issued, and that the
+    NaN flag has been reduced over the ranks before the first update of the step reads it."""
+    def __init__(self, model, flag=None, want_flag=None):
+        self.model, self.calls, self.flag, self.want_flag = model, [], flag, want_flag
     def update_range(self, lo, hi, scale):
         g = self.model._flat_grad[lo:hi]
-        assert torch.equal(g, torch.full_like(g, 3.0)), (lo, hi, g)       # ranks hold 1 and 2
+        assert torch.equal(g, torch.full_like(g, total)), (lo, hi, g)
+        if self.flag is not None:
+            assert self.flag[5:7].tolist() == self.want_flag, self.flag
         self.calls.append((lo, hi, scale))
 
 m = Model()
-for step in range(2):
+for step in range(3):
     m._flat_grad = torch.full((100,), float(rank + 1))
-    opt = Opt(m)
+    # step 1: only the LAST rank sees a NaN loss (per-GPU negatives: every rank has its own loss) -> every rank must see the flag
+    nce_out = torch.zeros(8)
+    if step == 1 and rank == world - 1:
+        nce_out[5:7] = 1.0
+    opt = Opt(m, nce_out, [1.0, 1.0] if step == 1 else [0.0, 0.0])
     sync = GradAllReduce(m, optimizer=opt)
-    assert sync.world == 2 and sync.grad_scale == 0.5
+    assert sync.world == world and sync.grad_scale == 1.0 / world
+    sync.reduce_flag(nce_out)
+    time.sleep(0.05 * ((rank * 7 + step * 3) % world))      # ranks reach their hooks at different times
     sync.hook(60, 100)
     assert opt.calls == []                       # nothing is applied before a later hook / finish
+    time.sleep(0.03 * ((rank * 5 + step) % world))
     sync.hook(20, 60)
-    assert opt.calls == [(60, 100, 0.5)]
+    assert opt.calls == [(60, 100, 1.0 / world)]
+    time.sleep(0.02 * ((world - rank + step) % world))
     sync.finish()
-    assert opt.calls == [(60, 100, 0.5), (20, 60, 0.5)]
-    assert torch.equal(m._flat_grad, torch.full((100,), 3.0))          # head [0, 20) reduced by finish(); step() updates it
+    assert opt.calls == [(60, 100, 1.0 / world), (20, 60, 1.0 / world)]
+    assert torch.equal(m._flat_grad, torch.full((100,), total))        # head [0, 20) reduced by finish(); step() updates it
     assert sync.pending == [] and sync.split is None
+    assert nce_out[5:7].tolist() == ([1.0, 1.0] if step == 1 else [0.0, 0.0])
 # without an optimizer: plain overlapped reduction
 m._flat_grad = torch.full((100,), float(rank + 1))
 sync = GradAllReduce(m)
 sync.hook(50, 100)
 sync.finish()
-assert torch.equal(m._flat_grad, torch.full((100,), 3.0))
+assert torch.equal(m._flat_grad, torch.full((100,), total))
 if rank == 0:
     print("PIECES-OK")
 dist.destroy_process_group()
 '''
 
 
-def test_gradient_pieces_are_updated_only_after_their_reduction_gloo_world2(tmp_path):
-    """engine.GradAllReduce with an optimizer attached (the data-parallel train step): Adam on a piece of the flat gradient is
-    issued at the NEXT hook call / in finish(), after that piece's all-reduce, never before."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_pieces_are_updated_only_after_their_reduction_gloo(tmp_path, world):
+    """engine.GradAllReduce with an optimizer attached (the data-parallel train step), 2 and 4 ranks that reach their hooks at
+    different times: Adam on a piece of the flat gradient is issued at the NEXT hook call / in finish(), after that piece's
+    all-reduce, never before; the NaN flag of ONE rank (per-GPU negatives) reaches every rank before any update reads it."""
     script = tmp_path / "worker_pieces.py"
     script.write_text(WORKER_PIECES)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29641 + world), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
     procs = []
-    for r in range(2):
+    for r in range(world):
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]

@@ -136,6 +136,56 @@ def test_small_model_train_matches_reference(golden_dir, dtype):
                 assert tight.float().mean().item() > 0.97, (run["tag"], name, tight.float().mean().item())
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("bad_step", [0, 2])
+def test_nan_guard_keeps_the_last_good_parameters(golden_dir, dtype, bad_step):
+    """Reference :124-133: a NaN loss makes train() return BEFORE backward() / optimizer.step(), so the model keeps the
+    parameters of the last good step.  Here the updates are issued without waiting for the host: an inf in one clip of batch
+    `bad_step` must leave train() returning None with training_step == bad_step, exactly `bad_step` steps logged, and the
+    parameters bit for bit those of a clean run of `bad_step` steps (for bad_step 0: the initial ones) — although the
+    host learns of the NaN one step late and has launched another step by then."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"]).clone()
+    for run in [r for r in meta["runs"] if r["steps"] > 1]:          # both loss branches (run4: all timesteps, run6: default)
+        _nan_guard_case(g, meta, data, run, dtype, bad_step)
+
+
+def _nan_guard_case(g, meta, data, run, dtype, bad_step):
+    from cpc_audio_amd.audio_dataset import FileBatchSampler
+    random.seed(run["python_seed"])
+    batches = [list(b) for b in FileBatchSampler([data.shape[0]], meta["B"], 1, True, verbose=False)]
+    assert len(batches) > bad_step + 1
+    victim = batches[bad_step][1]
+    assert all(victim not in b for b in batches[:bad_step])
+
+    def go(clips, steps):
+        model = _small_model(g, meta, dtype)
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(clips, device=DEV), logger=logger, device=DEV,
+                                          regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
+                                          score_function=SCORE[run["score"]], prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        ret = tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=steps)
+        torch.cuda.synchronize()
+        return ret, tr, logger, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    if bad_step == 0:
+        good = {k: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+        good = {k[len("param/"):]: v for k, v in good.items()}
+    else:
+        _, tr0, _, good = go(data, bad_step)
+        assert tr0.training_step == bad_step
+    poisoned = data.clone()
+    poisoned[victim, poisoned.shape[1] // 2] = float("inf")
+    ret, tr, logger, after = go(poisoned, bad_step + 3)
+    assert ret is None and tr.training_step == bad_step
+    assert len(logger.loss_meter.values) == bad_step and logger.steps == list(range(bad_step))
+    for k, v in good.items():
+        assert torch.equal(after[k], v), k
+
+
 def test_validate_matches_reference(golden_dir):
     g = _load(golden_dir, "validate.npz")
     meta = json.load(open(os.path.join(golden_dir, "validate.json")))
