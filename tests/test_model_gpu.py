@@ -3,6 +3,7 @@
 configuration) is held to 1e-3 relative on the loss, as BASELINE.json's north star states, and to bf16-rounding-sized
 bounds on tensors."""
 import json
+import math
 import os
 import random
 
@@ -186,6 +187,69 @@ def _nan_guard_case(g, meta, data, run, dtype, bad_step):
         assert torch.equal(after[k], v), k
 
 
+def test_calc_test_task_data_matches_oracle_context_vectors(golden_dir):
+    """ContrastiveEstimationTrainer.calc_test_task_data (reference :271-303): the context vector c of every item of a labelled
+    set through the HIP forward (eval mode), in dataset order with its labels, incl. a ragged last batch — against the
+    oracle's c = autoregressive_model(z) for the same clips."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"])[:10]
+    labels = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3]
+
+    class Labelled(torch.utils.data.Dataset):
+        def __len__(self):
+            return data.shape[0]
+
+        def __getitem__(self, i):
+            return data[i], labels[i]
+
+    params = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    with torch.no_grad():
+        c_ref = O.cpc_forward(data.unsqueeze(1), params, meta["V"], meta["K"])[3]
+    for dtype, tol in (("fp32", 2e-4), ("bf16", 2.5e-2)):
+        model = _small_model(g, meta, dtype)
+        tr = ContrastiveEstimationTrainer(model=model, dataset=None, test_task_set=Labelled(), device=DEV,
+                                          prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        task_data, task_labels = tr.calc_test_task_data(batch_size=4, num_workers=0)
+        assert task_data.shape == (10, meta["H"]) and task_labels.tolist() == labels
+        assert _rel(task_data, c_ref) < tol, dtype
+        assert model.training                                   # the reference switches back to train mode (:302)
+
+
+def test_reference_snapshot_runs_on_the_gpu(golden_dir):
+    """A whole-module pickle as the reference's SnapshotManager writes it (setup_functions.py:134-164), read without the
+    reference's code, loaded into a model that already lives on the GPU (and into one moved there afterwards): the HIP forward
+    on the restored parameters equals the oracle's on the snapshot's tensors."""
+    from cpc_audio_amd.checkpoint import load_reference_snapshot
+    path = os.path.join(golden_dir, "reference_snapshot_small.pt")
+    meta = json.load(open(os.path.join(golden_dir, "reference_snapshot_small.json")))
+    ref = np.load(os.path.join(golden_dir, "reference_snapshot_small.npz"))
+    params = {k: torch.from_numpy(ref[k]) for k in ref.files}
+    c, H, K, V = meta["channels"], meta["ar_size"], meta["K"], meta["V"]
+    L = 465 + (V + K) * 160
+    x = torch.randn(5, L, generator=torch.Generator().manual_seed(4)) * 0.5
+    with torch.no_grad():
+        want = O.cpc_forward(x.unsqueeze(1), params, V, K)
+    for order in ("gpu_then_load", "load_then_gpu"):
+        enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [c] * 5, 'bias': True})
+        model = AudioPredictiveCodingModel(enc, AudioGRUModel(c, H), enc_size=c, ar_size=H, visible_steps=V, prediction_steps=K,
+                                           compute_dtype="fp32")
+        if order == "gpu_then_load":
+            model = model.to(DEV)
+            model(x.to(DEV).unsqueeze(1))                       # engine + flat parameter buffer exist before the load
+            load_reference_snapshot(model, path)
+        else:
+            load_reference_snapshot(model, path)
+            model = model.to(DEV)
+        for k, v in model.state_dict().items():
+            assert v.is_cuda and torch.equal(v.cpu(), params[k]), (order, k)
+        with torch.no_grad():
+            got = model(x.to(DEV).unsqueeze(1))
+        for a, b, name in zip(got, want, ("predicted_z", "targets", "z", "c")):
+            assert _rel(a, b) < 2e-4, (order, name)
+
+
 def test_validate_matches_reference(golden_dir):
     g = _load(golden_dir, "validate.npz")
     meta = json.load(open(os.path.join(golden_dir, "validate.json")))
@@ -257,14 +321,22 @@ def test_generic_path_gradients_match_oracle():
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 1e-3)])
 def test_cfg1_trajectory_matches_reference(golden_dir, dtype, tol):
-    """BASELINE config 1 (B=8, L=20480, 512 channels, GRU 256, K=12): 5-step loss trajectory recorded from the reference."""
+    """BASELINE config 1 (B=8, L=20480, 512 channels, GRU 256, K=12): 5-step loss trajectories recorded from the reference —
+    softplus scores, linear scores (degenerate: ln 8 throughout), and linear scores on doubled encoder weights (2.35 -> 2.22)."""
     meta = json.load(open(os.path.join(golden_dir, "cfg1_trajectory.json")))
+    assert any(r.get("encoder_weight_scale", 1.0) != 1.0 and abs(r["loss"][0] - r["loss"][4]) > 0.05 for r in meta["runs"])
     for run in meta["runs"]:
         torch.manual_seed(meta["model_seed"])
         enc = AudioEncoder()
         ar = AudioGRUModel(input_size=512, hidden_size=256)
         model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=meta["V"],
-                                           prediction_steps=meta["K"], compute_dtype=dtype).to(DEV)
+                                           prediction_steps=meta["K"], compute_dtype=dtype)
+        if run.get("encoder_weight_scale", 1.0) != 1.0:       # the non-degenerate linear-score run (the plain one sits at ln 8)
+            with torch.no_grad():
+                for n_, p_ in model.named_parameters():
+                    if n_.startswith("encoder.") and n_.endswith("weight"):
+                        p_.mul_(run["encoder_weight_scale"])
+        model = model.to(DEV)
         ds = SyntheticAudioDataset(meta["n_items"], meta["L"], seed=meta["data_seed"], device=DEV)
         logger = Logger()
         tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=run["reg"],
@@ -278,11 +350,14 @@ def test_cfg1_trajectory_matches_reference(golden_dir, dtype, tol):
 
 
 def test_full_size_properties_b256():
-    """BASELINE config 2 size (B=256, L=20480): properties that need no oracle run — bf16 vs exact-f32 loss within
-    1e-3 relative, invariance of the loss under a permutation of the batch, and finite gradients everywhere."""
+    """BASELINE config 2 size (B=256, L=20480): the exact-f32 HIP loss against the CPU oracle's forward pass on the same
+    256 clips (1e-4 relative) and the bf16 loss against that same oracle number (the north star's 1e-3); invariance of the
+    loss under a permutation of the batch; finite gradients everywhere; bf16 gradients aligned with the f32 ones."""
     B, L = 256, 20480
-    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    x_cpu = torch.randn(B, L, generator=torch.Generator().manual_seed(1)) * 0.5
+    x = x_cpu.to(DEV)
     losses, grads = {}, {}
+    oracle_loss = None
     for dtype in ("fp32", "bf16"):
         torch.manual_seed(0)
         model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256,
@@ -291,6 +366,13 @@ def test_full_size_properties_b256():
             for n, p in model.named_parameters():
                 if "encoder" in n and n.endswith("weight"):
                     p.mul_(2.0)                               # make the scores non-degenerate
+        if oracle_loss is None:
+            # contrastive_estimation_training.py:104-122,141 on the CPU (oracle/cpc_oracle.py), forward only: ~1.6 TFLOP
+            params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                pz, tg, _, _ = O.cpc_forward(x_cpu.unsqueeze(1), params, 100, 12)
+                oracle_loss = float(O.info_nce_loss(O.softplus_scores(pz, tg), False, 1.0)[0])
+            del pz, tg, params
         model.to(DEV)
         eng = model.engine(B, L)
         out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
@@ -304,7 +386,9 @@ def test_full_size_properties_b256():
             assert abs(float(out2[0]) - losses["fp32"]) < 2e-5 * abs(losses["fp32"])
         del eng, model
         torch.cuda.empty_cache()
-    assert abs(losses["bf16"] - losses["fp32"]) < 1e-3 * abs(losses["fp32"]), losses
+    assert abs(oracle_loss - math.log(B)) > 0.05, oracle_loss       # not the degenerate uniform-score value ln 256
+    assert abs(losses["fp32"] - oracle_loss) < 1e-4 * abs(oracle_loss), (losses, oracle_loss)
+    assert abs(losses["bf16"] - oracle_loss) < 1e-3 * abs(oracle_loss), (losses, oracle_loss)
     # bf16 gradients point the same way as the exact-f32 ones, parameter by parameter
     for n, g32 in grads["fp32"].items():
         cos = torch.dot(g32, grads["bf16"][n]) / (g32.norm() * grads["bf16"][n].norm() + 1e-30)
