@@ -1,8 +1,8 @@
 """Host-side mirror of the reference's attention context network (reference attention_model.py:9-82 and the vendored
 transformer.py:131-171, :223-272): the same constructor arguments, attribute names and ``state_dict`` keys, so checkpoints
-move in both directions.  The modules here only HOLD parameters (standard torch containers, default initialisers, the
+move in both directions.  The transformer containers here only HOLD parameters (standard torch containers, default initialisers, the
 reference's construction order); the arithmetic runs in the HIP kernels behind ``engine.AttentionContext`` when the model is
-used as ``AudioPredictiveCodingModel.autoregressive_model``.
+used as ``AudioPredictiveCodingModel.autoregressive_model`` (or called stand-alone as ``AttentionModel(z)``, inference only).
 """
 import copy
 import math
@@ -26,7 +26,18 @@ class PositionalEncoder(nn.Module):
         self.register_buffer('pe', table.unsqueeze(1))
 
     def forward(self, x):
-        raise NotImplementedError("PositionalEncoder runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        """x (steps, batch, code_size) on the GPU -> x * sqrt(code_size) + pe[:steps] (reference attention_model.py:28-35) through
+        cpc_pe_scale_fwd.  Inference only when called stand-alone (inside AudioPredictiveCodingModel the same kernel runs as part
+        of engine.AttentionContext, where its gradient exists); unlike the reference the caller's tensor is not rescaled in place."""
+        from . import _hip
+        if not x.is_cuda:
+            raise RuntimeError("PositionalEncoder runs on the GPU only (no CPU fallback)")
+        S, B, C = x.shape
+        xb = x.detach().permute(1, 0, 2).contiguous().float()
+        pe = self.pe[:S, 0, :].detach().to(device=x.device, dtype=torch.float32).contiguous()
+        out = torch.empty(B, S, C, device=x.device, dtype=torch.float32)
+        _hip.call("cpc_pe_scale_fwd", _hip.ptr(xb), _hip.ptr(pe), _hip.ptr(out), B, S, C, S * C, math.sqrt(self.code_size), _hip.F32)
+        return out.permute(1, 0, 2).to(x.dtype)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -45,7 +56,9 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
 
     def forward(self, *args, **kwargs):
-        raise NotImplementedError("TransformerEncoderLayer runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        raise NotImplementedError("a stand-alone TransformerEncoderLayer call is not part of the HIP path: the layer runs inside "
+                                  "AttentionModel (engine.AttentionContext); call AttentionModel(z) or the whole model "
+                                  "(INTEGRATION.md, 'Deviations from the reference surface')")
 
 
 class TransformerEncoder(nn.Module):
@@ -59,7 +72,9 @@ class TransformerEncoder(nn.Module):
         self.norm = norm
 
     def forward(self, *args, **kwargs):
-        raise NotImplementedError("TransformerEncoder runs fused inside AudioPredictiveCodingModel.forward on the HIP path")
+        raise NotImplementedError("a stand-alone TransformerEncoder call is not part of the HIP path: it runs inside AttentionModel "
+                                  "(engine.AttentionContext); call AttentionModel(z) or the whole model "
+                                  "(INTEGRATION.md, 'Deviations from the reference surface')")
 
 
 class AttentionModel(nn.Module):

@@ -1,8 +1,7 @@
 """Drop-in model surface: AudioEncoder, AudioGRUModel, AudioPredictiveCodingModel (+ activation taps).
 
 Same constructor arguments, attributes, state_dict keys and forward return values as the reference's
-``audio_model.py`` (AudioEncoder :14-44, AudioGRUModel :47-77, AudioPredictiveCodingModel :164-219, ActivationRegister /
-ActivationWriter :222-284), but ``forward`` runs the hand-written HIP path (``engine.CPCEngine``) instead of ATen
+``audio_model.py`` (AudioEncoder :14-44, AudioGRUModel :47-77, AudioPredictiveCodingModel :164-219, ActivationWriter :274-284), but ``forward`` runs the hand-written HIP path (``engine.CPCEngine``) instead of ATen
 convolutions / GRUCell loops.  Parameters stay ``nn.Parameter``s in the reference's shapes (so checkpoints and
 ``model.parameters()``-built optimizers keep working); on the device they are views into one flat f32 buffer.
 
@@ -363,51 +362,17 @@ def _standalone_owner(encoder):
     return owner
 
 
-class ActivationRegister:
-    """Collects tapped activations by name (reference audio_model.py:222-271)."""
-
-    def __init__(self, writing_condition=None, clone_activations=False, batch_filter=None, move_to_cpu=False, devices=None):
-        self.devices = devices
-        if devices is not None:
-            self.activations = {dev: OrderedDict() for dev in devices}
-        else:
-            self.activations = OrderedDict()
-        self.active = True
-        self.writing_condition = writing_condition
-        self.clone_activations = clone_activations
-        self.batch_filter = batch_filter
-        self.move_to_cpu = move_to_cpu
-
-    def write_activation(self, name, value):
-        if not self.active:
-            return
-        if self.writing_condition is not None and not self.writing_condition(value):
-            return
-        if self.batch_filter is not None:
-            value = value[self.batch_filter]
-        dev = value.device.index if self.devices is not None else None
-        if self.move_to_cpu:
-            value = value.cpu()
-        if self.clone_activations:
-            value = value.clone()
-        if self.devices is not None:
-            self.activations[dev][name] = value
-        else:
-            self.activations[name] = value
-
-    def get_activations(self):
-        if self.devices is None:
-            return self.activations
-        first = self.devices[0]
-        return {key: torch.cat([self.activations[dev][key].to(f"cuda:{first}") for dev in self.devices], dim=0)
-                for key in self.activations[first].keys()}
-
-
 class ActivationWriter(nn.Module):
+    """Pass-through tap (reference audio_model.py:274-284).  The hot path never registers anything: ``register`` is None in
+    every training configuration, and the module is kept only because it sits in the reference's module tree (ModuleList
+    indices, and with them the state_dict keys, count it).  A caller-supplied register object is served through the one
+    method the reference's writer uses, ``write_activation(name, value)``; the registers themselves (``ActivationRegister``:
+    per-device dictionaries for the dreaming / activation-statistics tools) are outside this path (SURVEY.md section 2, rows
+    12-13) and are not provided."""
+
     def __init__(self, register, name):
         super().__init__()
-        self.register = register
-        self.name = name
+        self.register, self.name = register, name
 
     def forward(self, x):
         if self.register is not None:
@@ -415,16 +380,5 @@ class ActivationWriter(nn.Module):
         return x
 
 
-def load_to_cpu(path):
-    model = torch.load(path, map_location=lambda storage, loc: storage)
-    model.cpu()
-    return model
-
-
 def num_parameters(model):
     return sum(int(np.prod(p.shape)) for p in model.parameters())
-
-
-def cuda0_writing_condition(x):
-    """Write only if x is on the CPU or the first GPU."""
-    return x.device.index == 0 if x.device.type == 'cuda' else True

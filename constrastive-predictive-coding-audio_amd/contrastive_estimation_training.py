@@ -7,9 +7,9 @@ DeterministicSampler :363-382, grad_mean_var :385-391).  ``train`` has two route
   setting), Adam.  Forward, InfoNCE loss, analytic backward and the Adam update all run as
   HIP kernels (engine.CPCEngine); with torch.distributed initialised, one process per GPU, the flat gradient buffer is
   all-reduced over RCCL before the update (per-GPU in-batch negatives).
-* generic: any other score function or optimizer: the model forward and backward still run on
-  the HIP path (through the autograd bridge); the loss itself is assembled with torch ops on the GPU exactly as the
-  reference does (:106-122, :141).
+* generic: any other score function or optimizer: the model forward and backward run on the HIP path through the autograd
+  bridge, the score function is the caller's, and the loss (:106-122, :141) and its gradient come from the same loss kernels
+  (``_InfoNCE``).  ``validate`` takes its per-step losses / accuracies from ``cpc_nce_eval`` on both routes.
 """
 from __future__ import annotations
 
@@ -25,14 +25,54 @@ from .audio_model import *          # noqa: F401,F403  (the reference re-exports
 from .audio_dataset import FileBatchSampler
 
 
-def softplus_score_function(predicted_z, targets):
-    """scores[b, k, b', k'] = softplus(sum_e predicted_z[b,k,e] * targets[b',e,k'])  (reference :12-16)."""
-    return F.softplus(torch.tensordot(predicted_z, targets, dims=([2], [1])))
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} runs on the GPU only (libcpc_hip.so; there is no CPU fallback): move the tensors to the device")
+
+
+class _ScoreContraction(torch.autograd.Function):
+    """scores[b, k, b', k'] = sum_e predicted_z[b, k, e] * targets[b', e, k'] as ONE cpc_gemm_nt call (f32, exact-f32 MFMA) over
+    the (B K) x E operands; the gradients are the two matching contractions (cpc_gemm_nt / cpc_gemm_tn)."""
+
+    @staticmethod
+    def forward(ctx, predicted_z, targets):
+        from . import _hip
+        _need_gpu(predicted_z, "the score contraction")
+        B, K, E = predicted_z.shape
+        if tuple(targets.shape) != (B, E, K) or E % 4 or (B * K) % 4:
+            raise ValueError("score contraction: expected predicted_z (B, K, E) and targets (B, E, K) with E and B*K multiples of 4")
+        R = B * K
+        A = predicted_z.detach().reshape(R, E).float().contiguous()
+        Tt = targets.detach().permute(0, 2, 1).reshape(R, E).float().contiguous()
+        S = torch.empty(R, R, device=A.device, dtype=torch.float32)
+        _hip.gemm_nt(_hip.ptr(A), _hip.ptr(Tt), _hip.ptr(S), R, R, E, E, E, R, _hip.F32)
+        ctx.save_for_backward(A, Tt)
+        ctx.shape = (B, K, E)
+        return S.view(B, K, B, K)
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        from . import _hip
+        A, Tt = ctx.saved_tensors
+        B, K, E = ctx.shape
+        R = B * K
+        dS = d_scores.reshape(R, R).float().contiguous()
+        dA = torch.empty(R, E, device=dS.device, dtype=torch.float32)
+        dT = torch.empty(R, E, device=dS.device, dtype=torch.float32)
+        TtT = Tt.t().contiguous()                                                        # [E][R]
+        _hip.gemm_nt(_hip.ptr(dS), _hip.ptr(TtT), _hip.ptr(dA), R, E, R, R, R, E, _hip.F32)          # dA = dS Tt
+        _hip.gemm_tn(_hip.ptr(dS), _hip.ptr(A), _hip.ptr(dT), R, R, E, R, E, E, _hip.F32, flags=_hip.GEMM_OUT_F32)   # dT = dS^T A
+        return dA.view(B, K, E), dT.view(B, K, E).permute(0, 2, 1)
 
 
 def linear_score_function(predicted_z, targets):
     """scores[b, k, b', k'] = sum_e predicted_z[b,k,e] * targets[b',e,k']  (reference :19-22)."""
-    return torch.tensordot(predicted_z, targets, dims=([2], [1]))
+    return _ScoreContraction.apply(predicted_z, targets)
+
+
+def softplus_score_function(predicted_z, targets):
+    """softplus of the linear scores (reference :12-16)."""
+    return F.softplus(_ScoreContraction.apply(predicted_z, targets))
 
 
 def difference_score_function(predicted_z, targets):
@@ -41,17 +81,57 @@ def difference_score_function(predicted_z, targets):
     return 1 / torch.sum(diff ** 2, dim=2)
 
 
-def _loss_terms(scores, batch_size, prediction_steps, all_timesteps):
-    """(scores, noise_scoring, valid_scores) exactly as the reference forms them (:108-119), including the raw
-    ``view(-1, batch, steps)`` reinterpretation in the default branch."""
+def _score_layout(scores4, all_timesteps):
+    """The 4-D score tensor of ANY score function in the layout the loss kernels read: the (B K) x (B K) matrix, or in the default
+    branch its K equal-step blocks S[k][b][b'] = scores[b, k, b', k] with rows padded to a multiple of 8 floats."""
+    B, K = scores4.shape[0], scores4.shape[1]
     if all_timesteps:
-        noise = torch.logsumexp(scores.view(-1, batch_size, prediction_steps), dim=0)
-        valid = torch.diagonal(torch.diagonal(scores, dim1=0, dim2=2), dim1=0, dim2=1)
-        return scores, noise, valid
-    s = torch.diagonal(scores, dim1=1, dim2=3).permute([0, 2, 1]).contiguous()
-    noise = torch.logsumexp(s.view(-1, batch_size, prediction_steps), dim=0)
-    valid = torch.diagonal(s, dim1=0, dim2=2).permute([1, 0])
-    return s, noise, valid
+        return scores4.reshape(B * K, B * K).float().contiguous(), B * K
+    ld = -(-B // 8) * 8
+    S = torch.zeros(K, B, ld, device=scores4.device, dtype=torch.float32)
+    S[:, :, :B] = torch.diagonal(scores4, dim1=1, dim2=3).permute(2, 0, 1)
+    return S, ld
+
+
+class _InfoNCE(torch.autograd.Function):
+    """Loss of the train step (reference :108-122, :141) from a 4-D score tensor, through the same kernels as the fused route
+    (cpc_nce_loss / cpc_nce_loss_all with the score function already applied): returns (loss incl. regulariser, max score,
+    NaN indicator of the loss before the regulariser); the backward hands d loss / d scores back to autograd."""
+
+    @staticmethod
+    def forward(ctx, scores4, all_timesteps, regularization):
+        import ctypes as C
+        from . import _hip
+        _need_gpu(scores4, "the InfoNCE loss")
+        B, K = scores4.shape[0], scores4.shape[1]
+        S, ld = _score_layout(scores4.detach(), all_timesteps)
+        dev, f32 = S.device, torch.float32
+        out = torch.zeros(8, device=dev, dtype=f32)
+        dS, dST = torch.zeros_like(S), torch.zeros_like(S)
+        if all_timesteps:
+            ws = torch.empty(int(_hip.lib().cpc_nce_all_workspace_floats(B, K)), device=dev, dtype=f32)
+            ST = S.t().contiguous()
+            _hip.call("cpc_nce_loss_all", _hip.ptr(S), _hip.ptr(ST), _hip.ptr(dS), _hip.ptr(dST), _hip.ptr(out), _hip.ptr(ws), B, K, ld, 0,
+                      C.c_float(regularization), _hip.F32)
+        else:
+            ws = torch.empty(int(_hip.lib().cpc_nce_workspace_floats(B, K)), device=dev, dtype=f32)
+            _hip.call("cpc_nce_loss", _hip.ptr(S), _hip.ptr(dS), _hip.ptr(dST), _hip.ptr(out), _hip.ptr(ws), B, K, ld, 0,
+                      C.c_float(regularization), _hip.F32)
+        ctx.save_for_backward(dS)
+        ctx.meta = (B, K, bool(all_timesteps), scores4.dtype)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out):
+        (dS,) = ctx.saved_tensors
+        B, K, all_t, dtype = ctx.meta
+        if all_t:
+            d = dS.view(B, K, B, K) * d_loss
+        else:
+            d = torch.zeros(B, K, B, K, device=dS.device, dtype=torch.float32)
+            torch.diagonal(d, dim1=1, dim2=3).copy_(dS[:, :, :B].permute(1, 2, 0) * d_loss)
+        return d.to(dtype), None, None
 
 
 class ContrastiveEstimationTrainer:
@@ -328,73 +408,70 @@ class ContrastiveEstimationTrainer:
         return None
 
     def _generic_step(self, batch, batch_size, optimizer, world):
+        """Any score function / optimizer: model forward and backward through the autograd bridge (HIP), the score function as the
+        caller wrote it, the loss and its gradient through the loss kernels (_InfoNCE).  This route reads the loss every step, so
+        the NaN guard sits where the reference has it: in front of backward() and optimizer.step() (:124-133)."""
         predicted_z, targets, _, _ = self.model(self._model_input(batch))
         scores = self.score_function(predicted_z, targets)
-        scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, self.prediction_steps,
-                                                          self.score_over_all_timesteps)
-        prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=1)
-        loss = torch.mean(prediction_losses)
-        nan = torch.isnan(loss)
+        loss, out = _InfoNCE.apply(scores, bool(self.score_over_all_timesteps), float(self.regularization))
+        nan = out[5:6].clone()
         if world > 1:          # every rank has its own loss: all ranks leave at the same step
             import torch.distributed as dist
-            nan = nan.float()
             dist.all_reduce(nan, op=dist.ReduceOp.MAX)
-        if bool(nan.item()):   # reference :124-133: return before backward() / optimizer.step() (this route reads the loss every step)
-            z = torch.zeros_like(loss.detach())
-            return torch.stack([loss.detach(), torch.max(scores).detach(), z, z, z, z + 1])
-        loss = loss + self.regularization * torch.mean(torch.mean(scores, dim=1) ** 2)
+        vals = torch.cat([out[:5], nan])
+        if float(nan.item()) != 0.0:
+            return vals
         self.model.zero_grad()
         loss.backward()
         if world > 1:
-            import torch.distributed as dist
             for p in self.model.parameters():
                 dist.all_reduce(p.grad)
                 p.grad.div_(world)
         optimizer.step()
-        z = torch.zeros_like(loss.detach())
-        return torch.stack([loss.detach(), torch.max(scores).detach(), z, z, z, z])
+        return vals
 
     # ------------------------------------------------------------------------------------------ validate
     def validate(self, batch_size=64, num_workers=1, max_steps=None):
-        """Reference validate (:178-269): per-step loss (with the reference's dim=0 mean over the reinterpreted view),
-        argmax accuracy, mean score, mutual-information lower bound log(n) - loss."""
+        """Reference validate (:178-269): per-step loss, per-step arg-max accuracy, mean score and the mutual-information lower
+        bound log(n) - loss over the validation set (eval mode, FileBatchSampler(seed=0, file_batch_size=8)).  The per-batch
+        quantities come from cpc_nce_eval on the train step's own score matrices and are summed on the device; the host reads
+        2 K + 1 numbers once, after the last batch."""
+        import ctypes as C
+        from . import _hip
         if self.validation_set is None:
             print("No validation set")
             return 0, 0
         device = self._device()
+        K, all_t = self.prediction_steps, bool(self.score_over_all_timesteps)
+        counts = self.validation_set.get_example_count_per_file()
+        n_batches = sum(1 for _ in FileBatchSampler(counts, batch_size, 8, True, seed=0, verbose=False))
+        steps = n_batches if max_steps is None else min(max_steps, n_batches)
+        sampler = FileBatchSampler(index_count_per_file=counts, batch_size=batch_size, file_batch_size=8, drop_last=True, seed=0,
+                                   verbose=self.verbose)
+        sums = torch.zeros(2 * K + 1, device=device, dtype=torch.float32)
+        ws = torch.empty(int(_hip.lib().cpc_nce_eval_workspace_floats(batch_size, K)), device=device, dtype=torch.float32)
+        kernel_scores = self.score_function in (softplus_score_function, linear_score_function)
         self.model.eval()
-        sampler = FileBatchSampler(index_count_per_file=self.validation_set.get_example_count_per_file(),
-                                   batch_size=batch_size, file_batch_size=8, drop_last=True, seed=0, verbose=self.verbose)
-        K = self.prediction_steps
-        total_prediction_losses = torch.zeros(K, device=device)
-        total_accurate_predictions = torch.zeros(K, device=device)
-        n = batch_size * K if self.score_over_all_timesteps else batch_size
-        template = torch.arange(0, n, dtype=torch.long, device=device)
-        template = template.view(batch_size, K) if self.score_over_all_timesteps else template.unsqueeze(1).repeat(1, K)
-        total_score = 0
-        n_batches = len(list(iter(FileBatchSampler(self.validation_set.get_example_count_per_file(), batch_size, 8, True,
-                                                   seed=0, verbose=False))))
-        max_steps = n_batches if max_steps is None else min(max_steps, n_batches)
+        done = 0
         with torch.no_grad():
-            for step, batch in enumerate(self._batches(self.validation_set, sampler, device, num_workers, False, 0, 1)):
-                predicted_z, targets, _, _ = self.model(self._model_input(batch))
-                scores = self.score_function(predicted_z, targets)
-                scores, noise_scoring, valid_scores = _loss_terms(scores, batch_size, K, self.score_over_all_timesteps)
-                prediction_losses = -torch.mean(valid_scores - noise_scoring, dim=0)
-                max_score = torch.argmax(scores.view(batch_size, K, -1), dim=2)
-                correctly_predicted = torch.eq(template, max_score)
-                prediction_accuracy = torch.sum(correctly_predicted, dim=0).type_as(batch) / n
-                total_prediction_losses += prediction_losses
-                total_accurate_predictions += prediction_accuracy
-                total_score += torch.mean(scores).item()
-                if step + 1 >= max_steps:
+            for batch in self._batches(self.validation_set, sampler, device, num_workers, False, 0, 1):
+                if done >= steps:
                     break
-        total_prediction_losses /= max_steps
-        total_accurate_predictions /= max_steps
-        total_score /= max_steps
-        mean_mutual_information_lb = math.log(n) - total_prediction_losses
+                x = self._model_input(batch)
+                if kernel_scores:
+                    eng = self.model.engine_for(x)
+                    eng.forward(x.float() if x.dim() == 4 else x[:, 0, :].contiguous().float())
+                    eng.nce_eval(self.score_function is softplus_score_function, all_t, sums, ws)
+                else:
+                    predicted_z, targets, _, _ = self.model(x)
+                    S, ld = _score_layout(self.score_function(predicted_z, targets), all_t)
+                    _hip.call("cpc_nce_eval", _hip.ptr(S), _hip.ptr(sums), _hip.ptr(ws), batch_size, K, ld, 0, 1 if all_t else 0, 1)
+                done += 1
         self.model.train()
-        return total_prediction_losses, total_accurate_predictions, total_score, mean_mutual_information_lb
+        sums = sums / max(steps, 1)
+        n = batch_size * K if all_t else batch_size
+        step_losses, step_accuracy = sums[:K].clone(), sums[K:2 * K].clone()
+        return step_losses, step_accuracy, float(sums[2 * K]), math.log(n) - step_losses
 
     def calc_test_task_data(self, batch_size=64, num_workers=1):
         """Context vectors c of every item of the test-task set (reference :271-303)."""

@@ -411,6 +411,14 @@ int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float
     return launch_nce_all(S, ST, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
 }
 
+long long cpc_nce_eval_workspace_floats(int B, int K) { return nce_eval_workspace_floats(B, K); }
+
+int cpc_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps, int accumulate,
+                 void* stream) {
+    if (!S || !out || !workspace) return CPC_EINVAL;
+    return launch_nce_eval(S, out, workspace, B, K, ld, softplus, all_timesteps, accumulate, (hipStream_t)stream);
+}
+
 int cpc_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
              float grad_scale, const float* skip, void* stream) {
     if (!p || !g || !m || !v) return CPC_EINVAL;

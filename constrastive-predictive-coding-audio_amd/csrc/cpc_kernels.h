@@ -100,6 +100,9 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
                    int softplus, float reg, int dtype, hipStream_t stream);
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream);
+long long nce_eval_workspace_floats(int B, int K);
+int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps,
+                    int accumulate, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
                 float grad_scale, const float* skip, hipStream_t stream);
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,

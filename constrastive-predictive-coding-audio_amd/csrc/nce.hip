@@ -365,6 +365,95 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
     if (bad != 0.f) out[6] = 1.f;
 }
 
+
+// ---- validation quantities (ContrastiveEstimationTrainer.validate, contrastive_estimation_training.py:227-247) ----
+// One wave per score row: sum of the transformed scores, first arg max over the row's columns, and the row's "valid" score
+// (the column `diag`).  Default branch: row r = (k, b) of S[k][b][b'], diag = b; all-timesteps branch: row r = (b, k) of the
+// R x R matrix, diag = r.
+__global__ __launch_bounds__(256) void nce_row_eval_kernel(const float* __restrict__ S, int rows, int cols, int ld, int diag_mod,
+                                                           int softplus, float* __restrict__ rsum, int* __restrict__ rarg,
+                                                           float* __restrict__ rvalid) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* row = S + (long long)r * ld;
+    float sum = 0.f, best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = score_tf(row[c], softplus);
+        sum += v;
+        if (v > best || (v != v && best == best)) { best = v; arg = c; }          // a NaN wins, as in torch.argmax
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        sum += __shfl_xor(sum, o, 64);
+        const bool take = (ob > best) || (ob != ob && best == best) || (ob == best && oa < arg);
+        if (take) { best = ob; arg = oa; }
+    }
+    if (lane == 0) {
+        rsum[r] = sum;
+        rarg[r] = arg;
+        rvalid[r] = score_tf(row[diag_mod > 0 ? r % diag_mod : r], softplus);
+    }
+}
+
+// out[0..K) (+)= per-step losses, out[K..2K) (+)= per-step accuracies, out[2K] (+)= mean score of this batch.
+// Default branch: the reference forms noise = logsumexp(s.view(-1, B, K), 0) from the CONTIGUOUS (b, k, b') tensor, i.e. it
+// reads the (k, b') array of column log-sum-exps as a (B, K) matrix in flat order, and averages
+// valid[j][l] - noise[j][l] over j: lse[j*K + l] with lse stored flat as [k*B + b'].
+__global__ __launch_bounds__(256) void nce_eval_finalize_kernel(const float* __restrict__ lse, const float* __restrict__ rsum,
+                                                                const int* __restrict__ rarg, const float* __restrict__ rvalid,
+                                                                float* __restrict__ out, int B, int K, int all_t, int accumulate) {
+    __shared__ float red[256];
+    const int R = B * K;
+    for (int k = 0; k < K; ++k) {
+        float dl = 0.f, hit = 0.f;
+        for (int j = threadIdx.x; j < B; j += 256) {
+            if (all_t) {
+                const int r = j * K + k;
+                dl += rvalid[r] - lse[r];
+                hit += rarg[r] == r ? 1.f : 0.f;
+            } else {
+                dl += rvalid[k * B + j] - lse[j * K + k];
+                hit += rarg[k * B + j] == j ? 1.f : 0.f;
+            }
+        }
+        red[threadIdx.x] = dl;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+        const float loss_k = -red[0] / (float)B;
+        __syncthreads();
+        red[threadIdx.x] = hit;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+        const float acc_k = red[0] / (float)(all_t ? R : B);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            out[k] = (accumulate ? out[k] : 0.f) + loss_k;
+            out[K + k] = (accumulate ? out[K + k] : 0.f) + acc_k;
+        }
+    }
+    float tot = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) tot += rsum[r];
+    red[threadIdx.x] = tot;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mean = red[0] / ((float)R * (float)(all_t ? R : B));
+        out[2 * K] = (accumulate ? out[2 * K] : 0.f) + mean;
+    }
+}
+
 }  // namespace
 
 // workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
@@ -451,6 +540,48 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
     }
 #undef NCE_ALL_GRAD
     hipLaunchKernelGGL(nce_all_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, n_colp, gradp, blocks, out, B, K, reg);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+
+// ---- validation ----
+// workspace: lse [R] + column partials + per-split (max, sum) [2][NCE_ALL_SPLITS][R] + row sums / arg max / valid [3][R]   (R = B*K)
+long long nce_eval_workspace_floats(int B, int K) {
+    const long long R = (long long)B * K;
+    return R + (R + 31) / 32 + K * (long long)((B + 31) / 32) + 2LL * NCE_ALL_SPLITS * R + 3 * R + 64;
+}
+
+int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps,
+                    int accumulate, hipStream_t stream) {
+    const int R = B * K;
+    if (B <= 0 || K <= 0 || (all_timesteps ? ld < R : (ld < B || ld > B + 7))) return CPC_EINVAL;
+    float* lse = workspace;
+    float* colp = lse + R;
+    float* pm = colp + (R + 31) / 32 + (long long)K * ((B + 31) / 32);
+    float* ps = pm + (long long)NCE_ALL_SPLITS * R;
+    float* rsum = ps + (long long)NCE_ALL_SPLITS * R;
+    int* rarg = (int*)(rsum + R);
+    float* rvalid = rsum + 2LL * R;
+    if (all_timesteps) {
+        const int ncb = (R + 31) / 32;
+        const int nsplit = R >= 8 * NCE_ALL_SPLITS ? NCE_ALL_SPLITS : 1;
+        if (nsplit > 1) {
+            const int rps = ((R + nsplit - 1) / nsplit + 7) / 8 * 8;
+            hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1, nsplit), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus, rps, pm, ps);
+            hipLaunchKernelGGL(nce_col_merge_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pm, ps, nsplit, R, lse, colp);
+        } else {
+            hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, 1, 1), dim3(256), 0, stream, S, lse, colp, R, 1, ld, softplus, R, (float*)nullptr,
+                               (float*)nullptr);
+        }
+        hipLaunchKernelGGL(nce_row_eval_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, S, R, R, ld, 0, softplus, rsum, rarg, rvalid);
+    } else {
+        hipLaunchKernelGGL(nce_col_kernel, dim3((B + 31) / 32, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B,
+                           (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(nce_row_eval_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, S, R, B, ld, B, softplus, rsum, rarg, rvalid);
+    }
+    hipLaunchKernelGGL(nce_eval_finalize_kernel, dim3(1), dim3(256), 0, stream, lse, rsum, rarg, rvalid, out, B, K, all_timesteps ? 1 : 0,
+                       accumulate ? 1 : 0);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -426,6 +426,29 @@ class CPCEngine:
         _hip.gemm_nt(_hip.ptr(self.dST_all), _hip.ptr(self.predT), _hip.ptr(dtop, tg), R, E, ld, ld, ld, E, code,
                      c_rpi=K, c_item=Ltop * E, c_valid=K)
 
+    def nce_eval(self, softplus: bool, all_timesteps: bool, sums, workspace):
+        """Adds this batch's validation quantities (per-step losses, per-step accuracies, mean score: include/cpc_hip.h,
+        cpc_nce_eval) to ``sums`` (2 K + 1 floats) — from the score matrices of the train step (forward() must have run)."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T = self.geo.alloc[-1], self.T
+        top = self.act[-1]
+        tg = (T - K) * E
+        if all_timesteps:
+            R = B * K
+            ld = _ceil_div(R, 8) * 8
+            if getattr(self, "S_all", None) is None:
+                self.S_all = torch.zeros(R * ld, device=self.device, dtype=torch.float32)
+            _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
+                         b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+            S = self.S_all
+        else:
+            ld = self.ldS
+            _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S), B, B, E, K * E, Ltop * E, ld, code,
+                         a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+            S = self.S
+        _hip.call("cpc_nce_eval", _hip.ptr(S), _hip.ptr(sums), _hip.ptr(workspace), B, K, ld, 1 if softplus else 0,
+                  1 if all_timesteps else 0, 1)
+
     # ------------------------------------------------------------------------------------------ backward
     def _tn_to_grad(self, A, B_, grad, M, I, J, lda, ldb, nsplit, grad_offset=0, scratch=None, **kw):
         """grad[grad_offset + i*J + j] = sum_m A[m][i] B[m][j] via f32 slabs + deterministic reduction."""

@@ -324,6 +324,17 @@ long long cpc_nce_all_workspace_floats(int B, int K);
 int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
                      int softplus, float regularization, int dtype, void* stream);
 
+/* The per-batch quantities of ContrastiveEstimationTrainer.validate (contrastive_estimation_training.py:227-247) from the same
+ * score matrices the train step uses (S of cpc_nce_loss when all_timesteps == 0, S of cpc_nce_loss_all otherwise; softplus as
+ * there): out[0..K) = prediction_losses per step (:237-241, including the reference's reading of the (k, b') log-sum-exps as a
+ * (B, K) matrix in flat order in the default branch), out[K..2K) = prediction_accuracy per step (:245-247: arg max over the
+ * targets of every prediction equal to its own target; first maximum on ties), out[2K] = mean score (:249).  accumulate != 0
+ * adds to out instead of overwriting it (validate sums over batches and divides once).  workspace:
+ * cpc_nce_eval_workspace_floats(B, K) f32. */
+long long cpc_nce_eval_workspace_floats(int B, int K);
+int cpc_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps, int accumulate,
+                 void* stream);
+
 /* torch.optim.Adam.step with default betas/eps semantics over one flat f32 buffer
  * (contrastive_estimation_training.py:83, :162).  step counts from 1; g is multiplied by grad_scale first.
  * skip (device pointer to one float, or NULL): the reference's NaN guard returns BEFORE backward() / optimizer.step()

@@ -250,6 +250,67 @@ def test_reference_snapshot_runs_on_the_gpu(golden_dir):
             assert _rel(a, b) < 2e-4, (order, name)
 
 
+@pytest.mark.parametrize("all_t", [False, True])
+def test_generic_route_through_the_loss_kernels(golden_dir, all_t):
+    """ContrastiveEstimationTrainer.train with a score function / optimizer the fused route does not cover: the model runs through
+    the autograd bridge, the loss and its gradient come from cpc_nce_loss(_all) (_InfoNCE).  (1) difference_score_function + Adam,
+    two steps, against the oracle's trainer; (2) softplus scores + SGD, one step: parameters = p - lr * oracle gradient."""
+    from cpc_audio_amd.audio_dataset import FileBatchSampler
+    from cpc_audio_amd.contrastive_estimation_training import difference_score_function
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"])
+    params = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    random.seed(5)
+    batches = [list(b) for b in FileBatchSampler([data.shape[0]], meta["B"], 1, True, verbose=False)]
+    for score, fn, opt_cls, steps, lr in (("difference", difference_score_function, torch.optim.Adam, 2, 1e-3),
+                                          ("softplus", softplus_score_function, torch.optim.SGD, 1, 1e-2)):
+        model = _small_model(g, meta, "fp32")
+        logger = Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=0.5, score_over_all_timesteps=all_t, score_function=fn, optimizer=opt_cls,
+                                          prediction_steps=meta["K"], ar_size=meta["H"])
+        tr.verbose = False
+        assert not tr._fused()
+        random.seed(5)
+        tr.train(batch_size=meta["B"], epochs=1, lr=lr, num_workers=0, max_steps=steps)
+        ot = O.OracleTrainer(params, meta["V"], meta["K"], score=score, all_timesteps=all_t, regularization=0.5, lr=lr)
+        for i in range(steps):
+            if opt_cls is torch.optim.Adam:
+                loss, smax = ot.step(data[batches[i]])
+            else:
+                loss, smax, grads = ot.loss_and_grads(data[batches[i]])
+                with torch.no_grad():
+                    for k, p_ in ot.params.items():
+                        p_ -= lr * grads[k]
+            assert abs(logger.loss_meter.values[i] - float(loss)) < 2e-4 * abs(float(loss)), (score, i)
+            assert abs(logger.score_meter.values[i] - float(smax)) < 2e-4 * abs(float(smax)) + 1e-6, (score, i)
+        for k, v in model.state_dict().items():
+            ref = ot.params[k].detach()
+            err = (v.cpu() - ref).abs()
+            if opt_cls is torch.optim.Adam:
+                # Adam moves every element by <= lr per step; an element whose tiny gradient flips sign moves the other way
+                assert err.max().item() <= 2 * lr * steps * 1.01 + 1e-6, (score, k)
+                tight = err <= 0.05 * lr * steps + 1e-4 * ref.abs()
+                assert tight.float().mean().item() > 0.97, (score, k, tight.float().mean().item())
+            else:           # SGD: p - lr * g
+                assert err.max().item() <= 2e-3 * (ref - params[k]).abs().max().item() + 1e-7, (score, k)
+
+
+def test_positional_encoder_standalone():
+    """PositionalEncoder.forward (reference attention_model.py:28-35, the module its own TestPositionalEncoder exercises):
+    x * sqrt(code_size) + pe[:steps] for a (steps, batch, code_size) input, through cpc_pe_scale_fwd."""
+    from cpc_audio_amd.attention_model import PositionalEncoder
+    pe = PositionalEncoder(code_size=64, max_seq_len=60).to(DEV)
+    x = torch.randn(17, 5, 64, generator=torch.Generator().manual_seed(2))
+    table = O.positional_encoding(60, 64)
+    want = x * math.sqrt(64) + table[:17].unsqueeze(1)
+    got = pe(x.to(DEV))
+    assert got.shape == x.shape and _rel(got, want) < 1e-6
+    with pytest.raises(RuntimeError):
+        pe(x)
+
+
 def test_validate_matches_reference(golden_dir):
     g = _load(golden_dir, "validate.npz")
     meta = json.load(open(os.path.join(golden_dir, "validate.json")))
