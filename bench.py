@@ -15,7 +15,11 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
                 FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
                 (every tenth: an event pair around a launch leaves ~12 us of idle queue).
   hbm_kernel    the HBM-bound piece of the conv stack (encoder layer 1, C_in = 1): algorithmic bytes / HIP-event duration vs 8 TB/s.
-  cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host on a bounded sample.
+  score_gemm    the InfoNCE score contraction alone (both loss branches): algorithmic FLOPs / HIP-event time vs the bf16 MFMA peak.
+  trainer_ms_per_step   the same step through ContrastiveEstimationTrainer.train (sampler, logger, loss readback, NaN guard).
+  cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host: CPU model, core count, 3 warm-up + median
+                of 10 steps, and the same under autograd anomaly detection (how the reference's train() runs).
+  n_ranks_seen  (N > 1) ranks that took part in the run's collectives.
 """
 import argparse
 import json
@@ -41,8 +45,22 @@ def build_model(dtype, device, seed=0):
     return model.to(device)
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle's train step (torch CPU ops, f32) on BASELINE config 1's shape (B=8 clips of 20480 samples)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline():
+    """The oracle's train step (torch CPU ops, f32) on BASELINE config 1's shape (B = 8 clips of 20480 samples), SURVEY.md 8(d)
+    protocol: all host cores of this process, 3 warm-up steps, median of 10 timed steps; headline with autograd anomaly detection
+    off, plus the same with it on — the reference's train() always runs under set_detect_anomaly(True)
+    (contrastive_estimation_training.py:96)."""
     from oracle import cpc_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:        # cgroup v2 CPU quota of the GPU box's container, when present
@@ -53,21 +71,87 @@ def cpu_baseline(budget_s=20.0):
         pass
     torch.set_num_threads(cores)
     threads = torch.get_num_threads()
-    B, L = 8, 20480
-    params = O.init_params(seed=0)
-    tr = O.OracleTrainer(params, 100, 12, score="softplus", regularization=1.0, lr=1e-4)
+    B, L, warm, timed = 8, 20480, 3, 10
     data = torch.randn(4 * B, L, generator=torch.Generator().manual_seed(0))
-    tr.step(data[:B])                                        # warm-up
-    t0, steps = time.perf_counter(), 0
-    while True:
-        tr.step(data[(steps % 4) * B:(steps % 4 + 1) * B])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or steps >= 40:
-            break
-    return {"value": round(B * 126 * steps / el, 1), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} train steps of B=8 x 20480 samples (config 1 shape), f32, {threads} torch threads, "
-                      f"{el / steps * 1e3:.0f} ms/step"}
+
+    def run(anomaly):
+        tr = O.OracleTrainer(O.init_params(seed=0), 100, 12, score="softplus", regularization=1.0, lr=1e-4)
+        times = []
+        with torch.autograd.set_detect_anomaly(anomaly):
+            for i in range(warm + timed):
+                t0 = time.perf_counter()
+                tr.step(data[(i % 4) * B:(i % 4 + 1) * B])
+                if i >= warm:
+                    times.append(time.perf_counter() - t0)
+        times.sort()
+        return 0.5 * (times[(timed - 1) // 2] + times[timed // 2])
+
+    med, med_anomaly = run(False), run(True)
+    return {"value": round(B * 126 / med, 1), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "anomaly_on": {"value": round(B * 126 / med_anomaly, 1), "ms_per_step": round(med_anomaly * 1e3, 1)},
+            "sample": f"median of {timed} train steps after {warm} warm-up steps, B=8 x 20480 samples (config 1 shape), f32, "
+                      f"{threads} torch threads, {med * 1e3:.0f} ms/step; anomaly_on = the same under torch.autograd."
+                      f"set_detect_anomaly(True), as the reference's train() runs"}
+
+
+def score_gemm_figures(eng, launches=50):
+    """HIP-event time of the InfoNCE score contraction (contrastive_estimation_training.py:12-22) on the engine's own buffers:
+    the equal-step form the default branch runs (K batched B x E x B products) and the full (B K) x E x (B K) form of
+    score_over_all_timesteps=True; algorithmic FLOPs / time against the dense bf16 MFMA peak."""
+    out = {}
+    for name, fn, shape in (("default", eng.score_gemm, f"{eng.K} x ({eng.B} x {eng.E} x {eng.B})"),
+                            ("all_timesteps", eng.score_gemm_all, f"{eng.B * eng.K} x {eng.E} x {eng.B * eng.K}")):
+        for _ in range(5):
+            flops = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / launches
+        tf = flops / (us * 1e-6) / 1e12
+        out[name] = {"shape": shape, "gflop": round(flops / 1e9, 3), "us_per_launch": round(us, 2), "achieved": round(tf, 1),
+                     "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+    out["note"] = "back-to-back launches (includes the launch-to-launch gap); one launch per train step in the product path"
+    return out
+
+
+def trainer_loop_ms(model, B, L, device, steps=60, warmup=10):
+    """ms per step through the drop-in surface itself — ContrastiveEstimationTrainer.train with a logger attached, FileBatchSampler,
+    device-resident synthetic dataset, loss readback and NaN guard — as opposed to the engine calls the headline loop issues."""
+    from cpc_audio_amd.audio_dataset import SyntheticAudioDataset
+    from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer, softplus_score_function
+
+    class Meter:
+        def __init__(self):
+            self.n = 0
+
+        def update(self, v):
+            self.n += 1
+
+    class Logger:
+        def __init__(self):
+            self.loss_meter, self.score_meter, self.marks = Meter(), Meter(), []
+
+        def log(self, step):
+            self.marks.append(time.perf_counter())
+
+    import contextlib
+    ds = SyntheticAudioDataset(B * 8, L, seed=3, device=device)
+    logger = Logger()
+    with contextlib.redirect_stdout(sys.stderr):          # stdout carries the one JSON line only
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=device, regularization=1.0,
+                                          score_function=softplus_score_function, prediction_steps=12, ar_size=256)
+        tr.verbose = False
+        torch.cuda.synchronize()
+        tr.train(batch_size=B, epochs=1000, lr=1e-4, num_workers=0, max_steps=warmup + steps)
+        torch.cuda.synchronize()
+    marks = logger.marks
+    # the logger sees step i one step late (host_sync_lag): steady-state spacing of the log calls = time per step
+    span = marks[-1] - marks[warmup]
+    return round(span / (len(marks) - 1 - warmup) * 1e3, 3), len(marks)
 
 
 def main():
@@ -78,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trainer-loop", action="store_true", help="skip the extra run through ContrastiveEstimationTrainer.train")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
     ap.add_argument("--graph", action="store_true", help="diagnostic: replay the step from a captured hipGraph (single GPU only)")
     ap.add_argument("--all-timesteps", action="store_true",
@@ -159,10 +244,14 @@ def main():
     elapsed = time.perf_counter() - t0
     _hip.set_timer(None)
     loss = float(out[0])
+    n_ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                     # how many ranks actually took part in the collectives of this run
+        n_ranks_seen = int(ones.item())
 
     summary = timer.summary()
     if rank == 0:
@@ -173,11 +262,15 @@ def main():
         flops = sum(v[2] for k, v in summary.items() if k.startswith(dom))
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
-        traffic = None
+        # HBM-side bytes per launch of the dominant kernel: NOT a quantity of this run — PMC counters need their own rocprofv3
+        # passes (MI355X_MICROARCH.md, HBM section); the committed summary of the latest such pass is quoted and labelled
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("gemm_nt_fast_bf16_256_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("gemm_nt_fast_bf16_256_hbm_bytes_per_launch")
+                traffic_source = f"{tj.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; not measured in this run)"
             except Exception:
                 traffic = None
         line = {
@@ -200,6 +293,7 @@ def main():
                        "loss_last_step": round(loss, 6)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": "gemm_nt_fast_kernel<bf16,bf16,2,4,8,4>" if args.dtype == "bf16" else "gemm_nt_fast_kernel<f32,f32,2,2,4,4>",
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
@@ -222,6 +316,15 @@ def main():
             for k, (cnt, kms, w) in rows:
                 tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
                 print(f"#   {k:58s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step {tf}", file=sys.stderr)
+        if world == 1 and args.dtype == "bf16" and not args.breakdown and not args.all_timesteps:
+            line["score_gemm"] = score_gemm_figures(eng)
+            if graphed is None and not args.no_trainer_loop:
+                ms_t, n_logged = trainer_loop_ms(model, B, L, device)
+                line["trainer_ms_per_step"] = ms_t
+                line["trainer_loop"] = (f"ContrastiveEstimationTrainer.train, logger attached, device-resident dataset, "
+                                        f"{n_logged} logged steps (first 10 discarded)")
+        if world > 1:
+            line["n_ranks_seen"] = n_ranks_seen
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

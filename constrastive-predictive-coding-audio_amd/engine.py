@@ -372,6 +372,27 @@ class CPCEngine:
         return pred, targets, z, self.ctx.c_float().clone()
 
     # ------------------------------------------------------------------------------------------ loss
+    def score_gemm(self):
+        """The score contraction of the default branch (contrastive_estimation_training.py:12-22 restricted to equal steps,
+        :116): K batched B x E x B products S[k] = predicted_z[:, k, :] targets[:, :, k]^T.  Returns its algorithmic FLOPs."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T, ld = self.geo.alloc[-1], self.T, self.ldS
+        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(self.act[-1], (T - K) * E), _hip.ptr(self.S), B, B, E, K * E, Ltop * E, ld, code,
+                     a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+        return 2.0 * K * B * B * E
+
+    def score_gemm_all(self):
+        """The full (B K) x E x (B K) score contraction of score_over_all_timesteps=True (:12-22, :108-114).  Returns its FLOPs."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T = self.geo.alloc[-1], self.T
+        R = B * K
+        ld = _ceil_div(R, 8) * 8
+        if getattr(self, "S_all", None) is None:
+            self.S_all = torch.zeros(R * ld, device=self.device, dtype=torch.float32)
+        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(self.act[-1], (T - K) * E), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
+                     b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+        return 2.0 * R * R * E
+
     def nce_forward_backward(self, softplus: bool, regularization: float):
         """Equal-step scores, InfoNCE loss + regulariser, and d loss / d (predicted_z, targets).
 
@@ -380,8 +401,7 @@ class CPCEngine:
         code, B, E, K = self.code, self.B, self.E, self.K
         Ltop, T, ld = self.geo.alloc[-1], self.T, self.ldS
         top, dtop = self.act[-1], self.dact[-1]
-        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, (T - K) * E), _hip.ptr(self.S), B, B, E, K * E, Ltop * E, ld, code,
-                     a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+        self.score_gemm()
         _hip.call("cpc_nce_loss", _hip.ptr(self.S), _hip.ptr(self.dS), _hip.ptr(self.dST), _hip.ptr(self.nce_out),
                   _hip.ptr(self.nce_ws), B, K, ld, 1 if softplus else 0, C.c_float(regularization), code)
         # d predicted_z[b][k][:] = sum_b' dS[k][b][b'] * targets[b'][k][:]
@@ -400,16 +420,16 @@ class CPCEngine:
         top, dtop = self.act[-1], self.dact[-1]
         R = B * K
         ld = _ceil_div(R, 8) * 8
-        if getattr(self, "S_all", None) is None:
+        if getattr(self, "ST_all", None) is None:
             f32 = torch.float32
-            self.S_all = torch.zeros(R * ld, device=self.device, dtype=f32)
+            if getattr(self, "S_all", None) is None:
+                self.S_all = torch.zeros(R * ld, device=self.device, dtype=f32)
             self.ST_all = torch.zeros(R * ld, device=self.device, dtype=f32)
             self.dS_all = torch.zeros(R * ld, device=self.device, dtype=self.dt)
             self.dST_all = torch.zeros(R * ld, device=self.device, dtype=self.dt)
             self.nce_all_ws = torch.empty(int(_hip.lib().cpc_nce_all_workspace_floats(B, K)), device=self.device, dtype=f32)
         tg = (T - K) * E
-        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
-                     b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+        self.score_gemm_all()
         _hip.gemm_nt(_hip.ptr(top, tg), _hip.ptr(self.pred), _hip.ptr(self.ST_all), R, R, E, E, E, ld, code,
                      a_rpi=K, a_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
         _hip.call("cpc_nce_loss_all", _hip.ptr(self.S_all), _hip.ptr(self.ST_all), _hip.ptr(self.dS_all), _hip.ptr(self.dST_all),
@@ -434,17 +454,12 @@ class CPCEngine:
         top = self.act[-1]
         tg = (T - K) * E
         if all_timesteps:
-            R = B * K
-            ld = _ceil_div(R, 8) * 8
-            if getattr(self, "S_all", None) is None:
-                self.S_all = torch.zeros(R * ld, device=self.device, dtype=torch.float32)
-            _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
-                         b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
+            ld = _ceil_div(B * K, 8) * 8
+            self.score_gemm_all()
             S = self.S_all
         else:
             ld = self.ldS
-            _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(top, tg), _hip.ptr(self.S), B, B, E, K * E, Ltop * E, ld, code,
-                         a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+            self.score_gemm()
             S = self.S
         _hip.call("cpc_nce_eval", _hip.ptr(S), _hip.ptr(sums), _hip.ptr(workspace), B, K, ld, 1 if softplus else 0,
                   1 if all_timesteps else 0, 1)

@@ -40,8 +40,26 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"launches_sampled": len(f), "fetch_size_kb_avg": sum(f) / len(f), "write_size_kb_avg": sum(w) / len(w),
               "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024}
 json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
-dom = [k for k in out if "gemm_nt_fast_kernel" in k and "Li2ELi4ELi8ELi4E" in k and "DF16bDF16b" in k]
-latest = {"source": f"profiles/{tag}_traffic.json", "kernel": dom[0] if dom else None,
-          "gemm_nt_fast_bf16_256_hbm_bytes_per_launch": out[dom[0]]["hbm_bytes_per_launch"] if dom else None}
+
+# matrix-pipe occupancy per kernel (the pass may be absent in older runs): SQ_VALU_MFMA_BUSY_CYCLES summed over the chip's 1024
+# SIMDs against GRBM_GUI_ACTIVE (summed over the 8 XCDs) -> fraction of SIMD-cycles with the matrix pipe busy
+try:
+    busy, act = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES", "mfma"), per_kernel("GRBM_GUI_ACTIVE", "mfma")
+    mf = {}
+    for k in sorted(busy):
+        b, a = busy[k], act.get(k, [0.0])
+        cyc = sum(a) / len(a) / 8.0            # cycles per dispatch (average over the XCDs)
+        mf[k] = {"launches_sampled": len(b), "mfma_busy_cycles_avg": sum(b) / len(b), "gui_active_avg": sum(a) / len(a),
+                 "mfma_busy_frac_of_simd_cycles": (sum(b) / len(b)) / (cyc * 1024.0) if cyc > 0 else None}
+    json.dump(mf, open(os.path.join(dst, f"{tag}_mfma.json"), "w"), indent=1)
+except (ValueError, FileNotFoundError) as e:
+    print("no mfma pass:", e)
+# the dominant kernel of bench.py's roofline object = the 256x256 bf16 -> bf16 NT GEMM in both epilogue forms (register epilogue:
+# conv forward; LDS-staged: data gradients), without the fused layer-1 variant (template flag C1, "...Lb1ELb1E...")
+dom = [k for k in out if "gemm_nt_fast_kernel" in k and "Li2ELi4ELi8ELi4E" in k and "DF16bDF16b" in k and "Li8ELi4ELb1ELb1E" not in k]
+n_dom = sum(out[k]["launches_sampled"] for k in dom)
+latest = {"source": f"profiles/{tag}_traffic.json", "kernels": dom,
+          "gemm_nt_fast_bf16_256_hbm_bytes_per_launch": (sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches_sampled"] for k in dom) / n_dom)
+          if n_dom else None}
 json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
