@@ -88,6 +88,9 @@ _SIGNATURES = {
     "cpc_maxpool2d_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_residual_add": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_residual_add_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_maxpool2d_select": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "cpc_gp_direction": ([_P, _P, _L, _I, _F, _P, _I, _P], _I),
+    "cpc_bn_gp_cross": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_relu_mask": ([_P, _P, _L, _I, _P], _I),
     "cpc_split3_bf16": ([_P, _P, _L, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),

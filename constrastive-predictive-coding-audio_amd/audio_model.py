@@ -254,14 +254,15 @@ class AudioPredictiveCodingModel(nn.Module):
         if device.type != "cuda":
             raise RuntimeError("the CPC hot path runs on the GPU only (no CPU fallback): call model.to('cuda') first")
         shape = tuple(int(v) for v in length) if self._scalogram else int(length)
-        key = (int(batch_size), shape, self.compute_dtype, str(device))
+        gp = bool(getattr(self, "gradient_penalty_engine", False)) and self._scalogram
+        key = (int(batch_size), shape, self.compute_dtype, str(device), gp)
         eng = self._engines.get(key)
         if eng is None or self._flat_param is None or any(
                 p.data_ptr() != self._param[n].data_ptr() for n, p in self.named_parameters()):
             self._flatten_parameters(device)
             if self._scalogram:
                 from .scalogram_engine import ScalogramCPCEngine
-                eng = ScalogramCPCEngine(self, (int(batch_size),) + shape, device, self.compute_dtype)
+                eng = ScalogramCPCEngine(self, (int(batch_size),) + shape, device, self.compute_dtype, gradient_penalty=gp)
             else:
                 eng = CPCEngine(self, batch_size, length, device, self.compute_dtype)
             self._engines[key] = eng

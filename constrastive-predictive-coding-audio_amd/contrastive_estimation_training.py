@@ -177,8 +177,15 @@ class ContrastiveEstimationTrainer:
         self.global_negatives = False
         self.verbose = True
         if wasserstein_gradient_penalty:
-            raise NotImplementedError("the Wasserstein gradient penalty (double backward through the encoder) is not "
-                                      "part of the HIP path yet (SURVEY.md section 8f, rank 3)")
+            # reference :144-158.  Its penalty differentiates the summed scores with respect to the PREPROCESSED batch, which only
+            # requires grad behind a preprocessing module (:100-102): without one the reference itself fails in autograd.grad.
+            if preprocessing is None:
+                raise ValueError("wasserstein_gradient_penalty needs a preprocessing module (the reference takes the penalty's "
+                                 "gradient with respect to the preprocessed batch, contrastive_estimation_training.py:100-102, :147)")
+            if score_function is not linear_score_function or optimizer is not torch.optim.Adam:
+                raise NotImplementedError("the gradient penalty on the HIP path covers linear_score_function + Adam (every reference "
+                                          "experiment with the penalty); see DESIGN.md section 8")
+            model.gradient_penalty_engine = True      # engines built from now on also give the gradient w.r.t. the scalogram
         if self.verbose:
             print("use score function", self.score_function)
 
@@ -371,11 +378,19 @@ class ContrastiveEstimationTrainer:
                         optimizer.skip_flag = eng.nan_flag()
                         if sync is not None:      # per-GPU negatives: mean of the shard gradients; global negatives: they add up
                             sync.grad_scale = 1.0 if gneg is not None else 1.0 / world
-                        out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
-                                                 regularization=float(self.regularization),
-                                                 all_timesteps=bool(self.score_over_all_timesteps),
-                                                 grad_ready_hook=sync.hook if sync is not None else getattr(optimizer, "hook", None),
-                                                 global_negatives=gneg, after_loss=sync.reduce_flag if sync is not None else None)
+                        if self.wasserstein_gradient_penalty:
+                            # three passes through the network (scalogram_engine.ScalogramCPCEngine._gp_step); the parameter
+                            # gradients are complete only at the end, so Adam runs once, after them
+                            out = eng.loss_and_grads(x_eng, softplus=False, regularization=float(self.regularization),
+                                                     all_timesteps=bool(self.score_over_all_timesteps), global_negatives=gneg,
+                                                     after_loss=sync.reduce_flag if sync is not None else None,
+                                                     gradient_penalty=float(self.gradient_penalty_factor))
+                        else:
+                            out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
+                                                     regularization=float(self.regularization),
+                                                     all_timesteps=bool(self.score_over_all_timesteps),
+                                                     grad_ready_hook=sync.hook if sync is not None else getattr(optimizer, "hook", None),
+                                                     global_negatives=gneg, after_loss=sync.reduce_flag if sync is not None else None)
                         if sync is not None:
                             sync.finish()
                         # per-GPU negatives: mean of the shard gradients; global negatives: the shard gradients add up

@@ -336,6 +336,23 @@ int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void*
     return launch_residual_add_bwd(dout, out, go, da, ga, dr, gr, oh, ow, relu, r_f32, dtype, (hipStream_t)stream);
 }
 
+int cpc_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,
+                         void* stream) {
+    if (!in || !sel || !out) return CPC_EINVAL;
+    return launch_maxpool2d_select(in, sel, gi, out, go, p, in_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_gp_direction(const float* g, float* v, long long npix, int C, float factor, float* partial, int nblocks, void* stream) {
+    if (!g || !v || !partial) return CPC_EINVAL;
+    return launch_gp_direction(g, v, npix, C, factor, partial, nblocks, (hipStream_t)stream);
+}
+
+int cpc_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out, const int* gx, const float* stats, const float* coef,
+                    int x_f32, int dtype, void* stream) {
+    if (!x || !yt || !delta || !out || !stats || !coef) return CPC_EINVAL;
+    return launch_bn_gp_cross(x, yt, delta, out, gx, stats, coef, x_f32, dtype, (hipStream_t)stream);
+}
+
 int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream) {
     if (!g || !y) return CPC_EINVAL;
     return launch_relu_mask(g, y, n, dtype, (hipStream_t)stream);

@@ -159,6 +159,11 @@ int launch_residual_add(const void* a, const int* ga, const void* r, const int* 
                         int r_f32, int dtype, hipStream_t stream);
 int launch_residual_add_bwd(const void* dout, const void* out, const int* go, void* da, const int* ga, void* dr, const int* gr, int oh,
                             int ow, int relu, int r_f32, int dtype, hipStream_t stream);
+int launch_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,
+                            hipStream_t st);
+int launch_gp_direction(const float* g, float* v, long long npix, int C, float factor, float* partial, int nblocks, hipStream_t st);
+int launch_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out, const int* gx, const float* stats, const float* coef,
+                       int x_f32, int dtype, hipStream_t st);
 int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,

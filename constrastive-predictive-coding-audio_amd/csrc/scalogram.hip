@@ -634,6 +634,76 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(T* __restrict__ g, const
     }
 }
 
+
+// ---- Wasserstein gradient penalty (contrastive_estimation_training.py:144-155) ----
+// out = the element of `sel` at the position of the FIRST maximum of `in` in each pooling window: a max pooling applied to a
+// tangent vector, selecting where the primal pooling selected (in and sel share one grid geometry).
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void maxpool2d_select_kernel(const TI* __restrict__ in, const TI* __restrict__ sel, Grid gi,
+                                                               T* __restrict__ out, Grid go, int p) {
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * go.C);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c = (int)(idx % go.C);
+        const int ho = (int)((idx / go.C) % go.H);
+        const int wo = (int)((idx / (unsigned)(go.C * go.H)) % go.W);
+        const int b = (int)(idx / (unsigned)(go.C * go.H * go.W));
+        float m = -INFINITY, pick = 0.f;
+        for (int dh = 0; dh < p; ++dh)
+            for (int dw = 0; dw < p; ++dw) {
+                const int h = ho * p + dh, w = wo * p + dw;
+                if (h < gi.H && w < gi.W) {
+                    const long long o = grid_off(gi, b, w, h) + c;
+                    const float v = to_f32(in[o]);
+                    if (v > m) { m = v; pick = to_f32(sel[o]); }
+                }
+            }
+        out[grid_off(go, b, wo, ho) + c] = from_f32<T>(pick);
+    }
+}
+
+// g: gradient of the summed scores w.r.t. the scalogram, f32 channels-last [npix][C] (the reference's dim 1 = channels is the
+// innermost axis here).  v = d penalty / d g = factor * 2 (|g| - 1) / |g| * g / npix per pixel; partial[block] = sum (|g| - 1)^2.
+__global__ __launch_bounds__(256) void gp_direction_kernel(const float* __restrict__ g, float* __restrict__ v, long long npix, int C,
+                                                           float factor, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        float n2 = 0.f;
+        for (int c = 0; c < C; ++c) { const float t = g[i * C + c]; n2 += t * t; }
+        const float n = sqrtf(n2);
+        acc += (n - 1.f) * (n - 1.f);
+        // |g| = 0: torch's norm backward yields 0 there (sub-gradient), and so does this
+        const float k = n > 0.f ? factor * 2.f * (n - 1.f) / (n * (float)npix) : 0.f;
+        for (int c = 0; c < C; ++c) v[i * C + c] = k * g[i * C + c];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// Second-order terms of a train-mode BatchNorm under the penalty: out = A[c] * xhat + Bc[c] * yt + Cc[c] * delta over the valid
+// positions of the grid (xhat = (x - mean[c]) * rstd[c]; coef = [A | Bc | Cc], 3 C floats), zero elsewhere untouched.
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void bn_gp_cross_kernel(const TX* __restrict__ x, const T* __restrict__ yt, const TX* __restrict__ delta,
+                                                          TX* __restrict__ out, Grid gx, const float* __restrict__ stats,
+                                                          const float* __restrict__ coef) {
+    const int C = gx.C;
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * C);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c = (int)(idx % C);
+        const int h = (int)((idx / C) % gx.H);
+        const unsigned col = idx / (unsigned)(C * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const long long o = grid_off(gx, b, w, h) + c;
+        const float xh = (to_f32(x[o]) - stats[c]) * stats[C + c];
+        out[o] = from_f32<TX>(coef[c] * xh + coef[C + c] * to_f32(yt[o]) + coef[2 * C + c] * to_f32(delta[o]));
+    }
+}
+
 }  // namespace
 
 int launch_scalogram_pointwise(const float* cq, const float* fixed_pd, const float* pd_scale, float* out, int B, int Tn, int bins,
@@ -910,6 +980,45 @@ int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t st) {
     if (n <= 0) return CPC_EINVAL;
     hipLaunchKernelGGL(split3_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+
+int launch_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,
+                            hipStream_t st) {
+    if (!pool_ok(gi, go, p)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)go[0] * go[1] * go[2] * go[5]);
+    if (in_f32) {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((maxpool2d_select_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)in, (const float*)sel, mk(gi), (bf16_t*)out, mk(go), p),
+                  hipLaunchKernelGGL((maxpool2d_select_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, (const float*)sel, mk(gi), (float*)out, mk(go), p));
+    } else {
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((maxpool2d_select_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)sel, mk(gi), (bf16_t*)out, mk(go), p),
+                  hipLaunchKernelGGL((maxpool2d_select_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)in, (const float*)sel, mk(gi), (float*)out, mk(go), p));
+    }
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_gp_direction(const float* g, float* v, long long npix, int C, float factor, float* partial, int nblocks, hipStream_t st) {
+    if (npix <= 0 || C <= 0 || nblocks <= 0) return CPC_EINVAL;
+    hipLaunchKernelGGL(gp_direction_kernel, dim3(nblocks), dim3(256), 0, st, g, v, npix, C, factor, partial);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out, const int* gx, const float* stats, const float* coef,
+                       int x_f32, int dtype, hipStream_t st) {
+    if (!grid_ok(gx)) return CPC_EINVAL;
+    const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * gx[5]);
+    if (dtype == CPC_DTYPE_BF16 && x_f32)
+        hipLaunchKernelGGL((bn_gp_cross_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)x, (const bf16_t*)yt, (const float*)delta, (float*)out, mk(gx), stats, coef);
+    else
+        DISPATCH2(dtype,
+                  hipLaunchKernelGGL((bn_gp_cross_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)yt, (const bf16_t*)delta, (bf16_t*)out, mk(gx), stats, coef),
+                  hipLaunchKernelGGL((bn_gp_cross_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)x, (const float*)yt, (const float*)delta, (float*)out, mk(gx), stats, coef));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

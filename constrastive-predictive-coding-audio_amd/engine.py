@@ -1077,6 +1077,8 @@ def make_context(eng, ar):
         # later one, stride 1); every other configuration runs on the grid kernels
         lean = not (ar.batch_norm or ar.residual) and all(s == 1 for s in ar.strides) and ar.poolings[0] == 1 and \
             all(p > 1 for p in ar.poolings[1:])
+        if getattr(eng, "gp_capable", False):
+            lean = False          # the gradient penalty's tangent pass lives in the grid implementation
         if not lean:
             from .scalogram_engine import ConvArGridContext
             return ConvArGridContext(eng, ar)

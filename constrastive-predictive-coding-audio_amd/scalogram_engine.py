@@ -25,6 +25,7 @@ class Grid:
     def __init__(self, B, W, H, C_, device, dtype, top=0, tail=0, guard_rows=96):
         self.B, self.W, self.H, self.C, self.top = int(B), int(W), int(H), int(C_), int(top)
         self.Ha = self.top + self.H + int(tail)
+        self.guard_rows = int(guard_rows)
         self.dtype = dtype
         self.code = _hip.dtype_code(dtype)
         self.rows = self.B * self.W * self.Ha
@@ -49,6 +50,15 @@ class Grid:
 
 def _desc(t, desc):
     return C.cast(desc, C.c_void_p)
+
+
+def _twin(eng, grid: Grid) -> Grid:
+    """The grid that holds the TANGENT of ``grid`` during a gradient-penalty step (same geometry, dtype and guards), made on
+    first use.  Keyed by identity, so grids that alias in the primal graph alias in the tangent graph too."""
+    tw = eng._twins.get(id(grid))
+    if tw is None:
+        tw = eng._twins[id(grid)] = grid.like(grid.t.device, guard_rows=grid.guard_rows)
+    return tw
 
 
 def _col_group(cout, kw=1, stride=(1, 1), pad=0):
@@ -153,44 +163,58 @@ class _Conv:
             self.w_fwd[:, :self.K].copy_(flat)
             self.w_t[:self.K, :].copy_(flat.t())
 
-    def forward(self):
+    def forward(self, tangent=False):
+        """tangent=True (gradient-penalty step): the same GEMM on the TANGENT of the input, written to the tangent of the output —
+        no bias, and where the convolution carries the block's ReLU the PRIMAL output is the mask (a tangent passes where the
+        activation was positive)."""
         e, gin, y0 = self.eng, self.gin, self.y0
         p, code = e.model._param, self.code
         bias = _hip.ptr(p.get(self.bname)) if self.bname else None
         flags = _hip.GEMM_RELU if self.relu else 0
+        col, mask, mask_w = getattr(self, "col", None), None, None
+        if tangent:
+            if self.mode == 'win':
+                if getattr(self, "col_t", None) is None:
+                    self.col_t = torch.empty_like(self.col)     # the primal im2col matrix is still needed by the weight gradient
+                col = self.col_t
+            if self.relu:
+                mask, mask_w = y0.ptr(), y0.ptr(y0.top * self.cout)
+            gin, y0, bias, flags = _twin(e, gin), _twin(e, y0), None, 0
         if self.mode == 'col' and self.G > 1:
             G = self.G
             Kg, Ng = self.Rw * self.cin, G * self.cout
             Hg = _ceil_div(self.Ho, G)
             _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M // G, Ng, Kg, G * self.cin, Kg, Ng, code,
-                         bias=_hip.ptr(self.bias_g) if self.bname else None, c_rpi=gin.Ha // G, c_item=y0.Ha * self.cout,
-                         c_valid=Hg, flags=flags)
+                         bias=(_hip.ptr(self.bias_g) if self.bname else None) if not tangent else None, mask=mask,
+                         c_rpi=gin.Ha // G, c_item=y0.Ha * self.cout, c_valid=Hg, flags=flags)
             if Hg * G > self.Ho:          # rows of the last super-row beyond the valid output
                 y0.t.view(-1, y0.Ha, self.cout)[:, self.Ho:Hg * G, :] = 0
         elif self.mode == 'col':
             _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M, self.cout, self.K, self.cin, self.K, self.cout, code,
-                         bias=bias, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
+                         bias=bias, mask=mask, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
         else:
-            _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(self.col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
+            _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
                       self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if self.in_f32 else 0, code)
-            _hip.gemm_nt(_hip.ptr(self.col), _hip.ptr(self.w_fwd), y0.ptr(y0.top * self.cout), self.M, self.cout, self.Kp, self.Kp, self.Kp,
-                         self.cout, code, bias=bias, c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
+            _hip.gemm_nt(_hip.ptr(col), _hip.ptr(self.w_fwd), y0.ptr(y0.top * self.cout), self.M, self.cout, self.Kp, self.Kp, self.Kp,
+                         self.cout, code, bias=bias, mask=mask_w, c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
 
-    def backward(self, din: Optional[Grid], accumulate=False, mask_input=False):
-        """dy0 (gradient of the convolution output) -> bias / weight gradients, and the input gradient into ``din``
-        (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
-        e, gin, dy0 = self.eng, self.gin, self.dy0
-        g, code = e.model._grad, self.code
-        # The short reductions of the weight-gradient path (bias column sum, slab sums) run on the engine's side stream beside
-        # the next GEMMs of the main stream; the slabs of this convolution therefore live in a buffer of their own.
+    def _scratch(self):
+        e = self.eng
         if getattr(self, "_wslab", None) is None:
             self._wslab = torch.empty(max(self.slab, 1), device=e.device, dtype=torch.float32)
             self._bscratch = torch.empty(e.colsum_blocks * self.cout, device=e.device, dtype=torch.float32)
             self._ev = (torch.cuda.Event(), torch.cuda.Event())
-        wslab = self._wslab
-        if self.bname and self.bname in g:
+        return self._wslab
+
+    def _wgrad(self, gin: Grid, col, dy0: Grid, gw, gb):
+        """gw (the weight's gradient view, reference layout) = correlation of the input ``gin`` (or its im2col matrix ``col``)
+        with the output gradient ``dy0``; gb (or None) = its column sums.  The short reductions (bias column sum, slab sums) run on
+        the engine's side stream beside the next GEMMs of the main stream; the slabs live in a buffer of this convolution."""
+        e, code = self.eng, self.code
+        wslab = self._scratch()
+        if gb is not None:
             with e.side(self._ev[0]):
-                e._colsum_to_grad(dy0.ptr(), g[self.bname], dy0.rows, self.cout, code, scratch=self._bscratch)
+                e._colsum_to_grad(dy0.ptr(), gb, dy0.rows, self.cout, code, scratch=self._bscratch)
         if self.mode == 'col' and self.G > 1:
             G = self.G
             Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.M // G
@@ -200,56 +224,72 @@ class _Conv:
             with e.side(self._ev[1]):
                 # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
                 S = wslab[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
-                gw = g[self.wname].view(self.cout, self.cin, self.kh)
                 acc = S[0:self.kh, :, 0, :]
                 for dh in range(1, G):
                     acc = acc + S[dh:dh + self.kh, :, dh, :]
-                gw.copy_(acc.permute(2, 1, 0))
-            if din is not None and self.need_dgrad:
-                dst = din
-                if accumulate:
-                    if getattr(self, "_din_tmp", None) is None:
-                        self._din_tmp = din.like(e.device, e.dt)
-                    dst = self._din_tmp
-                Kd = self.Rd * self.cout
-                _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
-                             Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
-                if accumulate:
-                    din.t.add_(dst.t)
+                gw.view(self.cout, self.cin, self.kh).copy_(acc.permute(2, 1, 0))
         elif self.mode == 'col':
             chunk = e._chunk(self.M, self.nsplit)
             _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
                          nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32)
             with e.side(self._ev[1]):
-                _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(g[self.wname]), self.cin, self.cout, self.kh, self.nsplit,
+                _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(gw), self.cin, self.cout, self.kh, self.nsplit,
                           self.K * self.cout)
-            if din is not None and self.need_dgrad:
-                D = self.kh
-                dst = din
-                if accumulate:          # the overlapped-row GEMM overwrites: go through a scratch grid of the same layout
-                    if getattr(self, "_din_tmp", None) is None:
-                        self._din_tmp = din.like(e.device, e.dt)
-                    dst = self._din_tmp
-                _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
-                             D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
-                if accumulate:
-                    din.t.add_(dst.t)
         else:
             chunk = e._chunk(self.M, self.nsplit, self.dt)
-            _hip.gemm_tn(_hip.ptr(self.col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp, self.cout,
+            _hip.gemm_tn(_hip.ptr(col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp, self.cout,
                          self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit, m_chunk=chunk,
                          slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
             taps = self.kh * self.kw
             with e.side(self._ev[1]):
-                _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(g[self.wname]), self.K, self.cout, self.nsplit, self.Kp * self.cout,
+                _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(gw), self.K, self.cout, self.nsplit, self.Kp * self.cout,
                           self.cin, self.cin * taps, 1, taps)
-            if din is not None and self.need_dgrad:
-                _hip.gemm_nt(dy0.ptr(dy0.top * self.cout), _hip.ptr(self.w_t), _hip.ptr(self.dcol), self.M, self.Kp, self.cout, self.cout,
-                             self.cout, self.Kp, code, a_rpi=self.Ho, a_item=dy0.Ha * self.cout)
-                _hip.call("cpc_col2im2d", _hip.ptr(self.dcol), din.ptr(), _desc(din, din.padded_desc), self.kh, self.kw, self.sh, self.sw,
-                          self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if accumulate else 0, code)
-                if mask_input:
-                    _hip.call("cpc_relu_mask", din.ptr(), gin.ptr(), din.rows * din.C, code)
+
+    def gp_wgrad(self, gp_grad):
+        """Penalty part of the weight gradient: (tangent of the input) x (gradient of the summed scores w.r.t. the output, which
+        the first backward pass of the step left in dy0); nothing for the bias, which the tangent does not see."""
+        e = self.eng
+        self._wgrad(_twin(e, self.gin), getattr(self, "col_t", None), self.dy0, gp_grad[self.wname], None)
+
+    def backward(self, din: Optional[Grid], accumulate=False, mask_input=False):
+        """dy0 (gradient of the convolution output) -> bias / weight gradients, and the input gradient into ``din``
+        (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
+        e, gin, dy0 = self.eng, self.gin, self.dy0
+        g, code = e.model._grad, self.code
+        self._wgrad(gin, getattr(self, "col", None), dy0, g[self.wname], g[self.bname] if (self.bname and self.bname in g) else None)
+        if din is None or not self.need_dgrad:
+            return
+        if self.mode == 'col' and self.G > 1:
+            G = self.G
+            Mg = self.M // G
+            dst = din
+            if accumulate:
+                if getattr(self, "_din_tmp", None) is None:
+                    self._din_tmp = din.like(e.device, e.dt)
+                dst = self._din_tmp
+            Kd = self.Rd * self.cout
+            _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
+                         Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
+            if accumulate:
+                din.t.add_(dst.t)
+        elif self.mode == 'col':
+            D = self.kh
+            dst = din
+            if accumulate:          # the overlapped-row GEMM overwrites: go through a scratch grid of the same layout
+                if getattr(self, "_din_tmp", None) is None:
+                    self._din_tmp = din.like(e.device, e.dt)
+                dst = self._din_tmp
+            _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
+                         D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
+            if accumulate:
+                din.t.add_(dst.t)
+        else:
+            _hip.gemm_nt(dy0.ptr(dy0.top * self.cout), _hip.ptr(self.w_t), _hip.ptr(self.dcol), self.M, self.Kp, self.cout, self.cout,
+                         self.cout, self.Kp, code, a_rpi=self.Ho, a_item=dy0.Ha * self.cout)
+            _hip.call("cpc_col2im2d", _hip.ptr(self.dcol), din.ptr(), _desc(din, din.padded_desc), self.kh, self.kw, self.sh, self.sw,
+                      self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if accumulate else 0, code)
+            if mask_input:
+                _hip.call("cpc_relu_mask", din.ptr(), gin.ptr(), din.rows * din.C, code)
 
 
 class _SepConv:
@@ -381,6 +421,74 @@ class _BatchNorm:
         _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
                   _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
                   float(self.y0.count), 1, 1 if self.trained else 0, self.x_f32, code)
+        gp = getattr(e, "_gp_phase", 0)
+        if gp == 1:          # first backward pass of a gradient-penalty step (seeds: the summed scores): keep sum q xhat
+            if getattr(self, "s2", None) is None:
+                self.s2 = torch.empty_like(gw)
+            self.s2.copy_(gw)
+        elif gp == 3:        # last pass: the second-order terms of this BatchNorm join the adjoint of its input (gp_terms)
+            self.dy0.t.add_(self.xterm.t)
+
+    # ---- Wasserstein gradient penalty: tangent pass and second-order terms
+    def tangent(self):
+        """Tangent of relu(BatchNorm(.)) in train mode: with the batch statistics depending on the input, the tangent of the
+        normalisation is the BatchNorm BACKWARD formula applied to the tangent, y. = (gamma / sigma) P a.  (P u = u - <u> - xhat <xhat u>),
+        then the primal ReLU mask.  Keeps y. (before the mask) and the sums <a.>, <xhat a.> for gp_terms."""
+        e = self.eng
+        p, code = e.model._param, e.code
+        if not self.trained:
+            raise NotImplementedError("gradient penalty through an eval-mode BatchNorm")
+        if self.x_f32:
+            raise NotImplementedError("gradient penalty in bf16 mode (float32 first-stage BatchNorm); use compute_dtype='fp32'")
+        y0, a = self.y0, self.a
+        y0_t, a_t = _twin(e, y0), _twin(e, a)
+        C_ = self.C
+        if getattr(self, "yt", None) is None:
+            dev = e.device
+            self.yt = y0.like(dev, guard_rows=y0.guard_rows)
+            self.xterm = y0.like(dev, guard_rows=y0.guard_rows)
+            self.t_dgamma = torch.zeros(C_, device=dev, dtype=torch.float32)
+            self.t_dbeta = torch.zeros(C_, device=dev, dtype=torch.float32)
+            self.s1 = torch.zeros(C_, device=dev, dtype=torch.float32)
+            self.ident = torch.cat([torch.zeros(C_), torch.ones(C_)]).to(dev)             # "statistics" of an identity normalisation
+            self.ones, self.zeros = torch.ones(C_, device=dev), torch.zeros(C_, device=dev)
+            self.coef = torch.zeros(3 * C_, device=dev, dtype=torch.float32)
+            self.inv_gamma_stats = torch.zeros(2 * C_, device=dev, dtype=torch.float32)
+        # sums over the batch of a. and xhat a. (no mask: the tangent enters the normalisation itself)
+        _hip.call("cpc_bn_bwd_reduce", y0_t.ptr(), None, _desc(y0, y0.desc), y0.ptr(), _desc(y0, y0.desc), _hip.ptr(self.stats),
+                  _hip.ptr(e.slabs), 0, self.nb_bwd, self.x_f32, code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(self.t_dgamma), 1, C_, self.nb_bwd, 2 * C_, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, C_), _hip.ptr(self.t_dbeta), 1, C_, self.nb_bwd, 2 * C_, 1, 1, 0, 0)
+        # y. = gamma rstd (a. - <a.> - xhat <xhat a.>)
+        _hip.call("cpc_bn_bwd_apply", y0_t.ptr(), None, _desc(y0, y0.desc), y0.ptr(), self.yt.ptr(), _desc(y0, y0.desc), _hip.ptr(self.stats),
+                  _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(self.t_dgamma), _hip.ptr(self.t_dbeta), float(y0.count), 0, 1,
+                  self.x_f32, code)
+        # into the activation's geometry (identity "normalisation": mean 0, rstd 1, gamma 1, beta 0, no ReLU), then the primal mask
+        _hip.call("cpc_bn_apply", self.yt.ptr(), _desc(y0, y0.desc), a_t.ptr(), _desc(a, a.desc), _hip.ptr(self.ident), _hip.ptr(self.ones),
+                  _hip.ptr(self.zeros), 0, self.x_f32, code)
+        _hip.call("cpc_relu_mask", a_t.ptr(), a.ptr(), a.rows * a.C, code)
+
+    def gp_terms(self, da: Grid, gp_grad):
+        """After the first backward pass (``da`` = its adjoint at this BatchNorm's output, before the ReLU mask; dy0 = at its input)
+        and the tangent pass: the penalty's gradient for the scale, gamma_bar = sum q y./gamma (q = masked da), and the terms the
+        input's adjoint gains in the last pass:  -(gamma/sigma) (<q a^.> xhat + <q xhat> a^.) - (<xhat a.>/sigma) delta_in."""
+        e = self.eng
+        p, code = e.model._param, e.code
+        C_, n = self.C, float(self.y0.count)
+        gamma = p[self.prefix + ".weight"].detach()
+        rstd = self.stats[1]
+        # S1 = sum q a^.  with a^. = y. / gamma: the backward reduction run on x := y., "statistics" (0, 1/gamma)
+        self.inv_gamma_stats[:C_].zero_()
+        self.inv_gamma_stats[C_:].copy_(1.0 / gamma)
+        _hip.call("cpc_bn_bwd_reduce", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.yt.ptr(), _desc(self.y0, self.y0.desc),
+                  _hip.ptr(self.inv_gamma_stats), _hip.ptr(e.slabs), 1, self.nb_bwd, self.x_f32, code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(self.s1), 1, C_, self.nb_bwd, 2 * C_, 1, 1, 0, 0)
+        gp_grad[self.prefix + ".weight"].copy_(self.s1)
+        self.coef[:C_].copy_(-(gamma * rstd) * self.s1 / n)                  # on xhat
+        self.coef[C_:2 * C_].copy_(-rstd * self.s2 / n)                      # on y. (= gamma a^.)
+        self.coef[2 * C_:].copy_(-rstd * self.t_dgamma / n)                  # on delta_in
+        _hip.call("cpc_bn_gp_cross", self.y0.ptr(), self.yt.ptr(), self.dy0.ptr(), self.xterm.ptr(), _desc(self.y0, self.y0.desc),
+                  _hip.ptr(self.stats), _hip.ptr(self.coef), self.x_f32, code)
 
 
 class _Block:
@@ -541,6 +649,50 @@ class _Block:
             _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
                       self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)
 
+    # ---- Wasserstein gradient penalty
+    def tangent(self):
+        """The block applied to the tangent of its input: bias-free convolutions, BatchNorm tangents, pooling and ReLU selections
+        taken from the primal pass."""
+        e, code = self.eng, self.eng.code
+        T = lambda grid: _twin(e, grid)
+        self.conv_a.forward(tangent=True)
+        if self.bn_a is not None:
+            self.bn_a.tangent()
+        if self.pool1 > 1:
+            _hip.call("cpc_maxpool2d_select", self.a_full.ptr(), T(self.a_full).ptr(), _desc(self.a_full, self.a_full.desc),
+                      T(self.a_a).ptr(), _desc(self.a_a, self.a_a.desc), self.pool1, 0, code)
+        self.conv_b.forward(tangent=True)
+        if self.bn_b is not None:
+            self.bn_b.tangent()
+        if self.pool2 > 1:
+            _hip.call("cpc_maxpool2d_select", self.main_full.ptr(), T(self.main_full).ptr(), _desc(self.main_full, self.main_full.desc),
+                      T(self.main).ptr(), _desc(self.main, self.main.desc), self.pool2, 0, code)
+        if self.blk.residual:
+            if self.rp is not None:
+                _hip.call("cpc_maxpool2d_select", self.gin.ptr(), T(self.gin).ptr(), _desc(self.gin, self.gin.desc), T(self.rp).ptr(),
+                          _desc(self.rp, self.rp.desc), self.blk.res_pool, 1 if self.in_f32 else 0, self.rp.code)
+            if self.res_conv is not None:
+                self.res_conv.forward(tangent=True)
+            out_t = T(self.out)
+            _hip.call("cpc_residual_add", T(self.main).ptr(), _desc(self.main, self.main.desc), T(self.res).ptr(),
+                      _desc(self.res, self.res.desc), out_t.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0, self.r_f32, code)
+            if not self.last:
+                _hip.call("cpc_relu_mask", out_t.ptr(), self.out.ptr(), self.out.rows * self.out.C, code)
+
+    def gp_grads(self, gp_grad):
+        """Penalty parts of this block's parameter gradients + the BatchNorms' second-order terms (between the first backward
+        pass, whose adjoints are still in the gradient grids, and the last one)."""
+        if isinstance(self.conv_a, _SepConv) or isinstance(self.conv_b, _SepConv):
+            raise NotImplementedError("gradient penalty through Conv2dSeparable")
+        self.conv_a.gp_wgrad(gp_grad)
+        self.conv_b.gp_wgrad(gp_grad)
+        if self.res_conv is not None:
+            self.res_conv.gp_wgrad(gp_grad)
+        if self.bn_b is not None:
+            self.bn_b.gp_terms(self.d_main_full if self.pool2 > 1 else self.d_main, gp_grad)
+        if self.bn_a is not None:
+            self.bn_a.gp_terms(self.d_a_full if self.pool1 > 1 else self.d_a, gp_grad)
+
     def backward(self):
         e, code = self.eng, self.eng.code
         first = not self.need_input_grad
@@ -596,8 +748,12 @@ class _Block:
 class ScalogramCPCEngine(CPCEngine):
     """CPCEngine whose encoder is a ScalogramResidualEncoder fed with (B, C, bins, frames) scalograms."""
 
-    def __init__(self, model, in_shape, device, dtype: torch.dtype):
+    def __init__(self, model, in_shape, device, dtype: torch.dtype, gradient_penalty: bool = False):
+        """``gradient_penalty``: also provide the gradient with respect to the input scalogram and the tangent pass the
+        Wasserstein gradient penalty needs (loss_and_grads(..., gradient_penalty=factor))."""
         enc, ar = model.encoder, model.autoregressive_model
+        self.gp_capable = bool(gradient_penalty)
+        self._twins, self._gp_phase = {}, 0
         self.model = model
         self.device = torch.device(device)
         self.dt = dtype
@@ -624,7 +780,7 @@ class ScalogramCPCEngine(CPCEngine):
         for i, blk in enumerate(blocks):
             last = i == len(blocks) - 1
             next_top = 0 if last else (blocks[i + 1].cfg['top_padding_1'] or 0)
-            b = _Block(self, i, blk, gin, in_f32, last, next_top)
+            b = _Block(self, i, blk, gin, in_f32, last, next_top, need_input_grad=True if (i == 0 and self.gp_capable) else None)
             self.blocks.append(b)
             gin, in_f32 = b.out, False
         out = self.blocks[-1].out
@@ -633,7 +789,8 @@ class ScalogramCPCEngine(CPCEngine):
         self.T = out.W
         if self.T < self.V + self.K:
             raise ValueError(f"scalogram gives {self.T} encoder frames, need visible+prediction = {self.V + self.K}")
-        d_in = None
+        d_in = self.x_grid.like(self.device) if self.gp_capable else None      # gradient w.r.t. the scalogram (penalty only)
+        self.d_x = d_in
         for b in self.blocks:
             b.allocate_grads(d_in)
             d_in = b.d_out
@@ -668,6 +825,106 @@ class ScalogramCPCEngine(CPCEngine):
     def _backward_encoder(self, x, grad_ready_hook=None):
         for b in reversed(self.blocks):
             b.backward()
+
+    # ------------------------------------------------------------------ Wasserstein gradient penalty
+    def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
+                       global_negatives=None, after_loss=None, gradient_penalty=None):
+        if gradient_penalty is None:
+            return super().loss_and_grads(x, softplus, regularization, all_timesteps, grad_ready_hook, global_negatives, after_loss)
+        return self._gp_step(x, softplus, regularization, all_timesteps, float(gradient_penalty), global_negatives, after_loss)
+
+    def _gp_step(self, x, softplus, regularization, all_timesteps, factor, global_negatives, after_loss):
+        """One train step with the Wasserstein gradient penalty (contrastive_estimation_training.py:141-161):
+        loss = InfoNCE + regulariser + factor * mean((|d sum(scores) / d x|_2 over channels - 1)^2), x the scalogram batch.
+        d penalty / d theta = d/d theta of the directional derivative of sum(scores) along v = d penalty / d (input gradient):
+          pass 1  backward of the summed scores (adjoints delta of every activation, g = delta at the input);
+          tangent pass of v (bias-free convolutions, BatchNorm tangents, primal ReLU / pooling selections);
+          penalty weight gradients (tangent input) x delta per convolution, BatchNorm second-order terms;
+          pass 3  the ordinary backward of the real loss, seeded additionally with sum(tangent targets) on the predictions and
+                  sum(tangent predictions) on the targets, the BatchNorm terms joining in on the way down.
+        DESIGN.md section 8 has the derivation; tests compare with the reference's own double backward (tests/golden/scalogram_model_gp)."""
+        if not self.gp_capable:
+            raise RuntimeError("this engine was built without gradient-penalty support (model.gradient_penalty_engine = True first)")
+        if softplus or global_negatives is not None:
+            raise NotImplementedError("the gradient penalty is implemented for linear scores with per-GPU negatives (the reference's "
+                                      "experiments with the penalty all use linear_score_function)")
+        if self.dt != torch.float32:
+            raise NotImplementedError("the gradient penalty runs in the exact-f32 mode (compute_dtype='fp32')")
+        if not hasattr(self.ctx, "tangent"):
+            raise NotImplementedError(f"no gradient-penalty tangent pass for {type(self.ctx).__name__}")
+        model, code = self.model, self.code
+        B, E, K, V, T, H = self.B, self.E, self.K, self.V, self.T, self.H
+        Ltop = self.geo.alloc[-1]
+        top = self.act[-1].view(B, Ltop, E)
+        dtop = self.dact[-1].view(B, Ltop, E)
+        if getattr(self, "gp_flat", None) is None:
+            self.gp_flat = torch.zeros_like(model._flat_grad)
+            self.gp_grad = {n: self.gp_flat[model._offset[n]:model._offset[n] + p_.numel()].view(p_.shape) for n, p_ in model.named_parameters()}
+            self.gp_partial = torch.zeros(256, device=self.device, dtype=torch.float32)
+            self.pred_t = torch.zeros_like(self.pred)
+        self.forward(x)                                                                   # pass 0
+        # ---- pass 1: adjoints of S = sum of the scores the loss is built from (all (b,k,b',k') pairs, or the equal-step ones)
+        pred3 = self.pred.view(B, K, E)
+        tg = top[:, T - K:T, :]
+        if all_timesteps:
+            seed_p = tg.sum((0, 1), keepdim=True).expand(B, K, E)
+            seed_t = pred3.sum((0, 1), keepdim=True).expand(B, K, E)
+        else:
+            seed_p = tg.sum(0, keepdim=True).expand(B, K, E)
+            seed_t = pred3.sum(0, keepdim=True).expand(B, K, E)
+        self.dact[-1].zero_()
+        self.dpred.view(B, K, E).copy_(seed_p)
+        dtop[:, T - K:T, :].copy_(seed_t)
+        self._gp_phase = 1
+        self.backward(x)
+        # ---- direction v = d penalty / d g and the penalty's value
+        x_t = _twin(self, self.x_grid)
+        npix = self.x_grid.B * self.x_grid.W * self.x_grid.H
+        nb = min(256, max(1, npix // 256))
+        self.gp_partial.zero_()
+        _hip.call("cpc_gp_direction", self.d_x.ptr(), x_t.ptr(), C.c_longlong(npix), self.x_grid.C, factor, _hip.ptr(self.gp_partial), nb)
+        # ---- tangent pass
+        self._gp_phase = 2
+        for b in self.blocks:
+            b.tangent()
+        top_t = _twin(self, self.blocks[-1].out).t
+        ct, coff, cstride = self.ctx.tangent(top_t)
+        _hip.gemm_nt(_hip.ptr(ct, coff), _hip.ptr(self.w_p), _hip.ptr(self.pred_t), B, K * E, H, H, H, K * E, code, a_rpi=1, a_item=cstride)
+        # ---- penalty parts of the parameter gradients (pass-1 adjoints are still in the gradient grids)
+        self.gp_flat.zero_()
+        for b in self.blocks:
+            b.gp_grads(self.gp_grad)
+        self.ctx.gp_grads(self.gp_grad)
+        # predictor: W_bar += (pass-1 adjoint of the predictions)^T x (tangent of c)
+        _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(ct, coff), _hip.ptr(self.gp_grad["prediction_model.weight"]), B, K * E, H,
+                     K * E, H, H, code, b_rpi=1, b_item=cstride, flags=_hip.GEMM_OUT_F32)
+        if self.use_aux:       # the slab reductions of the penalty's weight gradients (side stream) read buffers pass 3 reuses
+            torch.cuda.current_stream().wait_stream(self.aux)
+        # ---- pass 3: the real loss, plus the penalty's seeds on the primal stream
+        top_t3 = top_t.view(B, Ltop, E)
+        tg_t, pred_t3 = top_t3[:, T - K:T, :], self.pred_t.view(B, K, E)
+        if all_timesteps:
+            add_p = tg_t.sum((0, 1), keepdim=True).expand(B, K, E)
+            add_t = pred_t3.sum((0, 1), keepdim=True).expand(B, K, E)
+        else:
+            add_p = tg_t.sum(0, keepdim=True).expand(B, K, E)
+            add_t = pred_t3.sum(0, keepdim=True).expand(B, K, E)
+        add_p, add_t = add_p.clone(), add_t.clone()
+        self.dact[-1].zero_()
+        if all_timesteps:
+            self.nce_all_forward_backward(False, regularization)
+        else:
+            self.nce_forward_backward(False, regularization)
+        if after_loss is not None:
+            after_loss(self.nce_out)
+        self.dpred.view(B, K, E).add_(add_p)
+        dtop[:, T - K:T, :].add_(add_t)
+        self._gp_phase = 3
+        self.backward(x)
+        self._gp_phase = 0
+        model._flat_grad.add_(self.gp_flat)
+        self.nce_out[0:1].add_(self.gp_partial.sum() * (factor / npix))
+        return self.nce_out
 
 
 # =====================================================================================================================
@@ -754,6 +1011,31 @@ class _ArBlock:
             _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
                       self.out.ptr(), _desc(self.out, self.out.desc), self.oh, 0, 0, 0, code)
 
+    def tangent(self):
+        e, code = self.eng, self.eng.code
+        T = lambda grid: _twin(e, grid)
+        if self.pool > 1:
+            _hip.call("cpc_maxpool2d_select", self.gin.ptr(), T(self.gin).ptr(), _desc(self.gin, self.gin.desc), T(self.xp).ptr(),
+                      _desc(self.xp, self.xp.desc), self.pool, 0, code)
+        self.conv.forward(tangent=True)
+        if self.bn is not None:
+            self.bn.tangent()
+        if self.residual:
+            if self.rp is not None and self.rp is not self.xp:
+                _hip.call("cpc_maxpool2d_select", self.gin.ptr(), T(self.gin).ptr(), _desc(self.gin, self.gin.desc), T(self.rp).ptr(),
+                          _desc(self.rp, self.rp.desc), self.pool * self.stride, 0, code)
+            if self.res_conv is not None:
+                self.res_conv.forward(tangent=True)
+            _hip.call("cpc_residual_add", T(self.main).ptr(), _desc(self.main, self.main.desc), T(self.res).ptr(),
+                      _desc(self.res, self.res.desc), T(self.out).ptr(), _desc(self.out, self.out.desc), self.oh, 0, 0, 0, code)
+
+    def gp_grads(self, gp_grad):
+        self.conv.gp_wgrad(gp_grad)
+        if self.res_conv is not None:
+            self.res_conv.gp_wgrad(gp_grad)
+        if self.bn is not None:
+            self.bn.gp_terms(self.d_main, gp_grad)
+
     def backward(self):
         code = self.eng.code
         if self.residual:
@@ -839,6 +1121,20 @@ class ConvArGridContext:
         self.c32.copy_(out.t.view(out.B, out.Ha, out.C)[:, out.top + out.H - 1, :])
         return self.c32
 
+    # ---- Wasserstein gradient penalty: tangent of c, penalty parts of the parameter gradients
+    def tangent(self, top_t):
+        """``top_t``: tangent of the encoder's top buffer; returns (tensor, offset, item stride) of the tangent of c."""
+        e = self.eng
+        _twin(e, self.x0).t.view(e.B, e.V, e.E).copy_(self._z_rows(top_t))
+        for b in self.blocks:
+            b.tangent()
+        out = self.blocks[-1].out
+        return _twin(e, out).t, (out.top + out.H - 1) * out.C, out.Ha * out.C
+
+    def gp_grads(self, gp_grad):
+        for b in self.blocks:
+            b.gp_grads(gp_grad)
+
     def backward(self, dc):
         e = self.eng
         last = self.blocks[-1]
@@ -909,6 +1205,19 @@ class ResNetArContext:
     def c_operand(self):
         out = self.blocks[-1].out
         return out.t, out.top * out.C, out.W * out.Ha * out.C
+
+    # ---- Wasserstein gradient penalty (see ConvArGridContext)
+    def tangent(self, top_t):
+        e = self.eng
+        _twin(e, self.x0).t.view(e.B, e.V, e.E).copy_(self._z_rows(top_t))
+        for b in self.blocks:
+            b.tangent()
+        out = self.blocks[-1].out
+        return _twin(e, out).t, out.top * out.C, out.W * out.Ha * out.C
+
+    def gp_grads(self, gp_grad):
+        for b in self.blocks:
+            b.gp_grads(gp_grad)
 
     def c_float(self):
         self.c32.copy_(self._first_step(self.blocks[-1].out))

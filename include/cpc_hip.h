@@ -268,6 +268,26 @@ int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void*
  * relative) — the "bf16x3" precision of constant_q_transform.CQT. */
 int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream);
 
+/* ---- Wasserstein gradient penalty (contrastive_estimation_training.py:144-155: the gradient of the summed scores with respect
+ * to the preprocessed batch, its 2-norm over the channel axis pushed towards 1, differentiated again by loss.backward()) ----
+ * The penalty's parameter gradient is the parameter gradient of the directional derivative of the summed scores along
+ * v = d penalty / d (input gradient); it is computed as a tangent (forward-mode) pass of v through the network plus extra
+ * weight-gradient GEMMs and, at every train-mode BatchNorm, the second-order terms below.  The tangent
+ * pass reuses the forward entry points with bias-free operands and the PRIMAL activations as ReLU masks; these three calls are
+ * what it needs beyond them:
+ * cpc_maxpool2d_select: out = element of `sel` at the first maximum of `in` in every p x p window (a max pooling applied to a
+ *   tangent, selecting where the primal pooling selected); grids as for cpc_maxpool2d_fwd, `in` and `sel` share gi.
+ * cpc_gp_direction: g f32 [npix][C] = gradient of the summed scores w.r.t. the channels-last scalogram; writes
+ *   v = factor * 2 (|g| - 1) / |g| * g / npix (norm over the C channels of a pixel, :153) and per-block partial sums of
+ *   (|g| - 1)^2 (penalty = factor * sum / npix).
+ * cpc_bn_gp_cross: out = coef[c] * xhat + coef[C + c] * yt + coef[2C + c] * delta on the valid positions of grid gx, with
+ *   xhat = (x - stats[c]) * stats[C + c]: the terms a train-mode BatchNorm adds to the adjoint of its input under the penalty. */
+int cpc_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,
+                         void* stream);
+int cpc_gp_direction(const float* g, float* v, long long npix, int C, float factor, float* partial, int nblocks, void* stream);
+int cpc_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out, const int* gx, const float* stats, const float* coef,
+                    int x_f32, int dtype, void* stream);
+
 /* g[i] = y[i] > 0 ? g[i] : 0 for i < n (n % 4 == 0): ReLU backward on whole buffers where no fused epilogue applies. */
 int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream);
 

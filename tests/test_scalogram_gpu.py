@@ -293,7 +293,7 @@ def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
         assert _rel(sd[k.split("/", 1)[1]].float(), g[k]) < (1e-4 if dtype == "fp32" else 2e-2), k
     for run in meta["runs"]:
         if run.get("gp") is not None:
-            continue          # Wasserstein gradient penalty: oracle only so far (tests/test_oracle_golden.py); the trainer refuses it
+            continue          # Wasserstein gradient penalty: test_gradient_penalty_matches_reference
         pre, model = _build_scalogram_model(g, meta, dtype)
         ds = TensorAudioDataset(data, device=DEV)
         logger = _Logger()
@@ -325,6 +325,109 @@ def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
             sd = model.state_dict()
             for k in [k for k in g if k.startswith(run["tag"] + "/after/")]:
                 assert _rel(sd[k.split("/after/")[1]].float(), g[k]) < (2e-3 if dtype == "fp32" else 5e-2), k
+
+
+@pytest.mark.parametrize("fixture", ["scalogram_model_gp"])
+def test_gradient_penalty_matches_reference(golden_dir, fixture):
+    """wasserstein_gradient_penalty=True (reference :144-158, the double backward with respect to the preprocessed batch) on the
+    HIP path, exact-f32 mode: losses, every parameter gradient and the parameters after three steps against runs of the
+    reference itself (scalogram encoder with BatchNorm / residual blocks + BatchNorm ConvolutionalArModel, linear scores, both
+    loss branches)."""
+    g = _load(golden_dir, fixture + ".npz")
+    meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
+    B, K, H = meta["B"], meta["K"], meta["H"]
+    data = torch.from_numpy(g["data"])
+    ran = 0
+    for run in meta["runs"]:
+        if run.get("gp") is None:
+            continue
+        ran += 1
+        pre, model = _build_scalogram_model(g, meta, "fp32")
+        logger = _Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
+                                          score_function=SCORE[run["score"]], prediction_steps=K, ar_size=H, preprocessing=pre,
+                                          wasserstein_gradient_penalty=True, gradient_penalty_factor=run["gp"])
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=B, epochs=10, lr=run["lr"], num_workers=0, max_steps=run["steps"])
+        for i in range(run["steps"]):
+            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= 1e-4 * abs(run["loss"][i]) * (1 + 4 * i), (run["tag"], i,
+                                                                                                                logger.loss_meter.values)
+        if run["steps"] == 1:
+            keys = [k for k in g if k.startswith(run["tag"] + "/grad/")]
+            largest = max(float(np.abs(g[k]).max()) for k in keys)
+            for k in keys:
+                name = k.split("/grad/")[1]
+                got = dict(model.named_parameters())[name].grad
+                ref = torch.from_numpy(g[k]).double()
+                if ref.abs().max().item() < 1e-6 * largest:
+                    # a convolution bias in front of a train-mode BatchNorm: its true gradient is zero, both sides hold rounding
+                    # noise (measured 1e-7 ... 3e-7 of the largest gradient)
+                    assert got.abs().max().item() < 1e-5 * largest, (run["tag"], name)
+                    continue
+                l2 = ((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)).item()
+                assert l2 < 1e-3, (run["tag"], name, l2)                 # measured: <= 1.5e-5
+        else:
+            sd = model.state_dict()
+            for k in [k for k in g if k.startswith(run["tag"] + "/after/")]:
+                assert _rel(sd[k.split("/after/")[1]].float(), g[k]) < 2e-3, k
+    assert ran >= 3
+
+
+def test_gradient_penalty_plain_conv_context_against_oracle(golden_dir):
+    """The penalty with a ConvolutionalArModel WITHOUT BatchNorm (the reference's default context, ar_conv_default_dict: its
+    ReLU is fused into the convolution, so the tangent pass masks by the primal output; a gradient-penalty engine routes it to
+    the grid implementation) — no reference run exists for this combination: compared with the oracle's double backward."""
+    import copy
+    g = _load(golden_dir, "scalogram_model_gp.npz")
+    meta = copy.deepcopy(json.load(open(os.path.join(golden_dir, "scalogram_model_gp.json"))))
+    meta["ar"] = dict(meta["ar"], batch_norm=False)
+    B, K, H, V = meta["B"], meta["K"], meta["H"], meta["V"]
+    # fresh seeded parameters for the context network (the fixture's state_dict has BatchNorm entries)
+    blocks = copy.deepcopy(meta["blocks"])
+    for b in blocks:
+        b["kernel_size_1"], b["kernel_size_2"] = tuple(b["kernel_size_1"]), tuple(b["kernel_size_2"])
+    from cpc_audio_amd.audio_model import ConvolutionalArModel
+    torch.manual_seed(12)
+    pre = PreprocessingModule(cqt_dict=meta["cqt"], **meta.get("pre", {"phase": True}))
+    enc = ScalogramResidualEncoder(args_dict={'phase': True, 'blocks': blocks, 'activation_register': None}, preprocessing_module=pre)
+    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(dict(meta["ar"], activation_register=None)), enc_size=meta["E"], ar_size=H,
+                                       visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+    enc_state = {k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/encoder.")}
+    model.load_state_dict(enc_state, strict=False)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pre, model = pre.to(DEV), model.to(DEV)
+    data = torch.from_numpy(g["data"])
+    for all_t, reg, factor in ((False, 0.01, 2.0), (True, 0.0, 10.0)):
+        logger = _Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=reg, score_over_all_timesteps=all_t, score_function=SCORE["linear"],
+                                          prediction_steps=K, ar_size=H, preprocessing=pre, wasserstein_gradient_penalty=True,
+                                          gradient_penalty_factor=factor)
+        tr.verbose = False
+        model.load_state_dict(params)
+        random.seed(91)
+        from cpc_audio_amd.audio_dataset import FileBatchSampler
+        idx = [list(b) for b in FileBatchSampler([data.shape[0]], B, 1, True, verbose=False)][0]
+        random.seed(91)
+        tr.train(batch_size=B, epochs=1, lr=0.0, num_workers=0, max_steps=1)              # lr 0: parameters stay, gradients remain
+        with torch.no_grad():
+            scal = pre(data[idx].to(DEV).unsqueeze(1)).cpu()
+        oblocks = [dict(b) for b in blocks]
+        oblocks[0]["in_channels"] = 2             # phase=True: (log power, phase difference) channels
+        ot = O.OracleTrainer(params, V, K, score="linear", all_timesteps=all_t, regularization=reg, lr=0.0,
+                             scalogram=oblocks, conv_ar=meta["ar"], gradient_penalty_factor=factor)
+        loss, smax, grads = ot.loss_and_grads(scal)
+        assert abs(logger.loss_meter.values[0] - float(loss)) < 1e-4 * abs(float(loss)), (all_t, logger.loss_meter.values, float(loss))
+        largest = max(float(v.abs().max()) for v in grads.values() if v is not None)
+        for name, ref in grads.items():
+            got = dict(model.named_parameters())[name].grad.double().cpu()
+            if ref.abs().max().item() < 1e-6 * largest:
+                assert got.abs().max().item() < 1e-5 * largest, (all_t, name)
+                continue
+            l2 = ((got - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
+            assert l2 < 1e-3, (all_t, name, l2)
 
 
 def _cosines(model_a, model_b):
