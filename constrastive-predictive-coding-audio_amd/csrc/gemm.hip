@@ -1421,7 +1421,10 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
     }
 }
 
-int g_nt_stagger64 = 0;
+// start stagger of the 256x256 kernel (GemmNT::stagger) in 1/64 of a tile time: applied to launches with a ReLU-backward mask and
+// at least three rounds of tiles, whose every tile ends in a 2 x 32 MB burst (mask read + store) when all CUs run in step
+// (tools/nt_ab.py --stagger: layer-3 data gradient 285 -> 278 us, layer-2 1036 -> 1021 us; no gain without a mask)
+int g_nt_stagger64 = 32;
 
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
@@ -1459,7 +1462,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
-    if (big && g_nt_stagger64 > 0 && big_tiles * batch >= 3 * 256) {
+    if (big && g_nt_stagger64 > 0 && p.mask && big_tiles * batch >= 3 * 256) {
         // a tile takes about nk * 3600 + 20000 cycles; the largest phase (7) starts g_nt_stagger64 / 64 of that late
         const long long tile_cycles = (long long)(p.K / bk) * 3600 + 20000;
         q.stagger = (int)std::max<long long>(1, tile_cycles * g_nt_stagger64 / 64 / 7 / 4096);

@@ -81,8 +81,8 @@ for name, Lo, kw, s in LAYERS:
             _hip.lib().cpc_debug_set(1, 0)
         return run
 
-    fv = {"direct": lambda: fwd(0), "lds": lambda: fwd(_hip.GEMM_NO_PERS), "lds-lin": lambda: fwd(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
-    dv = {"direct": lambda: dgrad(0), "lds": lambda: dgrad(_hip.GEMM_NO_PERS), "lds-lin": lambda: dgrad(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
+    fv = {"default": lambda: fwd(0), "lds": lambda: fwd(_hip.GEMM_NO_PERS), "lds-lin": lambda: fwd(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
+    dv = {"default": lambda: dgrad(0), "lds": lambda: dgrad(_hip.GEMM_NO_PERS), "lds-lin": lambda: dgrad(_hip.GEMM_NO_PERS | _hip.GEMM_LINEAR_K)}
     for v in a.stagger:
         fv[f"st{v}"] = stag(fwd, v)
         dv[f"st{v}"] = stag(dgrad, v)
