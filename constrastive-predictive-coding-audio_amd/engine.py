@@ -528,12 +528,12 @@ class CPCEngine:
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             bname = f"encoder.layers.{l}.bias"
             flops = 2.0 * B * La[l] * cout * kw * cin
-            wg_mode = os.environ.get("CPC_WGRAD_STREAM", "1")
+            wg_mode = os.environ.get("CPC_WGRAD_STREAM", "0")
 
-            # The weight-gradient GEMM of layer l and the data-gradient GEMM of layer l both read dact[l] and are independent: the
-            # weight gradient goes to the side stream, where it runs beside the data-gradient chain of the main stream (the tiles
-            # of two kernels interleave on the CUs: their epilogue bursts no longer coincide and the partly filled last round of
-            # one is filled by the other; measured 4.72 -> 4.69 ms per step; CPC_WGRAD_STREAM=0 keeps it on the main stream)
+            # The weight-gradient GEMM of layer l and the data-gradient GEMM of layer l both read dact[l] and are independent.
+            # CPC_WGRAD_STREAM=1 issues the weight gradient on the side stream, beside the data-gradient chain (the tiles of the
+            # two kernels interleave on the CUs): 4.72 -> 4.69 ms per step, but every kernel then runs longer by itself and the
+            # per-kernel roofline figures of bench.py no longer mean much — not the default for 0.6 %.
             def wgrad_call():
                 _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
                           La[l], self.nsplit[l], C.c_longlong(self.guard[l - 1]), code,
