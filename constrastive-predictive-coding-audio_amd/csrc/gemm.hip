@@ -348,8 +348,10 @@ __device__ __forceinline__ int direct_b_col(int r) {
     return (r & ~63) + 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3);
 }
 
-template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false, bool DIRECT = false>
+template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false, bool DIRECT = false, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
+    // DBG: timing probes for tools/nt_probe.py (cpc_debug_set key 4; never in the product path, the results are garbage):
+    // 1 = K loop without its LDS-DMA requests, 2 = without its MFMAs, 16 = only the B tile is requested
     static_assert(!DIRECT || (DMA && !C1 && sizeof(T) == 2 && sizeof(TO) == 2 && TJ == 4), "direct epilogue: bf16 LDS-DMA variants");
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
@@ -542,13 +544,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
         switch (idx) {                                                                                           \
-        case 0: NT_DMA1(ga0 + (k0), da); break;                                                                  \
+        case 0: if constexpr (!(DBG & 16)) NT_DMA1(ga0 + (k0), da); break;                                       \
         case 1: NT_DMA1(gb0 + (k0), db); break;                                                                  \
-        case 2: NT_DMA1(ga1 + (k0), da + 1024); break;                                                           \
+        case 2: if constexpr (!(DBG & 16)) NT_DMA1(ga1 + (k0), da + 1024); break;                                \
         case 3: NT_DMA1(gb1 + (k0), db + 1024); break;                                                           \
-        case 4: NT_DMA1(ga2 + (k0), da + 2048); break;                                                           \
+        case 4: if constexpr (!(DBG & 16)) NT_DMA1(ga2 + (k0), da + 2048); break;                                \
         case 5: NT_DMA1(gb2 + (k0), db + 2048); break;                                                           \
-        case 6: NT_DMA1(ga3 + (k0), da + 3072); break;                                                           \
+        case 6: if constexpr (!(DBG & 16)) NT_DMA1(ga3 + (k0), da + 3072); break;                                \
         case 7: NT_DMA1(gb3 + (k0), db + 3072); break;                                                           \
         default: break;                                                                                          \
         }                                                                                                        \
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         if (DO_DMA) { if (++kj == taps) { kj = 0; kb += BK; } }                                                  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
-                mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));                                    \
+                if constexpr (!(DBG & 2)) mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));          \
                 NT_READ1(i * TJ + j, fa1, fb1, aA1, aB1, cur);                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }                                                                                                    \
@@ -586,8 +588,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         __syncthreads();                                                                                         \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
-                mfma_chunk<T>(acc[i][j], as_uint4(fb1[j]), as_uint4(fa1[i]));                                    \
-                if (DO_DMA) NT_DMA_PIECE(i * TJ + j, t & 1, k2);                                                 \
+                if constexpr (!(DBG & 2)) mfma_chunk<T>(acc[i][j], as_uint4(fb1[j]), as_uint4(fa1[i]));          \
+                if constexpr (!(DBG & 1)) { if (DO_DMA) NT_DMA_PIECE(i * TJ + j, t & 1, k2); }                   \
                 if (DO_READ) NT_READ1(i * TJ + j - (DO_DMA ? 8 : 0), fa0, fb0, aA0, aB0, nxt);                   \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }                                                                                                    \
@@ -1425,6 +1427,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
 // at least three rounds of tiles, whose every tile ends in a 2 x 32 MB burst (mask read + store) when all CUs run in step
 // (tools/nt_ab.py --stagger: layer-3 data gradient 285 -> 278 us, layer-2 1036 -> 1021 us; no gain without a mask)
 int g_nt_stagger64 = 32;
+int g_nt_probe = 0;
 
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
@@ -1497,6 +1500,9 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
             if (of32) NT_LAUNCH(bf16_t, float, 2, 4, 8, 4, 512, q);
+            else if (direct && g_nt_probe == 1) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 1>), grid, dim3(512), 0, stream, q);
+            else if (direct && g_nt_probe == 2) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 2>), grid, dim3(512), 0, stream, q);
+            else if (direct && g_nt_probe == 16) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 16>), grid, dim3(512), 0, stream, q);
             else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true>), grid, dim3(512), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {

@@ -1,0 +1,56 @@
+"""Timing probes of the K loop of the 256 x 256 NT kernel (register epilogue): what does a 64-deep stage cost without its LDS-DMA
+requests, without its MFMAs, with only the B tile requested?  Plain-row GEMMs,
+M = 7 rounds of tiles, N = 512; the slope between two K gives the per-stage cost of each variant.  Results of the probes are garbage
+(cpc_debug_set key 4); the default launch is bit-exact.
+
+    python tools/nt_probe.py [--K 2048,8192]"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cpc_audio_amd import _hip
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--K", type=lambda t: [int(v) for v in t.split(",")], default=[2048, 8192])
+ap.add_argument("--N", type=int, default=512)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--rounds", type=int, default=5)
+a = ap.parse_args()
+dev, bf, P = "cuda:0", torch.bfloat16, _hip.ptr
+N = a.N
+M = 256 * 128 * 7 * 512 // N          # 7 rounds of 256 tiles
+out = torch.zeros(M * N, device=dev, dtype=bf)
+NAMES = {0: "full", 1: "no DMA", 2: "no MFMA", 16: "B requests only"}
+
+
+def timed(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / a.iters)
+    return sorted(ts)[len(ts) // 2]
+
+
+res = {}
+for K in a.K:
+    A = torch.randn(M * K, device=dev).to(bf)
+    Bt = torch.randn(N * K, device=dev).to(bf)
+    line = f"K={K:5d} us per round of tiles:"
+    for probe, name in NAMES.items():
+        _hip.lib().cpc_debug_set(4, probe)
+        t = timed(lambda: _hip.gemm_nt(P(A), P(Bt), P(out), M, N, K, K, K, N, 1)) * 1e3 / 7
+        res[(K, probe)] = t
+        line += f"  {name}: {t:7.2f}"
+    _hip.lib().cpc_debug_set(4, 0)
+    print(line, flush=True)
+    del A, Bt
+if len(a.K) >= 2:
+    k0, k1 = a.K[0], a.K[-1]
+    print("per 64-deep stage: " + "  ".join(f"{name}: {(res[(k1, p)] - res[(k0, p)]) / ((k1 - k0) / 64):.3f} us" for p, name in NAMES.items()))
