@@ -303,6 +303,8 @@ def main():
             # encoder layer 1 (C_in = 1): writes its [B][L_alloc][512] output once, reads 4 B per input sample
             esz = 2 if args.dtype == "bf16" else 4
             nbytes = float(B) * eng.geo.alloc[0] * eng.channels[0] * esz + float(B) * eng.L_eff * 4
+            if eng.act_bits[0] is not None:                       # + the sign-bit mask of the output, one bit per element
+                nbytes += float(B) * eng.geo.alloc[0] * eng.channels[0] / 8
             cn, cms = sum(v[0] for v in c1), sum(v[1] for v in c1)
             gbs = nbytes * cn / (cms * 1e-3) / 1e9
             line["hbm_kernel"] = {"kernel": "conv1_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0,

@@ -51,13 +51,14 @@ _SIGNATURES = {
     "cpc_gemm_tn": ([C.POINTER(GemmTNArgs), _P], _I),
     "cpc_reduce_slabs": ([_P, _P, _I, _I, _I, _L, _I, _L, _L, _L, _P], _I),
     "cpc_colsum": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
-    "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P], _I),
+    "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P], _I),
+    "cpc_sign_bits": ([_P, _P, _L, _I, _P], _I),
     "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
     "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
-    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P], _I),
     "cpc_conv_dgrad_conv1_floats": ([_I, _I, _I, _I, _I, _I], _L),
-    "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P, _P], _I),
     "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
@@ -128,7 +129,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 2:
+        if handle.cpc_abi_version() != 3:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -42,18 +42,29 @@ __device__ __forceinline__ void load8<float>(const float* src, float* v) {
 }
 
 // grid: (ceil(L_alloc / C1_FPOS), B).  Threads: lanes_per_row = C/8 lanes cover one output row; 256/lanes_per_row rows
-// are produced per pass.
-template <typename T, int KW, int C1_FPOS>
+// are produced per pass.  WROW (C = 512): a row is exactly one wave, so the row index, its validity and its address offset are
+// wave-uniform (scalar registers and branches instead of per-lane ones).  BITS (needs WROW): y_bits, the sign-bit mask of y
+// (include/cpc_hip.h at cpc_sign_bits) — the waves then take CONTIGUOUS blocks of rows (wave w rows [w RPW, (w+1) RPW)) instead of
+// interleaved ones, so that a wave's bytes are one contiguous piece of memory: collected in its own slice of LDS and written as
+// 16-byte chunks at the end, no block barrier, no byte store per row.
+constexpr int C1_FPOS = 256;
+
+template <typename T, int KW, bool WROW, bool BITS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int C,
-                                                        int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu) {
+                                                        int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu,
+                                                        unsigned char* __restrict__ y_bits) {
+    static_assert(!BITS || WROW, "sign bits: one wave per row");
     const int kw = KW > 0 ? KW : kw_rt;
     __shared__ float xs[C1_FPOS * 8 + C1_MAXK + 8];     // stride <= 8 supported
+    __shared__ __attribute__((aligned(16))) unsigned char bimg[BITS ? C1_FPOS * 64 : 16];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * C1_FPOS;
     const int tid = threadIdx.x;
-    const int lpr = C / 8;
-    const int cg = tid % lpr, rl = tid / lpr, nrl = 256 / lpr;
+    const int lpr = WROW ? 64 : C / 8;
+    const int cg = tid % lpr, nrl = 256 / lpr;
+    const int rl = WROW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / lpr;
+    constexpr int RPW = C1_FPOS / 4;
 
     // stage the input window of positions [t0, t0 + C1_FPOS): samples [t0*stride, (t0+C1_FPOS-1)*stride + kw)
     const int npos = min(C1_FPOS, L_valid - t0);          // valid positions in this block (may be <= 0)
@@ -73,9 +84,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 
     T* yb = y + ((long long)b * L_alloc + t0) * C + cg * 8;
     const int nrows = min(C1_FPOS, L_alloc - t0);
-    for (int r = rl; r < nrows; r += nrl) {
-        float v[8];
+    const int niter = BITS ? RPW : (nrows - rl + nrl - 1) / nrl;
+    // Pad rows are stored from their own branch (no per-row zero fill of v).  Tried against this loop and not faster: one v_max_f32 per
+    // value instead of relu_f's compare / select pair (with a NaN put-back), and a persistent kernel that streams the rows in memory
+    // order with scalar loads of the input samples (370 us against 212 for 956 MB; a plain fill of the buffer takes 137).
+    for (int k = 0; k < niter; ++k) {
+        const int r = BITS ? rl * RPW + k : rl + k * nrl;
+        if (r >= nrows) break;
+        unsigned b8 = 0;
         if (r < npos) {
+            float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = br[e];
 #pragma unroll
@@ -88,11 +106,29 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
             }
-        } else {
+            store8<T>(yb + (long long)r * C, v);
+            if constexpr (BITS) {
+                if (relu) {                                    // relu_f output > 0 <=> its bit pattern is not zero
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;      // pad rows are written as zeros
+                    for (int e = 7; e >= 0; --e) b8 = (b8 << 1) | relu_positive_bit(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b8 |= (v[e] > 0.f ? 1u << e : 0u);
+                }
+            }
+        } else {
+            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // pad rows are written as zeros
+            store8<T>(yb + (long long)r * C, z);
         }
-        store8<T>(yb + (long long)r * C, v);
+        if constexpr (BITS) bimg[r * 64 + cg] = (unsigned char)b8;
+    }
+    if constexpr (BITS) {
+        // wave rl wrote rows [rl RPW, ...) itself; the LDS executes a wave's operations in order
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int r0 = rl * RPW, nb = (min(nrows, r0 + RPW) - r0) * 64;
+        unsigned char* dst = y_bits + ((long long)b * L_alloc + t0 + r0) * 64;
+        for (int i = cg * 16; i < nb; i += 64 * 16) *(uint4*)(dst + i) = *(const uint4*)(bimg + r0 * 64 + i);
     }
 }
 
@@ -173,17 +209,16 @@ static bool c1_ok(int C, int stride, int kw) {
 }
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream) {
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream) {
     if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid) return CPC_EINVAL;
-    // output positions per workgroup: the 88 weight / bias registers of a thread are loaded once per workgroup (A/B switch)
-    static const int fpos = getenv("CPC_C1_FPOS") ? atoi(getenv("CPC_C1_FPOS")) : 256;
-    dim3 grid((L_alloc + fpos - 1) / fpos, B);
+    if (y_bits && (C != 512 || (uintptr_t)y_bits % 16)) return CPC_EINVAL;        // sign bits: one wave per row (see the kernel)
+    // 256 output positions per workgroup: the 88 weight / bias registers of a thread are loaded once per workgroup
+    dim3 grid((L_alloc + C1_FPOS - 1) / C1_FPOS, B);
 #define LAUNCH(T, KWT) \
     do { \
-        if (fpos == 64) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 64>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
-        else if (fpos == 128) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 128>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
-        else if (fpos == 256) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, 256>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu); \
-        else return CPC_EINVAL; \
+        if (y_bits) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, true>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
+        else if (C == 512) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
+        else hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, false, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
     } while (0)
     if (dtype == CPC_DTYPE_BF16) {
         if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);

@@ -15,7 +15,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 2; }
+int cpc_abi_version(void) { return 3; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -77,10 +77,15 @@ int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nbl
 }
 
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw, long long ldx,
-                  int L_valid, int L_alloc, int relu, int dtype, void* stream) {
+                  int L_valid, int L_alloc, int relu, int dtype, void* y_bits, void* stream) {
     if (!x || !w || !y) return CPC_EINVAL;
     if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
-    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, relu, dtype, (hipStream_t)stream);
+    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, relu, dtype, (unsigned char*)y_bits, (hipStream_t)stream);
+}
+
+int cpc_sign_bits(const void* x, void* bits, long long n, int dtype, void* stream) {
+    if (!x || !bits || n <= 0 || n % 32) return CPC_EINVAL;
+    return launch_sign_bits(x, (unsigned char*)bits, n, dtype, (hipStream_t)stream);
 }
 
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx, int L_valid,
@@ -109,7 +114,7 @@ int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, i
 }
 
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
-                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, void* stream) {
+                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, const void* x_act_bits, void* stream) {
     if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;
     (void)Lin_valid;   // positions >= Lin_valid receive zeros because the pad rows of dy are zero
     const int D = (kw + stride - 1) / stride;
@@ -117,6 +122,7 @@ int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void*
     GemmNT p = {};
     p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);   // D-1 zero guard rows precede the buffer
     p.Bt = w_dgrad; p.C = dx; p.bias = nullptr; p.mask = x_act;
+    p.mask_bits = (const unsigned char*)x_act_bits;
     p.M = B * Lout_alloc; p.N = stride * Cin; p.K = D * Cout;
     p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
     p.flags = dtype == CPC_DTYPE_F32 ? GEMM_OUT_F32 : 0;
@@ -131,14 +137,15 @@ long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc
 
 int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
                          int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
-                         long long dy_head, int dtype, void* stream) {
-    if (!dy || !w_dgrad || !x_act || !x || !slabs || B <= 0 || Lout_alloc <= 0 || dtype != CPC_DTYPE_BF16) return CPC_EINVAL;
+                         long long dy_head, int dtype, const void* x_act_bits, void* stream) {
+    if (!dy || !w_dgrad || !(x_act || x_act_bits) || !x || !slabs || B <= 0 || Lout_alloc <= 0 || dtype != CPC_DTYPE_BF16) return CPC_EINVAL;
     if (Cin % 256 || kw1 < 1 || kw1 > 15 || stride1 < 1 || L1_valid < 1 || kw <= 0 || stride <= 0) return CPC_EINVAL;
     const int D = (kw + stride - 1) / stride;
     if (dy_head < (long long)(D - 1) * Cout) return CPC_EINVAL;
     GemmNT p = {};
     p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);
     p.Bt = w_dgrad; p.C = slabs /* not written */; p.bias = nullptr; p.mask = x_act;
+    p.mask_bits = (const unsigned char*)x_act_bits;
     p.M = B * Lout_alloc; p.N = stride * Cin; p.K = D * Cout;
     p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
     p.flags = GEMM_EPI_CONV1;

@@ -30,7 +30,13 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 
 // relu as torch computes it: a NaN stays a NaN (fmaxf(NaN, 0) = 0 would swallow it, and with it the trainer's NaN guard,
 // contrastive_estimation_training.py:124-133)
-__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+// ... and -0 becomes +0, so that a relu output is > 0 exactly when its bit pattern is not zero (relu_positive_bit: what the
+// sign-bit masks of include/cpc_hip.h are made of, two integer operations per element)
+__device__ __forceinline__ float relu_f(float v) { return v <= 0.f ? 0.f : v; }
+__device__ __forceinline__ unsigned relu_positive_bit(float relu_out) {
+    const unsigned u = __builtin_bit_cast(unsigned, relu_out);
+    return u < 1u ? u : 1u;
+}
 
 // Store 4 consecutive values held as f32 into a T* (8 B for bf16, 16 B for f32). dst must be aligned to that size.
 __device__ __forceinline__ void store4(float* dst, f32x4 v) { *(f32x4*)dst = v; }

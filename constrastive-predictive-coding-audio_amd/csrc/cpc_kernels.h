@@ -23,6 +23,10 @@ struct GemmNT {
     void* C;              // [M][N]
     const float* bias;    // [N] or null
     const void* mask;     // same addressing/type as C's storage dtype; out = mask > 0 ? out : 0  (relu backward); or null
+    // The same mask as one byte per 8 elements (bit e of byte i = element 8 i + e of the mask array is > 0; cpc_sign_bits makes it),
+    // addressed by the C element offset / 8.  When set it replaces `mask` in the 256x256 bf16 LDS-staged epilogues: the tile's 8 KiB of
+    // bits are fetched by LDS-DMA before the K loop starts, so the epilogue reads no mask from memory at all.
+    const unsigned char* mask_bits = nullptr;
     int M, N, K;
     long long lda, ldb, ldc;
     int a_rpi; long long a_item;
@@ -82,7 +86,7 @@ int launch_cast2d_batch(const void* jobs, int njobs, int dtype, hipStream_t stre
 int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, hipStream_t stream);
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream);
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
 int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,
@@ -104,6 +108,7 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
 long long nce_eval_workspace_floats(int B, int K);
 int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps,
                     int accumulate, hipStream_t stream);
+int launch_sign_bits(const void* x, unsigned char* bits, long long n, int dtype, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
                 float grad_scale, const float* skip, hipStream_t stream);
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,

@@ -360,7 +360,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     constexpr int NA = TBM * 8 / NTHR, NB = TBN * 8 / NTHR, RSTEP = NTHR / 8;     // staged chunks per thread, row step
     constexpr int EPI_RS = TBN * 2 + 16;                                            // bf16 output tile row stride in LDS
     constexpr int EPI_BYTES = sizeof(TO) == 2 ? TBM * EPI_RS + (C1 ? 2 * TBM * 32 : 0) : 0;
-    constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    constexpr int CORE_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    // 256x256 bf16 LDS-staged epilogues: room for the tile's sign-bit mask (GemmNT::mask_bits), TBM rows x TBN / 8 bytes, fetched by
+    // LDS-DMA before the K loop starts so that the epilogue finds it in LDS
+    constexpr bool BITS_IN_LDS = DMA && !DIRECT && sizeof(TO) == 2 && TI == 8 && TBN == 256;
+    constexpr int BITS_OFF = CORE_BYTES;
+    constexpr int LDS_BYTES = CORE_BYTES + (BITS_IN_LDS ? TBM * (TBN / 8) : 0);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -597,6 +603,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         if (DO_READ) NT_WAIT_SET(fa0, fb0);                                                                      \
     } while (0)
         static_assert(TI * TJ >= 8 + NFRAG, "block 1 must have room for 8 DMA pieces and one fragment set");
+        if constexpr (BITS_IN_LDS) {
+            if (p.mask_bits) {
+                // tile rows r, 32 bytes each: one DMA instruction = 8 rows x (8 lanes x 4 B); wave w fetches rows 32 w .. 32 w + 31.
+                // Older than every stage request of this tile, so the first vmcnt(0) of the K loop covers it.
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = (wave_u * 4 + k) * 8 + (lane >> 3);
+                    const int m = min(m0 + r, p.M - 1);
+                    const unsigned char* src = p.mask_bits + (((long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n0) >> 3) + (lane & 7) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds3 + BITS_OFF + (wave_u * 4 + k) * 256), 4, 0, 0);
+                }
+            }
+        }
         NT_DMA_STAGE(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -684,7 +704,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     vw[0] = 0u; vw[1] = 0u; vw[2] = 0u; vw[3] = 0u;
                 }
                 uint4* dst = (uint4*)(Cb + off[i] + 32 * pr);
-                if (full || (m0 + (wm * TI + i) * 16 + frow < p.M && nb + 32 * pr < p.N)) *dst = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                if (full || (m0 + (wm * TI + i) * 16 + frow < p.M && nb + 32 * pr < p.N)) {
+                    *dst = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
             }
         }
         return;
@@ -701,8 +723,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             const int n = n0 + cc * 8;
             // ReLU-backward mask: all of a thread's mask chunks are requested here, before the accumulators go to LDS, so the
             // tile pays the HBM latency once and under the LDS writes (the fragment registers of the K loop are free by now)
+            // With GemmNT::mask_bits the mask comes as ONE BYTE per 8 elements (bit e = element e of the chunk is > 0; written by
+            // the kernel that produced the activation): 1/16 of the bytes, and the 2 x 32 MB burst (mask read + store) that every
+            // round of tiles ends in loses its read half.  Same decision per element, bit-identical results.
             uint4 mk[NPASS];
-            if (Mb && n < p.N) {
+            unsigned mbits[NPASS];
+            const unsigned char* Mbits = p.mask_bits;
+            if (Mbits && n < p.N) {
+                if constexpr (BITS_IN_LDS) {
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) mbits[q] = lds[BITS_OFF + (rr + q * RPP) * (TBN / 8) + cc];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NPASS; ++q) {
+                        const int m = min(m0 + rr + q * RPP, p.M - 1);
+                        mbits[q] = Mbits[((long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n) >> 3];
+                    }
+                }
+            } else if (Mb && n < p.N) {
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
                     const int m = min(m0 + rr + q * RPP, p.M - 1);
@@ -767,14 +805,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     for (int q = 0; q < NPASS; ++q) {
                         const int r = rr + q * RPP;
                         uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
-                        const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
                         unsigned vw[4] = {v.x, v.y, v.z, v.w};
+                        if (Mbits) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned lo = mw[e] & 0xffffu, hi = mw[e] >> 16;
-                            const unsigned keep = ((lo != 0u && lo < 0x8000u) ? 0xffffu : 0u) |
-                                                  ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
-                            vw[e] &= keep;
+                            for (int e = 0; e < 4; ++e)
+                                vw[e] &= ((mbits[q] >> (2 * e)) & 1u ? 0xffffu : 0u) | ((mbits[q] >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                        } else {
+                            const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo = mw[e] & 0xffffu, hi = mw[e] >> 16;
+                                const unsigned keep = ((lo != 0u && lo < 0x8000u) ? 0xffffu : 0u) |
+                                                      ((hi != 0u && hi < 0x8000u) ? 0xffff0000u : 0u);
+                                vw[e] &= keep;
+                            }
                         }
                         *(uint4*)(lds + r * EPI_RS + cc * 16) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                     }
@@ -787,7 +831,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     if (m >= p.M) break;
                     const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
                     uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
-                    if (Mb) {
+                    if (Mbits) {
+                        unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            vw[e] &= ((mbits[q] >> (2 * e)) & 1u ? 0xffffu : 0u) | ((mbits[q] >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                        v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                    } else if (Mb) {
                         // bf16 > 0  <=>  sign bit clear and not zero
                         const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
                         unsigned vw[4] = {v.x, v.y, v.z, v.w};
@@ -1465,7 +1515,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
-    if (big && g_nt_stagger64 > 0 && p.mask && big_tiles * batch >= 3 * 256) {
+    if (big && g_nt_stagger64 > 0 && (p.mask || p.mask_bits) && big_tiles * batch >= 3 * 256) {
         // a tile takes about nk * 3600 + 20000 cycles; the largest phase (7) starts g_nt_stagger64 / 64 of that late
         const long long tile_cycles = (long long)(p.K / bk) * 3600 + 20000;
         q.stagger = (int)std::max<long long>(1, tile_cycles * g_nt_stagger64 / 64 / 7 / 4096);
@@ -1485,7 +1535,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     } while (0)
     if (p.flags & GEMM_EPI_CONV1) {
         // fused layer-1 weight gradient: only the 256x256 LDS-DMA kernel with the LDS-staged epilogue has that variant
-        if (!(big && dma && (q.flags & GEMM_WIDE_EPI) && p.mask && batch == 1 && p.c1_x && p.c1_slabs && p.c1_sub > 0 &&
+        if (!(big && dma && (q.flags & GEMM_WIDE_EPI) && (p.mask || p.mask_bits) && batch == 1 && p.c1_x && p.c1_slabs && p.c1_sub > 0 &&
               p.N % p.c1_sub == 0 && (p.N / p.c1_sub) % 256 == 0 && p.c1_kw >= 1 && p.c1_kw <= 15 && p.c1_rpi > 0))
             return CPC_EINVAL;
         hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, true>), grid, dim3(512), 0, stream, q);
@@ -1496,7 +1546,11 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     // (measured, tools/nt_ab.py: conv forward launches +4.5 ... 9 %; with a ReLU-backward mask the 64-byte row segments of the
     // mask reads cost what the missing LDS round trip saves, so masked launches keep the LDS-staged epilogue)
     const bool direct = fast && dma && dtype == CPC_DTYPE_BF16 && (q.flags & GEMM_WIDE_EPI) && !(p.flags & GEMM_NO_PERS) &&
-                        (!p.bias || (uintptr_t)p.bias % 16 == 0) && (!p.mask || (p.flags & GEMM_DIRECT_MASK));
+                        (!p.bias || (uintptr_t)p.bias % 16 == 0) && !p.mask_bits && (!p.mask || (p.flags & GEMM_DIRECT_MASK));
+    // the byte-per-8-elements masks exist in the 256x256 bf16 kernels with the LDS-staged epilogue only
+    if (p.mask_bits && !(big && dma && dtype == CPC_DTYPE_BF16 && !of32 && (q.flags & GEMM_WIDE_EPI) && p.N % 256 == 0 && p.ldc % 32 == 0 &&
+                         p.c_item % 32 == 0 && p.c_batch % 32 == 0 && (uintptr_t)p.mask_bits % 4 == 0))
+        return CPC_EINVAL;
     if (dtype == CPC_DTYPE_BF16) {
         if (big) {
             if (of32) NT_LAUNCH(bf16_t, float, 2, 4, 8, 4, 512, q);

@@ -310,3 +310,43 @@ int launch_relu_row_bwd(const float* dc, const void* y, void* dy, int B, int C, 
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
+
+// ---- sign-bit masks (include/cpc_hip.h, cpc_sign_bits): out[i] bit e = x[8 i + e] > 0.  A block turns 8192 elements into 1 KiB:
+// four passes in which thread t takes the 8 elements 2048 q + 8 t (16-byte loads, contiguous over the wave) and writes byte 256 q + t.
+template <typename T>
+__global__ __launch_bounds__(256) void sign_bits_kernel(const T* __restrict__ x, unsigned char* __restrict__ out, long long n8) {
+    const long long nchunk = (n8 + 1023) / 1024;
+    for (long long c = blockIdx.x; c < nchunk; c += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long i = c * 1024 + q * 256 + threadIdx.x;          // 8-element group
+            if (i >= n8) break;
+            unsigned b8 = 0;
+            if constexpr (sizeof(T) == 2) {
+                const uint4 v = *(const uint4*)(x + i * 8);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // bf16 > 0  <=>  not zero and sign clear  <=>  (h - 1) < 0x7fff
+                    b8 |= (((w4[e] & 0xffffu) - 1u) < 0x7fffu ? 1u : 0u) << (2 * e);
+                    b8 |= (((w4[e] >> 16) - 1u) < 0x7fffu ? 1u : 0u) << (2 * e + 1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b8 |= ((float)x[i * 8 + e] > 0.f ? 1u : 0u) << e;
+            }
+            out[i] = (unsigned char)b8;
+        }
+    }
+}
+
+int launch_sign_bits(const void* x, unsigned char* bits, long long n, int dtype, hipStream_t stream) {
+    if (n % 32 || ((uintptr_t)x % 16) || ((uintptr_t)bits % 4)) return CPC_EINVAL;
+    const long long n8 = n / 8;
+    const unsigned grid = (unsigned)std::min<long long>((n8 + 1023) / 1024, 256 * 32);
+    if (dtype == CPC_DTYPE_BF16) hipLaunchKernelGGL(sign_bits_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, bits, n8);
+    else if (dtype == CPC_DTYPE_F32) hipLaunchKernelGGL(sign_bits_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, bits, n8);
+    else return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

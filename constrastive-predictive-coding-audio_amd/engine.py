@@ -167,6 +167,20 @@ class CPCEngine:
                 self._keep.append(full)
                 store.append(view)
             self.guard.append(g_el)
+        # Sign-bit mask of layer 1's output (include/cpc_hip.h, cpc_sign_bits): act[0] > 0 as one byte per 8 elements, written by the
+        # layer-1 forward kernel and read by the data gradient of layer 2 (the fused one) in place of act[0]: the tile's 8 KiB of
+        # bits arrive by LDS-DMA before its K loop, so the epilogue of a tile reads no mask from memory (it used to end in a 32 MB
+        # burst per round of tiles; 0.96 GB of the launch's traffic).  Measured (tools/bits_ab.py, B = 256): that launch 1 035 ->
+        # 950 us, layer-1 forward +20 us.  For the deeper layers the same trade is even (the forward GEMMs' epilogues pay 2-6 % for
+        # writing the bits — one workgroup per CU, nothing to hide an epilogue instruction behind — and a separate kernel costs what
+        # the data gradients gain), so they keep reading their masks from the activations.  CPC_MASK_BITS=0: plain masks (A/B).
+        self.act_bits: List[Optional[torch.Tensor]] = [None] * n
+        if (dt == torch.bfloat16 and os.environ.get("CPC_MASK_BITS", "1") != "0" and n >= 2 and self.channels[0] == 512
+                and _hip.nt_tile(self.code, B * La[1], self.strides[1] * 512, self.geo.taps[1] * self.channels[1]) == 256
+                and self.guard[0] % 128 == 0):
+            full = torch.zeros((2 * self.guard[0] + B * La[0] * 512) // 8, device=dev, dtype=torch.uint8)
+            self._keep.append(full)
+            self.act_bits[0] = full[self.guard[0] // 8:]
         # weight operand layouts (storage dtype)
         self.w_fwd: List[Optional[torch.Tensor]] = [None] * n
         self.w_dgrad: List[Optional[torch.Tensor]] = [None] * n
@@ -333,7 +347,7 @@ class CPCEngine:
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
         _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
-                  1 if self.n > 1 else 0, code)
+                  1 if self.n > 1 else 0, code, _hip.ptr(self.act_bits[0]))
         for l in range(1, self.n):
             _hip.call("cpc_conv_fwd", _hip.ptr(self.act[l - 1]), _hip.ptr(self.w_fwd[l]), _hip.ptr(p.get(f"encoder.layers.{l}.bias")),
                       _hip.ptr(self.act[l]), B, self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l],
@@ -564,11 +578,12 @@ class CPCEngine:
             if l == 1 and self.fuse_c1:
                 _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
                           _hip.ptr(x, self.x_off), _hip.ptr(self.c1_slabs), B, cin, cout, kw, s, La[1], self.L, self.kernels[0],
-                          self.strides[0], Lv[0], C.c_longlong(self.guard[1]), code,
+                          self.strides[0], Lv[0], C.c_longlong(self.guard[1]), code, _hip.ptr(self.act_bits[0]),
                           **dict(tkey, key=tkey["key"].replace("gemm_nt", "gemm_nt_conv1")))
             else:
                 _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
-                          _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], C.c_longlong(self.guard[l]), code, **tkey)
+                          _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], C.c_longlong(self.guard[l]), code,
+                          _hip.ptr(self.act_bits[l - 1]), **tkey)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
         if self.fuse_c1:

@@ -100,8 +100,15 @@ int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nbl
 /* AudioEncoder layer 1 (C_in = 1): y[b][t][co] = act(bias[co] + sum_j x[b][t*stride+j] * w[co][j]), act = relu when
  * relu != 0 (audio_model.py:38-41 for l == 0: the last layer of the stack has no activation, so a one-layer encoder passes
  * relu = 0).  x: f32 [B][ldx]; w: f32 [C][kw] (reference layout); y: T [B][L_alloc][C]. */
+/* y_bits (may be NULL; C = 512 only, 16-byte aligned): the sign-bit mask of y, see cpc_sign_bits — written from the f32 values
+ * before they are rounded to the storage type (what the reference's ReLU mask is taken from). */
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                  long long ldx, int L_valid, int L_alloc, int relu, int dtype, void* stream);
+                  long long ldx, int L_valid, int L_alloc, int relu, int dtype, void* y_bits, void* stream);
+/* SIGN-BIT MASKS: bits[i] bit e = x[8 i + e] > 0 (for bf16: of the stored value), n elements (a multiple of 32; x 16-byte, bits
+ * 4-byte aligned).  The ReLU-backward mask of a data gradient at 1/16 of the bytes of the activation it is taken from:
+ * cpc_conv_dgrad / cpc_conv_dgrad_conv1 take it as x_act_bits in place of x_act — the same decision per element, identical
+ * results — addressed by the element offset / 8, so a bits buffer mirrors its activation buffer (guard rows included). */
+int cpc_sign_bits(const void* x, void* bits, long long n, int dtype, void* stream);
 /* Weight/bias gradient of layer 1: slabs[nblk_b*nblk_t][(kw+1)][C] partials (row kw = bias); reduce with
  * cpc_reduce_slabs.  nblk_t blocks split the positions, nblk_b (<= B) blocks stride over the items. */
 int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
@@ -117,7 +124,7 @@ int cpc_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, in
 long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what);
 int cpc_conv_dgrad_conv1(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
                          int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
-                         long long dy_head, int dtype, void* stream);
+                         long long dy_head, int dtype, const void* x_act_bits, void* stream);
 int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int B, int Cin, int stride, int Lout_alloc,
                            int kw1, void* stream);
 
@@ -131,11 +138,15 @@ int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db,
  * max(0, kw - stride) * Cin elements BEYOND the B * Lin_alloc * Cin elements of x (the window of the last row); the data
  * gradient reads (ceil(kw / stride) - 1) * Cout elements BEFORE dy.  The caller states how many elements are readable there
  * (x_tail after the end of x, dy_head in front of dy; zeros expected in dy_head, values in x_tail only ever meet pad rows);
- * CPC_EINVAL when that is less than the call needs. */
+ * CPC_EINVAL when that is less than the call needs.
+ * x_act_bits: the sign-bit mask cpc_sign_bits makes of x_act (NULL: the mask is read from x_act).  Only the bf16 256 x 256-tile
+ * kernel knows the format (>= 200 such tiles, stride * Cin a multiple of 256): CPC_EINVAL where the launch would take another
+ * kernel, never a silent fall-back.  With x_act_bits, x_act may be NULL. */
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw,
                  int stride, int Lout_alloc, int Lout_valid, int relu, long long x_tail, int dtype, void* stream);
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
-                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, void* stream);
+                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, const void* x_act_bits,
+                   void* stream);
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride,
                    int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,

@@ -275,7 +275,15 @@ def test_conv1_fwd_bwd(dt, C, kw, stride):
     code = _hip.dtype_code(dt)
     dx, dw, db = dev(x), dev(w), dev(bias)
     y = torch.full((B, La, C), float("nan"), device=DEV, dtype=dt)
-    _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(y), B, C, stride, kw, L, Lv, La, 1, code)
+    ybits = torch.full((B * La * C // 8,), 0xA5, device=DEV, dtype=torch.uint8) if C == 512 else None
+    _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(y), B, C, stride, kw, L, Lv, La, 1, code, _hip.ptr(ybits))
+    if ybits is not None:
+        # sign-bit mask (taken from the f32 values; for this data the same as of the stored ones): bit e of byte i = y[8 i + e] > 0
+        want = (y.reshape(-1, 8) > 0).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))
+        assert torch.equal(ybits.to(torch.int32), want.sum(1))
+        yp = torch.full_like(y, float("nan"))
+        _hip.call("cpc_conv1_fwd", _hip.ptr(dx), _hip.ptr(dw), _hip.ptr(db), _hip.ptr(yp), B, C, stride, kw, L, Lv, La, 1, code, None)
+        assert torch.equal(yp, y)                      # the row order inside a block differs, the values do not
     xr = x.double().unsqueeze(1).requires_grad_(False)
     wr = w.double().requires_grad_(True)
     br = bias.double().requires_grad_(True)
@@ -343,7 +351,7 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     dybuf = padded(dy)
     dxbuf = torch.full((guard + B * Lin_alloc * Cin + guard,), float("nan"), device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(xbuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, Lout_alloc, Lin_valid, C.c_longlong(guard), code)
+              kw, stride, Lout_alloc, Lin_valid, C.c_longlong(guard), code, None)
     xin = rounded(x, dt)[:, :Lin_valid].transpose(1, 2).clone().requires_grad_(True)
     wr = rounded(w, dt).clone().requires_grad_(True)
     out = F.conv1d(xin, wr, None, stride=stride)
@@ -392,7 +400,7 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     _hip.call("cpc_conv_w_prep", _hip.ptr(w.to(DEV)), _hip.ptr(wf), _hip.ptr(wd), Cout, Cin, kw, stride, code)
     dxbuf = torch.zeros(guard + B * La0 * Cin + guard, device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, La1, Lv0, C.c_longlong(guard), code)
+              kw, stride, La1, Lv0, C.c_longlong(guard), code, None)
     G = dxbuf[guard:guard + B * La0 * Cin].view(B, La0, Cin).double().cpu()[:, :Lv0]
     win = xwave.double().unfold(1, kw1, s1)[:, :Lv0]                 # (B, Lv0, kw1)
     ref_w = torch.einsum("btc,btj->cj", G, win)
@@ -403,12 +411,41 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     tmp = torch.full((n_tmp,), float("nan"), device=DEV)
     xd = xwave.to(DEV)
     _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(xd), _hip.ptr(slabs), B, Cin,
-              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, C.c_longlong(guard), code)
+              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, C.c_longlong(guard), code, None)
     dw = torch.full((Cin, 1, kw1), float("nan"), device=DEV)
     db = torch.full((Cin,), float("nan"), device=DEV)
     _hip.call("cpc_conv1_fused_reduce", _hip.ptr(slabs), _hip.ptr(tmp), _hip.ptr(dw), _hip.ptr(db), B, Cin, stride, La1, kw1)
     assert rel_err(dw[:, 0, :], ref_w) < 2e-4          # same bf16 tile in both paths; x enters as a (hi, lo) bf16 pair
     assert rel_err(db, ref_b) < 2e-4
+    # the same with the mask as sign bits (one byte per 8 elements, mirroring the activation buffer): identical slabs, and the
+    # plain data gradient likewise identical
+    bits = torch.zeros(abuf.numel() // 8, device=DEV, dtype=torch.uint8)
+    _hip.call("cpc_sign_bits", _hip.ptr(abuf), _hip.ptr(bits), C.c_longlong(abuf.numel()), code)
+    slabs2 = torch.full((n_sl,), float("nan"), device=DEV)
+    _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(dybuf, guard), _hip.ptr(wd), None, _hip.ptr(xd), _hip.ptr(slabs2), B, Cin,
+              Cout, kw, stride, La1, ldx, kw1, s1, Lv0, C.c_longlong(guard), code, _hip.ptr(bits, guard // 8))
+    assert torch.equal(slabs2, slabs)
+    dxbuf2 = torch.zeros_like(dxbuf)
+    _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), None, _hip.ptr(dxbuf2, guard), B, Cin, Cout,
+              kw, stride, La1, Lv0, C.c_longlong(guard), code, _hip.ptr(bits, guard // 8))
+    assert torch.equal(dxbuf2, dxbuf)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_sign_bits(dt):
+    """cpc_sign_bits: bit e of byte i = element 8 i + e is > 0 (zeros of both signs, negatives and NaN with the sign set: 0)."""
+    g = torch.Generator().manual_seed(5)
+    n = 32 * 12345
+    x = torch.randn(n, generator=g)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    x[5::13] = torch.relu(x[5::13])
+    xd = x.to(DEV).to(dt)
+    bits = torch.full((n // 8,), 0xA5, device=DEV, dtype=torch.uint8)
+    _hip.call("cpc_sign_bits", _hip.ptr(xd), _hip.ptr(bits), C.c_longlong(n), _hip.dtype_code(dt))
+    want = ((xd.view(-1, 8) > 0).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(1)
+    assert torch.equal(bits.to(torch.int32), want)
+    assert _hip.lib().cpc_sign_bits(_hip.ptr(xd), _hip.ptr(bits), C.c_longlong(n - 8), _hip.dtype_code(dt), _hip.stream_ptr()) == -22
 
 
 @pytest.mark.parametrize("N,K,relu,rpi", [(32, 8, 0, 0), (32, 32, 1, 0), (16, 20, 0, 0), (32, 20, 1, 37), (8, 4, 0, 0)])
