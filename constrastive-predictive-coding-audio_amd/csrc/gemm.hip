@@ -618,6 +618,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             }
         }
         NT_DMA_STAGE(0, 0);
+        if constexpr (C1) {
+            // Fused layer-1 weight gradient: beside the tile image its epilogue needs an image of the waveform windows of the tile's
+            // rows.  That image lives BEHIND the K loop's stage buffers, so it is built here, behind the requests of the first stage and before the loop
+            // (its global loads and the hi / lo split cost the epilogue nothing): xw[2][TBM][16] bf16 = (hi, lo) parts of
+            // x[b][t*stride + j] for slots j < kw, 1.0 in slot kw (bias gradient), 0 elsewhere / for rows that do not count
+            static_assert(NTHR == 2 * TBM, "two threads per tile row");
+            unsigned char* xw = lds + TBM * EPI_RS;
+            const int r = tid >> 1, half = tid & 1;
+            const int m = m0 + r;
+            const int cinN = p.N / p.c1_sub, rsel = n0 / cinN;
+            bool ok = m < p.M;
+            long long xo = 0;
+            if (ok) {
+                const int b = m / p.c1_rpi, t = (m % p.c1_rpi) * p.c1_sub + rsel;
+                ok = t < p.c1_valid;
+                xo = (long long)b * p.c1_ldx + (long long)t * p.c1_stride;
+            }
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                unsigned short h2[2], l2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = half * 8 + e2 * 2 + u;
+                    float xv = 0.f;
+                    if (ok) xv = j < p.c1_kw ? p.c1_x[xo + j] : (j == p.c1_kw ? 1.f : 0.f);
+                    const bf16_t hb = (bf16_t)xv;
+                    const bf16_t lb = (bf16_t)(xv - (float)hb);
+                    h2[u] = __builtin_bit_cast(unsigned short, hb);
+                    l2[u] = __builtin_bit_cast(unsigned short, lb);
+                }
+                hw[e2] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
+                lw[e2] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
+            }
+            *(uint4*)(xw + r * 32 + half * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *(uint4*)(xw + TBM * 32 + r * 32 + half * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (nk > 1) NT_DMA_STAGE(1, koff1);
@@ -763,41 +800,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 }
             }
             __syncthreads();
-            if constexpr (C1) {
-                // ... beside an image of the waveform windows of the tile's rows: xw[2][TBM][16] bf16 = (hi, lo) parts of
-                // x[b][t*stride + j] for slots j < kw, 1.0 in slot kw (bias gradient), 0 elsewhere / for rows that do not count
-                static_assert(NTHR == 2 * TBM, "two threads per tile row");
-                unsigned char* xw = lds + TBM * EPI_RS;
-                const int r = tid >> 1, half = tid & 1;
-                const int m = m0 + r;
-                const int cinN = p.N / p.c1_sub, rsel = n0 / cinN;
-                bool ok = m < p.M;
-                long long xo = 0;
-                if (ok) {
-                    const int b = m / p.c1_rpi, t = (m % p.c1_rpi) * p.c1_sub + rsel;
-                    ok = t < p.c1_valid;
-                    xo = (long long)b * p.c1_ldx + (long long)t * p.c1_stride;
-                }
-                unsigned hw[4], lw[4];
-#pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    unsigned short h2[2], l2[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = half * 8 + e2 * 2 + u;
-                        float xv = 0.f;
-                        if (ok) xv = j < p.c1_kw ? p.c1_x[xo + j] : (j == p.c1_kw ? 1.f : 0.f);
-                        const bf16_t hb = (bf16_t)xv;
-                        const bf16_t lb = (bf16_t)(xv - (float)hb);
-                        h2[u] = __builtin_bit_cast(unsigned short, hb);
-                        l2[u] = __builtin_bit_cast(unsigned short, lb);
-                    }
-                    hw[e2] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
-                    lw[e2] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
-                }
-                *(uint4*)(xw + r * 32 + half * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                *(uint4*)(xw + TBM * 32 + r * 32 + half * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-            }
             if (n < p.N) {
                 if constexpr (C1) {
                     // fused layer-1 weight gradient: the masked tile goes back to its LDS image (no global store) ...
