@@ -766,11 +766,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             uint4 mk[NPASS];
             unsigned mbits[NPASS];
             const unsigned char* Mbits = p.mask_bits;
+            // (BITS_IN_LDS: the bits already sit in LDS and are applied while the accumulators are written to the tile image below)
+            const bool bits_early = BITS_IN_LDS && Mbits != nullptr;
             if (Mbits && n < p.N) {
-                if constexpr (BITS_IN_LDS) {
-#pragma unroll
-                    for (int q = 0; q < NPASS; ++q) mbits[q] = lds[BITS_OFF + (rr + q * RPP) * (TBN / 8) + cc];
-                } else {
+                if constexpr (!BITS_IN_LDS) {
 #pragma unroll
                     for (int q = 0; q < NPASS; ++q) {
                         const int m = min(m0 + rr + q * RPP, p.M - 1);
@@ -787,6 +786,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int ml = (wm * TI + i) * 16 + frow;
+                // sign bits of this row's 64 columns of the wave (8 bytes of the tile's bit image); the nibble of the 4 columns a
+                // lane holds of MFMA tile j starts at bit (j & 1) * 16 + 4 fg of the low (j < 2) or high word
+                unsigned mlo = 0, mhi = 0;
+                if constexpr (BITS_IN_LDS) {
+                    if (bits_early) {
+                        const uint2 mb8 = *(const uint2*)(lds + BITS_OFF + ml * (TBN / 8) + wn * 8);
+                        mlo = mb8.x >> (4 * fg); mhi = mb8.y >> (4 * fg);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const int nl = (wn * TJ + j) * 16 + fg * 4;
@@ -796,6 +804,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
                     }
+                    if constexpr (BITS_IN_LDS) {
+                        if (bits_early) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                            uint2 w = __builtin_bit_cast(uint2, o);
+                            const unsigned nib = ((j < 2 ? mlo : mhi) >> ((j & 1) * 16)) & 0xfu;
+                            w.x &= (nib & 1u ? 0xffffu : 0u) | (nib & 2u ? 0xffff0000u : 0u);
+                            w.y &= (nib & 4u ? 0xffffu : 0u) | (nib & 8u ? 0xffff0000u : 0u);
+                            *(uint2*)((TO*)(lds + ml * EPI_RS) + nl) = w;
+                            continue;
+                        }
+                    }
                     store4((TO*)(lds + ml * EPI_RS) + nl, v);
                 }
             }
@@ -803,6 +824,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             if (n < p.N) {
                 if constexpr (C1) {
                     // fused layer-1 weight gradient: the masked tile goes back to its LDS image (no global store) ...
+                    if (!bits_early) {
 #pragma unroll
                     for (int q = 0; q < NPASS; ++q) {
                         const int r = rr + q * RPP;
@@ -824,6 +846,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         }
                         *(uint4*)(lds + r * EPI_RS + cc * 16) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                     }
+                    }
                 }
                 if constexpr (!C1) {
 #pragma unroll
@@ -834,11 +857,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
                     uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
                     if (Mbits) {
-                        unsigned vw[4] = {v.x, v.y, v.z, v.w};
+                        if (!bits_early) {
+                            unsigned vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            vw[e] &= ((mbits[q] >> (2 * e)) & 1u ? 0xffffu : 0u) | ((mbits[q] >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
-                        v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                            for (int e = 0; e < 4; ++e)
+                                vw[e] &= ((mbits[q] >> (2 * e)) & 1u ? 0xffffu : 0u) | ((mbits[q] >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                            v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                        }
                     } else if (Mb) {
                         // bf16 > 0  <=>  sign bit clear and not zero
                         const unsigned mw[4] = {mk[q].x, mk[q].y, mk[q].z, mk[q].w};
