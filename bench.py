@@ -10,6 +10,10 @@ Workload: BASELINE.json configs[1] — AudioPredictiveCodingModel (5-layer strid
 accumulation, softplus score, regularisation 1.0, Adam lr 1e-4.  Weak scaling: every rank runs its own 256 clips with its
 own in-batch negatives; gradients are averaged with one RCCL all-reduce per step.
 
+Before the W warm-up steps the script runs --prewarm (default 40, 0.2 s) further untimed steps: the first dozen steps of a process are
+6-8 % slower in every kernel (clock ramp under sustained load), which says nothing about the step a training run sees; the timed
+region is still exactly K full steps.  `prewarm_steps` in the JSON line records it.
+
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
                 FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
@@ -159,6 +163,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm", type=int, default=40,
+                    help="untimed steps BEFORE the W warm-up steps: the first dozen steps of a process run 6-8 %% slower (every kernel; the "
+                         "clocks ramp under sustained load, DESIGN.md section 9.3), which a 5-step warm-up does not cover; reported as "
+                         "prewarm_steps.  0 = off")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,6 +231,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.prewarm):             # clock ramp (see --prewarm); not part of W, not timed, reported in the JSON line
+        step(i)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -280,6 +290,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": args.prewarm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
