@@ -26,13 +26,14 @@ __device__ __forceinline__ float score_grad(float x, int softplus) {
 // an online (max, sum) over its rows of the split's row range, combined through LDS.  With nsplit == 1 it writes lse[k][b'] and
 // one partial sum of lse per block; otherwise the per-split (max, sum) pairs go to pm / ps [split][k][b'] for nce_col_merge_kernel
 // (the all-timesteps matrix has 3072 rows but only 96 column blocks: the rows must be split to fill the chip).
-__global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
-                                                      float* __restrict__ partial, int B, int K, int ld, int softplus,
-                                                      int rows_per_split, float* __restrict__ pm, float* __restrict__ ps) {
+// (body with explicit block coordinates: nce_col_kernel calls it with its own, nce_col_mean_kernel with a slice of a 1-D grid)
+__device__ __forceinline__ void nce_col_body(const float* __restrict__ S, float* __restrict__ lse, float* __restrict__ partial, int B,
+                                             int K, int ld, int softplus, int rows_per_split, float* __restrict__ pm,
+                                             float* __restrict__ ps, int bx, int by, int bz, int nbx, int nbz) {
     __shared__ float smx[8][32], ssum[8][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int k = blockIdx.y, bp = blockIdx.x * 32 + tx;
-    const int r0 = blockIdx.z * rows_per_split, r1 = min(B, r0 + rows_per_split);
+    const int k = by, bp = bx * 32 + tx;
+    const int r0 = bz * rows_per_split, r1 = min(B, r0 + rows_per_split);
     float mx = -INFINITY, sum = 0.f;
     if (bp < B) {
         const float* col = S + (long long)k * B * ld + bp;
@@ -65,10 +66,10 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
         float tot = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) tot += (smx[r][tx] == -INFINITY) ? 0.f : ssum[r][tx] * expf(smx[r][tx] - m);
-        if (gridDim.z > 1) {
+        if (nbz > 1) {
             if (bp < B) {
-                pm[((long long)blockIdx.z * K + k) * B + bp] = m;
-                ps[((long long)blockIdx.z * K + k) * B + bp] = tot;
+                pm[((long long)bz * K + k) * B + bp] = m;
+                ps[((long long)bz * K + k) * B + bp] = tot;
             }
             return;
         }
@@ -77,8 +78,14 @@ __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ 
         // sum the 32 columns of this block (one wave-half): shuffle reduction
         float acc = l;
         for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
-        if (tx == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = acc;
+        if (tx == 0) partial[by * nbx + bx] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
+                                                      float* __restrict__ partial, int B, int K, int ld, int softplus,
+                                                      int rows_per_split, float* __restrict__ pm, float* __restrict__ ps) {
+    nce_col_body(S, lse, partial, B, K, ld, softplus, rows_per_split, pm, ps, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
 }
 
 // Merges the per-split (max, sum) pairs of a column in split order: lse[c] and one partial sum of lse per block of 256 columns.
@@ -111,11 +118,11 @@ __global__ __launch_bounds__(256) void nce_col_merge_kernel(const float* __restr
 // for every pair once, plus per-block partials {sum of the valid scores sp[k][b][b], sum m^2, max sp}.  (The gradient kernel
 // used to recompute this mean in each of its K blocks per tile: 12 x the softplus work, 42 of the loss's 65 us.)
 template <int KT>
-__global__ __launch_bounds__(256) void nce_mean_kernel(const float* __restrict__ S, float* __restrict__ mean,
-                                                       float* __restrict__ partial, int B, int K_rt, int ld, int softplus) {
+__device__ __forceinline__ void nce_mean_body(const float* __restrict__ S, float* __restrict__ mean, float* __restrict__ partial, int B,
+                                              int K_rt, int ld, int softplus, int bx) {
     __shared__ float red[3][256];
     const int K = KT > 0 ? KT : K_rt;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)bx * 256 + threadIdx.x;
     float valid = 0.f, msq = 0.f, mx = -INFINITY;
     if (idx < (long long)B * B) {
         const int b = (int)(idx / B), bp = (int)(idx % B);
@@ -157,19 +164,76 @@ __global__ __launch_bounds__(256) void nce_mean_kernel(const float* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partial[blockIdx.x * 3 + 0] = red[0][0];
-        partial[blockIdx.x * 3 + 1] = red[1][0];
-        partial[blockIdx.x * 3 + 2] = red[2][0];
+        partial[bx * 3 + 0] = red[0][0];
+        partial[bx * 3 + 1] = red[1][0];
+        partial[bx * 3 + 2] = red[2][0];
     }
+}
+
+// The column log-sum-exps and the pair means read the same scores and do not depend on each other: ONE launch, the first
+// ncb * K workgroups take the columns, the rest the pairs (each launch of this latency-bound path costs 5-9 us by itself).
+template <int KT>
+__global__ __launch_bounds__(256) void nce_col_mean_kernel(const float* __restrict__ S, float* __restrict__ lse, float* __restrict__ colp,
+                                                           float* __restrict__ mean, float* __restrict__ pairp, int B, int K, int ld,
+                                                           int softplus, int ncb) {
+    const int ncol = ncb * K;
+    if ((int)blockIdx.x < ncol)
+        nce_col_body(S, lse, colp, B, K, ld, softplus, B, nullptr, nullptr, blockIdx.x % ncb, blockIdx.x / ncb, 0, ncb, 1);
+    else
+        nce_mean_body<KT>(S, mean, pairp, B, K, ld, softplus, blockIdx.x - ncol);
+}
+
+// out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
+__device__ __forceinline__ void nce_finalize_body(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
+                                                  int ngrad, float* __restrict__ out, int B, int K, float reg) {
+    // fixed-shape tree reduction: the summation order depends only on (ncol, ngrad), not on timing
+    __shared__ float red[4][256];
+    float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
+    for (int i = threadIdx.x; i < ncol; i += 256) lse_sum += col_partial[i];
+    for (int i = threadIdx.x; i < ngrad; i += 256) {
+        valid += grad_partial[i * 3 + 0];
+        msq += grad_partial[i * 3 + 1];
+        mx = fmaxf(mx, grad_partial[i * 3 + 2]);
+    }
+    red[0][threadIdx.x] = lse_sum; red[1][threadIdx.x] = valid; red[2][threadIdx.x] = msq; red[3][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s2];
+            red[2][threadIdx.x] += red[2][threadIdx.x + s2];
+            red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    lse_sum = red[0][0]; valid = red[1][0]; msq = red[2][0]; mx = red[3][0];
+    const float bk = (float)B * (float)K;
+    const float t_valid = -valid / bk, t_lse = lse_sum / bk, t_reg = reg * msq / ((float)B * (float)B);
+    out[0] = t_valid + t_lse + t_reg;
+    out[1] = mx;
+    out[2] = t_valid;
+    out[3] = t_lse;
+    out[4] = t_reg;
+    // NaN guard of the reference (contrastive_estimation_training.py:124-133: isnan of the loss BEFORE the regulariser, then
+    // `return` before backward() / optimizer.step()): out[5] = this step's indicator, out[6] = sticky (stays raised until the host
+    // clears it) — cpc_adam / cpc_adam_dev skip their update while it is raised
+    const float lb = t_valid + t_lse;
+    const float bad = (lb != lb) ? 1.f : 0.f;
+    out[5] = bad;
+    if (bad != 0.f) out[6] = 1.f;
 }
 
 // One thread per (b, b') pair, 32x32 pairs per block (blockDim = 32x8, 4 rows per thread).
 // Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T) and per-block partials {sum valid, sum m^2, max sp}.
 // Writes dS[k][b][b'] and dST[k][b'][b] (storage dtype T); grid (tiles, tiles, K).
+// The loss scalars (nce_finalize_body) depend on the partials of the launch before this one only, so workgroup (0, 0, 0) also
+// does that reduction: no launch of its own.
 template <typename T>
 __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ S, const float* __restrict__ lse,
                                                        const float* __restrict__ mean, T* __restrict__ dS, T* __restrict__ dST,
-                                                       int B, int K, int ld, int softplus, float reg) {
+                                                       int B, int K, int ld, int softplus, float reg, const float* __restrict__ colp,
+                                                       int ncol, const float* __restrict__ pairp, int npair, float* __restrict__ out) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
     const int bp0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
@@ -196,6 +260,7 @@ __global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__
         const int bp = bp0 + ty + 8 * r, b = b0 + tx;
         if (b < ld && bp < B) dST[((long long)k * B + bp) * ld + b] = from_f32<T>(tile[tx][ty + 8 * r]);
     }
+    if (out != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) nce_finalize_body(colp, ncol, pairp, npair, out, B, K, reg);
 }
 
 // score_over_all_timesteps=True branch (contrastive_estimation_training.py:108-114, :141): S is the full R x R score
@@ -324,48 +389,6 @@ __global__ __launch_bounds__(256) void nce_all_finalize_kernel(const float* __re
     if (bad != 0.f) out[6] = 1.f;
 }
 
-// out[0] = loss, out[1] = max score, out[2] = -mean valid, out[3] = mean lse, out[4] = reg term (already scaled)
-__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ col_partial, int ncol, const float* __restrict__ grad_partial,
-                                        int ngrad, float* __restrict__ out, int B, int K, float reg) {
-    // fixed-shape tree reduction: the summation order depends only on (ncol, ngrad), not on timing
-    __shared__ float red[4][256];
-    float lse_sum = 0.f, valid = 0.f, msq = 0.f, mx = -INFINITY;
-    for (int i = threadIdx.x; i < ncol; i += 256) lse_sum += col_partial[i];
-    for (int i = threadIdx.x; i < ngrad; i += 256) {
-        valid += grad_partial[i * 3 + 0];
-        msq += grad_partial[i * 3 + 1];
-        mx = fmaxf(mx, grad_partial[i * 3 + 2]);
-    }
-    red[0][threadIdx.x] = lse_sum; red[1][threadIdx.x] = valid; red[2][threadIdx.x] = msq; red[3][threadIdx.x] = mx;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
-            red[1][threadIdx.x] += red[1][threadIdx.x + s2];
-            red[2][threadIdx.x] += red[2][threadIdx.x + s2];
-            red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    lse_sum = red[0][0]; valid = red[1][0]; msq = red[2][0]; mx = red[3][0];
-    const float bk = (float)B * (float)K;
-    const float t_valid = -valid / bk, t_lse = lse_sum / bk, t_reg = reg * msq / ((float)B * (float)B);
-    out[0] = t_valid + t_lse + t_reg;
-    out[1] = mx;
-    out[2] = t_valid;
-    out[3] = t_lse;
-    out[4] = t_reg;
-    // NaN guard of the reference (contrastive_estimation_training.py:124-133: isnan of the loss BEFORE the regulariser, then
-    // `return` before backward() / optimizer.step()): out[5] = this step's indicator, out[6] = sticky (stays raised until the host
-    // clears it) — cpc_adam / cpc_adam_dev skip their update while it is raised
-    const float lb = t_valid + t_lse;
-    const float bad = (lb != lb) ? 1.f : 0.f;
-    out[5] = bad;
-    if (bad != 0.f) out[6] = 1.f;
-}
-
-
 // ---- validation quantities (ContrastiveEstimationTrainer.validate, contrastive_estimation_training.py:227-247) ----
 // One wave per score row: sum of the transformed scores, first arg max over the row's columns, and the row's "valid" score
 // (the column `diag`).  Default branch: row r = (k, b) of S[k][b][b'], diag = b; all-timesteps branch: row r = (b, k) of the
@@ -474,20 +497,19 @@ int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace
     const int nmb = (int)(((long long)B * B + 255) / 256);
     float* mean = gradp + 3LL * nmb;
     const int nb = (ld + 31) / 32;
-    hipLaunchKernelGGL(nce_col_kernel, dim3(ncb, K, 1), dim3(256), 0, stream, S, lse, colp, B, K, ld, softplus, B, (float*)nullptr,
-                       (float*)nullptr);
-    if (K == 12) hipLaunchKernelGGL(nce_mean_kernel<12>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
-    else if (K == 16) hipLaunchKernelGGL(nce_mean_kernel<16>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
-    else hipLaunchKernelGGL(nce_mean_kernel<0>, dim3(nmb), dim3(256), 0, stream, S, mean, gradp, B, K, ld, softplus);
+    // two launches: column log-sum-exps + pair means, then gradients + loss scalars (each launch of this path is latency-bound)
+    const dim3 g1(ncol + nmb);
+    if (K == 12) hipLaunchKernelGGL(nce_col_mean_kernel<12>, g1, dim3(256), 0, stream, S, lse, colp, mean, gradp, B, K, ld, softplus, ncb);
+    else if (K == 16) hipLaunchKernelGGL(nce_col_mean_kernel<16>, g1, dim3(256), 0, stream, S, lse, colp, mean, gradp, B, K, ld, softplus, ncb);
+    else hipLaunchKernelGGL(nce_col_mean_kernel<0>, g1, dim3(256), 0, stream, S, lse, colp, mean, gradp, B, K, ld, softplus, ncb);
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((nce_grad_kernel<bf16_t>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, mean, (bf16_t*)dS, (bf16_t*)dST,
-                           B, K, ld, softplus, reg);
+                           B, K, ld, softplus, reg, colp, ncol, gradp, nmb, out);
     else if (dtype == CPC_DTYPE_F32)
         hipLaunchKernelGGL((nce_grad_kernel<float>), dim3(nb, nb, K), dim3(256), 0, stream, S, lse, mean, (float*)dS, (float*)dST, B, K,
-                           ld, softplus, reg);
+                           ld, softplus, reg, colp, ncol, gradp, nmb, out);
     else
         return CPC_EINVAL;
-    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncol, gradp, nmb, out, B, K, reg);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
