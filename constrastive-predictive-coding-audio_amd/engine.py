@@ -508,10 +508,17 @@ class CPCEngine:
         t0 = T - K - V
         self._ahead = None          # prepare_ahead state of a step whose optimizer step never came (nothing was swapped in yet)
         top, dtop = self.act[-1], self.dact[-1]
-        # predictor: dW_p = dpred^T c ;  dc = dpred W_p
+        # predictor: dW_p = dpred^T c ;  dc = dpred W_p.  Only dc is on the path to the context network's backward pass: the weight
+        # gradient is issued later, inside the first side-stream block of the encoder's backward pass (no event of its own)
         ct, coff, cstride = self.ctx.c_operand()
-        _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(ct, coff), _hip.ptr(g["prediction_model.weight"]), B, K * E, H,
-                     K * E, H, H, code, b_rpi=1, b_item=cstride, flags=_hip.GEMM_OUT_F32)
+
+        def dwp_call():
+            _hip.gemm_tn(_hip.ptr(self.dpred), _hip.ptr(ct, coff), _hip.ptr(g["prediction_model.weight"]), B, K * E, H,
+                         K * E, H, H, code, b_rpi=1, b_item=cstride, flags=_hip.GEMM_OUT_F32)
+        if self.use_aux and n > 1:
+            self._deferred_side = [dwp_call]
+        else:
+            dwp_call()
         # (a B x H output with a K*E-long reduction: split the reduction over workgroups, sum the slabs in fixed order)
         ke = K * E
         ksplit = ke // 256 if (ke % 256 == 0 and ke >= 1024 and self.slabs.numel() >= (ke // 256) * B * H) else 1
@@ -528,6 +535,9 @@ class CPCEngine:
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
         self._backward_encoder(x, grad_ready_hook)
+        for fn in getattr(self, "_deferred_side", ()):           # an encoder backward without that side block (scalogram engine)
+            fn()
+        self._deferred_side = ()
         if self.use_aux:
             torch.cuda.current_stream().wait_stream(self.aux)
 
@@ -558,6 +568,9 @@ class CPCEngine:
             if wg_mode == "0":
                 wgrad_call()
             with self.side(self._ev_w[l]):
+                for fn in getattr(self, "_deferred_side", ()):       # work backward() put off the main stream (see there)
+                    fn()
+                self._deferred_side = ()
                 if wg_mode != "0":
                     wgrad_call()
                 # (ONE event per layer on the main stream: a recorded event between two GEMMs costs ~6 us of idle queue)
