@@ -56,7 +56,8 @@ _SIGNATURES = {
     "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
     "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
-    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P], _I),
+    "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P], _I),
+    "cpc_conv_dgrad_colsum_floats": ([_I, _I, _I, _I], _L),
     "cpc_conv_dgrad_conv1_floats": ([_I, _I, _I, _I, _I, _I], _L),
     "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P, _P], _I),
     "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
@@ -129,7 +130,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 3:
+        if handle.cpc_abi_version() != 4:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -15,7 +15,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 3; }
+int cpc_abi_version(void) { return 4; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -114,7 +114,8 @@ int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, i
 }
 
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
-                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, const void* x_act_bits, void* stream) {
+                   int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, const void* x_act_bits, float* dx_colsum_slabs,
+                   void* stream) {
     if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;
     (void)Lin_valid;   // positions >= Lin_valid receive zeros because the pad rows of dy are zero
     const int D = (kw + stride - 1) / stride;
@@ -123,10 +124,15 @@ int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void*
     p.A = (const char*)dy - (long long)(D - 1) * Cout * esize(dtype);   // D-1 zero guard rows precede the buffer
     p.Bt = w_dgrad; p.C = dx; p.bias = nullptr; p.mask = x_act;
     p.mask_bits = (const unsigned char*)x_act_bits;
+    p.colsum_slabs = dx_colsum_slabs;
     p.M = B * Lout_alloc; p.N = stride * Cin; p.K = D * Cout;
     p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
     p.flags = dtype == CPC_DTYPE_F32 ? GEMM_OUT_F32 : 0;
     return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+long long cpc_conv_dgrad_colsum_floats(int B, int Cin, int stride, int Lout_alloc) {
+    return (((long long)B * Lout_alloc + 255) / 256) * stride * Cin;
 }
 
 long long cpc_conv_dgrad_conv1_floats(int B, int Cin, int stride, int Lout_alloc, int kw1, int what) {

@@ -27,6 +27,10 @@ struct GemmNT {
     // addressed by the C element offset / 8.  When set it replaces `mask` in the 256x256 bf16 LDS-staged epilogues: the tile's 8 KiB of
     // bits are fetched by LDS-DMA before the K loop starts, so the epilogue reads no mask from memory at all.
     const unsigned char* mask_bits = nullptr;
+    // Per-tile column sums of the stored result (256x256 bf16 LDS-staged epilogue): slabs[ceil(M / 256)][N] f32, slab mt = the sums over the
+    // rows of M-tile mt (rows beyond M and skipped pad rows count as zero).  Reduced by reduce_slabs: the bias gradient of the layer below
+    // a conv data gradient without a separate pass over the gradient it just wrote.
+    float* colsum_slabs = nullptr;
     int M, N, K;
     long long lda, ldb, ldc;
     int a_rpi; long long a_item;

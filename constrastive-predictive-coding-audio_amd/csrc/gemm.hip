@@ -365,7 +365,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     // LDS-DMA before the K loop starts so that the epilogue finds it in LDS
     constexpr bool BITS_IN_LDS = DMA && !DIRECT && sizeof(TO) == 2 && TI == 8 && TBN == 256;
     constexpr int BITS_OFF = CORE_BYTES;
-    constexpr int LDS_BYTES = CORE_BYTES + (BITS_IN_LDS ? TBM * (TBN / 8) : 0);
+    // ... and, without the fused layer-1 epilogue, for the cross-thread reduction of the tile's column sums (GemmNT::colsum_slabs)
+    constexpr bool CS_IN_LDS = BITS_IN_LDS && !C1;
+    constexpr int CS_OFF = CORE_BYTES + (BITS_IN_LDS ? TBM * (TBN / 8) : 0);
+    constexpr int LDS_BYTES = CS_OFF + (CS_IN_LDS ? 16 * (TBN / 8) * 8 * 4 : 0);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -765,6 +768,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             // round of tiles ends in loses its read half.  Same decision per element, bit-identical results.
             uint4 mk[NPASS];
             unsigned mbits[NPASS];
+            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool want_cs = CS_IN_LDS && p.colsum_slabs != nullptr;
             const unsigned char* Mbits = p.mask_bits;
             // (BITS_IN_LDS: the bits already sit in LDS and are applied while the accumulators are written to the tile image below)
             const bool bits_early = BITS_IN_LDS && Mbits != nullptr;
@@ -883,7 +888,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         v = make_uint4(0, 0, 0, 0);
                     }
                     *(uint4*)(Cb + coff + n) = v;
+                    if constexpr (CS_IN_LDS) {
+                        if (want_cs) {              // column sums of what was just stored (the bf16 values, as a pass over C would see them)
+                            const unsigned u4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                cs[2 * e] += __builtin_bit_cast(float, u4[e] << 16);
+                                cs[2 * e + 1] += __builtin_bit_cast(float, u4[e] & 0xffff0000u);
+                            }
+                        }
+                    }
                 }
+                }
+            }
+            if constexpr (CS_IN_LDS) {
+                // GemmNT::colsum_slabs: the tile's 256 column sums — 16 row groups per column chunk through LDS, fixed order — to
+                // slabs[mt][n]: the bias gradient of the layer below without another pass over this kernel's 0.06-0.24 GB output
+                if (want_cs) {
+                    float* red = (float*)(lds + CS_OFF);
+                    *(f32x4*)(red + (rr * CPR + cc) * 8) = (f32x4){cs[0], cs[1], cs[2], cs[3]};
+                    *(f32x4*)(red + (rr * CPR + cc) * 8 + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
+                    __syncthreads();
+                    if (tid < TBN && n0 + tid < p.N) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int g = 0; g < RPP; ++g) t += red[(g * CPR + (tid >> 3)) * 8 + (tid & 7)];
+                        p.colsum_slabs[(long long)mt * p.N + n0 + tid] = t;
+                    }
                 }
             }
             if constexpr (C1) {
@@ -1615,6 +1646,10 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     // mask reads cost what the missing LDS round trip saves, so masked launches keep the LDS-staged epilogue)
     const bool direct = fast && dma && dtype == CPC_DTYPE_BF16 && (q.flags & GEMM_WIDE_EPI) && !(p.flags & GEMM_NO_PERS) &&
                         (!p.bias || (uintptr_t)p.bias % 16 == 0) && !p.mask_bits && (!p.mask || (p.flags & GEMM_DIRECT_MASK));
+    // per-tile column sums: 256x256 bf16 LDS-staged epilogue only (a launch with a mask and without GEMM_DIRECT_MASK)
+    if (p.colsum_slabs && !(big && dma && dtype == CPC_DTYPE_BF16 && !of32 && (q.flags & GEMM_WIDE_EPI) && !direct && batch == 1 && p.m_off == 0 &&
+                            !(p.flags & GEMM_EPI_CONV1)))
+        return CPC_EINVAL;
     // the byte-per-8-elements masks exist in the 256x256 bf16 kernels with the LDS-staged epilogue only
     if (p.mask_bits && !(big && dma && dtype == CPC_DTYPE_BF16 && !of32 && (q.flags & GEMM_WIDE_EPI) && p.N % 256 == 0 && p.ldc % 32 == 0 &&
                          p.c_item % 32 == 0 && p.c_batch % 32 == 0 && (uintptr_t)p.mask_bits % 4 == 0))

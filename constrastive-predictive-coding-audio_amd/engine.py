@@ -181,6 +181,17 @@ class CPCEngine:
             full = torch.zeros((2 * self.guard[0] + B * La[0] * 512) // 8, device=dev, dtype=torch.uint8)
             self._keep.append(full)
             self.act_bits[0] = full[self.guard[0] // 8:]
+        # Bias gradients of layers 2 .. n-1 (indices 1 .. n-2) from the data gradient of the layer above: its epilogue leaves the
+        # column sums of every 256-row tile it stores (include/cpc_hip.h, dx_colsum_slabs), and a small reduction replaces the
+        # column-sum pass over the 0.06-0.24 GB gradient (beside the main-stream GEMMs those passes cost the step 58 us,
+        # CPC_PROBE runs).  bf16 and 256 x 256 tiles only; the top layer's gradient comes from other kernels and keeps its pass.
+        self.cs_slabs: List[Optional[torch.Tensor]] = [None] * n       # cs_slabs[l]: sums of dact[l], written by layer l+1's data gradient
+        if dt == torch.bfloat16 and os.environ.get("CPC_FUSED_COLSUM", "1") != "0":
+            for l in range(2, n):
+                cin, cout, s = self.channels[l - 1], self.channels[l], self.strides[l]
+                if _hip.nt_tile(self.code, B * La[l], s * cin, self.geo.taps[l] * cout) == 256 and (s * cin) % 8 == 0:
+                    nf = int(_hip.lib().cpc_conv_dgrad_colsum_floats(B, cin, s, La[l]))
+                    self.cs_slabs[l - 1] = torch.zeros(nf, device=dev, dtype=torch.float32)
         # weight operand layouts (storage dtype)
         self.w_fwd: List[Optional[torch.Tensor]] = [None] * n
         self.w_dgrad: List[Optional[torch.Tensor]] = [None] * n
@@ -575,7 +586,11 @@ class CPCEngine:
                     wgrad_call()
                 # (ONE event per layer on the main stream: a recorded event between two GEMMs costs ~6 us of idle queue)
                 if bname in g:
-                    self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
+                    if self.cs_slabs[l] is not None:           # per-tile sums left by layer l+1's data gradient
+                        _hip.call("cpc_reduce_slabs", _hip.ptr(self.cs_slabs[l]), _hip.ptr(g[bname]), 1, cout, self.cs_slabs[l].numel() // cout,
+                                  cout, 1, 1, 0, 0)
+                    else:
+                        self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
                 _hip.call("cpc_reduce_conv_w", _hip.ptr(self.wslab[l]), _hip.ptr(g[f"encoder.layers.{l}.weight"]), cin, cout, kw,
                           self.nsplit[l], kw * cin * cout)
                 if grad_ready_hook is not None and l <= 2:
@@ -596,7 +611,7 @@ class CPCEngine:
             else:
                 _hip.call("cpc_conv_dgrad", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
                           _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], Lv[l - 1], C.c_longlong(self.guard[l]), code,
-                          _hip.ptr(self.act_bits[l - 1]), **tkey)
+                          _hip.ptr(self.act_bits[l - 1]), _hip.ptr(self.cs_slabs[l - 1]), **tkey)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
         if self.fuse_c1:

@@ -144,9 +144,14 @@ int cpc_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db,
  * kernel, never a silent fall-back.  With x_act_bits, x_act may be NULL. */
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw,
                  int stride, int Lout_alloc, int Lout_valid, int relu, long long x_tail, int dtype, void* stream);
+/* dx_colsum_slabs (may be NULL): f32 [ceil(B * Lout_alloc / 256)][stride * Cin] = per 256-row tile of the launch the column sums
+ * of the dx it stores (cpc_conv_dgrad_colsum_floats floats); read as [tiles * stride][Cin] and summed by cpc_reduce_slabs this is the
+ * bias gradient of the layer below — d loss / d bias = sum over (b, t) of dx — without another pass over dx.  bf16, 256 x 256-tile
+ * kernel with a mask only (as x_act_bits: CPC_EINVAL elsewhere). */
+long long cpc_conv_dgrad_colsum_floats(int B, int Cin, int stride, int Lout_alloc);
 int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw,
                    int stride, int Lout_alloc, int Lin_valid, long long dy_head, int dtype, const void* x_act_bits,
-                   void* stream);
+                   float* dx_colsum_slabs, void* stream);
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride,
                    int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,

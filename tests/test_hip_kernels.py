@@ -351,7 +351,7 @@ def test_conv_fwd_dgrad_wgrad(dt, Cin, Cout, kw, stride):
     dybuf = padded(dy)
     dxbuf = torch.full((guard + B * Lin_alloc * Cin + guard,), float("nan"), device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(xbuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, Lout_alloc, Lin_valid, C.c_longlong(guard), code, None)
+              kw, stride, Lout_alloc, Lin_valid, C.c_longlong(guard), code, None, None)
     xin = rounded(x, dt)[:, :Lin_valid].transpose(1, 2).clone().requires_grad_(True)
     wr = rounded(w, dt).clone().requires_grad_(True)
     out = F.conv1d(xin, wr, None, stride=stride)
@@ -400,7 +400,7 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
     _hip.call("cpc_conv_w_prep", _hip.ptr(w.to(DEV)), _hip.ptr(wf), _hip.ptr(wd), Cout, Cin, kw, stride, code)
     dxbuf = torch.zeros(guard + B * La0 * Cin + guard, device=DEV, dtype=dt)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), _hip.ptr(abuf, guard), _hip.ptr(dxbuf, guard), B, Cin, Cout,
-              kw, stride, La1, Lv0, C.c_longlong(guard), code, None)
+              kw, stride, La1, Lv0, C.c_longlong(guard), code, None, None)
     G = dxbuf[guard:guard + B * La0 * Cin].view(B, La0, Cin).double().cpu()[:, :Lv0]
     win = xwave.double().unfold(1, kw1, s1)[:, :Lv0]                 # (B, Lv0, kw1)
     ref_w = torch.einsum("btc,btj->cj", G, win)
@@ -426,9 +426,15 @@ def test_conv_dgrad_fused_with_layer1_weight_gradient(Cin, B, La1):
               Cout, kw, stride, La1, ldx, kw1, s1, Lv0, C.c_longlong(guard), code, _hip.ptr(bits, guard // 8))
     assert torch.equal(slabs2, slabs)
     dxbuf2 = torch.zeros_like(dxbuf)
+    nf = int(_hip.lib().cpc_conv_dgrad_colsum_floats(B, Cin, stride, La1))
+    cs = torch.full((nf,), float("nan"), device=DEV)
     _hip.call("cpc_conv_dgrad", _hip.ptr(dybuf, guard), _hip.ptr(wd), None, _hip.ptr(dxbuf2, guard), B, Cin, Cout,
-              kw, stride, La1, Lv0, C.c_longlong(guard), code, _hip.ptr(bits, guard // 8))
+              kw, stride, La1, Lv0, C.c_longlong(guard), code, _hip.ptr(bits, guard // 8), _hip.ptr(cs))
     assert torch.equal(dxbuf2, dxbuf)
+    # ... and the per-tile column sums of what it stored: summed over tiles and phases = the column sums of the stored gradient
+    got = cs.view(-1, Cin).double().sum(0).cpu()
+    want = dxbuf[guard:guard + B * La0 * Cin].view(-1, Cin).double().sum(0).cpu()
+    assert rel_err(got, want) < 1e-5
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])

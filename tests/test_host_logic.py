@@ -86,7 +86,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert handle.cpc_abi_version() == 3
+    assert handle.cpc_abi_version() == 4
     nm = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cpc_\w+)", nm))
     assert exported == declared
@@ -103,7 +103,7 @@ def test_over_read_contract_is_checked_before_any_launch():
     s = C.c_void_p(0)
     assert lib.cpc_conv_fwd(P, P, None, P, B, Cin, Cout, kw, stride, La, La - 1, 1, C.c_longlong(need_tail - 1), _hip.BF16, s) == -22
     assert lib.cpc_conv_wgrad(P, P, P, B, Cin, Cout, kw, stride, La, 1, C.c_longlong(0), _hip.BF16, s) == -22
-    assert lib.cpc_conv_dgrad(P, P, None, P, B, Cin, Cout, kw, stride, La, La * stride, C.c_longlong(need_head - 1), _hip.BF16, None, s) == -22
+    assert lib.cpc_conv_dgrad(P, P, None, P, B, Cin, Cout, kw, stride, La, La * stride, C.c_longlong(need_head - 1), _hip.BF16, None, None, s) == -22
     assert lib.cpc_conv_dgrad_conv1(P, P, P, P, P, B, 256, Cout, kw, stride, La, 100, 10, 5, 10, C.c_longlong(need_head - 1), _hip.BF16, None, s) == -22
     # cpc_gemm_nt with stated extents: M rows of K = 512 at lda = 256 need (M - 1) * 256 + 512 readable elements
     M, N, K, lda = 40, 64, 512, 256

@@ -69,7 +69,7 @@ for name, Lo, kw, s in LAY:
     _hip.call("cpc_conv_fwd", P(prev, guard), P(wf), P(bias), P(y, guard), B, Cc, Cc, kw, s, Lo, Lo - 2, 1, C.c_longlong(guard), _hip.BF16)
     ab(f"{name} sign bits", {"cpc_sign_bits": lambda: mk(y, yb)})
     g = lambda bits: _hip.call("cpc_conv_dgrad", P(dy, guard), P(wd), None if bits else P(prev, guard), P(dx, guard), B, Cc, Cc, kw, s, Lo,
-                               Lo * s, C.c_longlong(guard), _hip.BF16, P(prevb, guard // 8) if bits else None)
+                               Lo * s, C.c_longlong(guard), _hip.BF16, P(prevb, guard // 8) if bits else None, None)
     ab(f"{name} data gradient", {"mask = activation": lambda: g(False), "mask = bits": lambda: g(True)})
     prev, prevb = y, yb
     del dy, dx
