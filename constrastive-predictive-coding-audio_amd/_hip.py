@@ -259,9 +259,14 @@ def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_r
     _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")
 
 
+_PROBE_SKIP = frozenset(v for v in os.environ.get("CPC_PROBE_SKIP", "").split(",") if v)
+
+
 def call(name, *args, key=None, work=0.0, shape=None):
     """Generic call of an exported function; appends the current stream and checks the status.
     ``key`` / ``work``: kernel symbol and algorithmic FLOPs (or bytes) this launch is booked under by a KernelTimer."""
+    if _PROBE_SKIP and name in _PROBE_SKIP:      # CPC_PROBE_SKIP=name,name: timing probes (the step's results are garbage)
+        return
     fn = getattr(lib(), name)
     if _timer is not None:
         _timer.run(key or name, work, lambda: _check(fn(*args, stream_ptr()), name), shape=shape)
