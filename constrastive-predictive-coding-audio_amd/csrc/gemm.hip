@@ -351,7 +351,8 @@ __device__ __forceinline__ int direct_b_col(int r) {
 template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false, bool DIRECT = false, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     // DBG: timing probes for tools/nt_probe.py (cpc_debug_set key 4; never in the product path, the results are garbage):
-    // 1 = K loop without its LDS-DMA requests, 2 = without its MFMAs, 16 = only the B tile is requested
+    // 1 = K loop without its LDS-DMA requests, 2 = without its MFMAs, 16 = only the B tile is requested, 32 = the A operand stored
+    // stage-major ([K / 64][M][64], a_item = elements per stage: a stage's A tile is then ONE dense 32 KiB range)
     static_assert(!DIRECT || (DMA && !C1 && sizeof(T) == 2 && sizeof(TO) == 2 && TJ == 4), "direct epilogue: bf16 LDS-DMA variants");
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
@@ -499,8 +500,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #define NT_DMA_STAGE(buf, k0)                                                                                    \
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
-        NT_DMA1(ga0 + (k0), da);        NT_DMA1(ga1 + (k0), da + 1024);                                          \
-        NT_DMA1(ga2 + (k0), da + 2048); NT_DMA1(ga3 + (k0), da + 3072);                                          \
+        NT_DMA1(ga0 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da);                                    \
+        NT_DMA1(ga1 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 1024);                             \
+        NT_DMA1(ga2 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 2048);                             \
+        NT_DMA1(ga3 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 3072);                             \
         NT_DMA1(gb0 + (k0), db);        NT_DMA1(gb1 + (k0), db + 1024);                                          \
         NT_DMA1(gb2 + (k0), db + 2048); NT_DMA1(gb3 + (k0), db + 3072);                                          \
     } while (0)
@@ -553,13 +556,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
         switch (idx) {                                                                                           \
-        case 0: if constexpr (!(DBG & 16)) NT_DMA1(ga0 + (k0), da); break;                                       \
+        case 0: if constexpr (!(DBG & 16)) NT_DMA1(ga0 + ((DBG & 32) ? kA_ : (k0)), da); break;                                       \
         case 1: NT_DMA1(gb0 + (k0), db); break;                                                                  \
-        case 2: if constexpr (!(DBG & 16)) NT_DMA1(ga1 + (k0), da + 1024); break;                                \
+        case 2: if constexpr (!(DBG & 16)) NT_DMA1(ga1 + ((DBG & 32) ? kA_ : (k0)), da + 1024); break;                                \
         case 3: NT_DMA1(gb1 + (k0), db + 1024); break;                                                           \
-        case 4: if constexpr (!(DBG & 16)) NT_DMA1(ga2 + (k0), da + 2048); break;                                \
+        case 4: if constexpr (!(DBG & 16)) NT_DMA1(ga2 + ((DBG & 32) ? kA_ : (k0)), da + 2048); break;                                \
         case 5: NT_DMA1(gb2 + (k0), db + 2048); break;                                                           \
-        case 6: if constexpr (!(DBG & 16)) NT_DMA1(ga3 + (k0), da + 3072); break;                                \
+        case 6: if constexpr (!(DBG & 16)) NT_DMA1(ga3 + ((DBG & 32) ? kA_ : (k0)), da + 3072); break;                                \
         case 7: NT_DMA1(gb3 + (k0), db + 3072); break;                                                           \
         default: break;                                                                                          \
         }                                                                                                        \
@@ -584,6 +587,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     do {                                                                                                         \
         const unsigned cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;                                       \
         const long long k2 = kb + kj * tstride;                                                                  \
+        const long long kA_ = (long long)(t + 2) * p.a_item;   /* DBG 32: A stored stage-major, [K / 64][M][64] */ \
+        (void)kA_;                                                                                               \
         if (DO_DMA) { if (++kj == taps) { kj = 0; kb += BK; } }                                                  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
@@ -1660,6 +1665,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
             else if (direct && g_nt_probe == 1) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 1>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 2) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 2>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 16) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 16>), grid, dim3(512), 0, stream, q);
+            else if (direct && g_nt_probe == 32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 32>), grid, dim3(512), 0, stream, q);
             else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true>), grid, dim3(512), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {

@@ -48,9 +48,18 @@ for K in a.K:
         t = timed(lambda: _hip.gemm_nt(P(A), P(Bt), P(out), M, N, K, K, K, N, 1)) * 1e3 / 7
         res[(K, probe)] = t
         line += f"  {name}: {t:7.2f}"
+    # the same product with the A operand stored stage-major: [K / 64][M][64], a stage's A tile = one dense 32 KiB range
+    Ad = torch.randn((K // 64) * M * 64 + 64, device=dev).to(bf)
+    _hip.lib().cpc_debug_set(4, 32)
+    t = timed(lambda: _hip.gemm_nt(P(Ad), P(Bt), P(out), M, N, K, 64, K, N, 1, a_item=M * 64)) * 1e3 / 7
+    res[(K, 32)] = t
+    line += f"  A stage-major: {t:7.2f}"
+    del Ad
     _hip.lib().cpc_debug_set(4, 0)
     print(line, flush=True)
     del A, Bt
 if len(a.K) >= 2:
     k0, k1 = a.K[0], a.K[-1]
-    print("per 64-deep stage: " + "  ".join(f"{name}: {(res[(k1, p)] - res[(k0, p)]) / ((k1 - k0) / 64):.3f} us" for p, name in NAMES.items()))
+    names = dict(NAMES)
+    names[32] = "A stage-major"
+    print("per 64-deep stage: " + "  ".join(f"{name}: {(res[(k1, p)] - res[(k0, p)]) / ((k1 - k0) / 64):.3f} us" for p, name in names.items()))
