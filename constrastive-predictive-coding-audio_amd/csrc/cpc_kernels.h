@@ -75,6 +75,7 @@ struct GemmTN {
 
 // tuning knobs (cpc_debug_set): key 1 = stagger of the 256x256 NT kernel in 1/64 of a tile time (default see gemm.hip)
 extern int g_nt_stagger64;
+extern int g_nt_probe_taps;     // key 5: taps of the chunk-major A operand of probe 32
 extern int g_nt_probe;          // key 4: timing probes of the 256x256 NT kernel (DBG in gemm.hip; the results are garbage)
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);

@@ -500,10 +500,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #define NT_DMA_STAGE(buf, k0)                                                                                    \
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
-        NT_DMA1(ga0 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da);                                    \
-        NT_DMA1(ga1 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 1024);                             \
-        NT_DMA1(ga2 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 2048);                             \
-        NT_DMA1(ga3 + ((DBG & 32) ? (long long)(buf) * p.a_item : (k0)), da + 3072);                             \
+        NT_DMA1(ga0 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da);            \
+        NT_DMA1(ga1 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 1024);     \
+        NT_DMA1(ga2 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 2048);     \
+        NT_DMA1(ga3 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 3072);     \
         NT_DMA1(gb0 + (k0), db);        NT_DMA1(gb1 + (k0), db + 1024);                                          \
         NT_DMA1(gb2 + (k0), db + 2048); NT_DMA1(gb3 + (k0), db + 3072);                                          \
     } while (0)
@@ -587,7 +587,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     do {                                                                                                         \
         const unsigned cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;                                       \
         const long long k2 = kb + kj * tstride;                                                                  \
-        const long long kA_ = (long long)(t + 2) * p.a_item;   /* DBG 32: A stored stage-major, [K / 64][M][64] */ \
+        /* DBG 32: A stored chunk-major, [K / (64 taps)][rows][64]; the taps of a chunk are 64 elements (one row) apart */ \
+        const long long kA_ = (long long)((t + 2) / taps) * p.a_item + (long long)((t + 2) % taps) * 64;         \
         (void)kA_;                                                                                               \
         if (DO_DMA) { if (++kj == taps) { kj = 0; kb += BK; } }                                                  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
@@ -1581,7 +1582,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
 // at least three rounds of tiles, whose every tile ends in a 2 x 32 MB burst (mask read + store) when all CUs run in step
 // (tools/nt_ab.py --stagger: layer-3 data gradient 285 -> 278 us, layer-2 1036 -> 1021 us; no gain without a mask)
 int g_nt_stagger64 = 32;
-int g_nt_probe = 0;
+int g_nt_probe = 0, g_nt_probe_taps = 1;
 
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
@@ -1615,6 +1616,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         q.k_taps = (int)(p.K / p.lda);
         q.k_tap_stride = p.lda;
     }
+    if (g_nt_probe == 32) { q.k_taps = g_nt_probe_taps; q.k_tap_stride = p.K / g_nt_probe_taps; }      // (timing probe: see DBG 32)
     if (q.k_taps > 1 && (!fast || (long long)q.k_taps * q.k_tap_stride != p.K || q.k_tap_stride % bk)) return CPC_EINVAL;
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))

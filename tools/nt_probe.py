@@ -63,3 +63,25 @@ if len(a.K) >= 2:
     names = dict(NAMES)
     names[32] = "A stage-major"
     print("per 64-deep stage: " + "  ".join(f"{name}: {(res[(k1, p)] - res[(k0, p)]) / ((k1 - k0) / 64):.3f} us" for p, name in names.items()))
+
+# Conv shapes of BASELINE config 2 with the activation operand chunk-major ([C / 64][frames][64]) against the row-major one
+# (overlapped rows): forward of layer 3 (kernel 4, stride 2: 4 taps, rows 2 frames apart) and data gradient of layer 3 (2 taps,
+# rows 1 frame apart).  Results of the chunk-major launches are not checked (probe).
+Cc = 512
+for name, Mrows, Nn, taps, rstep in (("layer-3 forward", 256 * 456, 512, 4, 2), ("layer-3 data gradient", 256 * 456, 1024, 2, 1)):
+    K = taps * Cc
+    lda = rstep * Cc
+    frames = Mrows * rstep + taps + 16
+    A = torch.relu(torch.randn(frames * Cc + 64, device=dev)).to(bf)
+    Bt = (torch.randn(Nn * K, device=dev) * 0.05).to(bf)
+    o2 = torch.zeros(Mrows * Nn, device=dev, dtype=bf)
+    t_row = timed(lambda: _hip.gemm_nt(P(A), P(Bt), P(o2), Mrows, Nn, K, lda, K, Nn, 1, flags=_hip.GEMM_RELU)) * 1e3
+    plane = frames * 64
+    Ad = torch.relu(torch.randn((Cc // 64) * plane + 64, device=dev)).to(bf)
+    _hip.lib().cpc_debug_set(4, 32)
+    _hip.lib().cpc_debug_set(5, taps)
+    t_chk = timed(lambda: _hip.gemm_nt(P(Ad), P(Bt), P(o2), Mrows, Nn, K, rstep * 64, K, Nn, 1, a_item=plane, flags=_hip.GEMM_RELU)) * 1e3
+    _hip.lib().cpc_debug_set(4, 0)
+    _hip.lib().cpc_debug_set(5, 1)
+    print(f"{name}: row-major activations {t_row:7.1f} us, chunk-major {t_chk:7.1f} us", flush=True)
+    del A, Ad, Bt, o2
