@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int nrows = min(C1_FPOS, L_alloc - t0);
     const int niter = BITS ? RPW : (nrows - rl + nrl - 1) / nrl;
     // Pad rows are stored from their own branch (no per-row zero fill of v).  Tried against this loop and not faster: one v_max_f32 per
-    // value instead of relu_f's compare / select pair (with a NaN put-back), and a persistent kernel that streams the rows in memory
-    // order with scalar loads of the input samples (370 us against 212 for 956 MB; a plain fill of the buffer takes 137).
+    // value instead of relu_f's compare / select pair (with a NaN put-back); persistent kernels that stream the rows in memory order
+    // (scalar loads of the input samples: 370 us; one vector load per 4-row group + v_readlane: 240 us; this kernel: 199-212 us for
+    // 956 MB, a plain fill of the buffer 137-144).  The arithmetic is not what binds it: with one tap instead of ten it takes 194 us.
     for (int k = 0; k < niter; ++k) {
         const int r = BITS ? rl * RPW + k : rl + k * nrl;
         if (r >= nrows) break;
