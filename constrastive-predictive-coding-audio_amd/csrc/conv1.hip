@@ -19,7 +19,10 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *(bf16x8*)dst = o;
+    // non-temporal: the layer-1 output (956 MB at B = 256) is far larger than L2 + Infinity Cache and is next read from the top;
+    // as ordinary stores its dirty lines are still being written back while the layer-2 GEMM starts (step 4.62 -> 4.58 ms)
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(__builtin_bit_cast(v4u, o), (v4u*)dst);
 }
 template <>
 __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
