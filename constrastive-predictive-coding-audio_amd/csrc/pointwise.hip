@@ -16,7 +16,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const long long n4 = n / 4;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        // gradient and moments are touched once per step: non-temporal, so that 130 MB of them per step do not push the activations and
+        // gradients the backward GEMMs are working on out of the Infinity Cache (the parameters are read again by the layout kernels)
+        f32x4 pp = ((f32x4*)p)[i], gg = __builtin_nontemporal_load((const f32x4*)g + i), mm = __builtin_nontemporal_load((f32x4*)m + i),
+              vv = __builtin_nontemporal_load((f32x4*)v + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ge = gg[e] * grad_scale;
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
             pp[e] = pp[e] - step_size * (mm[e] / denom);
         }
-        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        ((f32x4*)p)[i] = pp; __builtin_nontemporal_store(mm, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
     }
     // tail
     for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
