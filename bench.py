@@ -17,7 +17,9 @@ region is still exactly K full steps.  `prewarm_steps` in the JSON line records 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
                 FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
-                (every tenth: an event pair around a launch leaves ~12 us of idle queue).
+                (every tenth: an event pair around a launch leaves ~12 us of idle queue).  In the step the
+                weight-gradient GEMMs run beside these launches on a second stream; `alone` = the same kernel with everything on
+                one stream, from 6 extra untimed steps after the timed region.
   hbm_kernel    the HBM-bound piece of the conv stack (encoder layer 1, C_in = 1): algorithmic bytes / HIP-event duration vs 8 TB/s.
   score_gemm    the InfoNCE score contraction alone (both loss branches): algorithmic FLOPs / HIP-event time vs the bf16 MFMA peak.
   trainer_ms_per_step   the same step through ContrastiveEstimationTrainer.train (sampler, logger, loss readback, NaN guard).
@@ -254,6 +256,34 @@ def main():
     elapsed = time.perf_counter() - t0
     _hip.set_timer(None)
     loss = float(out[0])
+    # The encoder's weight-gradient GEMMs run on a second stream beside the dominant kernel's launches (engine.py,
+    # CPC_WGRAD_STREAM), so a launch's duration in the step includes the share of the chip it gives up.  A short extra pass AFTER
+    # the timed region, with everything on one stream, gives the same kernel's figures alone (`roofline.alone`).
+    alone = None
+    if graphed is None and args.dtype == "bf16" and os.environ.get("CPC_WGRAD_STREAM", "1") != "0":
+        prev = os.environ.get("CPC_WGRAD_STREAM")
+        os.environ["CPC_WGRAD_STREAM"] = "0"
+        try:
+            for i in range(3):
+                step(i)
+            t_alone = _hip.KernelTimer(only=[DOMINANT])
+            _hip.set_timer(t_alone)
+            t_alone.active = True
+            for i in range(6):
+                step(i)
+            fence()
+            _hip.set_timer(None)
+            sa = t_alone.summary()
+            na = sum(v[0] for k, v in sa.items() if k.startswith(DOMINANT))
+            msa = sum(v[1] for k, v in sa.items() if k.startswith(DOMINANT))
+            fla = sum(v[2] for k, v in sa.items() if k.startswith(DOMINANT))
+            if na and msa > 0:
+                alone = {"achieved": round(fla / (msa * 1e-3) / 1e12, 2), "avg_launch_ms": round(msa / na, 4), "launches": na}
+        finally:
+            if prev is None:
+                os.environ.pop("CPC_WGRAD_STREAM", None)
+            else:
+                os.environ["CPC_WGRAD_STREAM"] = prev
     n_ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -309,6 +339,12 @@ def main():
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
         }
+        if alone is not None:
+            alone["frac"] = round(alone["achieved"] / peak, 4)
+            line["roofline"]["alone"] = alone
+            line["roofline"]["note"] = ("achieved / frac: the launches as they run in the timed step, beside the weight-gradient GEMMs on a "
+                                        "second stream; alone: the same kernel with everything on one stream (6 untimed steps after the "
+                                        "timed region, CPC_WGRAD_STREAM=0)")
         c1 = [v for k, v in summary.items() if k.startswith("cpc_conv1_fwd")]
         if c1 and sum(v[1] for v in c1) > 0:
             # encoder layer 1 (C_in = 1): writes its [B][L_alloc][512] output once, reads 4 B per input sample

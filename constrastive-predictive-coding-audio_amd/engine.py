@@ -563,12 +563,14 @@ class CPCEngine:
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             bname = f"encoder.layers.{l}.bias"
             flops = 2.0 * B * La[l] * cout * kw * cin
-            wg_mode = os.environ.get("CPC_WGRAD_STREAM", "0")
+            wg_mode = os.environ.get("CPC_WGRAD_STREAM", "1")
 
-            # The weight-gradient GEMM of layer l and the data-gradient GEMM of layer l both read dact[l] and are independent.
-            # CPC_WGRAD_STREAM=1 issues the weight gradient on the side stream, beside the data-gradient chain (the tiles of the
-            # two kernels interleave on the CUs): 4.72 -> 4.69 ms per step, but every kernel then runs longer by itself and the
-            # per-kernel roofline figures of bench.py no longer mean much — not the default for 0.6 %.
+            # The weight-gradient GEMM of layer l and the data-gradient GEMM of layer l both read dact[l] and are independent: the
+            # weight gradient is issued on the side stream, beside the data-gradient chain (the tiles of the two kernels interleave on
+            # the CUs, the partial last rounds of tiles of one launch are filled by the other, and both read dact[l] while it is in the
+            # caches): 4.61 -> 4.55 ms per step at the end of round 2 (4.72 -> 4.69 before the side stream was cleared of the
+            # column-sum passes).  Every kernel then runs longer BY ITSELF: bench.py reports the dominant kernel's roofline both as
+            # it runs in the step and alone (CPC_WGRAD_STREAM=0: everything on the main stream, the round-1 arrangement).
             def wgrad_call():
                 _hip.call("cpc_conv_wgrad", _hip.ptr(self.act[l - 1]), _hip.ptr(self.dact[l]), _hip.ptr(self.wslab[l]), B, cin, cout, kw, s,
                           La[l], self.nsplit[l], C.c_longlong(self.guard[l - 1]), code,
