@@ -101,6 +101,8 @@ _SIGNATURES = {
     "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_gru_gp_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
+    "cpc_gru_gp_bwd": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_gru_set_streaming": ([_I], _I),
     "cpc_debug_set": ([_I, _I], _I),
     "cpc_nce_workspace_floats": ([_I, _I], _L),

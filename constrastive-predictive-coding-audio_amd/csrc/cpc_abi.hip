@@ -409,6 +409,17 @@ int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG,
     return launch_gru_bwd(dc, tape, WTfrag, dG, B, V, H, dtype, (hipStream_t)stream);
 }
 
+int cpc_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const float* bhh, float* tape, float* ct_out, int B,
+                   int V, int H, void* stream) {
+    if (!Gi || !GiT || !WT || !bhh || !tape || !ct_out) return CPC_EINVAL;
+    return launch_gru_gp_fwd(Gi, GiT, WT, bhh, tape, ct_out, B, V, H, (hipStream_t)stream);
+}
+
+int cpc_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA, int B, int V, int H, void* stream) {
+    if (!dc || !tape || !W || !dA) return CPC_EINVAL;
+    return launch_gru_gp_bwd(dc, tape, W, dA, B, V, H, (hipStream_t)stream);
+}
+
 extern int g_gru_force_streaming;
 extern int g_gru_waves;
 extern int g_gru_debug;

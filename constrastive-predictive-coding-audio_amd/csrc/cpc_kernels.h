@@ -103,6 +103,9 @@ int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Ha
                    int V, int H, int dtype, hipStream_t stream);
 int launch_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
                    hipStream_t stream);
+int launch_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const float* bhh, float* tape, float* ct_out, int B,
+                      int V, int H, hipStream_t stream);
+int launch_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA, int B, int V, int H, hipStream_t stream);
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
 long long nce_workspace_floats(int B, int K);
 long long nce_all_workspace_floats(int B, int K);

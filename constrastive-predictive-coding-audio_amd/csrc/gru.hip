@@ -647,3 +647,130 @@ int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, i
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
+
+// =====================================================================================================================
+// Wasserstein gradient penalty through the GRU context (contrastive_estimation_training.py:144-158 differentiated through
+// audio_model.py:66-77).  The penalty's parameter gradient is the gradient of a directional derivative of the summed scores
+// (DESIGN.md section 8): reverse mode over the JOINT program (primal recurrence, tangent recurrence).  gru_gp_fwd_kernel runs
+// the two recurrences together and keeps everything the reverse sweep needs; gru_gp_bwd_kernel carries two adjoints per hidden
+// unit down the sequence: G, the adjoint of the summed scores (equal to the adjoint of the tangent variables, the tangent
+// program being linear with the primal Jacobians), and N, the adjoint the primal variables gain through the coefficients of the
+// tangent program (the second derivatives of sigmoid / tanh and the products r*q, z*h, (1-z)*n).  f32 only (the penalty runs in
+// the exact-f32 mode); one workgroup per batch item, one thread per hidden unit, weights streamed from L2 every step: a
+// parity path of ~B workgroups, not a tuned one (a penalty step costs about three plain steps anyway).
+// tape f32 [B][V][10][H]: r, z, n, q = W_hn h + b_hn, h_{t-1}, tangents of the pre-activations of r and z, of q, of the
+// pre-activation of n, and of h_{t-1}.
+#define GRU_GP_SLOTS 10
+
+__global__ __launch_bounds__(256) void gru_gp_fwd_kernel(const float* __restrict__ Gi, const float* __restrict__ GiT,
+                                                         const float* __restrict__ WT, const float* __restrict__ bhh,
+                                                         float* __restrict__ tape, float* __restrict__ ct_out, int V, int H) {
+    extern __shared__ float gp_lds[];
+    float* hs = gp_lds;          // h_{t-1}
+    float* hts = gp_lds + H;     // its tangent
+    const int b = blockIdx.x, j = threadIdx.x;
+    const bool on = j < H;
+    if (on) { hs[j] = 0.f; hts[j] = 0.f; }
+    const float br = on ? bhh[j] : 0.f, bz = on ? bhh[H + j] : 0.f, bn = on ? bhh[2 * H + j] : 0.f;
+    float h = 0.f, ht = 0.f;
+    for (int t = 0; t < V; ++t) {
+        __syncthreads();
+        float ar = br, az = bz, q = bn, art = 0.f, azt = 0.f, qt = 0.f;
+        if (on) {
+            for (int i = 0; i < H; ++i) {
+                const float* w = WT + (size_t)i * 3 * H + j;
+                const float hv = hs[i], tv = hts[i];
+                const float wr = w[0], wz = w[H], wn = w[2 * H];
+                ar = fmaf(wr, hv, ar); az = fmaf(wz, hv, az); q = fmaf(wn, hv, q);
+                art = fmaf(wr, tv, art); azt = fmaf(wz, tv, azt); qt = fmaf(wn, tv, qt);
+            }
+        }
+        __syncthreads();
+        if (on) {
+            const size_t row = ((size_t)b * V + t) * 3 * H;
+            ar += Gi[row + j]; az += Gi[row + H + j];
+            art += GiT[row + j]; azt += GiT[row + H + j];
+            const float r = 1.f / (1.f + expf(-ar)), z = 1.f / (1.f + expf(-az));
+            const float n = tanhf(Gi[row + 2 * H + j] + r * q);
+            const float rt = r * (1.f - r) * art, zt = z * (1.f - z) * azt;
+            const float ant = GiT[row + 2 * H + j] + rt * q + r * qt;
+            const float nt = (1.f - n * n) * ant;
+            float* tp = tape + ((size_t)b * V + t) * GRU_GP_SLOTS * H + j;
+            tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = q; tp[4 * H] = h;
+            tp[5 * H] = art; tp[6 * H] = azt; tp[7 * H] = qt; tp[8 * H] = ant; tp[9 * H] = ht;
+            const float hn = (1.f - z) * n + z * h;
+            ht = zt * (h - n) + (1.f - z) * nt + z * ht;
+            h = hn;
+            hs[j] = h; hts[j] = ht;
+        }
+    }
+    if (on) ct_out[(size_t)b * H + j] = ht;
+}
+
+// dA f32 [B][V][8][H] = [d r_pre | d z_pre | d n_pre | d q] of the summed scores (the adjoints of the tangent pre-activations),
+// then the same four for the second-order adjoint N.  W: weight_hh in the reference's layout [3H][H].
+__global__ __launch_bounds__(256) void gru_gp_bwd_kernel(const float* __restrict__ dc, const float* __restrict__ tape,
+                                                         const float* __restrict__ W, float* __restrict__ dA, int V, int H) {
+    extern __shared__ float gp_lds[];
+    float* dv = gp_lds;              // [3][H]: d r_pre, d z_pre, d q
+    float* vv = gp_lds + 3 * H;      // [3][H]: the same of N
+    const int b = blockIdx.x, i = threadIdx.x;
+    const bool on = i < H;
+    float G = on ? dc[(size_t)b * H + i] : 0.f, N = 0.f;
+    for (int t = V - 1; t >= 0; --t) {
+        float gz = 0.f, v_h = 0.f;
+        if (on) {
+            const float* tp = tape + ((size_t)b * V + t) * GRU_GP_SLOTS * H + i;
+            const float r = tp[0], z = tp[H], n = tp[2 * H], q = tp[3 * H], hp = tp[4 * H];
+            const float art = tp[5 * H], azt = tp[6 * H], qt = tp[7 * H], ant = tp[8 * H], htp = tp[9 * H];
+            const float sr = r * (1.f - r), sz = z * (1.f - z), sn = 1.f - n * n;
+            const float rt = sr * art, zt = sz * azt, nt = sn * ant;
+            // adjoints of the summed scores
+            const float d_n = G * (1.f - z), d_z = G * (hp - n);
+            const float d_an = d_n * sn, d_r = d_an * q, d_q = d_an * r, d_ar = d_r * sr, d_az = d_z * sz;
+            // what the primal variables gain through the tangent program's coefficients
+            const float s_h = G * zt;
+            const float s_n = -G * zt - 2.f * n * d_n * ant;
+            const float s_z = G * (htp - nt) + d_z * (1.f - 2.f * z) * azt;
+            const float s_q = d_an * rt;
+            const float s_r = d_an * qt + d_r * (1.f - 2.f * r) * art;
+            const float v_n = N * (1.f - z) + s_n, v_z = N * (hp - n) + s_z;
+            v_h = N * z + s_h;
+            const float v_an = v_n * sn, v_r = v_an * q + s_r, v_q = v_an * r + s_q, v_ar = v_r * sr, v_az = v_z * sz;
+            float* o = dA + ((size_t)b * V + t) * 8 * H + i;
+            o[0] = d_ar; o[H] = d_az; o[2 * H] = d_an; o[3 * H] = d_q;
+            o[4 * H] = v_ar; o[5 * H] = v_az; o[6 * H] = v_an; o[7 * H] = v_q;
+            dv[i] = d_ar; dv[H + i] = d_az; dv[2 * H + i] = d_q;
+            vv[i] = v_ar; vv[H + i] = v_az; vv[2 * H + i] = v_q;
+            gz = G * z;
+        }
+        __syncthreads();
+        if (on) {
+            float accG = gz, accN = v_h;
+            for (int g = 0; g < 3; ++g)
+                for (int j = 0; j < H; ++j) {
+                    const float w = W[((size_t)g * H + j) * H + i];
+                    accG = fmaf(w, dv[g * H + j], accG);
+                    accN = fmaf(w, vv[g * H + j], accN);
+                }
+            G = accG; N = accN;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const float* bhh, float* tape, float* ct_out, int B,
+                      int V, int H, hipStream_t stream) {
+    if (B <= 0 || V <= 0 || H <= 0 || H > 256) return CPC_EINVAL;
+    hipLaunchKernelGGL(gru_gp_fwd_kernel, dim3(B), dim3((H + 63) / 64 * 64), 2 * H * sizeof(float), stream, Gi, GiT, WT, bhh, tape,
+                       ct_out, V, H);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA, int B, int V, int H, hipStream_t stream) {
+    if (B <= 0 || V <= 0 || H <= 0 || H > 256) return CPC_EINVAL;
+    hipLaunchKernelGGL(gru_gp_bwd_kernel, dim3(B), dim3((H + 63) / 64 * 64), 6 * H * sizeof(float), stream, dc, tape, W, dA, V, H);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

@@ -719,6 +719,10 @@ class GRUContext:
         e, H = self.eng, self.H
         g, code, B, V, E, K = e.model._grad, e.code, e.B, e.V, e.E, e.K
         Ltop, t0, top, dtop = e.geo.alloc[-1], e.T - K - V, e.act[-1], e.dact[-1]
+        phase = getattr(e, "_gp_phase", 0)
+        if phase == 1:               # gradient penalty, pass 1: dc is the adjoint of the summed scores (gp_grads starts from it)
+            self._gp_buffers()
+            self.gp_dc1.copy_(dc)
         _hip.call("cpc_gru_bwd", _hip.ptr(dc), _hip.ptr(self.tape), _hip.ptr(self.w_hh_t_frag), _hip.ptr(self.dG), B, V, H, code)
         # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
         # [3H,4H) that of the recurrent term
@@ -743,6 +747,77 @@ class GRUContext:
         # dz -> rows [t0, t0+V) of the top-layer gradient
         _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
                      c_rpi=V, c_item=Ltop * E, c_valid=V)
+        if phase == 3:               # gradient penalty, pass 3: what z gains through the tangent recurrence's coefficients
+            dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(self.gp_dz.view(B, V, E))
+
+    # ---- Wasserstein gradient penalty (scalogram_engine._gp_step; exact-f32 mode): tangent of c, penalty parts of the gradients
+    def _gp_buffers(self):
+        if getattr(self, "gp_tape", None) is not None:
+            return
+        e, H = self.eng, self.H
+        B, V, E, dev = e.B, e.V, e.E, e.device
+        if e.dt != torch.float32:
+            raise NotImplementedError("the gradient penalty runs in the exact-f32 mode (compute_dtype='fp32')")
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.gp_dc1 = torch.empty(B, H, **f32)
+        self.gp_GiT = torch.empty(B * V * 3 * H, **f32)
+        self.gp_whh_t = torch.empty(H * 3 * H, **f32)                 # [H][3H]
+        self.gp_tape = torch.empty(B * V * 10 * H, **f32)
+        self.gp_ct = torch.empty(B, H, **f32)
+        self.gp_dA = torch.empty(B * V * 8 * H, **f32)
+        self.gp_dz = torch.empty(B * V * E, **f32)
+        self.gp_scratch = torch.empty(2 * self.slab_floats(), **f32)
+
+    def tangent(self, top_t):
+        """``top_t``: tangent of the encoder's top buffer; returns (tensor, offset, item stride) of the tangent of c.  Runs the
+        primal and the tangent recurrence together (cpc_gru_gp_fwd) and keeps what gp_grads' reverse sweep reads."""
+        e, H = self.eng, self.H
+        p, code, B, V, E, K = e.model._param, e.code, e.B, e.V, e.E, e.K
+        Ltop, t0 = e.geo.alloc[-1], e.T - K - V
+        self._gp_buffers()
+        _hip.gemm_nt(_hip.ptr(top_t, t0 * E), _hip.ptr(self.w_ih), _hip.ptr(self.gp_GiT), B * V, 3 * H, E, E, E, 3 * H, code,
+                     a_rpi=V, a_item=Ltop * E)
+        _hip.call("cpc_cast2d", _hip.ptr(p[self.prefix + "weight_hh"]), _hip.ptr(self.gp_whh_t), H, 3 * H, 1, H, code)
+        _hip.call("cpc_gru_gp_fwd", _hip.ptr(self.Gi), _hip.ptr(self.gp_GiT), _hip.ptr(self.gp_whh_t),
+                  _hip.ptr(p[self.prefix + "bias_hh"]), _hip.ptr(self.gp_tape), _hip.ptr(self.gp_ct), B, V, H)
+        self._gp_top_t = top_t
+        return self.gp_ct, 0, H
+
+    def gp_grads(self, gp_grad):
+        """Penalty parts of the GRU's parameter gradients and of dz.  With dA = [delta | nu] from cpc_gru_gp_bwd (delta: adjoints of
+        the summed scores, nu: second-order adjoints): dW_ih = delta^T (tangent x) + nu^T x, dW_hh = delta'^T (tangent h) + nu'^T h,
+        the biases take the column sums of nu, z takes nu W_ih (added to the top-layer gradient in pass 3)."""
+        e, H = self.eng, self.H
+        p, code, B, V, E, K = e.model._param, e.code, e.B, e.V, e.E, e.K
+        Ltop, t0, top, top_t = e.geo.alloc[-1], e.T - K - V, e.act[-1], self._gp_top_t
+        if (self.prefix + "bias_hh") not in p:
+            raise NotImplementedError("gradient penalty through a GRU without biases")
+        _hip.call("cpc_gru_gp_bwd", _hip.ptr(self.gp_dc1), _hip.ptr(self.gp_tape), _hip.ptr(p[self.prefix + "weight_hh"]),
+                  _hip.ptr(self.gp_dA), B, V, H)
+        dA, tape, sl = self.gp_dA, self.gp_tape, self.gp_scratch
+        M = B * V
+
+        def pair(grad, I, J, nsplit, first, second, grad_offset=0):
+            # grad = first product + second product: both into f32 slabs, one fixed-order reduction over all of them
+            chunk = e._chunk(M, nsplit)
+            for idx, (a_off, b_ptr, ldb, kw) in enumerate((first, second)):
+                _hip.gemm_tn(_hip.ptr(dA, a_off), b_ptr, _hip.ptr(sl, idx * nsplit * I * J), M, I, J, 8 * H, ldb, J, code, nsplit=nsplit,
+                             m_chunk=chunk, slab_stride=I * J, flags=_hip.GEMM_OUT_F32, **kw)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(grad, grad_offset), I, J, 2 * nsplit, I * J, 1, 1, J, 0)
+
+        rows = dict(b_rpi=V, b_item=Ltop * E)
+        g_ih, g_hh = gp_grad[self.prefix + "weight_ih"], gp_grad[self.prefix + "weight_hh"]
+        pair(g_ih, 3 * H, E, self.split_ih, (0, _hip.ptr(top_t, t0 * E), E, rows), (4 * H, _hip.ptr(top, t0 * E), E, rows))
+        ht_prev, h_prev = _hip.ptr(tape, 9 * H), _hip.ptr(tape, 4 * H)
+        pair(g_hh, 2 * H, H, self.split_hh, (0, ht_prev, 10 * H, {}), (4 * H, h_prev, 10 * H, {}))
+        pair(g_hh, H, H, self.split_hh, (3 * H, ht_prev, 10 * H, {}), (7 * H, h_prev, 10 * H, {}), grad_offset=2 * H * H)
+        nb = min(e.colsum_blocks, max(1, M // 64))
+        _hip.call("cpc_colsum", _hip.ptr(dA), _hip.ptr(sl), M, 8 * H, 8 * H, nb, code)
+        g_bi, g_bh = gp_grad[self.prefix + "bias_ih"], gp_grad[self.prefix + "bias_hh"]
+        _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 4 * H), _hip.ptr(g_bi), 1, 3 * H, nb, 8 * H, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 4 * H), _hip.ptr(g_bh), 1, 2 * H, nb, 8 * H, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 7 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 8 * H, 1, 1, 0, 0)
+        _hip.gemm_nt(_hip.ptr(dA, 4 * H), _hip.ptr(self.w_ih_t), _hip.ptr(self.gp_dz), M, E, 3 * H, 8 * H, 3 * H, E, code)
 
 
 class ConvArContext:

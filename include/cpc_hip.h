@@ -333,6 +333,21 @@ int cpc_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall,
 int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
                 void* stream);
 
+/* The Wasserstein gradient penalty through AudioGRUModel (contrastive_estimation_training.py:144-158: loss.backward() through
+ * torch.autograd.grad(..., create_graph=True), here for the GRUCell loop of audio_model.py:66-77).  f32 only, H <= 256.
+ * cpc_gru_gp_fwd: primal and tangent recurrence together.  Gi as for cpc_gru_fwd (f32); GiT [B][V][3H] = (tangent of x_t) W_ih^T
+ * (no bias); WT [H][3H] = weight_hh transposed; bhh [3H]; tape f32 [B][V][10][H] (r, z, n, W_hn h + b_hn, h_{t-1}, then the
+ * tangents of the pre-activations of r and z, of W_hn h, of the pre-activation of n, and of h_{t-1}); ct_out [B][H] = tangent of
+ * the last hidden state.
+ * cpc_gru_gp_bwd: reverse sweep of the joint program seeded with dc [B][H], the adjoint of the SUMMED SCORES at the last hidden
+ * state; W = weight_hh [3H][H].  dA f32 [B][V][8][H]: columns [0,4H) = [d r_pre | d z_pre | d n_pre | d n_pre * r] of the summed
+ * scores (to be contracted with the TANGENT inputs / hidden states for the weight gradients), columns [4H,8H) the same four of
+ * the second-order adjoint (contracted with the primal inputs / hidden states; [4H,7H) W_ih is what the encoder's top-layer
+ * gradient gains). */
+int cpc_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const float* bhh, float* tape, float* ct_out, int B,
+                   int V, int H, void* stream);
+int cpc_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA, int B, int V, int H, void* stream);
+
 /* A/B switch: on != 0 forces the weight-streaming GRU kernels where the weight-resident bf16 ones would be used
  * (H in {32,64,128,256}); returns the previous setting.  Not stream-ordered (host-side flag). */
 int cpc_gru_set_streaming(int on);

@@ -327,12 +327,13 @@ def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
                 assert _rel(sd[k.split("/after/")[1]].float(), g[k]) < (2e-3 if dtype == "fp32" else 5e-2), k
 
 
-@pytest.mark.parametrize("fixture", ["scalogram_model_gp"])
+@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model"])
 def test_gradient_penalty_matches_reference(golden_dir, fixture):
     """wasserstein_gradient_penalty=True (reference :144-158, the double backward with respect to the preprocessed batch) on the
     HIP path, exact-f32 mode: losses, every parameter gradient and the parameters after three steps against runs of the
     reference itself (scalogram encoder with BatchNorm / residual blocks + BatchNorm ConvolutionalArModel, linear scores, both
-    loss branches)."""
+    loss branches; ``scalogram_model``: the same encoder with the AudioGRUModel context, runs 3-5 of that fixture — the second
+    derivatives of the gates, engine.GRUContext.gp_grads)."""
     g = _load(golden_dir, fixture + ".npz")
     meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
     B, K, H = meta["B"], meta["K"], meta["H"]
