@@ -73,6 +73,10 @@ _SIGNATURES = {
     "cpc_attn_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _I, _P], _I),
     "cpc_attn_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _I, _P], _I),
     "cpc_add_ln_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _I, _P], _I),
+    "cpc_ln_tangent": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P], _I),
+    "cpc_ln_gp": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U32, _P], _I),
+    "cpc_attn_tangent": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _P], _I),
+    "cpc_attn_gp": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _P], _I),
     "cpc_ln_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _F, _U64, _U32, _I, _P], _I),
     "cpc_mean_time": ([_P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_scalogram_pointwise": ([_P, _P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _F, _F, _I, _I, _P], _I),

@@ -475,3 +475,249 @@ int launch_dropout_mask(float* mask, long long n, float drop_p, unsigned long lo
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
+
+// =====================================================================================================================
+// Wasserstein gradient penalty through the attention context (contrastive_estimation_training.py:144-158 differentiated through
+// attention_model.py:72-82 / transformer.py:262-271).  The penalty's parameter gradient is the reverse sweep of the joint (primal,
+// tangent) program (tools/gp_attention_algebra.py checks the algebra against autograd's double backward):
+//   ln_tangent / attn_tangent     the tangent pass through residual + LayerNorm and through the (item, head) attention;
+//   ln_gp / attn_gp               what the primal inputs of those two gain through the tangent program's coefficients, given the
+//                                 adjoint delta of the SUMMED SCORES at their output (added to the adjoints of the last pass), and
+//                                 the penalty part of the LayerNorm weight gradient.
+// f32 only (the penalty runs in the exact-f32 mode); parity kernels: operands straight from global memory, S x S matrices in LDS.
+namespace {
+
+// rt = at + dropout(bt);  yt = w * rstd * (rt - <rt> - xh <xh rt>),  xh = (r - mean) * rstd      — one wave per row
+__global__ __launch_bounds__(256) void ln_tangent_kernel(const float* __restrict__ at, const float* __restrict__ bt,
+                                                         const float* __restrict__ r, const float* __restrict__ stats,
+                                                         const float* __restrict__ w, float* __restrict__ rt_out,
+                                                         float* __restrict__ yt, int M, int C, Drop dr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+        const long long o = (long long)m * C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float v = at[o + c];
+            if (bt) v += bt[o + c] * drop_factor(dr, (unsigned long long)o + c);
+            if (rt_out) rt_out[o + c] = v;
+            s1 += v;
+            s2 += v * (r[o + c] - mean) * rstd;
+        }
+        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+        for (int c = lane; c < C; c += 64) {
+            float v = at[o + c];
+            if (bt) v += bt[o + c] * drop_factor(dr, (unsigned long long)o + c);
+            const float xh = (r[o + c] - mean) * rstd;
+            yt[o + c] = w[c] * rstd * (v - m1 - xh * m2);
+        }
+    }
+}
+
+// dy = g1 * gscale (+ g2) (g1 row m / bcast when bcast > 0), p = dy * w, Pu = u - <u> - xh <xh u>:
+//   dr[m] += -rstd^2 (xh <p P rt> + <xh rt> P p + <p xh> P rt)      (and dr_b[m] += the same times the dropout factor)
+//   slabs[blk][c] = sum over the block's rows of dy * rstd * P rt     (penalty part of the LayerNorm weight gradient)
+__global__ __launch_bounds__(256) void ln_gp_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                    const float* __restrict__ rt, const float* __restrict__ r,
+                                                    const float* __restrict__ stats, const float* __restrict__ w,
+                                                    float* __restrict__ dr, float* __restrict__ dr_b, float* __restrict__ slabs, int M,
+                                                    int C, int bcast, float gscale, Drop drp) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [4 waves][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int IT = 16;           // C <= 1024
+    float gw[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) gw[u] = 0.f;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+        const long long o = (long long)m * C, go = bcast > 0 ? (long long)(m / bcast) * C : o;
+        float s_rt = 0.f, s_xrt = 0.f, s_p = 0.f, s_px = 0.f, s_prt = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float dy = g1[go + c] * gscale;
+            if (g2) dy += g2[o + c];
+            const float p = dy * w[c], xh = (r[o + c] - mean) * rstd, t = rt[o + c];
+            s_rt += t; s_xrt += xh * t; s_p += p; s_px += p * xh; s_prt += p * t;
+        }
+        const float inv = 1.f / (float)C;
+        const float m_rt = wave_sum(s_rt) * inv, b = wave_sum(s_xrt) * inv, m_p = wave_sum(s_p) * inv, a = wave_sum(s_px) * inv;
+        const float ppr = wave_sum(s_prt) * inv - m_p * m_rt - a * b;      // <p P rt>
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int c = lane + 64 * u;
+            if (c < C) {
+                float dy = g1[go + c] * gscale;
+                if (g2) dy += g2[o + c];
+                const float p = dy * w[c], xh = (r[o + c] - mean) * rstd, t = rt[o + c];
+                const float pr = t - m_rt - xh * b, pp = p - m_p - xh * a;
+                const float src = -rstd * rstd * (xh * ppr + b * pp + a * pr);
+                dr[o + c] += src;
+                if (dr_b) dr_b[o + c] += src * drop_factor(drp, (unsigned long long)o + c);
+                gw[u] += dy * rstd * pr;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int c = lane + 64 * u;
+        if (c < C) acc[wave * C + c] = gw[u];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        slabs[(long long)blockIdx.x * C + c] = acc[c] + acc[C + c] + acc[2 * C + c] + acc[3 * C + c];
+}
+
+__device__ __forceinline__ float dot_rows(const float* a, const float* b, int d) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < d; c += 4) acc += *(const f32x4*)(a + c) * *(const f32x4*)(b + c);
+    return acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+// Tangent of the (item, head) attention: u = scale (qt k^T + q kt^T), pt = P (u - <P, u>), out_t = (pt m) v + (P m) vt, m the
+// dropout factors of the attention weights.
+__global__ __launch_bounds__(256) void attn_tangent_kernel(const float* __restrict__ qkv, const float* __restrict__ qkvt,
+                                                           const float* __restrict__ P, float* __restrict__ out_t, int S, int C,
+                                                           int heads, float scale, Drop dr) {
+    __shared__ float u[ATT_S][ATT_S + 1], pm[ATT_S][ATT_S + 1];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
+    const float* base = qkv + (long long)b * S * 3 * C + h * d;
+    const float* tbase = qkvt + (long long)b * S * 3 * C + h * d;
+    const float* Pb = P + (long long)bh * S * S;
+    auto row = [&](const float* p0, int t, int which) { return p0 + (long long)t * 3 * C + which * C; };
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        u[i][j] = j <= i ? scale * (dot_rows(row(tbase, i, 0), row(base, j, 1), d) + dot_rows(row(base, i, 0), row(tbase, j, 1), d)) : 0.f;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 2, part = tid & 3;
+        if (i < S) {
+            float mrow = 0.f;
+            for (int j = part; j <= i; j += 4) mrow = fmaf(Pb[i * S + j], u[i][j], mrow);
+            mrow += __shfl_xor(mrow, 1, 64);
+            mrow += __shfl_xor(mrow, 2, 64);
+            for (int j = part; j < S; j += 4) {
+                const float pv = j <= i ? Pb[i * S + j] : 0.f;
+                const float mf = drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + j);
+                u[i][j] = pv * (u[i][j] - mrow) * mf;
+                pm[i][j] = pv * mf;
+            }
+        }
+    }
+    __syncthreads();
+    const int d4 = d / 4;
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int i = idx / d4, c = (idx % d4) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j <= i; ++j) o += u[i][j] * *(const f32x4*)(row(base, j, 2) + c) + pm[i][j] * *(const f32x4*)(row(tbase, j, 2) + c);
+        *(f32x4*)(out_t + ((long long)b * S + i) * C + h * d + c) = o;
+    }
+}
+
+// Second-order terms of the attention: with a = m (dO v^T), cc = <P, a>, dS = P (a - cc), u and pt as in attn_tangent,
+// e = m (dO vt^T), w = e + (a - cc)(u - <P,u>), sig = P (w - <P, w>):
+//   dq += scale (sig k + dS kt),  dk += scale (sig^T q + dS^T qt),  dv += (pt m)^T dO.       dO: adjoint of the summed scores.
+__global__ __launch_bounds__(256) void attn_gp_kernel(const float* __restrict__ qkv, const float* __restrict__ qkvt,
+                                                      const float* __restrict__ P, const float* __restrict__ dout,
+                                                      float* __restrict__ dqkv, int S, int C, int heads, float scale, Drop dr) {
+    __shared__ float u[ATT_S][ATT_S + 1], a[ATT_S][ATT_S + 1], e[ATT_S][ATT_S + 1];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, d = C / heads, tid = threadIdx.x;
+    const float* base = qkv + (long long)b * S * 3 * C + h * d;
+    const float* tbase = qkvt + (long long)b * S * 3 * C + h * d;
+    const float* go = dout + (long long)b * S * C + h * d;
+    const float* Pb = P + (long long)bh * S * S;
+    auto row = [&](const float* p0, int t, int which) { return p0 + (long long)t * 3 * C + which * C; };
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        float uv = 0.f, av = 0.f, ev = 0.f;
+        if (j <= i) {
+            const float mf = drop_factor(dr, (unsigned long long)bh * S * S + idx);
+            uv = scale * (dot_rows(row(tbase, i, 0), row(base, j, 1), d) + dot_rows(row(base, i, 0), row(tbase, j, 1), d));
+            av = mf * dot_rows(go + (long long)i * C, row(base, j, 2), d);
+            ev = mf * dot_rows(go + (long long)i * C, row(tbase, j, 2), d);
+        }
+        u[i][j] = uv; a[i][j] = av; e[i][j] = ev;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 2, part = tid & 3;
+        if (i < S) {
+            float mrow = 0.f, cc = 0.f;
+            for (int j = part; j <= i; j += 4) { const float pv = Pb[i * S + j]; mrow = fmaf(pv, u[i][j], mrow); cc = fmaf(pv, a[i][j], cc); }
+            mrow += __shfl_xor(mrow, 1, 64); mrow += __shfl_xor(mrow, 2, 64);
+            cc += __shfl_xor(cc, 1, 64); cc += __shfl_xor(cc, 2, 64);
+            float pw = 0.f;
+            for (int j = part; j <= i; j += 4) {
+                const float wv = e[i][j] + (a[i][j] - cc) * (u[i][j] - mrow);
+                e[i][j] = wv;
+                pw = fmaf(Pb[i * S + j], wv, pw);
+            }
+            pw += __shfl_xor(pw, 1, 64); pw += __shfl_xor(pw, 2, 64);
+            for (int j = part; j < S; j += 4) {
+                const float pv = j <= i ? Pb[i * S + j] : 0.f;
+                const float mf = drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + j);
+                const float uu = u[i][j], aa = a[i][j], ww = e[i][j];
+                u[i][j] = pv * (uu - mrow) * mf;       // pt m
+                a[i][j] = pv * (aa - cc);              // dS
+                e[i][j] = pv * (ww - pw);              // sig
+            }
+        }
+    }
+    __syncthreads();
+    const int d4 = d / 4;
+    for (int idx = tid; idx < S * d4; idx += 256) {
+        const int t = idx / d4, c = (idx % d4) * 4;
+        f32x4 sq = {0.f, 0.f, 0.f, 0.f}, sk = sq, sv = sq;
+        for (int j = 0; j <= t; ++j)
+            sq += e[t][j] * *(const f32x4*)(row(base, j, 1) + c) + a[t][j] * *(const f32x4*)(row(tbase, j, 1) + c);
+        for (int i = t; i < S; ++i) {
+            sk += e[i][t] * *(const f32x4*)(row(base, i, 0) + c) + a[i][t] * *(const f32x4*)(row(tbase, i, 0) + c);
+            sv += u[i][t] * *(const f32x4*)(go + (long long)i * C + c);
+        }
+        float* o = dqkv + ((long long)b * S + t) * 3 * C + h * d + c;
+        *(f32x4*)o += sq * scale;
+        *(f32x4*)(o + C) += sk * scale;
+        *(f32x4*)(o + 2 * C) += sv;
+    }
+}
+
+}  // namespace
+
+int launch_ln_tangent(const float* at, const float* bt, const float* r, const float* stats, const float* w, float* rt_out, float* yt,
+                      int M, int C, float drop_p, unsigned long long seed, unsigned site, hipStream_t st) {
+    if (M <= 0 || C <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
+    hipLaunchKernelGGL(ln_tangent_kernel, dim3(min(2048, (M + 3) / 4)), dim3(256), 0, st, at, bt, r, stats, w, rt_out, yt, M, C, dr);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_ln_gp(const float* g1, const float* g2, const float* rt, const float* r, const float* stats, const float* w, float* dr,
+                 float* dr_b, float* slabs, int M, int C, int bcast, float gscale, int nblocks, float drop_p, unsigned long long seed,
+                 unsigned site, hipStream_t st) {
+    if (M <= 0 || C <= 0 || C > 1024 || nblocks <= 0 || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop drp = make_drop(drop_p, seed, site);
+    hipLaunchKernelGGL(ln_gp_kernel, dim3(nblocks), dim3(256), (size_t)4 * C * sizeof(float), st, g1, g2, rt, r, stats, w, dr, dr_b,
+                       slabs, M, C, bcast, gscale, drp);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_attn_tangent(const float* qkv, const float* qkvt, const float* P, float* out_t, int B, int S, int C, int heads,
+                        float drop_p, unsigned long long seed, unsigned site, hipStream_t st) {
+    if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
+    hipLaunchKernelGGL(attn_tangent_kernel, dim3(B * heads), dim3(256), 0, st, qkv, qkvt, P, out_t, S, C, heads,
+                       1.f / sqrtf((float)(C / heads)), dr);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_attn_gp(const float* qkv, const float* qkvt, const float* P, const float* dout, float* dqkv, int B, int S, int C, int heads,
+                   float drop_p, unsigned long long seed, unsigned site, hipStream_t st) {
+    if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
+    const Drop dr = make_drop(drop_p, seed, site);
+    hipLaunchKernelGGL(attn_gp_kernel, dim3(B * heads), dim3(256), 0, st, qkv, qkvt, P, dout, dqkv, S, C, heads,
+                       1.f / sqrtf((float)(C / heads)), dr);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

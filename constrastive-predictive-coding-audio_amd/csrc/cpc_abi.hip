@@ -245,6 +245,31 @@ int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats
                          (hipStream_t)stream);
 }
 
+int cpc_ln_tangent(const float* at, const float* bt, const float* r, const float* stats, const float* w, float* rt_out, float* yt,
+                   int M, int C, float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!at || !r || !stats || !w || !yt) return CPC_EINVAL;
+    return launch_ln_tangent(at, bt, r, stats, w, rt_out, yt, M, C, drop_p, seed, site, (hipStream_t)stream);
+}
+
+int cpc_ln_gp(const float* g1, const float* g2, const float* rt, const float* r, const float* stats, const float* w, float* dr,
+              float* dr_b, float* slabs, int M, int C, int bcast, float gscale, int nblocks, float drop_p, unsigned long long seed,
+              unsigned site, void* stream) {
+    if (!g1 || !rt || !r || !stats || !w || !dr || !slabs) return CPC_EINVAL;
+    return launch_ln_gp(g1, g2, rt, r, stats, w, dr, dr_b, slabs, M, C, bcast, gscale, nblocks, drop_p, seed, site, (hipStream_t)stream);
+}
+
+int cpc_attn_tangent(const float* qkv, const float* qkvt, const float* P, float* out_t, int B, int S, int C, int heads, float drop_p,
+                     unsigned long long seed, unsigned site, void* stream) {
+    if (!qkv || !qkvt || !P || !out_t) return CPC_EINVAL;
+    return launch_attn_tangent(qkv, qkvt, P, out_t, B, S, C, heads, drop_p, seed, site, (hipStream_t)stream);
+}
+
+int cpc_attn_gp(const float* qkv, const float* qkvt, const float* P, const float* dout, float* dqkv, int B, int S, int C, int heads,
+                float drop_p, unsigned long long seed, unsigned site, void* stream) {
+    if (!qkv || !qkvt || !P || !dout || !dqkv) return CPC_EINVAL;
+    return launch_attn_gp(qkv, qkvt, P, dout, dqkv, B, S, C, heads, drop_p, seed, site, (hipStream_t)stream);
+}
+
 int cpc_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, void* stream) {
     if (!x) return CPC_EINVAL;
     return launch_dropout(x, n, drop_p, seed, site, dtype, (hipStream_t)stream);

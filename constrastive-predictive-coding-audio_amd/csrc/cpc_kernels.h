@@ -144,6 +144,15 @@ int launch_add_ln_fwd(const void* a, const void* b, const float* w, const float*
 int launch_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
                   int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
                   int dtype, hipStream_t stream);
+int launch_ln_tangent(const float* at, const float* bt, const float* r, const float* stats, const float* w, float* rt_out, float* yt,
+                      int M, int C, float drop_p, unsigned long long seed, unsigned site, hipStream_t st);
+int launch_ln_gp(const float* g1, const float* g2, const float* rt, const float* r, const float* stats, const float* w, float* dr,
+                 float* dr_b, float* slabs, int M, int C, int bcast, float gscale, int nblocks, float drop_p, unsigned long long seed,
+                 unsigned site, hipStream_t st);
+int launch_attn_tangent(const float* qkv, const float* qkvt, const float* P, float* out_t, int B, int S, int C, int heads,
+                        float drop_p, unsigned long long seed, unsigned site, hipStream_t st);
+int launch_attn_gp(const float* qkv, const float* qkvt, const float* P, const float* dout, float* dqkv, int B, int S, int C, int heads,
+                   float drop_p, unsigned long long seed, unsigned site, hipStream_t st);
 int launch_dropout(void* x, long long n, float drop_p, unsigned long long seed, unsigned site, int dtype, hipStream_t stream);
 int launch_dropout_mask(float* mask, long long n, float drop_p, unsigned long long seed, unsigned site, hipStream_t stream);
 int launch_mean_time(const void* x, void* out, int B, int S, int C, int dtype, hipStream_t stream);

@@ -18,6 +18,7 @@ import contextlib
 import ctypes as C
 import math
 import os
+from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
 import torch
@@ -1138,8 +1139,145 @@ class AttentionContext:
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[wname + ".weight"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, C), _hip.ptr(g[wname + ".bias"]), 1, C, nb, 2 * C, 1, 1, 0, 0)
 
+    # ---- Wasserstein gradient penalty (scalogram_engine._gp_step; exact-f32 mode).  The context is not piecewise linear, so the
+    # penalty's gradient is the reverse sweep of the JOINT (primal, tangent) program: tangent() runs the tangent pass and keeps the
+    # tangent of every Linear's input; the last pass (_backward_gp) carries two adjoints down the layers — lambda, the real loss's
+    # (the ordinary backward, which also takes the second-order terms of LayerNorm and of the attention core on the way:
+    # cpc_ln_gp, cpc_attn_gp), and delta, the summed scores' (pass 1 again, seeded with the dc kept from it), whose products with the
+    # tangent inputs are the penalty parts of the weight gradients.  tools/gp_attention_algebra.py checks the algebra on the CPU.
+    def _gp_buffers(self):
+        if getattr(self, "gp", None) is not None:
+            return
+        e = self.eng
+        if e.dt != torch.float32:
+            raise NotImplementedError("the gradient penalty runs in the exact-f32 mode (compute_dtype='fp32')")
+        B, C, FF, S, N, H = e.B, self.C, self.FF, self.S, self.N, self.out
+        M = B * S
+        new = lambda *shape: torch.empty(*shape, device=e.device, dtype=torch.float32)
+        self.gp = SimpleNamespace(
+            dc1=new(B, H), zero_pe=torch.zeros(S * C, device=e.device, dtype=torch.float32),
+            Xt=[new(M * C) for _ in range(N + 1)], qkvt=[new(M * 3 * C) for _ in range(N)], attt=[new(M * C) for _ in range(N)],
+            r1t=[new(M * C) for _ in range(N)], x1t=[new(M * C) for _ in range(N)], f1t=[new(M * FF) for _ in range(N)],
+            r2t=[new(M * C) for _ in range(N)], ytmp=new(M * C), xnt=new(M * C), meant=new(B * C), ct=new(B, H),
+            # the delta sweep's own gradient buffers
+            dmean=new(B * C), gA=new(M * C), gB=new(M * C), gC=new(M * C), gD=new(M * C), gAd=new(M * C), gBd=new(M * C),
+            df1=new(M * FF), dqkv=new(M * 3 * C), datt=new(M * C), slabs=new(max(self.slab_floats(), self.ln_blocks * 2 * C)))
+
+    def tangent(self, top_t):
+        """``top_t``: tangent of the encoder's top buffer; returns (tensor, offset, item stride) of the tangent of c."""
+        e = self.eng
+        p, code, B = e.model._param, e.code, e.B
+        C, FF, S, H = self.C, self.FF, self.S, self.out
+        M = B * S
+        Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
+        P = _hip.ptr
+        self._gp_buffers()
+        gp, dp, seed = self.gp, self.drop_p, self.drop_seed
+
+        def ln_t(at, bt, r, stats, wname, rt_out, yt, site=0):
+            _hip.call("cpc_ln_tangent", P(at), P(bt), P(r), P(stats), P(p[wname + ".weight"]), P(rt_out), P(yt), M, C,
+                      dp if bt is not None else 0.0, seed, site)
+        _hip.call("cpc_pe_scale_fwd", P(top_t, t0 * C), P(gp.zero_pe), P(gp.Xt[0]), B, S, C, Ltop * C, self.z_scale, code)
+        for l in range(self.N):
+            Xt, w = gp.Xt[l], self.w[l]
+            _hip.gemm_nt(P(Xt), P(w["in"]), P(gp.qkvt[l]), M, 3 * C, C, C, C, 3 * C, code)
+            _hip.call("cpc_attn_tangent", P(self.qkv[l]), P(gp.qkvt[l]), P(self.P[l]), P(gp.attt[l]), B, S, C, self.heads, dp, seed,
+                      4 * l + self.SITE_ATTN)
+            _hip.gemm_nt(P(gp.attt[l]), P(w["o"]), P(gp.ytmp), M, C, C, C, C, C, code)
+            ln_t(Xt, gp.ytmp, self.r1[l], self.st1[l], self._lname(l, "norm1"), gp.r1t[l], gp.x1t[l], 4 * l + self.SITE_DROP1)
+            _hip.gemm_nt(P(gp.x1t[l]), P(w["l1"]), P(gp.f1t[l]), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
+            if dp > 0.0:
+                gp.f1t[l].mul_(1.0 / (1.0 - dp))          # the stored f1 is the dropped activation: its zeros carry the keep mask
+            _hip.gemm_nt(P(gp.f1t[l]), P(w["l2"]), P(gp.ytmp), M, C, FF, FF, FF, C, code)
+            ln_t(gp.x1t[l], gp.ytmp, self.r2[l], self.st2[l], self._lname(l, "norm2"), gp.r2t[l], gp.Xt[l + 1], 4 * l + self.SITE_DROP2)
+        ln_t(gp.Xt[self.N], None, self.X[self.N], self.stn, self.prefix + "encoder.norm", None, gp.xnt)
+        _hip.call("cpc_mean_time", P(gp.xnt), P(gp.meant), B, S, C, code)
+        _hip.gemm_nt(P(gp.meant), P(self.w_end), P(gp.ct), B, H, C, C, C, H, code, flags=_hip.GEMM_OUT_F32)
+        return gp.ct, 0, H
+
+    def gp_grads(self, gp_grad):
+        self._gp_grad = gp_grad           # filled by the last pass (_backward_gp)
+
+    def _backward_gp(self, dc):
+        """The last pass of a gradient-penalty step: the ordinary backward of ``dc`` (lambda) with the second-order terms joining
+        on the way down, beside the sweep of the summed scores' adjoint (delta, from the dc of pass 1) that gives the penalty parts
+        of the weight gradients.  Everything on the main stream."""
+        e = self.eng
+        g, p, code, B = e.model._grad, e.model._param, e.code, e.B
+        C, FF, S, H = self.C, self.FF, self.S, self.out
+        M = B * S
+        Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
+        P = _hip.ptr
+        gp, gpg, dp, seed = self.gp, self._gp_grad, self.drop_p, self.drop_seed
+        drop = dp > 0.0
+        sc, nb = gp.slabs, self.ln_blocks
+
+        def ln_pair(lam, dl, rt, r, stats, wname, lam_out, lam_out_b, dl_out, dl_out_b, bcast=0, gscale=1.0, site=0):
+            # lambda through the LayerNorm (+ its weight / bias gradients), the second-order terms from delta, then delta itself
+            self._ln_bwd(lam[0], lam[1], r, stats, wname, lam_out, bcast=bcast, gscale=gscale, dr_b=lam_out_b, site=site)
+            _hip.call("cpc_ln_gp", P(dl[0]), P(dl[1]), P(rt), P(r), P(stats), P(p[wname + ".weight"]), P(lam_out), P(lam_out_b), P(sc),
+                      M, C, bcast, gscale, nb, dp if lam_out_b is not None else 0.0, seed, site)
+            _hip.call("cpc_reduce_slabs", P(sc), P(gpg[wname + ".weight"]), 1, C, nb, C, 1, 1, 0, 0)
+            _hip.call("cpc_ln_bwd", P(dl[0]), P(dl[1]), P(r), P(stats), P(p[wname + ".weight"]), P(dl_out), P(sc), M, C, bcast, gscale,
+                      nb, P(dl_out_b), dp if dl_out_b is not None else 0.0, seed, site, code)
+
+        def linear_grads(lam_y, dl_y, x, xt, k, l, rows, cols):
+            e._colsum_to_grad(P(lam_y), g[self._lname(l, self._BNAMES[k])], M, rows, scratch=sc)
+            e._tn_to_grad(P(lam_y), P(x), g[self._lname(l, self._WNAMES[k])], M, rows, cols, rows, cols, self.split[k], scratch=sc)
+            e._tn_to_grad(P(dl_y), P(xt), gpg[self._lname(l, self._WNAMES[k])], M, rows, cols, rows, cols, self.split[k], scratch=sc)
+
+        # end_layer and the mean over time
+        _hip.call("cpc_cast2d", P(dc), P(self.dct), B, H, H, 1, code)
+        _hip.gemm_tn(P(self.dct), P(self.mean), P(g[self.prefix + "end_layer.weight"]), B, H, C, H, C, C, code, flags=_hip.GEMM_OUT_F32)
+        e._colsum_to_grad(P(self.dct), g[self.prefix + "end_layer.bias"], B, H)
+        _hip.gemm_nt(P(self.dct), P(self.w_end_t), P(self.dmean), B, C, H, H, H, C, code)
+        _hip.gemm_tn(P(gp.dc1), P(gp.meant), P(gpg[self.prefix + "end_layer.weight"]), B, H, C, H, C, C, code, flags=_hip.GEMM_OUT_F32)
+        _hip.gemm_nt(P(gp.dc1), P(self.w_end_t), P(gp.dmean), B, C, H, H, H, C, code)
+        lamA, lamB, lamAd, lamBd = self.gA[0], self.gB[0], self.gAd[0], self.gBd[0]
+        ln_pair((self.dmean, None), (gp.dmean, None), gp.Xt[self.N], self.X[self.N], self.stn, self.prefix + "encoder.norm",
+                self.gA[1], None, gp.gA, None, bcast=S, gscale=1.0 / S)
+        lam, dl = (self.gA[1], None), (gp.gA, None)
+        for l in range(self.N - 1, -1, -1):
+            wt = self.wt[l]
+            # norm2 over r2 = x1 + dropout(f2); delta's input gA is free again once this is done
+            ln_pair(lam, dl, gp.r2t[l], self.r2[l], self.st2[l], self._lname(l, "norm2"), lamB, lamBd if drop else None,
+                    gp.gB, gp.gBd if drop else None, site=4 * l + self.SITE_DROP2)
+            lam_y2, dl_y2 = (lamBd, gp.gBd) if drop else (lamB, gp.gB)
+            linear_grads(lam_y2, dl_y2, self.f1[l], gp.f1t[l], "l2", l, C, FF)
+            _hip.gemm_nt(P(lam_y2), P(wt["l2"]), P(self.df1[0]), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
+            _hip.gemm_nt(P(dl_y2), P(wt["l2"]), P(gp.df1), M, FF, C, C, C, FF, code, mask=P(self.f1[l]))
+            linear_grads(self.df1[0], gp.df1, self.x1[l], gp.x1t[l], "l1", l, FF, C)
+            _hip.gemm_nt(P(self.df1[0]), P(wt["l1"]), P(self.gC), M, C, FF, FF, FF, C, code)
+            _hip.gemm_nt(P(gp.df1), P(wt["l1"]), P(gp.gC), M, C, FF, FF, FF, C, code)
+            # norm1 over r1 = x + dropout(attention output projection)
+            ln_pair((lamB, self.gC), (gp.gB, gp.gC), gp.r1t[l], self.r1[l], self.st1[l], self._lname(l, "norm1"), lamA,
+                    lamAd if drop else None, gp.gA, gp.gAd if drop else None, site=4 * l + self.SITE_DROP1)
+            lam_y, dl_y = (lamAd, gp.gAd) if drop else (lamA, gp.gA)
+            linear_grads(lam_y, dl_y, self.att[l], gp.attt[l], "o", l, C, C)
+            _hip.gemm_nt(P(lam_y), P(wt["o"]), P(self.datt), M, C, C, C, C, C, code)
+            _hip.gemm_nt(P(dl_y), P(wt["o"]), P(gp.datt), M, C, C, C, C, C, code)
+            site = 4 * l + self.SITE_ATTN
+            _hip.call("cpc_attn_bwd", P(self.qkv[l]), P(self.P[l]), P(self.datt), P(self.dqkv[0]), B, S, C, self.heads, dp, seed, site, code)
+            _hip.call("cpc_attn_gp", P(self.qkv[l]), P(gp.qkvt[l]), P(self.P[l]), P(gp.datt), P(self.dqkv[0]), B, S, C, self.heads, dp,
+                      seed, site)
+            _hip.call("cpc_attn_bwd", P(self.qkv[l]), P(self.P[l]), P(gp.datt), P(gp.dqkv), B, S, C, self.heads, dp, seed, site, code)
+            linear_grads(self.dqkv[0], gp.dqkv, self.X[l], gp.Xt[l], "in", l, 3 * C, C)
+            _hip.gemm_nt(P(self.dqkv[0]), P(wt["in"]), P(self.gD), M, C, 3 * C, 3 * C, 3 * C, C, code)
+            _hip.gemm_nt(P(gp.dqkv), P(wt["in"]), P(gp.gD), M, C, 3 * C, 3 * C, 3 * C, C, code)
+            # (lamA is read by the next layer's norm2 and rewritten only by its norm1, after that read)
+            lam, dl = (lamA, self.gD), (gp.gA, gp.gD)
+        _hip.call("cpc_pe_scale_bwd", P(lam[0]), P(lam[1]), P(e.dact[-1], t0 * C), B, S, C, Ltop * C, self.z_scale, code)
+
     def backward(self, dc):
         e = self.eng
+        phase = getattr(e, "_gp_phase", 0)
+        if phase == 1:               # gradient penalty, pass 1: dc is the adjoint of the summed scores (the last pass starts from it)
+            self._gp_buffers()
+            self.gp.dc1.copy_(dc)
+        elif phase == 3:
+            if e.use_aux:
+                torch.cuda.current_stream().wait_stream(e.aux)
+            return self._backward_gp(dc)
         g, code, B = e.model._grad, e.code, e.B
         C, FF, S, H = self.C, self.FF, self.S, self.out
         M = B * S

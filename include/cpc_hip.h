@@ -203,6 +203,27 @@ int cpc_add_ln_fwd(const void* a, const void* b, const float* w, const float* bi
 int cpc_ln_bwd(const void* g1, const void* g2, const void* r, const float* stats, const float* w, void* dr, float* slabs, int M,
                int C, int bcast, float gscale, int nblocks, void* dr_b, float drop_p, unsigned long long seed, unsigned site,
                int dtype, void* stream);
+/* The Wasserstein gradient penalty through AttentionModel (contrastive_estimation_training.py:144-158: loss.backward() through
+ * torch.autograd.grad(..., create_graph=True), here for attention_model.py:72-82 / transformer.py:262-271).  f32 only.  "Tangent":
+ * the directional derivative along the penalty's direction; "delta": the adjoint of the SUMMED SCORES (pass 1 of DESIGN.md section 8).
+ * cpc_ln_tangent: rt = at + dropout(bt) (bt, rt_out may be NULL), yt = w * rstd * (rt - <rt> - xh <xh rt>), xh = (r - mean) * rstd with
+ *   (mean, rstd) = stats of the primal cpc_add_ln_fwd.
+ * cpc_ln_gp: the second-order terms of LayerNorm.  dy = g1 * gscale (+ g2) is delta at the output (bcast as in cpc_ln_bwd), rt the
+ *   tangent of the input: dr += -rstd^2 (xh <p P rt> + <xh rt> P p + <p xh> P rt), p = dy * w, P u = u - <u> - xh <xh u> (what the
+ *   input's adjoint of the LAST pass gains; dr_b, may be NULL, gains the same times the dropout factor); slabs f32 [nblocks][C] hold
+ *   per-block partial sums of the penalty part of the weight gradient, sum dy * rstd * P rt.  C <= 1024.
+ * cpc_attn_tangent: out_t = (pt m) v + (P m) vt, pt = P (u - <P,u>), u = scale (qt k^T + q kt^T), m the dropout factors; qkvt in
+ *   the layout of qkv.
+ * cpc_attn_gp: dqkv += the second-order terms of the attention core, dout = delta at its output (formulas in csrc/attn.hip). */
+int cpc_ln_tangent(const float* at, const float* bt, const float* r, const float* stats, const float* w, float* rt_out, float* yt,
+                   int M, int C, float drop_p, unsigned long long seed, unsigned site, void* stream);
+int cpc_ln_gp(const float* g1, const float* g2, const float* rt, const float* r, const float* stats, const float* w, float* dr,
+              float* dr_b, float* slabs, int M, int C, int bcast, float gscale, int nblocks, float drop_p, unsigned long long seed,
+              unsigned site, void* stream);
+int cpc_attn_tangent(const float* qkv, const float* qkvt, const float* P, float* out_t, int B, int S, int C, int heads, float drop_p,
+                     unsigned long long seed, unsigned site, void* stream);
+int cpc_attn_gp(const float* qkv, const float* qkvt, const float* P, const float* dout, float* dqkv, int B, int S, int C, int heads,
+                float drop_p, unsigned long long seed, unsigned site, void* stream);
 /* out[b][c] = mean_t x[(b,t)][c]  (attention_model.py:79) */
 int cpc_mean_time(const void* x, void* out, int B, int S, int C, int dtype, void* stream);
 

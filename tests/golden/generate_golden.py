@@ -26,6 +26,7 @@ Fixtures written (all float32 unless noted):
   reference_snapshot_small.pt  a whole-module pickle as the reference's SnapshotManager writes (+ .npz of the same tensors)
   scalogram_model_sep.npz  the same model with Conv2dSeparable convolutions (depthwise + 1x1)
   scalogram_model_gp.npz   scalogram encoder + BatchNorm ConvolutionalArModel, linear scores, Wasserstein gradient penalty runs
+  scalogram_model_gp_att.npz   the same with an AttentionModel context (dropout 0)
   scalogram_model.npz   PreprocessingModule + ScalogramResidualEncoder (3 blocks, BatchNorm, residuals) + GRU: forward (train / eval), runs with the Wasserstein gradient penalty,
                         trainer losses, gradients, BatchNorm running statistics
 """
@@ -399,6 +400,8 @@ def _scalogram_small_blocks_b():
     return [b0, b1, b2, b3]
 
 
+GP_ATT = {'channels': 64, 'num_layers': 2, 'num_heads': 8, 'feedforward_size': 96, 'dropout': 0.0, 'sequence_length': 10,
+          'output_size': 32}
 GP_AR = {'kernel_sizes': [3, 3], 'channel_count': [64, 48, 32], 'stride': [1, 1], 'pooling': [1, 2], 'bias': True, 'batch_norm': True,
          'residual': False, 'self_attention': [False, False]}
 
@@ -417,6 +420,11 @@ def gen_scalogram(variant="a"):
     elif variant == "sep":
         L = 256 + 32 * 60 + 1
         pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks_sep, True, "scalogram_model_sep"
+    elif variant == "gp_att":
+        # the reference's penalty experiments with an attention context (e20 / e27 / e30 / e31): dropout 0 so that the runs are
+        # reproducible (the reference draws its dropout masks from torch's generator stream)
+        L = 256 + 32 * 60 + 1
+        pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks, True, "scalogram_model_gp_att"
     elif variant == "gp":
         # the shape of the reference's gradient-penalty experiments (e22..): scalogram encoder, convolutional context network with
         # BatchNorm, linear scores, Wasserstein gradient penalty
@@ -435,6 +443,9 @@ def gen_scalogram(variant="a"):
         enc = ref_scal.ScalogramResidualEncoder(args_dict=enc_dict, preprocessing_module=pre)
         if variant == "gp":
             ar = ref_model.ConvolutionalArModel(dict(GP_AR, activation_register=None))
+        elif variant == "gp_att":
+            from attention_model import AttentionModel
+            ar = AttentionModel(dict(GP_ATT))
         else:
             ar = ref_model.AudioGRUModel(input_size=E, hidden_size=H)
         model = ref_model.AudioPredictiveCodingModel(enc, ar, enc_size=E, ar_size=H, visible_steps=V, prediction_steps=K)
@@ -445,6 +456,13 @@ def gen_scalogram(variant="a"):
                     p.mul_(scale[n])
                 if "main_modules" in n and p.dim() == 1 and ".weight" in n:      # BatchNorm gamma away from 1
                     p.add_(0.3 * torch.randn(p.shape, generator=g))
+                if variant == "gp_att" and n.startswith("autoregressive_model."):   # as in gen_attention: the default init would hide mix-ups
+                    if ".norm" in n and n.endswith("weight"):
+                        p.add_(0.3 * torch.randn(p.shape, generator=g))
+                    elif n.endswith("bias"):
+                        p.add_(0.2 * torch.randn(p.shape, generator=g))
+                    elif "encoder.layers" in n:
+                        p.mul_(1.0 + 0.5 * torch.rand(p.shape, generator=g))
             for n, b in model.named_buffers():
                 if n.endswith("running_mean"):
                     b.add_(0.1 * torch.randn(b.shape, generator=g))
@@ -479,12 +497,14 @@ def gen_scalogram(variant="a"):
     rid = 0
     if variant == "gp":
         meta["ar"] = GP_AR
+    if variant == "gp_att":
+        meta["attention"] = GP_ATT
     runs = [("softplus", ref_train.softplus_score_function, False, 1.0, 1, 1e-3, None),
             ("linear", ref_train.linear_score_function, True, 0.01, 1, 1e-3, None),
             ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4, None)]
-    if variant == "gp":
+    if variant in ("gp", "gp_att"):
         runs = []
-    if variant in ("a", "gp"):
+    if variant in ("a", "gp", "gp_att"):
         # Wasserstein gradient penalty (contrastive_estimation_training.py:144-155), the reference's e11.. experiment settings:
         # linear scores, both loss branches
         runs += [("linear", ref_train.linear_score_function, True, 0.0, 1, 1e-3, 10.0),
@@ -841,7 +861,7 @@ def gen_cfg1():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["snapshot", "small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "conv_ar_bn", "ar_resnet"]
+    which = sys.argv[1:] or ["snapshot", "small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "scalogram_gp_att", "conv_ar_bn", "ar_resnet"]
     if "ar_resnet" in which:
         _install_librosa_stand_in()
         gen_ar_resnet()
@@ -855,6 +875,8 @@ if __name__ == "__main__":
         gen_scalogram("sep")
     if "scalogram_gp" in which:
         gen_scalogram("gp")
+    if "scalogram_gp_att" in which:
+        gen_scalogram("gp_att")
     if "cqt" in which:
         gen_cqt()
     if "attention" in which:

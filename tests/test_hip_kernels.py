@@ -715,6 +715,103 @@ def test_add_layernorm_fwd_bwd(dt, M, C, bcast):
     assert rel_err(slabs.sum(0)[1], bias.grad) < t
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+@pytest.mark.parametrize("B,S,C,heads", [(3, 10, 64, 8), (2, 64, 128, 2), (2, 7, 32, 4)])
+def test_attention_gradient_penalty_kernels(B, S, C, heads, p_drop):
+    """cpc_attn_tangent / cpc_attn_gp (f32) against the float64 formulas that tools/gp_attention_algebra.py checks against
+    autograd's double backward; the dropout factors of the attention weights are materialised with cpc_dropout_mask."""
+    g = torch.Generator().manual_seed(S + C + heads)
+    d, M, seed, site = C // heads, B * S, 1234567, 5
+    f64 = lambda *sh: torch.randn(*sh, generator=g).float().double()
+    qkv, qkvt, dO, lam = f64(M, 3 * C), f64(M, 3 * C), f64(M, C), f64(M, 3 * C)
+    hd = lambda t: t.reshape(B, S, heads, d).permute(0, 2, 1, 3)
+    un = lambda t: t.permute(0, 2, 1, 3).reshape(M, C)
+    q, k, v = (hd(t) for t in qkv.split(C, 1))
+    qt, kt, vt = (hd(t) for t in qkvt.split(C, 1))
+    causal = torch.tril(torch.ones(S, S)).bool()
+    sc = 1.0 / math.sqrt(d)
+    P = torch.softmax(((q @ k.transpose(-1, -2)) * sc).masked_fill(~causal, float("-inf")), -1)
+    mask = torch.ones(B * heads * S * S, device=DEV)
+    if p_drop:
+        _hip.call("cpc_dropout_mask", _hip.ptr(mask), mask.numel(), p_drop, seed, site)
+    m = mask.cpu().double().reshape(B, heads, S, S)
+    u = ((qt @ k.transpose(-1, -2) + q @ kt.transpose(-1, -2)) * sc).masked_fill(~causal, 0.0)
+    mrow = (P * u).sum(-1, keepdim=True)
+    pt = P * (u - mrow)
+    out_t = un((pt * m) @ v + (P * m) @ vt)
+    a = m * (hd(dO) @ v.transpose(-1, -2))
+    cc = (P * a).sum(-1, keepdim=True)
+    dS = P * (a - cc)
+    w = m * (hd(dO) @ vt.transpose(-1, -2)) + (a - cc) * (u - mrow)
+    sig = P * (w - (P * w).sum(-1, keepdim=True))
+    src = torch.cat([un(sc * (sig @ k + dS @ kt)), un(sc * (sig.transpose(-1, -2) @ q + dS.transpose(-1, -2) @ qt)),
+                     un((pt * m).transpose(-1, -2) @ hd(dO))], 1)
+    d_qkv, d_qkvt, d_dO, d_P = dev(qkv.float()), dev(qkvt.float()), dev(dO.float()), dev(P.reshape(B * heads, S, S).float())
+    o = torch.full((M, C), float("nan"), device=DEV)
+    _hip.call("cpc_attn_tangent", _hip.ptr(d_qkv), _hip.ptr(d_qkvt), _hip.ptr(d_P), _hip.ptr(o), B, S, C, heads, p_drop, seed, site)
+    assert rel_err(o, out_t) < 1e-5
+    acc = dev(lam.float())
+    _hip.call("cpc_attn_gp", _hip.ptr(d_qkv), _hip.ptr(d_qkvt), _hip.ptr(d_P), _hip.ptr(d_dO), _hip.ptr(acc), B, S, C, heads, p_drop,
+              seed, site)
+    assert rel_err(acc.double().cpu() - lam, src) < 1e-4
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+@pytest.mark.parametrize("M,C,bcast", [(180, 64, 0), (37, 512, 0), (120, 96, 60), (24, 1024, 0)])
+def test_layernorm_gradient_penalty_kernels(M, C, bcast, p_drop):
+    """cpc_ln_tangent / cpc_ln_gp (f32) against the float64 formulas of tools/gp_attention_algebra.py (tangent of
+    LayerNorm(a + dropout(b)); second-order term on the input and the penalty part of the weight gradient)."""
+    g = torch.Generator().manual_seed(M + C)
+    seed, site = 424242, 3
+    f64 = lambda *sh: torch.randn(*sh, generator=g).float().double()
+    a, b, at, bt, lam = f64(M, C), f64(M, C) * 0.5, f64(M, C), f64(M, C), f64(M, C)
+    w, bias = (1 + 0.3 * f64(C)), 0.2 * f64(C)
+    mask = torch.ones(M * C, device=DEV)
+    if p_drop:
+        _hip.call("cpc_dropout_mask", _hip.ptr(mask), mask.numel(), p_drop, seed, site)
+    m = mask.cpu().double().reshape(M, C)
+    da, db, dw, dbias = dev(a.float()), dev(b.float()), dev(w.float()), dev(bias.float())
+    r = torch.empty(M, C, device=DEV)
+    y = torch.empty(M, C, device=DEV)
+    stats = torch.empty(M, 2, device=DEV)
+    _hip.call("cpc_add_ln_fwd", _hip.ptr(da), _hip.ptr(db), _hip.ptr(dw), _hip.ptr(dbias), _hip.ptr(r), _hip.ptr(y), _hip.ptr(stats),
+              M, C, 1e-5, p_drop, seed, site, _hip.F32)
+    rr = a + b * m
+    assert rel_err(r, rr) < 1e-6
+    mu = rr.mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((rr - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+    xh = (rr - mu) * rstd
+    proj = lambda t: t - t.mean(-1, keepdim=True) - xh * (xh * t).mean(-1, keepdim=True)
+    rt = at + bt * m
+    yt_ref = w * rstd * proj(rt)
+    rt_out = torch.full((M, C), float("nan"), device=DEV)
+    yt = torch.full((M, C), float("nan"), device=DEV)
+    d_at, d_bt = dev(at.float()), dev(bt.float())
+    _hip.call("cpc_ln_tangent", _hip.ptr(d_at), _hip.ptr(d_bt), _hip.ptr(r), _hip.ptr(stats), _hip.ptr(dw),
+              _hip.ptr(rt_out), _hip.ptr(yt), M, C, p_drop, seed, site)
+    assert rel_err(rt_out, rt) < 1e-6 and rel_err(yt, yt_ref) < 1e-5
+    if bcast:
+        gm = f64(M // bcast, C)
+        dy, g1, g2, gscale = gm.repeat_interleave(bcast, 0) / bcast, gm, None, 1.0 / bcast
+    else:
+        g1, g2, gscale = f64(M, C), f64(M, C), 1.0
+        dy = g1 + g2
+    p = dy * w
+    pr, pp = proj(rt), proj(p)
+    aa, bb = (p * xh).mean(-1, keepdim=True), (xh * rt).mean(-1, keepdim=True)
+    src = -(rstd ** 2) * (xh * (p * pr).mean(-1, keepdim=True) + bb * pp + aa * pr)
+    gw = (dy * rstd * pr).sum(0)
+    nb = 5
+    slabs = torch.full((nb, C), float("nan"), device=DEV)
+    acc, acc_b = dev(lam.float()), dev(lam.float())
+    d_g1, d_g2 = dev(g1.float()), (dev(g2.float()) if g2 is not None else None)
+    _hip.call("cpc_ln_gp", _hip.ptr(d_g1), _hip.ptr(d_g2), _hip.ptr(rt_out), _hip.ptr(r),
+              _hip.ptr(stats), _hip.ptr(dw), _hip.ptr(acc), _hip.ptr(acc_b), _hip.ptr(slabs), M, C, bcast, gscale, nb, p_drop, seed, site)
+    assert rel_err(acc.double().cpu() - lam, src) < 1e-4
+    assert rel_err(acc_b.double().cpu() - lam, src * m) < 1e-4
+    assert rel_err(slabs.sum(0), gw) < 1e-4
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_positional_scale_and_time_mean(dt):
     B, S, C, Ltop, t0 = 3, 11, 32, 20, 4

@@ -255,6 +255,9 @@ def _build_scalogram_model(g, meta, dtype):
     if "ar" in meta:
         from cpc_audio_amd.audio_model import ConvolutionalArModel
         ar = ConvolutionalArModel(dict(meta["ar"], activation_register=None))
+    elif "attention" in meta:
+        from cpc_audio_amd.attention_model import AttentionModel
+        ar = AttentionModel(dict(meta["attention"]))
     else:
         ar = AudioGRUModel(input_size=meta["E"], hidden_size=meta["H"])
     model = AudioPredictiveCodingModel(enc, ar, enc_size=meta["E"],
@@ -327,13 +330,14 @@ def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
                 assert _rel(sd[k.split("/after/")[1]].float(), g[k]) < (2e-3 if dtype == "fp32" else 5e-2), k
 
 
-@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model"])
+@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model", "scalogram_model_gp_att"])
 def test_gradient_penalty_matches_reference(golden_dir, fixture):
     """wasserstein_gradient_penalty=True (reference :144-158, the double backward with respect to the preprocessed batch) on the
     HIP path, exact-f32 mode: losses, every parameter gradient and the parameters after three steps against runs of the
     reference itself (scalogram encoder with BatchNorm / residual blocks + BatchNorm ConvolutionalArModel, linear scores, both
     loss branches; ``scalogram_model``: the same encoder with the AudioGRUModel context, runs 3-5 of that fixture — the second
-    derivatives of the gates, engine.GRUContext.gp_grads)."""
+    derivatives of the gates, engine.GRUContext.gp_grads; ``scalogram_model_gp_att``: an AttentionModel context, dropout 0 — the
+    second-order terms of LayerNorm, softmax and the two attention products, engine.AttentionContext._backward_gp)."""
     g = _load(golden_dir, fixture + ".npz")
     meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
     B, K, H = meta["B"], meta["K"], meta["H"]
@@ -420,6 +424,70 @@ def test_gradient_penalty_plain_conv_context_against_oracle(golden_dir):
         ot = O.OracleTrainer(params, V, K, score="linear", all_timesteps=all_t, regularization=reg, lr=0.0,
                              scalogram=oblocks, conv_ar=meta["ar"], gradient_penalty_factor=factor)
         loss, smax, grads = ot.loss_and_grads(scal)
+        assert abs(logger.loss_meter.values[0] - float(loss)) < 1e-4 * abs(float(loss)), (all_t, logger.loss_meter.values, float(loss))
+        largest = max(float(v.abs().max()) for v in grads.values() if v is not None)
+        for name, ref in grads.items():
+            got = dict(model.named_parameters())[name].grad.double().cpu()
+            if ref.abs().max().item() < 1e-6 * largest:
+                assert got.abs().max().item() < 1e-5 * largest, (all_t, name)
+                continue
+            l2 = ((got - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
+            assert l2 < 1e-3, (all_t, name, l2)
+
+
+def test_gradient_penalty_attention_context_with_dropout_against_oracle(golden_dir):
+    """The penalty through an AttentionModel in TRAIN mode with dropout (the reference's e20 / e27 / e30 / e31 settings, p = 0.1
+    there): the tangent pass and the second-order terms must use the masks of the primal pass.  The device masks are a function
+    of (seed, site, index): materialised with cpc_dropout_mask and handed to the oracle, whose double backward is the judge."""
+    import copy
+    from cpc_audio_amd import _hip
+    from cpc_audio_amd.audio_dataset import FileBatchSampler
+    g = _load(golden_dir, "scalogram_model_gp_att.npz")
+    meta = copy.deepcopy(json.load(open(os.path.join(golden_dir, "scalogram_model_gp_att.json"))))
+    p_drop = 0.25
+    meta["attention"] = dict(meta["attention"], dropout=p_drop)
+    B, K, H, V, E = meta["B"], meta["K"], meta["H"], meta["V"], meta["E"]
+    layers, heads, FF = meta["attention"]["num_layers"], meta["attention"]["num_heads"], meta["attention"]["feedforward_size"]
+    pre, model = _build_scalogram_model(g, meta, "fp32")
+    model.train()
+    params = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    data = torch.from_numpy(g["data"])
+    oblocks = copy.deepcopy(meta["blocks"])
+    for b in oblocks:
+        b["kernel_size_1"], b["kernel_size_2"] = tuple(b["kernel_size_1"]), tuple(b["kernel_size_2"])
+    oblocks[0]["in_channels"] = 2
+    for all_t, reg, factor in ((False, 0.01, 2.0), (True, 0.0, 10.0)):
+        logger = _Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=reg, score_over_all_timesteps=all_t, score_function=SCORE["linear"],
+                                          prediction_steps=K, ar_size=H, preprocessing=pre, wasserstein_gradient_penalty=True,
+                                          gradient_penalty_factor=factor)
+        tr.verbose = False
+        random.seed(91)
+        idx = [list(b) for b in FileBatchSampler([data.shape[0]], B, 1, True, verbose=False)][0]
+        with torch.no_grad():
+            scal = pre(data[idx].to(DEV).unsqueeze(1))
+        eng = model.engine_for(scal)
+        eng.ctx.fixed_seed = 4321 + int(all_t)
+        random.seed(91)
+        tr.train(batch_size=B, epochs=1, lr=0.0, num_workers=0, max_steps=1)
+        assert eng.ctx.drop_p == p_drop
+        seed = eng.ctx.drop_seed
+
+        def factors(n, site):
+            m = torch.empty(n, device=DEV)
+            _hip.call("cpc_dropout_mask", _hip.ptr(m), n, p_drop, seed, site)
+            return m.cpu()
+
+        df = {}
+        for l in range(layers):
+            df[(l, 0)] = factors(B * heads * V * V, 4 * l + 0).view(B * heads, V, V)
+            df[(l, 1)] = factors(B * V * E, 4 * l + 1).view(B, V, E).transpose(0, 1)
+            df[(l, 2)] = factors(B * V * FF, 4 * l + 2).view(B, V, FF).transpose(0, 1)
+            df[(l, 3)] = factors(B * V * E, 4 * l + 3).view(B, V, E).transpose(0, 1)
+        ot = O.OracleTrainer(params, V, K, score="linear", all_timesteps=all_t, regularization=reg, lr=0.0, scalogram=oblocks,
+                             attention=(layers, heads, df), gradient_penalty_factor=factor)
+        loss, smax, grads = ot.loss_and_grads(scal.cpu())
         assert abs(logger.loss_meter.values[0] - float(loss)) < 1e-4 * abs(float(loss)), (all_t, logger.loss_meter.values, float(loss))
         largest = max(float(v.abs().max()) for v in grads.values() if v is not None)
         for name, ref in grads.items():
