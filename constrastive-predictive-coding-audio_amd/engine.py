@@ -174,7 +174,8 @@ class CPCEngine:
         # burst per round of tiles; 0.96 GB of the launch's traffic).  Measured (tools/bits_ab.py, B = 256): that launch 1 035 ->
         # 950 us, layer-1 forward +20 us.  For the deeper layers the same trade is even (the forward GEMMs' epilogues pay 2-6 % for
         # writing the bits — one workgroup per CU, nothing to hide an epilogue instruction behind — and a separate kernel costs what
-        # the data gradients gain), so they keep reading their masks from the activations.  CPC_MASK_BITS=0: plain masks (A/B).
+        # the data gradients gain — also when that kernel runs on the side stream while the GRU leaves 240 CUs idle: 4.52 -> 4.57 ms per
+        # step), so they keep reading their masks from the activations.  CPC_MASK_BITS=0: plain masks (A/B).
         self.act_bits: List[Optional[torch.Tensor]] = [None] * n
         if (dt == torch.bfloat16 and os.environ.get("CPC_MASK_BITS", "1") != "0" and n >= 2 and self.channels[0] == 512
                 and _hip.nt_tile(self.code, B * La[1], self.strides[1] * 512, self.geo.taps[1] * self.channels[1]) == 256

@@ -1,7 +1,10 @@
 """Per-step timeline from a rocprofv3 --kernel-trace CSV: for the last full train step, every kernel in start order with its
 stream (queue), duration and the idle gap since the previous kernel END on the same queue; totals of busy / idle per queue.
 
-    python tools/timeline.py gpurun_out/prof_<tag>/stats/**/..._kernel_trace.csv [--first conv1_fwd]
+    python tools/timeline.py gpurun_out/prof_<tag>/stats/**/..._kernel_trace.csv [--first conv1_fwd] [--back N]
+
+--back N: the step N steps before the last full one (bench.py ends with nine untimed steps on ONE stream for `roofline.alone`;
+--back 12 shows a step of the timed region, weight gradients on the second stream).
 """
 import csv
 import sys
@@ -10,7 +13,9 @@ from collections import defaultdict
 
 def main():
     path = sys.argv[1]
-    first = sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--first" else "conv_w_prep"
+    opts = dict(zip(sys.argv[2::2], sys.argv[3::2]))
+    first = opts.get("--first", "conv_w_prep")
+    back = int(opts.get("--back", "0"))
     rows = list(csv.DictReader(open(path)))
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -18,10 +23,10 @@ def main():
     # a step starts with the first `first` kernel after a non-`first` kernel
     starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"] and (i == 0 or first not in rows[i - 1]["Kernel_Name"])]
     starts = [i for j, i in enumerate(starts) if j == 0 or i - starts[j - 1] > 20]
-    if len(starts) < 3:
+    if len(starts) < 3 + back:
         print("steps not found", len(starts))
         return
-    a, b = starts[-3], starts[-2]
+    a, b = starts[-3 - back], starts[-2 - back]
     step = rows[a:b]
     t0 = step[0]["s"]
     print(f"step wall (start of first kernel to start of next step): {(rows[b]['s'] - t0) / 1e3:.1f} us, {len(step)} kernels")
