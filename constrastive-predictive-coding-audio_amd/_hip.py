@@ -113,6 +113,7 @@ _SIGNATURES = {
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_nce_all_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss_all": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
+    "cpc_gp_score_coeff": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_nce_eval_workspace_floats": ([_I, _I], _L),
     "cpc_nce_eval": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P], _I),

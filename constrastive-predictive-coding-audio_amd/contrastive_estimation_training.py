@@ -182,9 +182,9 @@ class ContrastiveEstimationTrainer:
             if preprocessing is None:
                 raise ValueError("wasserstein_gradient_penalty needs a preprocessing module (the reference takes the penalty's "
                                  "gradient with respect to the preprocessed batch, contrastive_estimation_training.py:100-102, :147)")
-            if score_function is not linear_score_function or optimizer is not torch.optim.Adam:
-                raise NotImplementedError("the gradient penalty on the HIP path covers linear_score_function + Adam (every reference "
-                                          "experiment with the penalty); see DESIGN.md section 8")
+            if score_function not in (linear_score_function, softplus_score_function) or optimizer is not torch.optim.Adam:
+                raise NotImplementedError("the gradient penalty on the HIP path covers linear_score_function / softplus_score_function "
+                                          "+ Adam; see DESIGN.md section 8")
             model.gradient_penalty_engine = True      # engines built from now on also give the gradient w.r.t. the scalogram
         if self.verbose:
             print("use score function", self.score_function)
@@ -381,7 +381,8 @@ class ContrastiveEstimationTrainer:
                         if self.wasserstein_gradient_penalty:
                             # three passes through the network (scalogram_engine.ScalogramCPCEngine._gp_step); the parameter
                             # gradients are complete only at the end, so Adam runs once, after them
-                            out = eng.loss_and_grads(x_eng, softplus=False, regularization=float(self.regularization),
+                            out = eng.loss_and_grads(x_eng, softplus=self.score_function is softplus_score_function,
+                                                     regularization=float(self.regularization),
                                                      all_timesteps=bool(self.score_over_all_timesteps), global_negatives=gneg,
                                                      after_loss=sync.reduce_flag if sync is not None else None,
                                                      gradient_penalty=float(self.gradient_penalty_factor))

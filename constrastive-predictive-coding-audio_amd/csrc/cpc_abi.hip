@@ -471,6 +471,12 @@ int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspa
     return launch_nce(S, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
 }
 
+int cpc_gp_score_coeff(const float* S, const float* St1, const float* St2, float* W, float* WT, int nmat, int rows, int cols, int ld,
+                       int ldT, int mode, void* stream) {
+    if (!S || !W || !WT) return CPC_EINVAL;
+    return launch_gp_score_coeff(S, St1, St2, W, WT, nmat, rows, cols, ld, ldT, mode, (hipStream_t)stream);
+}
+
 long long cpc_nce_all_workspace_floats(int B, int K) { return nce_all_workspace_floats(B, K); }
 
 int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,

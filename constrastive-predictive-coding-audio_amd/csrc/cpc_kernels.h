@@ -113,6 +113,8 @@ int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* 
                    int softplus, float reg, int dtype, hipStream_t stream);
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream);
+int launch_gp_score_coeff(const float* S, const float* St1, const float* St2, float* W, float* WT, int nmat, int rows, int cols, int ld,
+                          int ldT, int mode, hipStream_t stream);
 long long nce_eval_workspace_floats(int B, int K);
 int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, int ld, int softplus, int all_timesteps,
                     int accumulate, hipStream_t stream);

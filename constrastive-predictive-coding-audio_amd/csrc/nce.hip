@@ -607,3 +607,38 @@ int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, 
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
+
+// Wasserstein gradient penalty with softplus scores (contrastive_estimation_training.py:12-16 under :144-158): the summed scores
+// are sum softplus(s), so the seeds of the penalty's passes carry the coefficients sigmoid(s) (first order) and
+// sigmoid'(s) * (tangent of s) (second order) instead of the constant 1 and 0 of linear scores.
+//   mode 0:  w = d softplus(s) / d s          mode 1:  w = d^2 softplus(s) / d s^2 * (St1 + St2)     (St2 may be NULL)
+// S, St*: nmat matrices [rows][ld] f32;  W [nmat][rows][ld], WT [nmat][cols][ldT] (the transpose), both f32.
+__global__ __launch_bounds__(256) void gp_score_coeff_kernel(const float* __restrict__ S, const float* __restrict__ St1,
+                                                             const float* __restrict__ St2, float* __restrict__ W,
+                                                             float* __restrict__ WT, int rows, int cols, int ld, int ldT, int mode) {
+    const int m = blockIdx.y;
+    const long long total = (long long)rows * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx % cols);
+        const long long o = ((long long)m * rows + r) * ld + c;
+        const float x = S[o];
+        const float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+        float w = sg;
+        if (mode == 1) {
+            float t = St1[o];
+            if (St2) t += St2[o];
+            w = x > 20.f ? 0.f : sg * (1.f - sg) * t;
+        }
+        W[o] = w;
+        WT[((long long)m * cols + c) * ldT + r] = w;
+    }
+}
+
+int launch_gp_score_coeff(const float* S, const float* St1, const float* St2, float* W, float* WT, int nmat, int rows, int cols, int ld,
+                          int ldT, int mode, hipStream_t stream) {
+    if (nmat <= 0 || rows <= 0 || cols <= 0 || ld < cols || ldT < rows || (mode != 0 && mode != 1) || (mode == 1 && !St1)) return CPC_EINVAL;
+    const int blocks = (int)std::min<long long>(1024, ((long long)rows * cols + 255) / 256);
+    hipLaunchKernelGGL(gp_score_coeff_kernel, dim3(blocks, nmat), dim3(256), 0, stream, S, St1, St2, W, WT, rows, cols, ld, ldT, mode);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}

@@ -399,16 +399,18 @@ class CPCEngine:
         return pred, targets, z, self.ctx.c_float().clone()
 
     # ------------------------------------------------------------------------------------------ loss
-    def score_gemm(self):
+    def score_gemm(self, pred=None, top=None, out=None):
         """The score contraction of the default branch (contrastive_estimation_training.py:12-22 restricted to equal steps,
         :116): K batched B x E x B products S[k] = predicted_z[:, k, :] targets[:, :, k]^T.  Returns its algorithmic FLOPs."""
         code, B, E, K = self.code, self.B, self.E, self.K
         Ltop, T, ld = self.geo.alloc[-1], self.T, self.ldS
-        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(self.act[-1], (T - K) * E), _hip.ptr(self.S), B, B, E, K * E, Ltop * E, ld, code,
-                     a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
+        pred = self.pred if pred is None else pred
+        top = self.act[-1] if top is None else top
+        _hip.gemm_nt(_hip.ptr(pred), _hip.ptr(top, (T - K) * E), _hip.ptr(self.S if out is None else out), B, B, E, K * E, Ltop * E, ld,
+                     code, a_batch=E, b_batch=E, c_batch=B * ld, batch=K, flags=_hip.GEMM_OUT_F32)
         return 2.0 * K * B * B * E
 
-    def score_gemm_all(self):
+    def score_gemm_all(self, pred=None, top=None, out=None):
         """The full (B K) x E x (B K) score contraction of score_over_all_timesteps=True (:12-22, :108-114).  Returns its FLOPs."""
         code, B, E, K = self.code, self.B, self.E, self.K
         Ltop, T = self.geo.alloc[-1], self.T
@@ -416,7 +418,9 @@ class CPCEngine:
         ld = _ceil_div(R, 8) * 8
         if getattr(self, "S_all", None) is None:
             self.S_all = torch.zeros(R * ld, device=self.device, dtype=torch.float32)
-        _hip.gemm_nt(_hip.ptr(self.pred), _hip.ptr(self.act[-1], (T - K) * E), _hip.ptr(self.S_all), R, R, E, E, E, ld, code,
+        pred = self.pred if pred is None else pred
+        top = self.act[-1] if top is None else top
+        _hip.gemm_nt(_hip.ptr(pred), _hip.ptr(top, (T - K) * E), _hip.ptr(self.S_all if out is None else out), R, R, E, E, E, ld, code,
                      b_rpi=K, b_item=Ltop * E, flags=_hip.GEMM_OUT_F32)
         return 2.0 * R * R * E
 
@@ -431,11 +435,18 @@ class CPCEngine:
         self.score_gemm()
         _hip.call("cpc_nce_loss", _hip.ptr(self.S), _hip.ptr(self.dS), _hip.ptr(self.dST), _hip.ptr(self.nce_out),
                   _hip.ptr(self.nce_ws), B, K, ld, 1 if softplus else 0, C.c_float(regularization), code)
-        # d predicted_z[b][k][:] = sum_b' dS[k][b][b'] * targets[b'][k][:]
-        _hip.gemm_tn(_hip.ptr(self.dST), _hip.ptr(top, (T - K) * E), _hip.ptr(self.dpred), B, B, E, ld, Ltop * E, K * E, code,
+        self._score_grads(self.dS, self.dST, self.pred, top, self.dpred, dtop)
+
+    def _score_grads(self, W, WT, pred, top, out_pred, out_top):
+        """The two contractions behind d loss / d (predicted_z, targets) of the default branch, for any coefficients W[k][b][b']
+        (WT: its transpose per k) and operands in the layouts of ``self.pred`` / the top-layer buffer."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T, ld = self.geo.alloc[-1], self.T, self.ldS
+        # out_pred[b][k][:] = sum_b' W[k][b][b'] * targets[b'][k][:]
+        _hip.gemm_tn(_hip.ptr(WT), _hip.ptr(top, (T - K) * E), _hip.ptr(out_pred), B, B, E, ld, Ltop * E, K * E, code,
                      a_batch=B * ld, b_batch=E, c_batch=E, batch=K)
-        # d targets[b'][k][:] = sum_b dS[k][b][b'] * predicted_z[b][k][:]   -> rows T-K+k of the top-layer gradient
-        _hip.gemm_tn(_hip.ptr(self.dS), _hip.ptr(self.pred), _hip.ptr(dtop, (T - K) * E), B, B, E, ld, K * E, Ltop * E, code,
+        # out_top rows T-K+k of item b' = sum_b W[k][b][b'] * predicted_z[b][k][:]
+        _hip.gemm_tn(_hip.ptr(W), _hip.ptr(pred), _hip.ptr(out_top, (T - K) * E), B, B, E, ld, K * E, Ltop * E, code,
                      a_batch=B * ld, b_batch=E, c_batch=E, batch=K)
 
     def nce_all_forward_backward(self, softplus: bool, regularization: float):
@@ -464,13 +475,22 @@ class CPCEngine:
         # d predicted_z[(b,k)][:] = sum_c dS[(b,k)][c] * targets[c][:]  and  d targets[c][:] = sum_r dS[r][c] * predicted_z[r][:]
         # (the latter into rows T-K+k' of item b' of the top-layer gradient).  As NT GEMMs over the long axis — the reduction
         # form would put a 3072-row reduction on 24 workgroups — with the small right-hand operands transposed once (3 MB each).
+        self._score_grads_all(self.dS_all, self.dST_all, self.pred, top, self.dpred, dtop)
+
+    def _score_grads_all(self, W, WT, pred, top, out_pred, out_top):
+        """The same for the all-timesteps branch: W [(b,k)][(b',k')] and its transpose."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T = self.geo.alloc[-1], self.T
+        R = B * K
+        ld = _ceil_div(R, 8) * 8
+        tg = (T - K) * E
         if getattr(self, "targT", None) is None:
             self.targT = torch.zeros(E, ld, device=self.device, dtype=self.dt)
             self.predT = torch.zeros(E, ld, device=self.device, dtype=self.dt)
         self.targT[:, :R].copy_(top.view(B, Ltop, E)[:, T - K:T, :].reshape(R, E).t())
-        self.predT[:, :R].copy_(self.pred.view(R, E).t())
-        _hip.gemm_nt(_hip.ptr(self.dS_all), _hip.ptr(self.targT), _hip.ptr(self.dpred), R, E, ld, ld, ld, E, code)
-        _hip.gemm_nt(_hip.ptr(self.dST_all), _hip.ptr(self.predT), _hip.ptr(dtop, tg), R, E, ld, ld, ld, E, code,
+        self.predT[:, :R].copy_(pred.view(R, E).t())
+        _hip.gemm_nt(_hip.ptr(W), _hip.ptr(self.targT), _hip.ptr(out_pred), R, E, ld, ld, ld, E, code)
+        _hip.gemm_nt(_hip.ptr(WT), _hip.ptr(self.predT), _hip.ptr(out_top, tg), R, E, ld, ld, ld, E, code,
                      c_rpi=K, c_item=Ltop * E, c_valid=K)
 
     def nce_eval(self, softplus: bool, all_timesteps: bool, sums, workspace):

@@ -833,6 +833,17 @@ class ScalogramCPCEngine(CPCEngine):
             return super().loss_and_grads(x, softplus, regularization, all_timesteps, grad_ready_hook, global_negatives, after_loss)
         return self._gp_step(x, softplus, regularization, all_timesteps, float(gradient_penalty), global_negatives, after_loss)
 
+    def _gp_softplus_buffers(self, all_timesteps):
+        key = bool(all_timesteps)
+        if getattr(self, "_gp_sp", None) is not None and self._gp_sp.key == key:
+            return
+        B, K = self.B, self.K
+        n = (B * K) * ((B * K + 7) // 8 * 8) if all_timesteps else K * B * self.ldS
+        new = lambda m: torch.zeros(m, device=self.device, dtype=torch.float32)
+        self._gp_sp = SimpleNamespace(key=key, W1=new(n), W1T=new(n), W2=new(n), W2T=new(n), St1=new(n), St2=new(n),
+                                      pred_a=torch.zeros_like(self.pred), pred_b=torch.zeros_like(self.pred),
+                                      top_a=torch.zeros_like(self.dact[-1]), top_b=torch.zeros_like(self.dact[-1]))
+
     def _gp_step(self, x, softplus, regularization, all_timesteps, factor, global_negatives, after_loss):
         """One train step with the Wasserstein gradient penalty (contrastive_estimation_training.py:141-161):
         loss = InfoNCE + regulariser + factor * mean((|d sum(scores) / d x|_2 over channels - 1)^2), x the scalogram batch.
@@ -845,9 +856,8 @@ class ScalogramCPCEngine(CPCEngine):
         DESIGN.md section 8 has the derivation; tests compare with the reference's own double backward (tests/golden/scalogram_model_gp)."""
         if not self.gp_capable:
             raise RuntimeError("this engine was built without gradient-penalty support (model.gradient_penalty_engine = True first)")
-        if softplus or global_negatives is not None:
-            raise NotImplementedError("the gradient penalty is implemented for linear scores with per-GPU negatives (the reference's "
-                                      "experiments with the penalty all use linear_score_function)")
+        if global_negatives is not None:
+            raise NotImplementedError("the gradient penalty is implemented for per-GPU negatives")
         if self.dt != torch.float32:
             raise NotImplementedError("the gradient penalty runs in the exact-f32 mode (compute_dtype='fp32')")
         if not hasattr(self.ctx, "tangent"):
@@ -873,8 +883,23 @@ class ScalogramCPCEngine(CPCEngine):
             seed_p = tg.sum(0, keepdim=True).expand(B, K, E)
             seed_t = pred3.sum(0, keepdim=True).expand(B, K, E)
         self.dact[-1].zero_()
-        self.dpred.view(B, K, E).copy_(seed_p)
-        dtop[:, T - K:T, :].copy_(seed_t)
+        if softplus:
+            # softplus scores: the summed scores are sum softplus(s), the seeds carry W1 = sigmoid(s) (cpc_gp_score_coeff)
+            self._gp_softplus_buffers(all_timesteps)
+            sp = self._gp_sp
+            if all_timesteps:
+                R = B * K
+                ldR = (R + 7) // 8 * 8
+                self.score_gemm_all()
+                _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S_all), None, None, _hip.ptr(sp.W1), _hip.ptr(sp.W1T), 1, R, R, ldR, ldR, 0)
+                self._score_grads_all(sp.W1, sp.W1T, self.pred, self.act[-1], self.dpred, self.dact[-1])
+            else:
+                self.score_gemm()
+                _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S), None, None, _hip.ptr(sp.W1), _hip.ptr(sp.W1T), K, B, B, self.ldS, self.ldS, 0)
+                self._score_grads(sp.W1, sp.W1T, self.pred, self.act[-1], self.dpred, self.dact[-1])
+        else:
+            self.dpred.view(B, K, E).copy_(seed_p)
+            dtop[:, T - K:T, :].copy_(seed_t)
         self._gp_phase = 1
         self.backward(x)
         # ---- direction v = d penalty / d g and the penalty's value
@@ -903,7 +928,30 @@ class ScalogramCPCEngine(CPCEngine):
         # ---- pass 3: the real loss, plus the penalty's seeds on the primal stream
         top_t3 = top_t.view(B, Ltop, E)
         tg_t, pred_t3 = top_t3[:, T - K:T, :], self.pred_t.view(B, K, E)
-        if all_timesteps:
+        if softplus:
+            # nu_p = W1 (tangent targets) + W2 targets,  nu_t = W1^T (tangent predictions) + W2^T predictions,
+            # W2 = softplus''(s) * (tangent of s),  tangent of s = (tangent predictions) targets^T + predictions (tangent targets)^T
+            sp = self._gp_sp
+            sp.top_a.zero_(), sp.top_b.zero_()
+            if all_timesteps:
+                R = B * K
+                ldR = (R + 7) // 8 * 8
+                self.score_gemm_all(pred=self.pred_t, out=sp.St1)
+                self.score_gemm_all(top=top_t, out=sp.St2)
+                _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S_all), _hip.ptr(sp.St1), _hip.ptr(sp.St2), _hip.ptr(sp.W2), _hip.ptr(sp.W2T),
+                          1, R, R, ldR, ldR, 1)
+                self._score_grads_all(sp.W1, sp.W1T, self.pred_t, top_t, sp.pred_a, sp.top_a)
+                self._score_grads_all(sp.W2, sp.W2T, self.pred, self.act[-1], sp.pred_b, sp.top_b)
+            else:
+                self.score_gemm(pred=self.pred_t, out=sp.St1)
+                self.score_gemm(top=top_t, out=sp.St2)
+                _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S), _hip.ptr(sp.St1), _hip.ptr(sp.St2), _hip.ptr(sp.W2), _hip.ptr(sp.W2T),
+                          K, B, B, self.ldS, self.ldS, 1)
+                self._score_grads(sp.W1, sp.W1T, self.pred_t, top_t, sp.pred_a, sp.top_a)
+                self._score_grads(sp.W2, sp.W2T, self.pred, self.act[-1], sp.pred_b, sp.top_b)
+            add_p = sp.pred_a.view(B, K, E) + sp.pred_b.view(B, K, E)
+            add_t = sp.top_a.view(B, Ltop, E)[:, T - K:T, :] + sp.top_b.view(B, Ltop, E)[:, T - K:T, :]
+        elif all_timesteps:
             add_p = tg_t.sum((0, 1), keepdim=True).expand(B, K, E)
             add_t = pred_t3.sum((0, 1), keepdim=True).expand(B, K, E)
         else:
@@ -912,9 +960,9 @@ class ScalogramCPCEngine(CPCEngine):
         add_p, add_t = add_p.clone(), add_t.clone()
         self.dact[-1].zero_()
         if all_timesteps:
-            self.nce_all_forward_backward(False, regularization)
+            self.nce_all_forward_backward(softplus, regularization)
         else:
-            self.nce_forward_backward(False, regularization)
+            self.nce_forward_backward(softplus, regularization)
         if after_loss is not None:
             after_loss(self.nce_out)
         self.dpred.view(B, K, E).add_(add_p)

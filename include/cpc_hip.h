@@ -389,6 +389,13 @@ long long cpc_nce_workspace_floats(int B, int K);
 int cpc_nce_loss(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus,
                  float regularization, int dtype, void* stream);
 
+/* Wasserstein gradient penalty with softplus_score_function (contrastive_estimation_training.py:12-16 under :144-158): the
+ * coefficients the penalty's seeds carry.  S (and the tangent scores St1 + St2, St2 may be NULL): nmat f32 matrices [rows][ld].
+ * mode 0: w = softplus'(s) = sigmoid(s) (1 beyond torch's threshold 20); mode 1: w = softplus''(s) * (St1 + St2).
+ * W [nmat][rows][ld] and its transpose WT [nmat][cols][ldT], both f32. */
+int cpc_gp_score_coeff(const float* S, const float* St1, const float* St2, float* W, float* WT, int nmat, int rows, int cols, int ld,
+                       int ldT, int mode, void* stream);
+
 /* Same loss with score_over_all_timesteps=True (contrastive_estimation_training.py:108-114, :141): S is the full
  * (B*K) x (B*K) score matrix, row (b,k) = prediction, column (b',k') = target, ST its transpose (both f32, rows of ld
  * floats, produced by two cpc_gemm_nt calls); dS / dST (T, same ld) receive d loss / d linear score and its transpose. */

@@ -435,6 +435,57 @@ def test_gradient_penalty_plain_conv_context_against_oracle(golden_dir):
             assert l2 < 1e-3, (all_t, name, l2)
 
 
+@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model", "scalogram_model_gp_att"])
+def test_gradient_penalty_softplus_scores_against_oracle(golden_dir, fixture):
+    """The penalty with the trainer's DEFAULT score function, softplus_score_function (no reference experiment combines the two, so
+    there is no reference run: the oracle's double backward is the judge): the seeds of the penalty's passes carry sigmoid(s) and
+    softplus''(s) * (tangent of s) (cpc_gp_score_coeff) — convolutional, GRU and attention context networks, both loss branches."""
+    import copy
+    from cpc_audio_amd.audio_dataset import FileBatchSampler
+    g = _load(golden_dir, fixture + ".npz")
+    meta = copy.deepcopy(json.load(open(os.path.join(golden_dir, fixture + ".json"))))
+    B, K, H, V = meta["B"], meta["K"], meta["H"], meta["V"]
+    pre, model = _build_scalogram_model(g, meta, "fp32")
+    model.train()
+    params = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    data = torch.from_numpy(g["data"])
+    oblocks = copy.deepcopy(meta["blocks"])
+    for b in oblocks:
+        b["kernel_size_1"], b["kernel_size_2"] = tuple(b["kernel_size_1"]), tuple(b["kernel_size_2"])
+    oblocks[0]["in_channels"] = 2
+    okw = {}
+    if "ar" in meta:
+        okw["conv_ar"] = meta["ar"]
+    elif "attention" in meta:
+        okw["attention"] = (meta["attention"]["num_layers"], meta["attention"]["num_heads"], None)
+    for all_t, reg, factor in ((False, 1.0, 2.0), (True, 0.01, 10.0)):
+        logger = _Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=reg, score_over_all_timesteps=all_t, score_function=SCORE["softplus"],
+                                          prediction_steps=K, ar_size=H, preprocessing=pre, wasserstein_gradient_penalty=True,
+                                          gradient_penalty_factor=factor)
+        tr.verbose = False
+        model.load_state_dict(params)
+        random.seed(91)
+        idx = [list(b) for b in FileBatchSampler([data.shape[0]], B, 1, True, verbose=False)][0]
+        random.seed(91)
+        tr.train(batch_size=B, epochs=1, lr=0.0, num_workers=0, max_steps=1)
+        with torch.no_grad():
+            scal = pre(data[idx].to(DEV).unsqueeze(1)).cpu()
+        ot = O.OracleTrainer(params, V, K, score="softplus", all_timesteps=all_t, regularization=reg, lr=0.0, scalogram=oblocks,
+                             gradient_penalty_factor=factor, **okw)
+        loss, smax, grads = ot.loss_and_grads(scal)
+        assert abs(logger.loss_meter.values[0] - float(loss)) < 1e-4 * abs(float(loss)), (all_t, logger.loss_meter.values, float(loss))
+        largest = max(float(v.abs().max()) for v in grads.values() if v is not None)
+        for name, ref in grads.items():
+            got = dict(model.named_parameters())[name].grad.double().cpu()
+            if ref.abs().max().item() < 1e-6 * largest:
+                assert got.abs().max().item() < 1e-5 * largest, (all_t, name)
+                continue
+            l2 = ((got - ref.double()).norm() / (ref.double().norm() + 1e-30)).item()
+            assert l2 < 1e-3, (fixture, all_t, name, l2)
+
+
 def test_gradient_penalty_attention_context_with_dropout_against_oracle(golden_dir):
     """The penalty through an AttentionModel in TRAIN mode with dropout (the reference's e20 / e27 / e30 / e31 settings, p = 0.1
     there): the tangent pass and the second-order terms must use the masks of the primal pass.  The device masks are a function
