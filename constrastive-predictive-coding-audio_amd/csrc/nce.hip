@@ -13,6 +13,8 @@
 
 namespace {
 
+constexpr int NCE_CW = 8;       // columns per workgroup of the equal-step loss's column pass (nce_col_mean_kernel)
+
 __device__ __forceinline__ float score_tf(float x, int softplus) {
     if (!softplus) return x;
     return x > 20.f ? x : log1pf(expf(x));       // torch.nn.functional.softplus, beta = 1, threshold = 20
@@ -27,33 +29,35 @@ __device__ __forceinline__ float score_grad(float x, int softplus) {
 // one partial sum of lse per block; otherwise the per-split (max, sum) pairs go to pm / ps [split][k][b'] for nce_col_merge_kernel
 // (the all-timesteps matrix has 3072 rows but only 96 column blocks: the rows must be split to fill the chip).
 // (body with explicit block coordinates: nce_col_kernel calls it with its own, nce_col_mean_kernel with a slice of a 1-D grid)
+template <int CW>
 __device__ __forceinline__ void nce_col_body(const float* __restrict__ S, float* __restrict__ lse, float* __restrict__ partial, int B,
                                              int K, int ld, int softplus, int rows_per_split, float* __restrict__ pm,
                                              float* __restrict__ ps, int bx, int by, int bz, int nbx, int nbz) {
-    __shared__ float smx[8][32], ssum[8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int k = by, bp = bx * 32 + tx;
+    // CW columns x RL row lanes per workgroup.  The softplus / exp arithmetic is what this path costs (some hundred instructions per
+    // score): with 32 columns per workgroup the equal-step loss (K x B columns of B rows) ran on 96 workgroups, a lane walking 32
+    // rows; 8 columns x 32 row lanes spread the same work over four times as many waves (nce_col_mean_kernel: 18.6 -> 13.3 us at
+    // B = 256, K = 12; more loads in flight per lane had changed nothing: it is the arithmetic, not the latency).
+    constexpr int RL = 256 / CW;
+    __shared__ float smx[RL][CW], ssum[RL][CW];
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int k = by, bp = bx * CW + tx;
     const int r0 = bz * rows_per_split, r1 = min(B, r0 + rows_per_split);
     float mx = -INFINITY, sum = 0.f;
     if (bp < B) {
         const float* col = S + (long long)k * B * ld + bp;
-        // four rows per trip: the loads are independent of the running (max, sum), so they are in flight together
-        int b = r0 + ty;
-        for (; b + 24 < r1; b += 32) {
-            float v4[4];
+        // eight rows per trip: the loads are independent of the running (max, sum), so they are in flight together
+        for (int base = r0 + ty; base < r1; base += 8 * RL) {
+            float vv[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v4[u] = col[(long long)(b + 8 * u) * ld];
+            for (int u = 0; u < 8; ++u) vv[u] = (base + RL * u < r1) ? col[(long long)(base + RL * u) * ld] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float v = score_tf(v4[u], softplus);
-                if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
-                else sum += expf(v - mx);
+            for (int u = 0; u < 8; ++u) {
+                if (base + RL * u < r1) {
+                    const float v = score_tf(vv[u], softplus);
+                    if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
+                    else sum += expf(v - mx);
+                }
             }
-        }
-        for (; b < r1; b += 8) {
-            const float v = score_tf(col[(long long)b * ld], softplus);
-            if (v > mx) { sum = sum * expf(mx - v) + 1.f; mx = v; }
-            else sum += expf(v - mx);
         }
     }
     smx[ty][tx] = mx;
@@ -62,10 +66,10 @@ __device__ __forceinline__ void nce_col_body(const float* __restrict__ S, float*
     if (ty == 0) {
         float m = mx;
 #pragma unroll
-        for (int r = 1; r < 8; ++r) m = fmaxf(m, smx[r][tx]);
+        for (int r = 1; r < RL; ++r) m = fmaxf(m, smx[r][tx]);
         float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tot += (smx[r][tx] == -INFINITY) ? 0.f : ssum[r][tx] * expf(smx[r][tx] - m);
+        for (int r = 0; r < RL; ++r) tot += (smx[r][tx] == -INFINITY) ? 0.f : ssum[r][tx] * expf(smx[r][tx] - m);
         if (nbz > 1) {
             if (bp < B) {
                 pm[((long long)bz * K + k) * B + bp] = m;
@@ -75,9 +79,9 @@ __device__ __forceinline__ void nce_col_body(const float* __restrict__ S, float*
         }
         const float l = (bp < B) ? m + logf(tot) : 0.f;
         if (bp < B) lse[k * B + bp] = l;
-        // sum the 32 columns of this block (one wave-half): shuffle reduction
+        // sum the CW columns of this block: shuffle reduction over the first CW lanes
         float acc = l;
-        for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
+        for (int o = CW / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, CW);
         if (tx == 0) partial[by * nbx + bx] = acc;
     }
 }
@@ -85,7 +89,7 @@ __device__ __forceinline__ void nce_col_body(const float* __restrict__ S, float*
 __global__ __launch_bounds__(256) void nce_col_kernel(const float* __restrict__ S, float* __restrict__ lse,
                                                       float* __restrict__ partial, int B, int K, int ld, int softplus,
                                                       int rows_per_split, float* __restrict__ pm, float* __restrict__ ps) {
-    nce_col_body(S, lse, partial, B, K, ld, softplus, rows_per_split, pm, ps, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+    nce_col_body<32>(S, lse, partial, B, K, ld, softplus, rows_per_split, pm, ps, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
 }
 
 // Merges the per-split (max, sum) pairs of a column in split order: lse[c] and one partial sum of lse per block of 256 columns.
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void nce_col_mean_kernel(const float* __restri
                                                            int softplus, int ncb) {
     const int ncol = ncb * K;
     if ((int)blockIdx.x < ncol)
-        nce_col_body(S, lse, colp, B, K, ld, softplus, B, nullptr, nullptr, blockIdx.x % ncb, blockIdx.x / ncb, 0, ncb, 1);
+        nce_col_body<NCE_CW>(S, lse, colp, B, K, ld, softplus, B, nullptr, nullptr, blockIdx.x % ncb, blockIdx.x / ncb, 0, ncb, 1);
     else
         nce_mean_body<KT>(S, mean, pairp, B, K, ld, softplus, blockIdx.x - ncol);
 }
@@ -483,14 +487,14 @@ __global__ __launch_bounds__(256) void nce_eval_finalize_kernel(const float* __r
 // workspace: lse [K][B] + column partials [K * ceil(B/32)] + pair partials [3 * ceil(B*B/256)] + pair means [B][ld <= B + 7]
 long long nce_workspace_floats(int B, int K) {
     const long long nmb = ((long long)B * B + 255) / 256;
-    return (long long)K * B + (long long)K * ((B + 31) / 32) + 3 * nmb + (long long)B * (B + 8);
+    return (long long)K * B + (long long)K * ((B + NCE_CW - 1) / NCE_CW) + 3 * nmb + (long long)B * (B + 8);
 }
 
 int launch_nce(const float* S, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld, int softplus, float reg,
                int dtype, hipStream_t stream) {
     if (B <= 0 || K <= 0 || ld < B || ld > B + 7) return CPC_EINVAL;
     float* lse = workspace;
-    const int ncb = (B + 31) / 32;
+    const int ncb = (B + NCE_CW - 1) / NCE_CW;
     const int ncol = K * ncb;
     float* colp = lse + (long long)K * B;
     float* gradp = colp + ncol;
