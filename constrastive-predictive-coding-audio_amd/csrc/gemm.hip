@@ -1757,7 +1757,7 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream) {
     if (I <= 0 || J <= 0 || J % 4 || nslab <= 0 || cdiv <= 0) return CPC_EINVAL;
     const long long total4 = (long long)I * J / 4;
-    if (total4 <= 16384 && nslab >= 32) {
+    if (total4 <= 16384 && nslab >= 16) {     // (from 16 slabs: the predictor's data gradient, 24 slabs of 256 x 256: 10 -> 5 us)
         if (nslab >= 128)            // 64 slab lanes: a serial chain of nslab / 64 loads per thread (228-912 slabs: the per-tile column sums)
             hipLaunchKernelGGL(reduce_slabs_small_kernel<64>, dim3((unsigned)((total4 + 3) / 4)), dim3(256), 0, stream, slabs, out, I,
                                J, nslab, slab_stride, cdiv, s_j, s_hi, s_lo);
