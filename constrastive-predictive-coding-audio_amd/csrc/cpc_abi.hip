@@ -459,6 +459,7 @@ int cpc_gru_set_streaming(int on) {
 int cpc_debug_set(int key, int value) {
     if (key == 1) { const int old = g_nt_stagger64; g_nt_stagger64 = value; return old; }
     if (key == 4) { const int old = g_nt_probe; g_nt_probe = value; return old; }
+    if (key == 6) { const int old = g_nt_wt; g_nt_wt = value; return old; }
     if (key == 5) { const int old = g_nt_probe_taps; g_nt_probe_taps = value > 0 ? value : 1; return old; }
     return CPC_EINVAL;
 }

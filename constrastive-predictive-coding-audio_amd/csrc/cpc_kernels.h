@@ -15,6 +15,8 @@
 #define GEMM_NO_PERS 512        // NT/bf16: LDS-staged epilogue instead of the register epilogue (A-B check; see DIRECT in gemm.hip)
 #define GEMM_DIRECT_MASK 1024   // NT/bf16: register epilogue also for masked launches (A-B check)
 #define GEMM_LINEAR_K 256       // NT fast path: visit K in storage order even for overlapped-row operands (A-B check, see GemmNT::k_taps)
+#define GEMM_WT_AGENT 0x40000   // internal (cpc_debug_set key 6): output stores of the NT fast kernels write through at agent scope (sc1)
+#define GEMM_WT_SYSTEM 0x80000  // ... at system scope (sc0 sc1): the default
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
 
 struct GemmNT {
@@ -76,6 +78,7 @@ struct GemmTN {
 // tuning knobs (cpc_debug_set): key 1 = stagger of the 256x256 NT kernel in 1/64 of a tile time (default see gemm.hip)
 extern int g_nt_stagger64;
 extern int g_nt_probe_taps;     // key 5: taps of the chunk-major A operand of probe 32
+extern int g_nt_wt;             // key 6: output stores of the NT fast kernels written through the L2 (1: sc1, 2: sc0 sc1)
 extern int g_nt_probe;          // key 4: timing probes of the 256x256 NT kernel (DBG in gemm.hip; the results are garbage)
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);

@@ -348,6 +348,17 @@ __device__ __forceinline__ int direct_b_col(int r) {
     return (r & ~63) + 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3);
 }
 
+// Output store of the fast kernels: written through the XCD's L2 at once (default, GEMM_WT_SYSTEM) or plain.  A large output left dirty
+// in the L2s is written back when the kernel ends, before the next one may start; with the stores written through as they are issued
+// the step takes 4.469 instead of 4.478-4.490 ms (tools/wt_ab.py, interleaved A/B on one box; agent scope: 4.474-4.479).
+__device__ __forceinline__ void store_out16(uint4* dst, uint4 v, int flags) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u d = {v.x, v.y, v.z, v.w};
+    if (flags & GEMM_WT_SYSTEM) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
+    else if (flags & GEMM_WT_AGENT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(d) : "memory");
+    else *dst = v;
+}
+
 template <typename T, typename TO, int WM, int WN, int TI, int TJ, bool DMA, bool C1 = false, bool DIRECT = false, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     // DBG: timing probes for tools/nt_probe.py (cpc_debug_set key 4; never in the product path, the results are garbage):
@@ -751,7 +762,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 }
                 uint4* dst = (uint4*)(Cb + off[i] + 32 * pr);
                 if (full || (m0 + (wm * TI + i) * 16 + frow < p.M && nb + 32 * pr < p.N)) {
-                    *dst = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                    store_out16(dst, make_uint4(vw[0], vw[1], vw[2], vw[3]), p.flags);
                 }
             }
         }
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                         if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
                         v = make_uint4(0, 0, 0, 0);
                     }
-                    *(uint4*)(Cb + coff + n) = v;
+                    store_out16((uint4*)(Cb + coff + n), v, p.flags);
                     if constexpr (CS_IN_LDS) {
                         if (want_cs) {              // column sums of what was just stored (the bf16 values, as a pass over C would see them)
                             const unsigned u4[4] = {v.x, v.y, v.z, v.w};
@@ -1583,6 +1594,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(GemmNT p) {
 // (tools/nt_ab.py --stagger: layer-3 data gradient 285 -> 278 us, layer-2 1036 -> 1021 us; no gain without a mask)
 int g_nt_stagger64 = 32;
 int g_nt_probe = 0, g_nt_probe_taps = 1;
+int g_nt_wt = 2;       // output stores of the NT fast kernels: 0 plain, 1 written through at agent scope, 2 at system scope (default)
 
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
@@ -1610,6 +1622,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE) &&
                      (big_tiles >= 200 || big_tiles * batch >= 200);
     GemmNT q = p;
+    if (g_nt_wt == 1) q.flags |= GEMM_WT_AGENT; else if (g_nt_wt == 2) q.flags |= GEMM_WT_SYSTEM;
     // overlapped-row A operand (strided-conv view): visit K tap-innermost, see GemmNT::k_taps
     const int bk = 8 * ch;
     if (fast && p.k_taps == 0 && p.lda > 0 && p.lda < p.K && p.K % p.lda == 0 && p.lda % bk == 0 && !(p.flags & GEMM_LINEAR_K)) {

@@ -372,7 +372,9 @@ int cpc_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA
 /* A/B switch: on != 0 forces the weight-streaming GRU kernels where the weight-resident bf16 ones would be used
  * (H in {32,64,128,256}); returns the previous setting.  Not stream-ordered (host-side flag). */
 int cpc_gru_set_streaming(int on);
-/* Tuning knobs for A/B measurements (tools/): key 1 = start stagger of the 256x256 NT GEMM in 1/64 of a tile time (0 = off).
+/* Tuning knobs for A/B measurements (tools/): key 1 = start stagger of the 256x256 NT GEMM in 1/64 of a tile time (0 = off);
+ * keys 4, 5 = timing probes of that kernel's K loop (results are garbage, tools/nt_probe.py); key 6 = output stores of the NT fast
+ * kernels: 2 (default) written through the L2 at system scope, 1 at agent scope, 0 plain stores — same results in every mode.
  * Returns the previous value, CPC_EINVAL for an unknown key.  Not part of the product path. */
 int cpc_debug_set(int key, int value);
 
