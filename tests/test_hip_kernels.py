@@ -715,6 +715,58 @@ def test_add_layernorm_fwd_bwd(dt, M, C, bcast):
     assert rel_err(slabs.sum(0)[1], bias.grad) < t
 
 
+@pytest.mark.parametrize("B,V,E,H", [(3, 20, 64, 256), (5, 7, 32, 48), (2, 100, 16, 96)])
+def test_gru_gradient_penalty_kernels(B, V, E, H):
+    """cpc_gru_gp_fwd / cpc_gru_gp_bwd (f32) at hidden sizes up to the kernels' limit: the gradient of the directional derivative
+    D = <xt, d S / d x>, S = <wc, GRU(x)>, with respect to the GRU's parameters and its input, assembled from the kernels' outputs
+    as engine.GRUContext.gp_grads does, against autograd's double backward in float64."""
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    f64 = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).float().double()
+    Wih, Whh = f64(3 * H, E, s=E ** -0.5), f64(3 * H, H, s=H ** -0.5)
+    bih, bhh = f64(3 * H, s=0.3), f64(3 * H, s=0.3)
+    x, xt, wc = f64(B, V, E), f64(B, V, E), f64(B, H)
+    params = [t.clone().requires_grad_(True) for t in (Wih, Whh, bih, bhh, x)]
+    pWih, pWhh, pbih, pbhh, px = params
+    h = torch.zeros(B, H, dtype=torch.double)
+    for t in range(V):
+        gi, gh = px[:, t] @ pWih.T + pbih, h @ pWhh.T + pbhh
+        r, z = torch.sigmoid(gi[:, :H] + gh[:, :H]), torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+    gx, = torch.autograd.grad((wc * h).sum(), px, create_graph=True)
+    ref = torch.autograd.grad((gx * xt).sum(), params)
+    # device: the projections as the engine's GEMMs give them, then the two kernels
+    Gi = dev((x.reshape(B * V, E) @ Wih.T + bih).float().contiguous())
+    GiT = dev((xt.reshape(B * V, E) @ Wih.T).float().contiguous())
+    WT, W, d_bhh, d_wc = dev(Whh.T.float().contiguous()), dev(Whh.float().contiguous()), dev(bhh.float()), dev(wc.float().contiguous())
+    tape = torch.full((B, V, 10, H), float("nan"), device=DEV)
+    ct = torch.full((B, H), float("nan"), device=DEV)
+    _hip.call("cpc_gru_gp_fwd", _hip.ptr(Gi), _hip.ptr(GiT), _hip.ptr(WT), _hip.ptr(d_bhh), _hip.ptr(tape), _hip.ptr(ct), B, V, H)
+    dA = torch.full((B, V, 8, H), float("nan"), device=DEV)
+    _hip.call("cpc_gru_gp_bwd", _hip.ptr(d_wc), _hip.ptr(tape), _hip.ptr(W), _hip.ptr(dA), B, V, H)
+    assert torch.isfinite(tape).all() and torch.isfinite(dA).all() and torch.isfinite(ct).all()
+    tp, da = tape.double().cpu(), dA.double().cpu().reshape(B * V, 8 * H)
+    hp, htp = tp[:, :, 4].reshape(B * V, H), tp[:, :, 9].reshape(B * V, H)
+    X, XT = x.reshape(B * V, E), xt.reshape(B * V, E)
+    d3, v3 = da[:, :3 * H], da[:, 4 * H:7 * H]
+    dh, vh = torch.cat([da[:, :2 * H], da[:, 3 * H:4 * H]], 1), torch.cat([da[:, 4 * H:6 * H], da[:, 7 * H:]], 1)
+    got = [d3.T @ XT + v3.T @ X, dh.T @ htp + vh.T @ hp, v3.sum(0), vh.sum(0), (v3 @ Wih).reshape(B, V, E)]
+    for name, a, b in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh", "x"), got, ref):
+        l2 = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        assert l2 < 2e-4, (name, l2)
+    # the tangent of the last hidden state: directional derivative of the GRU output along xt (central difference in float64)
+    def gru64(xx):
+        hh = torch.zeros(B, H, dtype=torch.double)
+        for t in range(V):
+            gi, gh = xx[:, t] @ Wih.T + bih, hh @ Whh.T + bhh
+            r, z = torch.sigmoid(gi[:, :H] + gh[:, :H]), torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            hh = (1 - z) * torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]) + z * hh
+        return hh
+    eps = 1e-6
+    fd = (gru64(x + eps * xt) - gru64(x - eps * xt)) / (2 * eps)
+    assert rel_err(ct, fd) < 1e-4
+
+
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])
 @pytest.mark.parametrize("B,S,C,heads", [(3, 10, 64, 8), (2, 64, 128, 2), (2, 7, 32, 4)])
 def test_attention_gradient_penalty_kernels(B, S, C, heads, p_drop):
