@@ -137,7 +137,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 4:
+        if handle.cpc_abi_version() != 5:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

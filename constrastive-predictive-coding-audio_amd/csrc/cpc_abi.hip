@@ -15,7 +15,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 4; }
+int cpc_abi_version(void) { return 5; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;

@@ -36,6 +36,8 @@ extern "C" {
 #define CPC_GEMM_DIRECT_MASK 1024 /* NT/bf16: register epilogue also for launches with a mask (A/B check; default: LDS-staged there) */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
+/* 5 since the gradient-penalty entry points (cpc_gru_gp_*, cpc_ln_tangent / cpc_ln_gp, cpc_attn_tangent / cpc_attn_gp,
+ * cpc_gp_score_coeff) were added; 4: per-tile column sums of the data gradients; 3: sign-bit masks; 2: over-read contract. */
 int cpc_abi_version(void);
 
 /* Row addressing used by both GEMMs: row m of an operand starts at element
