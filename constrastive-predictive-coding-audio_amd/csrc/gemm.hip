@@ -502,6 +502,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         const T* gb1 = Bb + row_off(min(n0 + br1, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
         const T* gb2 = Bb + row_off(min(n0 + br2, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
         const T* gb3 = Bb + row_off(min(n0 + br3, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
+        // (timing probe DBG 64: the B operand as if stored stage-major, [N / 256][K / 64][256][64] — a stage's B tile one dense 32 KiB)
+        const T* gd0 = Bb + (long long)(n0 / 256) * 256 * p.K + br0 * 64 + sch * CH;
+        const T* gd1 = Bb + (long long)(n0 / 256) * 256 * p.K + br1 * 64 + sch * CH;
+        const T* gd2 = Bb + (long long)(n0 / 256) * 256 * p.K + br2 * 64 + sch * CH;
+        const T* gd3 = Bb + (long long)(n0 / 256) * 256 * p.K + br3 * 64 + sch * CH;
         typedef __attribute__((address_space(3))) unsigned char lds_byte;
         lds_byte* const lds3 = (lds_byte*)lds;
         const unsigned wdst = wave_u * 4096;                   // this wave's 4 KiB slice of an operand tile
@@ -515,8 +520,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         NT_DMA1(ga1 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 1024);     \
         NT_DMA1(ga2 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 2048);     \
         NT_DMA1(ga3 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 3072);     \
-        NT_DMA1(gb0 + (k0), db);        NT_DMA1(gb1 + (k0), db + 1024);                                          \
-        NT_DMA1(gb2 + (k0), db + 2048); NT_DMA1(gb3 + (k0), db + 3072);                                          \
+        if constexpr (DBG & 64) {                                                                                \
+            NT_DMA1(gd0 + (long long)(k0) * 256, db);        NT_DMA1(gd1 + (long long)(k0) * 256, db + 1024);    \
+            NT_DMA1(gd2 + (long long)(k0) * 256, db + 2048); NT_DMA1(gd3 + (long long)(k0) * 256, db + 3072);    \
+        } else {                                                                                                 \
+            NT_DMA1(gb0 + (k0), db);        NT_DMA1(gb1 + (k0), db + 1024);                                      \
+            NT_DMA1(gb2 + (k0), db + 2048); NT_DMA1(gb3 + (k0), db + 3072);                                      \
+        }                                                                                                        \
     } while (0)
         const unsigned lds_u32 = (unsigned)(unsigned long long)(lds3);
         // fragment addresses: rows i*16 apart differ by 2048 B with the same swizzle term -> one base per (operand, kk)
@@ -1681,6 +1691,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
             else if (direct && g_nt_probe == 2) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 2>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 16) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 16>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 32>), grid, dim3(512), 0, stream, q);
+            else if (direct && g_nt_probe == 64) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 64>), grid, dim3(512), 0, stream, q);
             else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true>), grid, dim3(512), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {

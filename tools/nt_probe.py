@@ -19,7 +19,7 @@ dev, bf, P = "cuda:0", torch.bfloat16, _hip.ptr
 N = a.N
 M = 256 * 128 * 7 * 512 // N          # 7 rounds of 256 tiles
 out = torch.zeros(M * N, device=dev, dtype=bf)
-NAMES = {0: "full", 1: "no DMA", 2: "no MFMA", 16: "B requests only"}
+NAMES = {0: "full", 1: "no DMA", 2: "no MFMA", 16: "B requests only", 64: "B stage-major"}
 
 
 def timed(fn):
