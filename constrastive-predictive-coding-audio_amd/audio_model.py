@@ -83,9 +83,13 @@ class AudioEncoder(nn.Module):
                                            self.kernel_sizes[l], self.strides[l], bias=args_dict['bias']))
 
     def forward(self, x):
-        """x (B, 1, L) on the GPU -> (B, C, T) float32.  Inference only when called stand-alone; gradients flow when the
-        encoder is used through AudioPredictiveCodingModel."""
+        """x (B, 1, L) on the GPU -> (B, C, T) float32, differentiable with respect to the encoder's parameters (stand-alone calls
+        go through the autograd bridge _EncoderForward; the input gets no gradient)."""
         owner = _standalone_owner(self)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            owner.engine_for(x)                           # (flattens the owner's parameters on first use)
+            names = [n for n, _ in owner.named_parameters() if n.startswith("encoder.")]
+            return _EncoderForward.apply(owner, names, x, *[dict(owner.named_parameters())[n] for n in names])
         return owner.encode(x)
 
 
@@ -103,8 +107,8 @@ class AudioGRUModel(nn.Module):
         self.reset_hidden = reset_hidden
 
     def forward(self, input):
-        """(batch, input_size, steps) on the GPU -> last hidden state (batch, hidden_size).  Inference only when called
-        stand-alone; gradients flow when the network is used through AudioPredictiveCodingModel."""
+        """(batch, input_size, steps) on the GPU -> last hidden state (batch, hidden_size), differentiable with respect to the
+        input and the parameters (stand-alone calls go through the autograd bridge _ContextForward)."""
         from .engine import standalone_context_forward
         return standalone_context_forward(self, input, self.hidden_size)
 
@@ -336,6 +340,53 @@ class _CPCForward(torch.autograd.Function):
         eng.backward(ctx.xin, add_dc=d_c, add_dz=d_z)
         grads = [eng.model._grad[n].clone() for n, _ in eng.model.named_parameters()]
         return (None, None, *grads)
+
+
+class _EncoderForward(torch.autograd.Function):
+    """Autograd bridge of a stand-alone encoder call (reference modules are ordinary differentiable nn.Modules, audio_model.py:36-44):
+    forward = the engine's encoder pass, backward = its encoder backward pass fed with the incoming gradient.  The input gets no
+    gradient (layer 1's data gradient is never formed on this path)."""
+
+    @staticmethod
+    def forward(ctx, owner, names, x, *params):
+        eng = owner.engine_for(x)
+        xin = x.detach().float() if x.dim() == 4 else x.detach()[:, 0, :].contiguous().float()
+        eng.prepare_weights()
+        eng.encoder_forward(xin)
+        ctx.eng, ctx.xin, ctx.names = eng, xin, names
+        return eng.view_top()[:, :eng.T, :].float().transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        eng = ctx.eng
+        B, E, T = eng.B, eng.E, eng.T
+        dtop = eng.dact[-1].view(B, eng.geo.alloc[-1], E)
+        dtop.zero_()
+        dtop[:, :T, :].copy_(d_out.transpose(1, 2))
+        eng._ahead = None
+        eng._backward_encoder(ctx.xin)
+        for fn in getattr(eng, "_deferred_side", ()):
+            fn()
+        eng._deferred_side = ()
+        if eng.use_aux:
+            torch.cuda.current_stream().wait_stream(eng.aux)
+        return (None, None, None, *[eng.model._grad[n].clone() for n in ctx.names])
+
+
+class _ContextForward(torch.autograd.Function):
+    """Autograd bridge of a stand-alone context-network call (reference audio_model.py:66-77, :139-161; attention_model.py:72-82):
+    gradients with respect to z and to the network's parameters."""
+
+    @staticmethod
+    def forward(ctx, eng, names, z, *params):
+        ctx.eng, ctx.names = eng, names
+        return eng.run(z.float())
+
+    @staticmethod
+    def backward(ctx, d_c):
+        eng = ctx.eng
+        dz = eng.backward_context(d_c.float())
+        return (None, None, dz.clone(), *[eng.model._grad[n].clone() for n in ctx.names])
 
 
 def _standalone_owner(encoder):

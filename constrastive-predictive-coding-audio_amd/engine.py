@@ -1422,6 +1422,17 @@ class ContextOnlyEngine(CPCEngine):
         self.ctx.forward()
         return self.ctx.c_float().clone()
 
+    def backward_context(self, dc):
+        """dc (B, H) -> d z (B, E, V) float32; the context network's parameter gradients go to the owner's flat gradient buffer
+        (the autograd bridge of a stand-alone call, audio_model._ContextForward)."""
+        self._ahead = None
+        self.dact[-1].zero_()
+        self.dc.copy_(dc)
+        self.ctx.backward(self.dc)
+        if self.use_aux:
+            torch.cuda.current_stream().wait_stream(self.aux)
+        return self.dact[-1].view(self.B, self.V, self.E).float().transpose(1, 2)
+
 
 def standalone_context_forward(ar, z, ar_size):
     """Host side of ``<context network>.forward(z)`` outside an AudioPredictiveCodingModel."""
@@ -1450,6 +1461,10 @@ def standalone_context_forward(ar, z, ar_size):
         owner._flatten_parameters(dev)
         eng = ContextOnlyEngine(owner, z.shape[0], z.shape[1], z.shape[2], dev, owner.compute_dtype)
         owner._engines = {key: eng}
+    if torch.is_grad_enabled() and (z.requires_grad or any(p_.requires_grad for p_ in ar.parameters())):
+        from .audio_model import _ContextForward
+        names = [n for n, _ in owner.named_parameters() if n.startswith("autoregressive_model.")]
+        return _ContextForward.apply(eng, names, z, *[dict(owner.named_parameters())[n] for n in names])
     return eng.run(z.float())
 
 

@@ -196,10 +196,14 @@ class ScalogramResidualEncoder(nn.Module):
             self.downsampling_factor *= block_dict['pooling_2'] * block_dict['stride_2']
 
     def forward(self, x):
-        """x (B, C, bins, frames) on the GPU -> (B, E, frames') float32 (the reference's x[:, :, 0, :]).  Inference only when
-        called stand-alone (BatchNorm follows self.training); gradients flow when the encoder is used through
-        AudioPredictiveCodingModel."""
-        from .audio_model import _standalone_owner
+        """x (B, C, bins, frames) on the GPU -> (B, E, frames') float32 (the reference's x[:, :, 0, :]); BatchNorm follows
+        self.training.  Differentiable with respect to the encoder's parameters, stand-alone too (audio_model._EncoderForward)."""
+        from .audio_model import _EncoderForward, _standalone_owner
         if x.dim() == 3:
             x = x.unsqueeze(2)
-        return _standalone_owner(self).encode(x)
+        owner = _standalone_owner(self)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            owner.engine_for(x)
+            names = [n for n, _ in owner.named_parameters() if n.startswith("encoder.")]
+            return _EncoderForward.apply(owner, names, x, *[dict(owner.named_parameters())[n] for n in names])
+        return owner.encode(x)

@@ -847,6 +847,86 @@ def test_context_networks_standalone_forward(golden_dir):
     assert _rel(att(z.to(DEV)), ref) < 2e-4
 
 
+def test_standalone_modules_are_differentiable(golden_dir):
+    """The reference's modules are ordinary differentiable nn.Modules (audio_model.py:36-44, :66-77, :139-161; attention_model.py:72-82):
+    a stand-alone call followed by .backward() gives the parameter gradients (and, for the context networks, the input gradient).
+    GRU: against the REFERENCE's own gradients (fixture gru.npz); encoder, convolutional and attention context: against autograd of
+    the oracle on the fixture parameters."""
+    import torch.nn.functional as F
+    # ---- AudioGRUModel
+    g = _load(golden_dir, "gru.npz")
+    gru = AudioGRUModel(input_size=32, hidden_size=64)
+    gru.load_state_dict({k[len("param/autoregressive_model."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")})
+    gru = gru.to(DEV)
+    z = torch.from_numpy(g["z"]).to(DEV).requires_grad_(True)
+    h = gru(z)
+    assert _rel(h, g["h"]) < 1e-4
+    (h * torch.from_numpy(g["dh"]).to(DEV)).sum().backward()
+    assert _rel(z.grad, g["dz"]) < 1e-3
+    for n, p_ in gru.named_parameters():
+        assert _rel(p_.grad, g["grad/autoregressive_model." + n]) < 1e-3, n
+    # ---- AudioEncoder (the reference test's shape, tests/test_audioEncoder.py:19-25)
+    ge = _load(golden_dir, "encoder_ref_test.npz")
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [32] * 5, 'bias': False})
+    enc.load_state_dict({k[len("param/encoder."):]: torch.from_numpy(v) for k, v in ge.items() if k.startswith("param/")})
+    enc = enc.to(DEV)
+    x = torch.from_numpy(ge["x"])
+    w_out = torch.randn(7, 32, 28, generator=torch.Generator().manual_seed(4))
+    y = enc(x.to(DEV))
+    assert _rel(y, ge["y"]) < 1e-4
+    (y * w_out.to(DEV)).sum().backward()
+    ws = [torch.from_numpy(ge[f"param/encoder.layers.{l}.weight"]).double().requires_grad_(True) for l in range(5)]
+    t = x.double()
+    for l, (wt, st) in enumerate(zip(ws, [5, 4, 2, 2, 2])):
+        t = F.conv1d(t, wt, stride=st)
+        if l < 4:
+            t = torch.relu(t)
+    (t * w_out.double()).sum().backward()
+    for l in range(5):
+        assert _rel(enc.layers[l].weight.grad, ws[l].grad) < 1e-3, l
+    # ---- ConvolutionalArModel (BatchNorm + residual, train mode) and AttentionModel (dropout 0)
+    gb = _load(golden_dir, "conv_ar_bn.npz")
+    mb = json.load(open(os.path.join(golden_dir, "conv_ar_bn.json")))
+    info = mb["variants"]["bn_res"]
+    state = {k[len("bn_res/param/"):]: torch.from_numpy(v) for k, v in gb.items() if k.startswith("bn_res/param/")}
+    ar = ConvolutionalArModel(dict(info["ar"], activation_register=None))
+    ar.load_state_dict({k[len("autoregressive_model."):]: v for k, v in state.items() if k.startswith("autoregressive_model.")})
+    ar = ar.to(DEV).train()
+    z0 = torch.randn(5, mb["C"], mb["V"], generator=torch.Generator().manual_seed(1))
+    wc = torch.randn(5, ar.ar_size, generator=torch.Generator().manual_seed(2))
+    z = z0.to(DEV).requires_grad_(True)
+    (ar(z) * wc.to(DEV)).sum().backward()
+    ostate = {k: (v.clone().double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    zo = z0.double().requires_grad_(True)
+    ref = O.conv_ar_forward(zo, ostate, info["ar"]["kernel_sizes"], info["ar"]["pooling"], strides=info["ar"]["stride"], batch_norm=True,
+                            residual=True, training=True)
+    (ref * wc.double()).sum().backward()
+    assert _rel(z.grad, zo.grad) < 2e-3
+    for n, p_ in ar.named_parameters():
+        r = ostate["autoregressive_model." + n].grad
+        if r is not None and r.abs().max() > 1e-9:
+            assert _rel(p_.grad, r) < 2e-3, n
+    ga = _load(golden_dir, "attention_model.npz")
+    ma = json.load(open(os.path.join(golden_dir, "attention_model.json")))
+    sa = {k[len("param/"):]: torch.from_numpy(v) for k, v in ga.items() if k.startswith("param/")}
+    att = AttentionModel(ma["ar"])
+    att.load_state_dict({k[len("autoregressive_model."):]: v for k, v in sa.items() if k.startswith("autoregressive_model.")})
+    att = att.to(DEV).eval()
+    z0 = torch.randn(4, ma["C"], ma["V"], generator=torch.Generator().manual_seed(2))
+    wc = torch.randn(4, ma["H"], generator=torch.Generator().manual_seed(3))
+    z = z0.to(DEV).requires_grad_(True)
+    (att(z) * wc.to(DEV)).sum().backward()
+    osa = {k: (v.clone().double().requires_grad_(True) if not k.endswith("positional_encoder.pe") else v.clone().double()) for k, v in sa.items()}
+    zo = z0.double().requires_grad_(True)
+    ref, _ = O.attention_forward(zo, osa, ma["ar"]["num_layers"], ma["ar"]["num_heads"])
+    (ref * wc.double()).sum().backward()
+    assert _rel(z.grad, zo.grad) < 2e-3
+    for n, p_ in att.named_parameters():
+        r = osa["autoregressive_model." + n].grad
+        if r is not None and r.abs().max() > 1e-9:
+            assert _rel(p_.grad, r) < 2e-3, n
+
+
 def test_graphed_step_matches_eager(golden_dir):
     """trainer.use_graph: the whole step replayed from a captured hipGraph (device-side Adam step count) follows the
     reference's recorded training runs exactly as the eager path does — same fixtures, same bounds (fp32)."""
