@@ -966,8 +966,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 const int slot = lane & 15, c4 = (lane >> 4) * 4;
                 if (slot <= p.c1_kw) {
                     float* sl = p.c1_slabs + ((long long)mt * numN + nt) * (p.c1_kw + 1) * TBN + (long long)slot * TBN;
-                    *(f32x4*)(sl + (wave * 2) * 16 + c4) = d0;
-                    *(f32x4*)(sl + (wave * 2 + 1) * 16 + c4) = d1;
+                    // (written through like the tile stores: 82 MB of slabs per launch, read by the reduction right behind this kernel)
+                    store_out16((uint4*)(sl + (wave * 2) * 16 + c4), __builtin_bit_cast(uint4, d0), p.flags);
+                    store_out16((uint4*)(sl + (wave * 2 + 1) * 16 + c4), __builtin_bit_cast(uint4, d1), p.flags);
                 }
             }
             return;
