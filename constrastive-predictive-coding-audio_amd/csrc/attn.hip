@@ -2,6 +2,7 @@
 // TransformerEncoderLayer, transformer.py:223-272) that are not GEMMs: positional encoding, causal multi-head attention
 // for short sequences (<= 64 steps: the whole (item, head) problem lives in one workgroup's LDS), residual + LayerNorm,
 // mean over time.  All work on channels-last rows x[(b, t)][C]; arithmetic in f32, storage type T.
+#include <cstdlib>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
 
@@ -132,6 +133,110 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j <= i; ++j) o += p[i][j] * load4(&v[j][c]);
         store4(out + ((long long)b * S + i) * C + h * d + c, o);
+    }
+}
+
+// ---- The same forward on the matrix pipe (bf16 storage, head size 64, S <= 64): both products are 64 x 64 x 64, one 16-row band per
+// wave.  scores^T fragments come out as (4 consecutive columns j, row i = lane % 16) per lane, so a row's softmax needs two lane
+// exchanges; P goes to LDS as bf16 (the A operand of the second product, and what is saved for the backward pass), V is read
+// transposed (ds_read_b64_tr_b16).  Operand tiles with 144-byte rows: every 16-byte chunk aligned, the 16 rows of a fragment read
+// on different banks.  Rows >= S are zero.
+__device__ __forceinline__ uint4 attn_frag_tr(const unsigned char* tile, int rowb, int cb, int ks, int lane) {
+    // (the TN GEMM's fragment read: reduction index along the tile's ROWS, 16 columns cb .. cb + 15)
+    const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const unsigned char* a1 = tile + (ks * 32 + 4 * g + q) * rowb + (cb + 4 * pp) * 2;
+    const unsigned char* a2 = a1 + 16 * rowb;
+    s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a2);
+    uint2 lo = __builtin_bit_cast(uint2, v1), hi = __builtin_bit_cast(uint2, v2);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            bf16_t* __restrict__ P, int S, int C, int heads, float scale, Drop dr) {
+    constexpr int LD = 72, D = 64;
+    __shared__ __attribute__((aligned(16))) bf16_t q[ATT_S][LD], k[ATT_S][LD], v[ATT_S][LD], pt[ATT_S][LD];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < ATT_S * 8; idx += 256) {
+        const int t = idx >> 3, ch = (idx & 7) * 8;
+        uint4 zq = make_uint4(0, 0, 0, 0), zk = zq, zv = zq;
+        if (t < S) {
+            const bf16_t* row = qkv + ((long long)b * S + t) * 3 * C + h * D + ch;
+            zq = *(const uint4*)row; zk = *(const uint4*)(row + C); zv = *(const uint4*)(row + 2 * C);
+        }
+        *(uint4*)&q[t][ch] = zq; *(uint4*)&k[t][ch] = zk; *(uint4*)&v[t][ch] = zv;
+    }
+    __syncthreads();
+    const int g = lane >> 4, il = lane & 15, i = wave * 16 + il;
+    // scores: acc[ct][r] = s[i][j = 16 ct + 4 g + r]
+    f32x4 sc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        sc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 fq = *(const uint4*)&q[i][32 * ks + 8 * g];
+            const uint4 fk = *(const uint4*)&k[16 * ct + il][32 * ks + 8 * g];
+            mfma_chunk<bf16_t>(sc[ct], fk, fq);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * ct + 4 * g + r;
+            sc[ct][r] = (j <= i && j < S) ? sc[ct][r] * scale : -INFINITY;
+            mx = fmaxf(mx, sc[ct][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = sc[ct][r] == -INFINITY ? 0.f : expf(sc[ct][r] - mx);
+            sc[ct][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;                 // (column 0 is never masked for a row < S; rows >= S are not stored)
+    const bool rowok = i < S;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int j0 = 16 * ct + 4 * g;
+        bf16x4 pv, pd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pr = rowok ? sc[ct][r] * inv : 0.f;
+            pv[r] = (bf16_t)pr;
+            pd[r] = (bf16_t)(pr * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + j0 + r));
+        }
+        if (rowok && j0 < S) {                   // the saved P stays undropped
+            bf16_t* dst = P + (long long)bh * S * S + (long long)i * S + j0;
+            if (S % 4 == 0) *(bf16x4*)dst = pv;
+            else
+                for (int r = 0; r < 4 && j0 + r < S; ++r) dst[r] = pv[r];
+        }
+        *(bf16x4*)&pt[i][j0] = pd;
+    }
+    __builtin_amdgcn_wave_barrier();             // a wave reads back only the 16 rows it wrote itself
+    // out[i][c] = sum_j pd[i][j] v[j][c]: acc[cb][r] = out[i][16 cb + 4 g + r]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // the transposed read hands lane group g the reduction indices 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 of the k-step:
+            // the P fragment takes the same ones
+            const uint2 plo = *(const uint2*)&pt[i][32 * ks + 4 * g], phi = *(const uint2*)&pt[i][32 * ks + 16 + 4 * g];
+            const uint4 fp = make_uint4(plo.x, plo.y, phi.x, phi.y);
+            const uint4 fv = attn_frag_tr((const unsigned char*)&v[0][0], LD * 2, 16 * cb, ks, lane);
+            mfma_chunk<bf16_t>(o, fv, fp);
+        }
+        if (rowok) store4(out + ((long long)b * S + i) * C + h * D + 16 * cb + 4 * g, o);
     }
 }
 
@@ -445,6 +550,14 @@ int launch_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, in
     if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
     const Drop dr = make_drop(drop_p, seed, site);
     const float scale = 1.f / sqrtf((float)(C / heads));
+    static const bool use_mfma = !(getenv("CPC_ATTN_MFMA") && atoi(getenv("CPC_ATTN_MFMA")) == 0);
+    if (use_mfma && dtype == CPC_DTYPE_BF16 && C / heads == 64 && C % 8 == 0 && ((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 8 == 0) &&
+        ((uintptr_t)P % 8 == 0)) {
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)P, S, C, heads,
+                           scale, dr);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, (bf16_t*)P, S, C, heads, scale, dr),
                hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (float*)out, (float*)P, S, C, heads, scale, dr));

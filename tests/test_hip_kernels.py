@@ -642,7 +642,7 @@ def test_unsupported_shapes_fail_loudly():
 
 # --------------------------------------------------------------------------------------- attention context kernels
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,S,C,heads", [(3, 60, 64, 8), (2, 64, 128, 2), (5, 7, 32, 4)])
+@pytest.mark.parametrize("B,S,C,heads", [(3, 60, 64, 8), (2, 64, 128, 2), (5, 7, 32, 4), (3, 60, 512, 8), (2, 37, 128, 2), (2, 5, 64, 1)])
 def test_attention_fwd_bwd(dt, B, S, C, heads):
     """cpc_attn_fwd / cpc_attn_bwd vs autograd of the definition (causal softmax(q k^T / sqrt(d)) v per head)."""
     g = torch.Generator().manual_seed(S * 3 + C)
