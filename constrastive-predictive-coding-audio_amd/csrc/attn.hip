@@ -349,6 +349,95 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 }
 
+// ---- The backward on the matrix pipe (bf16, head size 64, S <= 64).  dP = dO V^T comes out like the forward's scores (row i = the
+// wave's band + lane % 16, four consecutive columns per lane and tile), so the softmax backward stays in registers; ds and P m go to LDS
+// as bf16 tiles [i][j], and the three output products read them through the transposed fragment read: dq = ds K (ds as rows), dk =
+// ds^T Q and dv = (P m)^T dO (reduction along the tiles' rows on both sides).  Rows >= S are zero.
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
+                                                            const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int S, int C,
+                                                            int heads, float scale, Drop dr) {
+    constexpr int LD = 72, D = 64;
+    __shared__ __attribute__((aligned(16))) bf16_t q[ATT_S][LD], k[ATT_S][LD], v[ATT_S][LD], go[ATT_S][LD], dst[ATT_S][LD], pmt[ATT_S][LD];
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < ATT_S * 8; idx += 256) {
+        const int t = idx >> 3, ch = (idx & 7) * 8;
+        uint4 zq = make_uint4(0, 0, 0, 0), zk = zq, zv = zq, zg = zq;
+        if (t < S) {
+            const bf16_t* row = qkv + ((long long)b * S + t) * 3 * C + h * D + ch;
+            zq = *(const uint4*)row; zk = *(const uint4*)(row + C); zv = *(const uint4*)(row + 2 * C);
+            zg = *(const uint4*)(dout + ((long long)b * S + t) * C + h * D + ch);
+        }
+        *(uint4*)&q[t][ch] = zq; *(uint4*)&k[t][ch] = zk; *(uint4*)&v[t][ch] = zv; *(uint4*)&go[t][ch] = zg;
+    }
+    __syncthreads();
+    const int g = lane >> 4, il = lane & 15, i = wave * 16 + il;
+    const bool rowok = i < S;
+    // dP[i][j] = sum_c dO[i][c] V[j][c]: acc[ct][r] <-> j = 16 ct + 4 g + r
+    f32x4 dp[4], pr[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        dp[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 fg_ = *(const uint4*)&go[i][32 * ks + 8 * g];
+            const uint4 fv = *(const uint4*)&v[16 * ct + il][32 * ks + 8 * g];
+            mfma_chunk<bf16_t>(dp[ct], fv, fg_);
+        }
+        const int j0 = 16 * ct + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + r;
+            float pv = 0.f;
+            if (rowok && j <= i) pv = (float)P[(long long)bh * S * S + (long long)i * S + j];
+            const float mf = drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + j);
+            pr[ct][r] = pv;
+            dp[ct][r] = (rowok && j <= i) ? dp[ct][r] * mf : 0.f;
+            dot = fmaf(dp[ct][r], pv, dot);
+        }
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int j0 = 16 * ct + 4 * g;
+        bf16x4 dsv, pmv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dsv[r] = (bf16_t)(pr[ct][r] * (dp[ct][r] - dot) * scale);
+            pmv[r] = (bf16_t)(pr[ct][r] * drop_factor(dr, (unsigned long long)bh * S * S + (unsigned long long)i * S + j0 + r));
+        }
+        *(bf16x4*)&dst[i][j0] = dsv;
+        *(bf16x4*)&pmt[i][j0] = pmv;
+    }
+    __syncthreads();
+    // the wave's band of 16 rows t = 16 wave + lane % 16 of dq (rows i), dk and dv (rows j); acc[cb][r] <-> c = 16 cb + 4 g + r
+    const unsigned char* kb = (const unsigned char*)&k[0][0];
+    const unsigned char* qb = (const unsigned char*)&q[0][0];
+    const unsigned char* gb = (const unsigned char*)&go[0][0];
+    const unsigned char* db = (const unsigned char*)&dst[0][0];
+    const unsigned char* pb = (const unsigned char*)&pmt[0][0];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // dq: reduction over j, ds read as rows with the index pattern of the transposed read (forward kernel)
+            const uint2 dlo = *(const uint2*)&dst[i][32 * ks + 4 * g], dhi = *(const uint2*)&dst[i][32 * ks + 16 + 4 * g];
+            mfma_chunk<bf16_t>(aq, attn_frag_tr(kb, LD * 2, 16 * cb, ks, lane), make_uint4(dlo.x, dlo.y, dhi.x, dhi.y));
+            // dk, dv: reduction over i on both sides
+            mfma_chunk<bf16_t>(ak, attn_frag_tr(qb, LD * 2, 16 * cb, ks, lane), attn_frag_tr(db, LD * 2, 16 * wave, ks, lane));
+            mfma_chunk<bf16_t>(av, attn_frag_tr(gb, LD * 2, 16 * cb, ks, lane), attn_frag_tr(pb, LD * 2, 16 * wave, ks, lane));
+        }
+        if (rowok) {
+            bf16_t* row = dqkv + ((long long)b * S + i) * 3 * C + h * D + 16 * cb + 4 * g;
+            store4(row, aq);
+            store4(row + C, ak);
+            store4(row + 2 * C, av);
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -570,6 +659,14 @@ int launch_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv
     if (!attn_ok(B, S, C, heads) || drop_p < 0.f || drop_p >= 1.f) return CPC_EINVAL;
     const Drop dr = make_drop(drop_p, seed, site);
     const float scale = 1.f / sqrtf((float)(C / heads));
+    static const bool use_mfma = !(getenv("CPC_ATTN_MFMA") && atoi(getenv("CPC_ATTN_MFMA")) == 0);
+    if (use_mfma && dtype == CPC_DTYPE_BF16 && C / heads == 64 && C % 8 == 0 && ((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) &&
+        ((uintptr_t)dqkv % 8 == 0)) {
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)P, (const bf16_t*)dout,
+                           (bf16_t*)dqkv, S, C, heads, scale, dr);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)P, (const bf16_t*)dout, (bf16_t*)dqkv, S, C, heads, scale, dr),
                hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(B * heads), dim3(256), 0, st, (const float*)qkv, (const float*)P, (const float*)dout, (float*)dqkv, S, C, heads, scale, dr));

@@ -666,6 +666,36 @@ def test_attention_fwd_bwd(dt, B, S, C, heads):
     assert rel_err(dq, qkv.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,S,C,heads", [(3, 60, 512, 8), (2, 37, 128, 2), (3, 60, 64, 8)])
+def test_attention_fwd_bwd_with_dropout(dt, B, S, C, heads):
+    """The same with dropout on the attention weights (nn.MultiheadAttention's, p = 0.3): the device masks are a function of
+    (seed, site, index) and are materialised with cpc_dropout_mask for the reference.  Head size 64 in bf16 runs on the matrix-pipe
+    kernels, the other cases on the vector kernels."""
+    g = torch.Generator().manual_seed(S * 5 + C)
+    d, p_drop, seed, site = C // heads, 0.3, 987654321, 4
+    qkv = rounded(torch.randn(B * S, 3 * C, generator=g), dt).requires_grad_(True)
+    dout = rounded(torch.randn(B * S, C, generator=g), dt)
+    mask = torch.empty(B * heads * S * S, device=DEV)
+    _hip.call("cpc_dropout_mask", _hip.ptr(mask), mask.numel(), p_drop, seed, site)
+    m = mask.cpu().double().reshape(B, heads, S, S)
+    q, k, v = (t.reshape(B, S, heads, d).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(d) + torch.triu(torch.full((S, S), float("-inf"), dtype=torch.double), 1)
+    P = torch.softmax(sc, -1)
+    out = ((P * m) @ v).permute(0, 2, 1, 3).reshape(B * S, C)
+    out.backward(dout)
+    code = _hip.dtype_code(dt)
+    d_qkv, d_dout = dev(qkv.detach().float(), dt), dev(dout.float(), dt)
+    o = torch.full((B * S, C), float("nan"), device=DEV, dtype=dt)
+    Pd = torch.full((B * heads, S, S), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_attn_fwd", _hip.ptr(d_qkv), _hip.ptr(o), _hip.ptr(Pd), B, S, C, heads, p_drop, seed, site, code)
+    assert rel_err(o, out) < tol(dt)
+    assert rel_err(Pd, P.reshape(B * heads, S, S)) < tol(dt)          # the saved weights stay undropped
+    dq = torch.full((B * S, 3 * C), float("nan"), device=DEV, dtype=dt)
+    _hip.call("cpc_attn_bwd", _hip.ptr(d_qkv), _hip.ptr(Pd), _hip.ptr(d_dout), _hip.ptr(dq), B, S, C, heads, p_drop, seed, site, code)
+    assert rel_err(dq, qkv.grad) < (1e-4 if dt == torch.float32 else 2.5e-2)
+
+
 def test_attention_unsupported_shapes():
     x = torch.zeros(16, device=DEV)
     p = _hip.ptr(x)
