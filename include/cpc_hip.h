@@ -189,7 +189,10 @@ int cpc_dropout_mask(float* mask, long long n, float drop_p, unsigned long long 
 /* nn.MultiheadAttention core with the causal mask of attention_model.py:61-63, one (item, head) per workgroup:
  *   qkv T [(b,t)][3C] (q | k | v, head h at columns h*C/heads);  out T [(b,t)][C];  P T [B*heads][S][S] softmax rows (saved,
  *   before dropout; element index of the dropout mask = its offset in P).
- * Limits: S <= 64, C/heads <= 64 (-EINVAL otherwise).  The backward gives dqkv in the layout of qkv. */
+ * Limits: S <= 64, C/heads <= 64 (-EINVAL otherwise).  The backward gives dqkv in the layout of qkv.
+ * bf16 with C/heads == 64 (the reference's attention architectures) runs on the matrix pipe: scores, P V, dP, dq, dk, dv as 16x16x32
+ * MFMAs with P / ds rounded to bf16 for the second products; other head sizes and f32 use vector kernels (f32 accumulation throughout).
+ * CPC_ATTN_MFMA=0 in the environment forces the vector kernels (A/B). */
 int cpc_attn_fwd(const void* qkv, void* out, void* P, int B, int S, int C, int heads, float drop_p, unsigned long long seed,
                  unsigned site, int dtype, void* stream);
 int cpc_attn_bwd(const void* qkv, const void* P, const void* dout, void* dqkv, int B, int S, int C, int heads, float drop_p,
