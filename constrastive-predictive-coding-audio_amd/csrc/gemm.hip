@@ -1782,6 +1782,15 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream) {
     if (I <= 0 || J <= 0 || J % 4 || nslab <= 0 || cdiv <= 0) return CPC_EINVAL;
     const long long total4 = (long long)I * J / 4;
+    if (total4 <= 512 && nslab >= 512) {
+        // very small outputs from very many slabs (BatchNorm sums and bias gradients of the scalogram model: 32 ... 512 values from
+        // 1024 ... 2048 slabs): one workgroup per output float4 with 256 slab lanes — with 64 lanes such a launch was two to 32
+        // workgroups whose threads each walked 16 ... 32 dependent loads (scalogram step: 2.9 ms in these reductions)
+        hipLaunchKernelGGL(reduce_slabs_small_kernel<256>, dim3((unsigned)total4), dim3(256), 0, stream, slabs, out, I, J, nslab, slab_stride,
+                           cdiv, s_j, s_hi, s_lo);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (total4 <= 16384 && nslab >= 16) {     // (from 16 slabs: the predictor's data gradient, 24 slabs of 256 x 256: 10 -> 5 us)
         if (nslab >= 128)            // 64 slab lanes: a serial chain of nslab / 64 loads per thread (228-912 slabs: the per-tile column sums)
             hipLaunchKernelGGL(reduce_slabs_small_kernel<64>, dim3((unsigned)((total4 + 3) / 4)), dim3(256), 0, stream, slabs, out, I,
