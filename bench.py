@@ -10,9 +10,17 @@ Workload: BASELINE.json configs[1] — AudioPredictiveCodingModel (5-layer strid
 accumulation, softplus score, regularisation 1.0, Adam lr 1e-4.  Weak scaling: every rank runs its own 256 clips with its
 own in-batch negatives; gradients are averaged with one RCCL all-reduce per step.
 
-Before the W warm-up steps the script runs --prewarm (default 40, 0.2 s) further untimed steps: the first dozen steps of a process are
-6-8 % slower in every kernel (clock ramp under sustained load), which says nothing about the step a training run sees; the timed
-region is still exactly K full steps.  `prewarm_steps` in the JSON line records it.
+--workload selects the configuration (default cfg1 = BASELINE configs[1], the one the metric is quoted on; the others are BASELINE
+configs[2] / configs[3] at their stated sizes and print the same JSON line with their own dominant kernel in `roofline`):
+  scalogram   CQT (256 bins, hop 128) + PreprocessingModule + scalogram_resnet_architecture_7 + ar_conv_architecture_3, V = 60, K = 16,
+              128 clips of item_length = 97 024 samples per GPU (76 encoder frames per clip); the CQT is part of the step
+  conv_ar     AudioEncoder(512) + ConvolutionalArModel(ar_conv_architecture_3), V = 60, K = 12, 256 clips of 20 480 samples
+  attention   AudioEncoder(512) + AttentionModel(attention_architecture_1, train-mode dropout 0.1), same shapes
+
+The driver's protocol is what runs: W untimed warm-up steps, then exactly K timed steps (--prewarm adds further untimed steps in front,
+default 0: the first dozen steps of a process are 6-8 % slower in every kernel while the clocks ramp; `prewarm_steps` records it).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself (`python -m torch.distributed.run` as a
+child process, decided before anything touches the GPU) and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
@@ -160,16 +168,230 @@ def trainer_loop_ms(model, B, L, device, steps=60, warmup=10):
     return round(span / (len(marks) - 1 - warmup) * 1e3, 3), len(marks)
 
 
+# ------------------------------------------------------------------------------------------------ BASELINE configs[2] / configs[3]
+def secondary_workload(name, dtype, device, B):
+    """Model, input geometry and CPU-oracle arguments of --workload scalogram / conv_ar / attention (SURVEY.md 8(d) cfg 3 / cfg 4)."""
+    from types import SimpleNamespace
+    from cpc_audio_amd import configs
+    from cpc_audio_amd.audio_model import AudioEncoder, AudioPredictiveCodingModel, ConvolutionalArModel
+    torch.manual_seed(0)
+    if name == "scalogram":
+        from cpc_audio_amd.scalogram_model import PreprocessingModule, ScalogramResidualEncoder, cqt_default_dict
+        V, K = 60, 16
+        pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+        enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+        ar_cfg = configs.fresh(configs.ar_conv_architecture_3)
+        model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(dict(ar_cfg)), enc_size=512, ar_size=256, visible_steps=V,
+                                           prediction_steps=K, compute_dtype=dtype)
+        pre = pre.to(device)
+        pre.cqt.precision = "bf16x3" if dtype == "bf16" else "fp32"
+        L = int(model.item_length)
+        desc = ("BASELINE configs[2]: CQT(256 bins, hop 128, bf16x3) + PreprocessingModule(phase) + scalogram_resnet_architecture_7 + "
+                f"ConvolutionalArModel(ar_conv_architecture_3), V=60, K=16, softplus score, reg 1.0, Adam; per-GPU batch {B} x {L} samples")
+        return SimpleNamespace(model=model.to(device), pre=pre, L=L, V=V, K=K, desc=desc, amp=0.1, frames=None,
+                               oracle=dict(scalogram=[dict(b.cfg) for b in enc.blocks], conv_ar=dict(ar_cfg)), oracle_B=2)
+    V, K, L = 60, 12, 20480
+    if name == "conv_ar":
+        ar_cfg = configs.fresh(configs.ar_conv_architecture_3)
+        ar, oracle = ConvolutionalArModel(dict(ar_cfg)), dict(conv_ar=dict(ar_cfg))
+        what = "ConvolutionalArModel(ar_conv_architecture_3: six k=5 blocks, BatchNorm1d + residual)"
+    else:
+        from cpc_audio_amd.attention_model import AttentionModel
+        att = configs.fresh(configs.attention_architecture_1)
+        ar, oracle = AttentionModel(dict(att)), dict(attention=(att["num_layers"], att["num_heads"]))
+        what = "AttentionModel(attention_architecture_1: 3 layers, 8 heads, FF 512, dropout 0.1 in train mode)"
+    model = AudioPredictiveCodingModel(AudioEncoder(), ar, enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K, compute_dtype=dtype)
+    desc = (f"BASELINE configs[3]: AudioEncoder(5x512) + {what}, V=60, K=12, softplus score, reg 1.0, Adam; per-GPU batch "
+            f"{B} x {L} samples (126 frames/clip)")
+    return SimpleNamespace(model=model.to(device), pre=None, L=L, V=V, K=K, desc=desc, amp=1.0, frames=126, oracle=oracle, oracle_B=8)
+
+
+def cpu_baseline_secondary(name, wl):
+    """The oracle's train step of the same model family on a bounded sample: 2 warm-up + median of 5 steps at a small batch."""
+    from oracle import cpc_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    threads = torch.get_num_threads()
+    B, warm, timed = wl.oracle_B, 2, 5
+    params = {k: v.detach().float().cpu().clone() for k, v in wl.model.state_dict().items()}
+    tr = O.OracleTrainer(params, wl.V, wl.K, score="softplus", regularization=1.0, lr=1e-4, **wl.oracle)
+    data = torch.randn(2 * B, wl.L, generator=torch.Generator().manual_seed(0)) * wl.amp
+    weights = consts = None
+    if wl.pre is not None:
+        weights = [m.weight.detach().cpu() for m in wl.pre.cqt.conv_modules]
+        consts = (wl.pre.phase_diff.fixed_phase_diff.detach().cpu().reshape(-1).float(), wl.pre.phase_diff.scaling.detach().cpu().reshape(-1).float())
+    times = []
+    for i in range(warm + timed):
+        t0 = time.perf_counter()
+        x = data[(i % 2) * B:(i % 2 + 1) * B]
+        if wl.pre is not None:          # the scalogram is part of the step (contrastive_estimation_training.py:100-101)
+            with torch.no_grad():
+                x = O.preprocessing_forward(O.cqt_forward(x.unsqueeze(1), weights, 128), consts)
+        tr.step(x)
+        if i >= warm:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    frames = wl.frames
+    return {"value": round(B * frames / med, 1), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "sample": f"median of {timed} oracle train steps after {warm} warm-up steps, B={B} x {wl.L} samples, f32, {threads} torch "
+                      f"threads, {med * 1e3:.0f} ms/step"}
+
+
+def run_secondary(args, world, rank, device, dist):
+    """--workload scalogram / conv_ar / attention: the same protocol and JSON line as the headline workload."""
+    from cpc_audio_amd import _hip
+    from cpc_audio_amd.engine import FusedAdam, GradAllReduce
+    B = args.batch
+    wl = secondary_workload(args.workload, args.dtype, device, B)
+    model = wl.model
+    gen = torch.Generator().manual_seed(1000 + rank)
+    pool = [(torch.randn(B, wl.L, generator=gen) * wl.amp).to(device) for _ in range(2)]
+
+    def inputs(i):
+        w = pool[i % len(pool)]
+        return wl.pre(w.unsqueeze(1)) if wl.pre is not None else w
+
+    x0 = inputs(0)
+    eng = model.engine_for(x0) if wl.pre is not None else model.engine(B, wl.L)
+    if wl.frames is None:
+        wl.frames = int(eng.T)
+    opt = FusedAdam(model, lr=1e-4)
+    sync = GradAllReduce(model, optimizer=None) if world > 1 else None
+    opt.skip_flag = eng.nan_flag()
+
+    def step(i):
+        out = eng.loss_and_grads(inputs(i), softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
+                                 after_loss=sync.reduce_flag if sync is not None else None)
+        if sync is not None:
+            sync.finish()                       # one RCCL all-reduce (sum) of the flat gradient buffer
+        opt.step(grad_scale=1.0 / world)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.prewarm + args.warmup):
+        step(i)
+    fence()
+    timer = _hip.KernelTimer(only=None, by_shape=args.breakdown)
+    _hip.set_timer(timer)
+    every = 1 if args.breakdown else max(1, args.steps // 4)        # every kernel of about four sampled steps is event-timed
+    sampled = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timer.active = (i % every == 0)
+        sampled += 1 if timer.active else 0
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    _hip.set_timer(None)
+    loss = float(out[0])
+    n_ranks_seen = 1
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+    if rank != 0:
+        return
+    summary = timer.summary()
+    rows = sorted(summary.items(), key=lambda kv: -kv[1][1])
+    total_ms = sum(v[1] for _, v in rows)
+    gemms = [(k, v) for k, v in rows if v[2] > 0 and k.startswith("gemm_")]
+    # the dominant kernel SYMBOL: launches of the same kernel template summed (the timer's key = entry point + dtypes + tile)
+    dom_key, dom = gemms[0] if gemms else (None, None)
+    line = {
+        "metric": "CPC train-step audio frames/sec (enc+AR+InfoNCE)",
+        "value": round(B * wl.frames * world * args.steps / elapsed, 1),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "prewarm_steps": args.prewarm,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": wl.desc, "global_batch": B * world, "clip_samples": wl.L, "frames_per_clip": wl.frames,
+                   "clips_per_s": round(B * world * args.steps / elapsed, 1), "parallelism": f"dp{world}", "loss_last_step": round(loss, 6)},
+    }
+    if dom is not None:
+        cnt, ms, flops = dom
+        peak = 157.3 if dom_key.startswith(("gemm_nt<f32", "gemm_tn<f32")) else MFMA_BF16_PEAK_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                            "traffic": None, "kernel": dom_key, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                            "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+                            "ms_per_step": round(ms / sampled, 4),
+                            "note": "the GEMM symbol with the largest summed HIP-event time over the sampled steps of the timed region "
+                                    "(2 M N K booked per launch, executed shapes); `kernels` lists every symbol above 2 % of the step"}
+    line["kernels"] = [{"kernel": k, "launches_per_step": round(v[0] / sampled, 1), "ms_per_step": round(v[1] / sampled, 4),
+                        **({"tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} if v[2] > 0 and v[1] > 0 else {})}
+                       for k, v in rows if v[1] >= 0.02 * total_ms]
+    line["event_timed_ms_per_step"] = round(total_ms / sampled, 3)
+    if args.breakdown:
+        for k, (cnt, kms, w) in rows:
+            tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
+            print(f"#   {k:70s} {cnt / sampled:6.1f}/step {kms / sampled:9.4f} ms/step {tf}", file=sys.stderr)
+    if world > 1:
+        line["n_ranks_seen"] = n_ranks_seen
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_secondary(args.workload, wl)
+    print(json.dumps(line), flush=True)
+
+
+def launch_command(n, argv, port=None):
+    """The driver's own launch line for N ranks on one node (rendezvous on 127.0.0.1, a free port unless one is given)."""
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (this process has not
+    touched the GPU and never will), pass its stderr through, relay rank 0's JSON line on stdout, return its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(launch_command(n, sys.argv[1:]), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--prewarm", type=int, default=40,
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "scalogram", "conv_ar", "attention"],
+                    help="cfg1 = BASELINE configs[1] (headline); scalogram = configs[2]; conv_ar / attention = configs[3]")
+    ap.add_argument("--prewarm", type=int, default=0,
                     help="untimed steps BEFORE the W warm-up steps: the first dozen steps of a process run 6-8 %% slower (every kernel; the "
                          "clocks ramp under sustained load, DESIGN.md section 9.3), which a 5-step warm-up does not cover; reported as "
                          "prewarm_steps.  0 = off")
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 256; 128 for --workload scalogram)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trainer-loop", action="store_true", help="skip the extra run through ContrastiveEstimationTrainer.train")
@@ -178,6 +400,10 @@ def main():
     ap.add_argument("--all-timesteps", action="store_true",
                     help="diagnostic: score_over_all_timesteps=True (the full (B*K)^2 score matrix); not the headline configuration")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 128 if args.workload == "scalogram" else 256
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))              # before any GPU call: the ranks are child processes, this one only relays
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +429,13 @@ def main():
 
     from cpc_audio_amd import _hip
     from cpc_audio_amd.engine import FusedAdam, GradAllReduce, GraphedStep
+
+    if args.workload != "cfg1":
+        run_secondary(args, world, rank, device, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B, L, T = args.batch, 20480, 126
     model = build_model(args.dtype, device, seed=0)                 # identical parameters on every rank

@@ -266,7 +266,16 @@ def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_r
     _check(lib().cpc_gemm_tn(C.byref(args), stream_ptr()), "cpc_gemm_tn")
 
 
+# Timing probes (tools/): CPC_PROBE_SKIP=<entry point>,... drops those launches, so the step's RESULTS ARE GARBAGE.  Honoured only
+# together with CPC_ENABLE_PROBES=1, and announced on stderr; without the opt-in a stray CPC_PROBE_SKIP is refused loudly.
 _PROBE_SKIP = frozenset(v for v in os.environ.get("CPC_PROBE_SKIP", "").split(",") if v)
+PROBES_ENABLED = os.environ.get("CPC_ENABLE_PROBES", "0") == "1"
+if _PROBE_SKIP:
+    import sys as _sys
+    if not PROBES_ENABLED:
+        raise RuntimeError("CPC_PROBE_SKIP is set but CPC_ENABLE_PROBES=1 is not: timing probes drop kernel launches and make every "
+                           "result wrong; unset CPC_PROBE_SKIP, or opt in explicitly for a timing run")
+    print(f"[cpc_hip] WARNING: timing probe active, launches of {sorted(_PROBE_SKIP)} are SKIPPED -- results are garbage", file=_sys.stderr)
 
 
 def call(name, *args, key=None, work=0.0, shape=None):

@@ -349,16 +349,25 @@ class _EncoderForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, names, x, *params):
+        if x.requires_grad:
+            raise NotImplementedError("a stand-alone encoder call gives no gradient with respect to its input (layer 1's data gradient "
+                                      "is never formed on the HIP path): detach the input, or train through AudioPredictiveCodingModel")
         eng = owner.engine_for(x)
         xin = x.detach().float() if x.dim() == 4 else x.detach()[:, 0, :].contiguous().float()
         eng.prepare_weights()
         eng.encoder_forward(xin)
-        ctx.eng, ctx.xin, ctx.names = eng, xin, names
+        # the backward pass reads the engine's activation buffers: stamp this forward pass, so that a later one (which overwrites
+        # them) is noticed instead of silently differentiating the wrong activations
+        eng._standalone_stamp = getattr(eng, "_standalone_stamp", 0) + 1
+        ctx.eng, ctx.xin, ctx.names, ctx.stamp = eng, xin, names, eng._standalone_stamp
         return eng.view_top()[:, :eng.T, :].float().transpose(1, 2)
 
     @staticmethod
     def backward(ctx, d_out):
         eng = ctx.eng
+        if getattr(eng, "_standalone_stamp", 0) != ctx.stamp:
+            raise RuntimeError("another forward pass of this encoder ran before backward(): the engine keeps ONE set of activations "
+                               "(call backward() before the next forward, as a train loop does)")
         B, E, T = eng.B, eng.E, eng.T
         dtop = eng.dact[-1].view(B, eng.geo.alloc[-1], E)
         dtop.zero_()
@@ -418,9 +427,9 @@ class ActivationWriter(nn.Module):
     """Pass-through tap (reference audio_model.py:274-284).  The hot path never registers anything: ``register`` is None in
     every training configuration, and the module is kept only because it sits in the reference's module tree (ModuleList
     indices, and with them the state_dict keys, count it).  A caller-supplied register object is served through the one
-    method the reference's writer uses, ``write_activation(name, value)``; the registers themselves (``ActivationRegister``:
-    per-device dictionaries for the dreaming / activation-statistics tools) are outside this path (SURVEY.md section 2, rows
-    12-13) and are not provided."""
+    method the reference's writer uses, ``write_activation(name, value)``; ``ActivationRegister`` below is the host-side
+    container the reference's tools hand in (dreaming / activation statistics, SURVEY.md section 2 rows 12-13: outside the
+    hot path, kept for import compatibility)."""
 
     def __init__(self, register, name):
         super().__init__()
@@ -430,6 +439,50 @@ class ActivationWriter(nn.Module):
         if self.register is not None:
             self.register.write_activation(self.name, x)
         return x
+
+
+class ActivationRegister:
+    """Host-side container for tapped activations, same constructor and methods as the reference's (audio_model.py:222-271):
+    one ordered dictionary, or one per device index when ``devices`` is given (get_activations then concatenates the per-device
+    entries on the first device).  Pure bookkeeping around tensors a caller's ActivationWriter hands in; the train step never
+    registers anything."""
+
+    def __init__(self, writing_condition=None, clone_activations=False, batch_filter=None, move_to_cpu=False, devices=None):
+        from collections import OrderedDict
+        self.devices = devices
+        self.activations = OrderedDict() if devices is None else {d: OrderedDict() for d in devices}
+        self.active = True
+        self.writing_condition, self.clone_activations = writing_condition, clone_activations
+        self.batch_filter, self.move_to_cpu = batch_filter, move_to_cpu
+
+    def write_activation(self, name, value):
+        if not self.active or (self.writing_condition is not None and not self.writing_condition(value)):
+            return
+        if self.batch_filter is not None:
+            value = value[self.batch_filter]
+        slot = self.activations if self.devices is None else self.activations[value.device.index]
+        if self.move_to_cpu:
+            value = value.cpu()
+        slot[name] = value.clone() if self.clone_activations else value
+
+    def get_activations(self):
+        if self.devices is None:
+            return self.activations
+        first = self.devices[0]
+        return {key: torch.cat([self.activations[d][key].to(torch.device("cuda", first)) for d in self.devices], dim=0)
+                for key in self.activations[first].keys()}
+
+
+def load_to_cpu(path):
+    """torch.load of a whole-module snapshot onto the CPU (reference audio_model.py:287-290)."""
+    model = torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+    model.cpu()
+    return model
+
+
+def cuda0_writing_condition(x):
+    """Writing condition: keep what lives on the CPU or on the first GPU (reference audio_model.py:300-307)."""
+    return x.device.index == 0 if x.device.type == 'cuda' else True
 
 
 def num_parameters(model):

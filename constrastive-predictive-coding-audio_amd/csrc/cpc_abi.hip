@@ -1,5 +1,7 @@
 // extern "C" boundary of libcpc_hip.so: argument checking + translation of the domain-level calls (conv / GRU / NCE /
 // Adam) onto the kernel launchers.  See include/cpc_hip.h for the contract.
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
@@ -457,6 +459,20 @@ int cpc_gru_set_streaming(int on) {
 }
 
 int cpc_debug_set(int key, int value) {
+    // Keys 4 / 5 select timing-probe variants of the NT K loop whose RESULTS ARE GARBAGE: honoured only in a process that opted in
+    // with CPC_ENABLE_PROBES=1, and announced on stderr once, so that a stray call cannot silently corrupt a training run.
+    if (key == 4 || key == 5) {
+        const char* on = getenv("CPC_ENABLE_PROBES");
+        if (!on || on[0] != '1') {
+            fprintf(stderr, "[cpc_hip] cpc_debug_set(%d, %d) refused: timing probes need CPC_ENABLE_PROBES=1 (their results are garbage)\n", key, value);
+            return CPC_EINVAL;
+        }
+        static bool warned = false;
+        if (!warned && value != 0) {
+            fprintf(stderr, "[cpc_hip] WARNING: NT-GEMM timing probe active (cpc_debug_set %d = %d): results are garbage until it is reset\n", key, value);
+            warned = true;
+        }
+    }
     if (key == 1) { const int old = g_nt_stagger64; g_nt_stagger64 = value; return old; }
     if (key == 4) { const int old = g_nt_probe; g_nt_probe = value; return old; }
     if (key == 6) { const int old = g_nt_wt; g_nt_wt = value; return old; }

@@ -70,11 +70,18 @@ def _col_group(cout, kw=1, stride=(1, 1), pad=0):
     return 128 // cout
 
 
+def _col_ok(kw, sh, sw, pad, cin, in_f32):
+    """Does a convolution run as an overlapped-row GEMM (mode 'col')?  (k,1) kernel, stride 1, no padding."""
+    return kw == 1 and sh == 1 and sw == 1 and pad == 0 and cin % 8 == 0 and not in_f32
+
+
 class _Conv:
     """One nn.Conv2d of the encoder on grids.  mode 'col': (k,1) kernel, stride 1, no padding -> overlapped-row GEMMs;
     mode 'win': im2col + GEMM (+ col2im for the data gradient)."""
 
-    def __init__(self, eng, wname, bname, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False):
+    def __init__(self, eng, wname, bname, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False, out_pad=None):
+        """``out_pad`` = (top, tail, guard_rows): geometry of the output grid when the NEXT convolution reads it directly (a block
+        without BatchNorm whose second kernel has top padding, scalogram_model.py:411-412); mode 'win' only."""
         self.eng, self.wname, self.bname, self.gin, self.in_f32, self.need_dgrad, self.relu = eng, wname, bname, gin, in_f32, need_dgrad, relu
         # a convolution that reads float32 input (the scalogram, or its pooled copy) runs entirely in float32: its output
         # is normalised / added downstream, and bf16 would quantise away the signal riding on the log-amplitude offset
@@ -94,12 +101,13 @@ class _Conv:
         self.Wo = (gin.W + 2 * self.pad - self.kw) // self.sw + 1
         if self.Ho < 1 or self.Wo < 1:
             raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
-        col_ok = self.kw == 1 and self.sh == 1 and self.sw == 1 and self.pad == 0 and self.cin % 8 == 0 and not in_f32
-        self.mode = 'col' if col_ok else 'win'
+        self.mode = 'col' if _col_ok(self.kw, self.sh, self.sw, self.pad, self.cin, in_f32) else 'win'
         B = gin.B
         if self.cout % 8:
             raise NotImplementedError("scalogram encoder channel counts must be multiples of 8")
         if self.mode == 'col':
+            if out_pad is not None and (out_pad[0] or out_pad[1]):
+                raise AssertionError("an overlapped-row convolution writes its input's row geometry (use _CastRelu for other outputs)")
             self.y0 = Grid(B, gin.W, self.Ho, self.cout, dev, dt, top=0, tail=gin.Ha - self.Ho, guard_rows=self.kh + 16)
             self.K = self.kh * self.cin
             self.M = gin.rows
@@ -124,7 +132,8 @@ class _Conv:
                 self.nsplit = eng._pick_split(self.K, self.cout, self.M)
                 self.slab = self.nsplit * self.K * self.cout
         else:
-            self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt)
+            o_top, o_tail, o_guard = out_pad if out_pad is not None else (0, 0, 96)
+            self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt, top=o_top, tail=o_tail, guard_rows=o_guard)
             self.K = self.kh * self.kw * self.cin
             # K padded so that the fast GEMM paths apply (K-stage of 64 bf16 / 32 f32 elements); tiny K stays at a multiple of 8
             kq = 64 if dt == torch.bfloat16 else 32
@@ -297,7 +306,7 @@ class _SepConv:
     input (cpc_im2col2d + cpc_dw_fwd; backward cpc_dw_bwd_col + cpc_col2im2d and cpc_dw_bwd_w), the 1 x 1 convolution is an
     ordinary _Conv on the depthwise output.  Same interface as _Conv."""
 
-    def __init__(self, eng, prefix, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False, bias=True):
+    def __init__(self, eng, prefix, mod, gin: Grid, in_f32=False, need_dgrad=True, relu=False, bias=True, out_pad=None):
         self.eng, self.gin, self.in_f32, self.need_dgrad = eng, gin, in_f32, need_dgrad
         dev, dt = eng.device, (torch.float32 if in_f32 else eng.dt)
         self.dt, self.code = dt, _hip.dtype_code(dt)
@@ -327,6 +336,8 @@ class _SepConv:
         self.d_mid = self.mid.like(dev)
         self.pw = _Conv(eng, prefix + ".conv_1x1.weight", prefix + ".conv_1x1.bias" if bias else None, mod.conv_1x1, self.mid,
                         in_f32=in_f32, need_dgrad=True, relu=relu)
+        if out_pad is not None and (out_pad[0] or out_pad[1]):
+            raise AssertionError("a separable convolution writes a plain grid (use _CastRelu for padded outputs)")
         self.y0, self.cout, self.kh = self.pw.y0, self.pw.cout, 1
         self.nb = max(1, min(256, self.M // 256))
         self.slab = max(self.pw.slab, self.nb * self.C * self.taps)
@@ -491,6 +502,45 @@ class _BatchNorm:
                   _hip.ptr(self.stats), _hip.ptr(self.coef), self.x_f32, code)
 
 
+class _CastRelu:
+    """ReLU between a convolution output grid y0 and an activation grid ``a`` of another geometry or dtype, for blocks WITHOUT
+    BatchNorm (scalogram_model.py:399-400 skipped, :406 kept): the float32 output of a first block's convolution going to the
+    bf16 activation the next convolution reads, or an overlapped-row convolution's output going to a grid with top padding
+    (:411-412).  Same interface as _BatchNorm; runs on the normalisation kernels with the identity as "statistics"."""
+
+    def __init__(self, eng, y0: Grid, a: Grid):
+        self.eng, self.y0, self.a = eng, y0, a
+        self.C = y0.C
+        self.x_f32 = 1 if (y0.dtype == torch.float32 and eng.dt != torch.float32) else 0
+        dev = eng.device
+        self.ident = torch.cat([torch.zeros(self.C), torch.ones(self.C)]).to(dev)      # mean 0, 1/sigma 1
+        self.ones, self.zeros = torch.ones(self.C, device=dev), torch.zeros(self.C, device=dev)
+        self.slab = 0
+        self.dy0: Optional[Grid] = None
+        self.trained = False
+
+    def forward(self):
+        _hip.call("cpc_bn_apply", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc), _hip.ptr(self.ident),
+                  _hip.ptr(self.ones), _hip.ptr(self.zeros), 1, self.x_f32, self.eng.code)
+
+    def backward(self, da: Grid):
+        _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
+                  _desc(self.y0, self.y0.desc), _hip.ptr(self.ident), _hip.ptr(self.ones), _hip.ptr(self.zeros), _hip.ptr(self.zeros),
+                  float(self.y0.count), 1, 0, self.x_f32, self.eng.code)
+
+    def tangent(self):
+        e = self.eng
+        if self.x_f32:
+            raise NotImplementedError("gradient penalty in bf16 mode (float32 first stage); use compute_dtype='fp32'")
+        a_t = _twin(e, self.a)
+        _hip.call("cpc_bn_apply", _twin(e, self.y0).ptr(), _desc(self.y0, self.y0.desc), a_t.ptr(), _desc(self.a, self.a.desc),
+                  _hip.ptr(self.ident), _hip.ptr(self.ones), _hip.ptr(self.zeros), 0, self.x_f32, e.code)
+        _hip.call("cpc_relu_mask", a_t.ptr(), self.a.ptr(), self.a.rows * self.a.C, e.code)
+
+    def gp_terms(self, da: Grid, gp_grad):
+        pass          # piecewise linear, no parameters: nothing of second order
+
+
 class _Block:
     """One ScalogramEncoderBlock (scalogram_model.py:372-479) on grids."""
 
@@ -508,38 +558,48 @@ class _Block:
         has_bn = cfg['batch_norm']
         bias = cfg['bias']
         top2 = cfg['top_padding_2'] or 0
-        if in_f32 and not has_bn and dt != torch.float32:
-            raise NotImplementedError("a first scalogram block without batch_norm is supported in fp32 mode only")
         if (cfg['top_padding_1'] or 0) != gin.top:
             raise AssertionError("block input grid was not allocated with this block's top_padding_1")
         # ---- main branch
         i1, i2 = blk.index['conv_1'], blk.index['conv_2']
-        self.conv_a = _make_conv(eng, f"{pre}main_modules.{i1}", mm[i1], gin, bias, in_f32=in_f32, need_dgrad=not first,
-                                 relu=not has_bn)
-        ya = self.conv_a.y0
+        k1, k2 = tuple(cfg['kernel_size_1']), tuple(cfg['kernel_size_2'])
+        s1, p1 = int(cfg['stride_1']), int(cfg['padding_1'])
+        Hc, Wc = (gin.top + gin.H + 2 * p1 - k1[0]) // s1 + 1, (gin.W + 2 * p1 - k1[1]) // s1 + 1
         # [MaxPool2d(pooling_1)] sits between the BatchNorm and the ReLU in the reference (scalogram_model.py:401-405); max
         # pooling commutes with the monotone ReLU, so here the fused BatchNorm + ReLU output is pooled
-        Ha1, Wa1 = pooled(ya.H, self.pool1), pooled(ya.W, self.pool1)
-        if Ha1 < 1 or Wa1 < 1:
-            raise ValueError(f"block {idx}: pooling_1 leaves nothing of a {ya.H} x {ya.W} activation")
-        k2 = tuple(cfg['kernel_size_2'])
+        Ha1, Wa1 = pooled(Hc, self.pool1), pooled(Wc, self.pool1)
+        if Hc < 1 or Wc < 1 or Ha1 < 1 or Wa1 < 1:
+            raise ValueError(f"block {idx}: nothing left of a {gin.top + gin.H} x {gin.W} input after convolution 1 / pooling_1")
         G2 = _col_group(cfg['out_channels'], k2[1], (cfg['stride_2'],) * 2, cfg['padding_2'])
+        a_geom = dict(top=top2, tail=(-(top2 + Ha1)) % G2, guard_rows=k2[0] + 16)
+        # Without BatchNorm the convolution output (ReLU in the GEMM epilogue) IS the activation the second convolution reads, written
+        # straight into a grid with that convolution's top padding (:411-412) -- unless it has to change dtype (a first block's float32
+        # convolution in bf16 mode) or comes from a kernel that cannot address such a grid: then a _CastRelu pass stands where the
+        # BatchNorm would.
+        cast = (not has_bn) and in_f32 and dt != torch.float32
+        direct = (not has_bn) and (not cast) and self.pool1 == 1 and bool(a_geom['top'] or a_geom['tail'])
+        if direct and (cfg.get('separable') or _col_ok(k1[1], s1, s1, p1, cfg['in_channels'], in_f32)):
+            direct, cast = False, bool(top2)        # (a missing tail only costs the row grouping of the next GEMM)
+        self.conv_a = _make_conv(eng, f"{pre}main_modules.{i1}", mm[i1], gin, bias, in_f32=in_f32, need_dgrad=not first,
+                                 relu=not has_bn, out_pad=(a_geom['top'], a_geom['tail'], a_geom['guard_rows']) if direct else None)
+        ya = self.conv_a.y0
+        assert (ya.H, ya.W) == (Hc, Wc)
         self.a_full = None
         if has_bn:
-            self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, top=top2, tail=(-(top2 + Ha1)) % G2, guard_rows=k2[0] + 16)
+            self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, **a_geom)
             if self.pool1 > 1:
                 self.a_full = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt)
             self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya,
                                    self.a_full if self.pool1 > 1 else self.a_a)
         else:
-            if top2:
-                raise NotImplementedError("top_padding_2 without batch_norm is not part of the HIP path yet")
             self.bn_a = None
             if self.pool1 > 1:
-                self.a_full = ya
-                self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, guard_rows=k2[0] + 16)
+                self.a_full = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt) if cast else ya
+                self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, **a_geom)
             else:
-                self.a_a = ya
+                self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, **a_geom) if cast else ya
+            if cast:
+                self.bn_a = _CastRelu(eng, ya, self.a_full if self.pool1 > 1 else self.a_a)
         self.conv_b = _make_conv(eng, f"{pre}main_modules.{i2}", mm[i2], self.a_a, bias, relu=not has_bn)
         yb = self.conv_b.y0
         Hb2, Wb2 = pooled(yb.H, self.pool2), pooled(yb.W, self.pool2)

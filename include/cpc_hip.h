@@ -380,7 +380,8 @@ int cpc_gru_set_streaming(int on);
 /* Tuning knobs for A/B measurements (tools/): key 1 = start stagger of the 256x256 NT GEMM in 1/64 of a tile time (0 = off);
  * keys 4, 5 = timing probes of that kernel's K loop (results are garbage, tools/nt_probe.py); key 6 = output stores of the NT fast
  * kernels: 2 (default) written through the L2 at system scope, 1 at agent scope, 0 plain stores — same results in every mode.
- * Returns the previous value, CPC_EINVAL for an unknown key.  Not part of the product path. */
+ * Returns the previous value, CPC_EINVAL for an unknown key.  Not part of the product path.  The probe keys 4 / 5 are refused
+ * (CPC_EINVAL + a line on stderr) unless the process runs with CPC_ENABLE_PROBES=1, and announce themselves on stderr. */
 int cpc_debug_set(int key, int value);
 
 /* InfoNCE loss of ContrastiveEstimationTrainer.train, default branch score_over_all_timesteps=False

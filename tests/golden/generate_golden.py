@@ -24,6 +24,8 @@ Fixtures written (all float32 unless noted):
   conv_ar_bn.npz        ConvolutionalArModel with BatchNorm1d (trained: losses, gradients) and with BatchNorm1d + residual (forward only)
   ar_resnet_model.npz   AudioEncoder + ScalogramResidualEncoder as the context network (pooled (1,k) blocks): forward, losses, gradients
   reference_snapshot_small.pt  a whole-module pickle as the reference's SnapshotManager writes (+ .npz of the same tensors)
+  effective_configs.json   the reference's preset dictionaries as they are AFTER import (data only)
+  scalogram_model_c.npz    architecture-1 traits: no BatchNorm, padded 3x3 kernels, top-padded tall second kernel, cropped identity residual
   scalogram_model_sep.npz  the same model with Conv2dSeparable convolutions (depthwise + 1x1)
   scalogram_model_gp.npz   scalogram encoder + BatchNorm ConvolutionalArModel, linear scores, Wasserstein gradient penalty runs
   scalogram_model_gp_att.npz   the same with an AttentionModel context (dropout 0)
@@ -400,6 +402,21 @@ def _scalogram_small_blocks_b():
     return [b0, b1, b2, b3]
 
 
+def _scalogram_small_blocks_c():
+    """Shrunken scalogram_resnet_architecture_1 (the experiments' default, configs/scalogram_resnet_configs.py:46-99): NO BatchNorm
+    anywhere, padded 3x3 kernels, a strided block whose tall second kernel has top padding, an identity residual that is cropped,
+    a padded 1x1 residual projection on the raw scalogram."""
+    base = {'in_channels': 64, 'hidden_channels': None, 'out_channels': 64, 'kernel_size_1': (3, 3), 'kernel_size_2': (3, 3),
+            'top_padding_1': None, 'top_padding_2': None, 'padding_1': 1, 'padding_2': 0, 'stride_1': 1, 'stride_2': 1,
+            'pooling_1': 1, 'pooling_2': 1, 'bias': True, 'separable': False, 'residual': True, 'batch_norm': False,
+            'ceil_pooling': False}
+    b0 = dict(base, in_channels=1, out_channels=16, padding_2=1)
+    b1 = dict(base, in_channels=16, out_channels=32, stride_1=2, kernel_size_2=(6, 1), top_padding_2=5)
+    b2 = dict(base, in_channels=32, out_channels=32)
+    b3 = dict(base, in_channels=32, out_channels=64, stride_1=2, kernel_size_2=(5, 1))
+    return [b0, b1, b2, b3]
+
+
 GP_ATT = {'channels': 64, 'num_layers': 2, 'num_heads': 8, 'feedforward_size': 96, 'dropout': 0.0, 'sequence_length': 10,
           'output_size': 32}
 GP_AR = {'kernel_sizes': [3, 3], 'channel_count': [64, 48, 32], 'stride': [1, 1], 'pooling': [1, 2], 'bias': True, 'batch_norm': True,
@@ -425,6 +442,9 @@ def gen_scalogram(variant="a"):
         # reproducible (the reference draws its dropout masks from torch's generator stream)
         L = 256 + 32 * 60 + 1
         pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks, True, "scalogram_model_gp_att"
+    elif variant == "c":
+        L = 256 + 32 * 60 + 1
+        pre_kw, blocks_fn, phase, fname = dict(phase=True), _scalogram_small_blocks_c, True, "scalogram_model_c"
     elif variant == "gp":
         # the shape of the reference's gradient-penalty experiments (e22..): scalogram encoder, convolutional context network with
         # BatchNorm, linear scores, Wasserstein gradient penalty
@@ -454,6 +474,8 @@ def gen_scalogram(variant="a"):
             for n, p in model.named_parameters():
                 if n in scale:
                     p.mul_(scale[n])
+                if variant == "c" and p.dim() == 4:          # no normalisation anywhere: keep the activations at O(1) through 8 convolutions
+                    p.mul_(1.6)
                 if "main_modules" in n and p.dim() == 1 and ".weight" in n:      # BatchNorm gamma away from 1
                     p.add_(0.3 * torch.randn(p.shape, generator=g))
                 if variant == "gp_att" and n.startswith("autoregressive_model."):   # as in gen_attention: the default init would hide mix-ups
@@ -504,7 +526,7 @@ def gen_scalogram(variant="a"):
             ("softplus", ref_train.softplus_score_function, False, 1.0, 4, 1e-4, None)]
     if variant in ("gp", "gp_att"):
         runs = []
-    if variant in ("a", "gp", "gp_att"):
+    if variant in ("a", "c", "gp", "gp_att"):
         # Wasserstein gradient penalty (contrastive_estimation_training.py:144-155), the reference's e11.. experiment settings:
         # linear scores, both loss branches
         runs += [("linear", ref_train.linear_score_function, True, 0.0, 1, 1e-3, 10.0),
@@ -860,8 +882,36 @@ def gen_cfg1():
         json.dump(res, f, indent=1)
 
 
+def gen_configs():
+    """EFFECTIVE values of the reference's preset dictionaries after its config modules have been imported (their dict.copy()
+    aliasing shares block dictionaries between architectures): plain data, classes and functions replaced by their names."""
+    _install_librosa_stand_in()
+    import configs.scalogram_resnet_configs as S
+    import configs.autoregressive_model_configs as A
+    import configs.cqt_configs as Q
+    import configs.contrastive_estimation_configs as T
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        if isinstance(v, (int, float, bool, str)) or v is None:
+            return v
+        return getattr(v, "__name__", type(v).__name__)
+
+    out = {}
+    for mod in (S, A, Q, T):
+        for name, v in vars(mod).items():
+            if isinstance(v, dict) and not name.startswith("_") and not name.startswith("block"):
+                out[name] = plain(v)
+    with open(os.path.join(OUT, "effective_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("configs:", sorted(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["snapshot", "small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "scalogram_gp_att", "conv_ar_bn", "ar_resnet"]
+    which = sys.argv[1:] or ["configs", "scalogram_c", "snapshot", "small", "encoder", "gru", "validate", "samplers", "cfg1", "conv_ar", "attention", "cqt", "scalogram", "scalogram_b", "scalogram_sep", "scalogram_gp", "scalogram_gp_att", "conv_ar_bn", "ar_resnet"]
     if "ar_resnet" in which:
         _install_librosa_stand_in()
         gen_ar_resnet()
@@ -869,6 +919,10 @@ if __name__ == "__main__":
         gen_conv_ar_bn()
     if "scalogram" in which:
         gen_scalogram("a")
+    if "configs" in which:
+        gen_configs()
+    if "scalogram_c" in which:
+        gen_scalogram("c")
     if "scalogram_b" in which:
         gen_scalogram("b")
     if "scalogram_sep" in which:

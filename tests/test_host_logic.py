@@ -320,3 +320,64 @@ def test_reference_whole_module_snapshot_loads_without_the_reference(golden_dir)
     load_reference_snapshot(model, path)
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), torch.from_numpy(ref[k])), k
+
+
+def test_config_presets_equal_the_reference_effective_values(golden_dir):
+    """cpc_audio_amd.configs against the reference's preset dictionaries AS THEY ARE AFTER IMPORT (tests/golden/effective_configs.json,
+    written by generate_golden.py from the reference's own config modules: its dict.copy() aliasing makes e.g. architecture 5 = 6 = 7
+    and strips architecture 2 of its residual branches)."""
+    from cpc_audio_amd import configs
+    ref = json.load(open(os.path.join(golden_dir, "effective_configs.json")))
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        if isinstance(v, (int, float, bool, str)) or v is None:
+            return v
+        return getattr(v, "__name__", type(v).__name__)
+
+    names = [n for n in ref if hasattr(configs, n)]
+    for must in ("scalogram_resnet_architecture_1", "scalogram_resnet_architecture_2", "scalogram_resnet_architecture_2_wo_res",
+                 "scalogram_resnet_architecture_3", "scalogram_resnet_architecture_4", "scalogram_resnet_architecture_7",
+                 "scalogram_resnet_architecture_8", "scalogram_resnet_architecture_9", "ar_conv_default_dict", "ar_conv_architecture_3",
+                 "ar_conv_architecture_5", "attention_architecture_1", "attention_architecture_2", "cqt_default_dict", "cqt_high_res_dict"):
+        assert must in names, must
+    for n in names:
+        mine, theirs = plain(getattr(configs, n)), ref[n]
+        if "blocks" in theirs:
+            # the survey's note on architecture 7: the classification config flips BatchNorm of its LAST block off after import
+            assert len(mine["blocks"]) == len(theirs["blocks"]), n
+            for i, (a, b) in enumerate(zip(mine["blocks"], theirs["blocks"])):
+                b = dict(b)
+                if n.startswith("scalogram_resnet") or n.startswith("ar_resnet"):
+                    if i == 0 and theirs.get("phase"):
+                        b["in_channels"] = a["in_channels"]           # the constructor overwrites it with 2 (scalogram_model.py:495-496)
+                assert a == b, (n, i, a, b)
+            mine = {k: v for k, v in mine.items() if k != "blocks"}
+            theirs = {k: v for k, v in theirs.items() if k != "blocks"}
+        for k, v in theirs.items():
+            if k in mine:
+                assert mine[k] == v, (n, k, mine[k], v)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: the N ranks are started as a child torch.distributed.run
+    (never an exec of a process that touched the GPU), rendezvous on 127.0.0.1, and rank 0's JSON line is relayed.  Here the
+    command line is checked and the relay is exercised with a stand-in child."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    # the relay: a child that prints noise and one JSON line
+    fake = tmp_path / "child.py"
+    fake.write_text("import sys\nprint('W0 noise')\nprint('{\"metric\": \"x\", \"n_gpus\": 4}')\nsys.exit(0)\n")
+    src = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.launch_command = lambda n, argv: [sys.executable, {str(fake)!r}]; sys.exit(bench.self_launch(4))"
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == '{"metric": "x", "n_gpus": 4}' and "W0 noise" in r.stderr

@@ -405,9 +405,10 @@ def test_cfg1_trajectory_matches_reference(golden_dir, dtype, tol):
         tr.verbose = False
         random.seed(run["python_seed"])
         tr.train(batch_size=meta["B"], epochs=1, lr=meta["lr"], num_workers=0, max_steps=5)
-        for i in range(5):
-            assert abs(logger.loss_meter.values[i] - run["loss"][i]) <= tol * abs(run["loss"][i]) * (1 + i), (run["score"], i,
-                                                                                                           logger.loss_meter.values)
+        dev = [abs(logger.loss_meter.values[i] - run["loss"][i]) / abs(run["loss"][i]) for i in range(5)]
+        print(f"cfg1 trajectory {dtype} {run['score']} x{run.get('encoder_weight_scale', 1.0)}: relative deviations {['%.1e' % d for d in dev]}")
+        for i in range(5):          # one flat bound for all five steps (no growth allowance)
+            assert dev[i] <= tol, (run["score"], i, dev, logger.loss_meter.values)
 
 
 def test_full_size_properties_b256():
@@ -454,6 +455,53 @@ def test_full_size_properties_b256():
     for n, g32 in grads["fp32"].items():
         cos = torch.dot(g32, grads["bf16"][n]) / (g32.norm() * grads["bf16"][n].norm() + 1e-30)
         assert cos.item() > 0.995, (n, cos.item())
+
+
+@pytest.mark.parametrize("context", ["ar_conv_architecture_3", "attention_architecture_1", "ar_conv_default_dict"])
+def test_full_size_context_networks_b256_against_oracle(context):
+    """BASELINE configs[3] at its stated size (B = 256 clips of 20 480 samples, V = 60, K = 12; SURVEY.md 8(d) cfg 4): the
+    ConvolutionalArModel at its real configurations — ar_conv_architecture_3 (six k=5 blocks, BatchNorm1d + residual, 512 -> 256
+    channels) behind the 512-channel encoder, ar_conv_default_dict (k 9/9/9, pooling 1/2/2, 256 channels) behind an encoder whose last
+    layer has its 256 channels — and attention_architecture_1 (3 layers, 8 heads, dropout 0 for parity): exact-f32 HIP loss against the
+    CPU oracle's forward pass on the same clips (1e-4), bf16 loss against the same number (the north star's 1e-3)."""
+    from cpc_audio_amd import configs
+    B, L, V, K = 256, 20480, 60, 12
+    x_cpu = torch.randn(B, L, generator=torch.Generator().manual_seed(1)) * 0.5
+    x = x_cpu.to(DEV)
+    E = 256 if context == "ar_conv_default_dict" else 512
+    enc_cfg = {'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [512, 512, 512, 512, E], 'bias': True}
+    cfg = configs.fresh(getattr(configs, context))
+    if context.startswith("attention"):
+        cfg["dropout"] = 0.0
+    losses, oracle_loss = {}, None
+    for dtype in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        ar = AttentionModel(dict(cfg)) if context.startswith("attention") else ConvolutionalArModel(dict(cfg))
+        model = AudioPredictiveCodingModel(AudioEncoder(dict(enc_cfg)), ar, enc_size=E, ar_size=256, visible_steps=V, prediction_steps=K,
+                                           compute_dtype=dtype)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "encoder" in n and n.endswith("weight") and n.startswith("encoder."):
+                    p.mul_(2.0)                               # make the scores non-degenerate
+        if oracle_loss is None:
+            params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                if context.startswith("attention"):
+                    pz, tg, _, _ = O.cpc_forward(x_cpu.unsqueeze(1), params, V, K, attention=(cfg["num_layers"], cfg["num_heads"]))
+                else:
+                    pz, tg, _, _ = O.cpc_forward(x_cpu.unsqueeze(1), params, V, K, conv_ar=dict(cfg), training=True)
+                oracle_loss = float(O.info_nce_loss(O.softplus_scores(pz, tg), False, 1.0)[0])
+            del pz, tg, params
+        model.to(DEV)
+        eng = model.engine(B, L)
+        out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        losses[dtype] = float(out[0])
+        assert torch.isfinite(model._flat_grad).all() and model._flat_grad.abs().max().item() > 0
+        del eng, model
+        torch.cuda.empty_cache()
+    print(f"configs[3] {context}: oracle {oracle_loss:.6f}  f32 {losses['fp32']:.6f}  bf16 {losses['bf16']:.6f}")
+    assert abs(losses["fp32"] - oracle_loss) < 1e-4 * abs(oracle_loss), (losses, oracle_loss)
+    assert abs(losses["bf16"] - oracle_loss) < 1e-3 * abs(oracle_loss), (losses, oracle_loss)
 
 
 def test_gradient_allreduce_path_single_rank_nccl():

@@ -289,7 +289,7 @@ def _scalogram_blocks(meta):
     return blocks
 
 
-@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b", "scalogram_model_sep", "scalogram_model_gp"])
+@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b", "scalogram_model_sep", "scalogram_model_gp", "scalogram_model_c"])
 def test_scalogram_model(golden_dir, fixture):
     """PreprocessingModule + ScalogramResidualEncoder + GRU (fixture gp: + BatchNorm ConvolutionalArModel, every run with the
     Wasserstein gradient penalty): forward in train / eval mode, running statistics, trainer losses and all gradients vs the

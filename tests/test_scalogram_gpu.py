@@ -270,7 +270,7 @@ def _build_scalogram_model(g, meta, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b", "scalogram_model_sep"])
+@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b", "scalogram_model_sep", "scalogram_model_c"])
 def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
     """BASELINE configs[2] family at fixture size: CQT scalogram + ScalogramResidualEncoder + GRU — forward (eval and train
     BatchNorm), running statistics, trainer losses and all parameter gradients vs fixtures from the reference
@@ -330,7 +330,7 @@ def test_scalogram_model_matches_reference(golden_dir, dtype, fixture):
                 assert _rel(sd[k.split("/after/")[1]].float(), g[k]) < (2e-3 if dtype == "fp32" else 5e-2), k
 
 
-@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model", "scalogram_model_gp_att"])
+@pytest.mark.parametrize("fixture", ["scalogram_model_gp", "scalogram_model", "scalogram_model_gp_att", "scalogram_model_c"])
 def test_gradient_penalty_matches_reference(golden_dir, fixture):
     """wasserstein_gradient_penalty=True (reference :144-158, the double backward with respect to the preprocessed batch) on the
     HIP path, exact-f32 mode: losses, every parameter gradient and the parameters after three steps against runs of the
@@ -602,6 +602,105 @@ def test_full_size_scalogram_model_bf16_vs_fp32():
     # measured: 0.956 (first BatchNorm scale) ... 0.97 for the first two blocks' BatchNorm parameters and first-layer weights,
     # > 0.98 elsewhere, at random initialisation where the gradient signal itself is small
     assert worst[1] > 0.93, worst
+
+
+def _oracle_scalogram_loss(wave_cpu, pre, model, enc_blocks, ar_cfg, V, K, softplus=True, all_timesteps=False, reg=1.0, chunk=8, hop=128):
+    """contrastive_estimation_training.py:100-122,141 on the CPU from the WAVEFORM on (oracle/cpc_oracle.py): CQT + PreprocessingModule
+    per chunk of clips, then encoder (train-mode BatchNorm over the whole batch), context network, scores and loss."""
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    weights = [m.weight.detach().cpu() for m in pre.cqt.conv_modules]
+    consts = None
+    if pre.phase_diff is not None:
+        consts = (pre.phase_diff.fixed_phase_diff.detach().cpu().reshape(-1).float(), pre.phase_diff.scaling.detach().cpu().reshape(-1).float())
+    offset_zero = pre.offset != 0
+    scaling = pre.normalization_factor * pre.log_offset if offset_zero else pre.normalization_factor
+    with torch.no_grad():
+        scal = []
+        for i in range(0, wave_cpu.shape[0], chunk):
+            cq = O.cqt_forward(wave_cpu[i:i + chunk].unsqueeze(1), weights, hop)
+            scal.append(O.preprocessing_forward(cq, consts, offset_zero=offset_zero, output_power=pre.output_power, scaling=scaling,
+                                                pooling=pre.pooling))
+        scal = torch.cat(scal)
+        kw = dict(conv_ar=dict(ar_cfg)) if ar_cfg is not None else {}
+        pz, tg, _, _ = O.cpc_forward(scal, params, V, K, scalogram=enc_blocks, training=True, **kw)
+        scores = O.softplus_scores(pz, tg) if softplus else O.linear_scores(pz, tg)
+        return float(O.info_nce_loss(scores, all_timesteps, reg)[0]), tuple(scal.shape)
+
+
+def test_full_size_scalogram_b128_against_oracle():
+    """BASELINE configs[2] exactly as SURVEY.md 8(d) states it: cqt_default_dict + scalogram_resnet_architecture_7 +
+    ar_conv_architecture_3, V = 60, K = 16, B = 128 clips of item_length = 97 024 samples.  The exact-f32 HIP loss against the CPU
+    oracle's forward pass from the same waveforms (1e-4 relative) and the bf16 loss (bf16x3 CQT, f32 first stage) against that SAME
+    oracle number (the north star's 1e-3)."""
+    from cpc_audio_amd import configs
+    from cpc_audio_amd.audio_model import ConvolutionalArModel
+    from cpc_audio_amd.scalogram_model import cqt_default_dict
+    B, V, K = 128, 60, 16
+    wave_cpu = torch.randn(B, 97024, generator=torch.Generator().manual_seed(11)) * 0.1
+    wave = wave_cpu.to(DEV)
+    losses, oracle_loss, state = {}, None, None
+    for dtype in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+        enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+        ar_cfg = configs.fresh(configs.ar_conv_architecture_3)
+        model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(ar_cfg), enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
+                                           compute_dtype=dtype)
+        assert model.item_length == 97024 and enc.receptive_field == 19200 and enc.downsampling_factor == 1024
+        if oracle_loss is None:
+            oracle_loss, shape = _oracle_scalogram_loss(wave_cpu, pre, model, [dict(b.cfg) for b in enc.blocks], ar_cfg, V, K)
+            assert shape == (B, 2, 256, 629)
+        pre, model = pre.to(DEV), model.to(DEV)
+        pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
+        x = pre(wave.unsqueeze(1))
+        assert tuple(x.shape) == (B, 2, 256, 629)
+        eng = model.engine_for(x)
+        assert eng.T == 76
+        out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        losses[dtype] = float(out[0])
+        assert torch.isfinite(model._flat_grad).all() and model._flat_grad.abs().max().item() > 0
+        del eng, model, pre, x
+        torch.cuda.empty_cache()
+    assert abs(losses["fp32"] - oracle_loss) <= 1e-4 * abs(oracle_loss), (losses, oracle_loss)
+    assert abs(losses["bf16"] - oracle_loss) <= 1e-3 * abs(oracle_loss), (losses, oracle_loss)
+
+
+def test_no_batchnorm_architectures_at_real_shapes():
+    """The reference's architectures WITHOUT BatchNorm at their real shapes (experiments e0-e12):
+    scalogram_resnet_architecture_1 (the experiments' default dict: 7 blocks, padded 3x3 kernels, a top-padded (64,1) second kernel
+    behind a strided padded 3x3), _2 (no residuals; its BatchNorm-less FIRST block reads the float32 scalogram and feeds a top-padded
+    (64,1) kernel), _3 and _4, each with ar_conv_default_dict, V = 60, K = 16: the exact-f32 HIP loss against the CPU oracle from the
+    waveform on (1e-4), the bf16 loss against the same number (1e-3)."""
+    from cpc_audio_amd import configs
+    from cpc_audio_amd.audio_model import ConvolutionalArModel
+    from cpc_audio_amd.scalogram_model import cqt_default_dict
+    V, K = 60, 16
+    for arch, B, item_length in ((configs.scalogram_resnet_architecture_1, 4, 103680), (configs.scalogram_resnet_architecture_2, 8, 100096),
+                                 (configs.scalogram_resnet_architecture_3, 8, 97024), (configs.scalogram_resnet_architecture_4, 4, 107264)):
+        oracle_loss, losses = None, {}
+        for dtype in ("fp32", "bf16"):
+            torch.manual_seed(0)
+            pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+            enc = ScalogramResidualEncoder(args_dict=configs.fresh(arch), preprocessing_module=pre)
+            ar_cfg = configs.fresh(configs.ar_conv_default_dict)
+            model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(ar_cfg), enc_size=256, ar_size=256, visible_steps=V, prediction_steps=K,
+                                               compute_dtype=dtype)
+            assert model.item_length == item_length and enc.downsampling_factor == 1024
+            if oracle_loss is None:
+                wave_cpu = torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(5)) * 0.1
+                oracle_loss, _ = _oracle_scalogram_loss(wave_cpu, pre, model, [dict(b.cfg) for b in enc.blocks], ar_cfg, V, K, chunk=4)
+            pre, model = pre.to(DEV), model.to(DEV)
+            pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
+            x = pre(wave_cpu.to(DEV).unsqueeze(1))
+            eng = model.engine_for(x)
+            assert eng.T >= V + K
+            out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+            losses[dtype] = float(out[0])
+            assert torch.isfinite(model._flat_grad).all() and model._flat_grad.abs().max().item() > 0
+            del eng, model, pre, x
+            torch.cuda.empty_cache()
+        assert abs(losses["fp32"] - oracle_loss) <= 1e-4 * abs(oracle_loss), (losses, oracle_loss)
+        assert abs(losses["bf16"] - oracle_loss) <= 1e-3 * abs(oracle_loss), (losses, oracle_loss)
 
 
 def test_scalogram_encoder_with_batchnorm_conv_context_forward(golden_dir):

@@ -21,6 +21,8 @@ if a.summarize:
         for c, v in sorted(cs.items()):
             print(f"    {c:32s} {sum(v) / len(v):16.1f}   (n={len(v)})")
     sys.exit(0)
+import os
+os.environ.setdefault("CPC_ENABLE_PROBES", "1")      # this tool IS a timing probe (see cpc_debug_set in include/cpc_hip.h)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpc_audio_amd import _hip

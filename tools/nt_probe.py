@@ -5,6 +5,8 @@ M = 7 rounds of tiles, N = 512; the slope between two K gives the per-stage cost
 
     python tools/nt_probe.py [--K 2048,8192]"""
 import argparse, os, sys
+import os
+os.environ.setdefault("CPC_ENABLE_PROBES", "1")      # this tool IS a timing probe (see cpc_debug_set in include/cpc_hip.h)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpc_audio_amd import _hip
