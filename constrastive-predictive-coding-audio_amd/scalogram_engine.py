@@ -844,8 +844,15 @@ class ScalogramCPCEngine(CPCEngine):
             self.blocks.append(b)
             gin, in_f32 = b.out, False
         out = self.blocks[-1].out
-        if out.H != 1 or out.Ha != 1 or out.C != self.E:
-            raise NotImplementedError(f"scalogram encoder must end with one frequency row of enc_size channels, got H={out.H}, C={out.C}")
+        if out.C != self.E:
+            raise ValueError(f"the scalogram encoder ends with {out.C} channels, the model's enc_size is {self.E}")
+        # The reference returns x[:, :, 0, :] (scalogram_model.py:529): the FIRST frequency row of whatever is left.  With one row
+        # left (architectures 1, 3-9) the last grid IS the [B][frames][E] buffer the context networks read; with more
+        # (scalogram_resnet_architecture_2 ends with two) row 0 is copied out, and its gradient copied back beside zeros.
+        self.top_grid = self.d_top_grid = None
+        if out.H != 1 or out.Ha != 1:
+            self.top_grid = Grid(B, out.W, 1, self.E, self.device, dtype)
+            self.d_top_grid = self.top_grid.like(self.device)
         self.T = out.W
         if self.T < self.V + self.K:
             raise ValueError(f"scalogram gives {self.T} encoder frames, need visible+prediction = {self.V + self.K}")
@@ -855,7 +862,10 @@ class ScalogramCPCEngine(CPCEngine):
             b.allocate_grads(d_in)
             d_in = b.d_out
         self.geo = SimpleNamespace(alloc=[self.T], valid=[self.T])
-        self.act, self.dact = [out.t], [self.blocks[-1].d_out.t]
+        if self.top_grid is not None:
+            self.act, self.dact = [self.top_grid.t], [self.d_top_grid.t]
+        else:
+            self.act, self.dact = [out.t], [self.blocks[-1].d_out.t]
         self.aux = side_stream(self.device)      # side stream, see engine.CPCEngine
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
         need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)]
@@ -881,8 +891,27 @@ class ScalogramCPCEngine(CPCEngine):
         self.x_grid.t.view(cl.shape).copy_(cl)
         for b in self.blocks:
             b.forward()
+        if self.top_grid is not None:
+            self.top_grid.t.view(self.B, self.T, self.E).copy_(self._row0(self.blocks[-1].out))
+
+    @staticmethod
+    def _row0(grid):
+        return grid.t.view(grid.B, grid.W, grid.Ha, grid.C)[:, :, grid.top, :]
+
+    def _top_tangent(self):
+        """Tangent of the encoder's top buffer during a gradient-penalty step."""
+        out_t = _twin(self, self.blocks[-1].out)
+        if self.top_grid is None:
+            return out_t.t
+        top_t = _twin(self, self.top_grid)
+        top_t.t.view(self.B, self.T, self.E).copy_(self._row0(out_t))
+        return top_t.t
 
     def _backward_encoder(self, x, grad_ready_hook=None):
+        if self.top_grid is not None:
+            d_out = self.blocks[-1].d_out
+            d_out.t.zero_()
+            self._row0(d_out).copy_(self.d_top_grid.t.view(self.B, self.T, self.E))
         for b in reversed(self.blocks):
             b.backward()
 
@@ -972,7 +1001,7 @@ class ScalogramCPCEngine(CPCEngine):
         self._gp_phase = 2
         for b in self.blocks:
             b.tangent()
-        top_t = _twin(self, self.blocks[-1].out).t
+        top_t = self._top_tangent()
         ct, coff, cstride = self.ctx.tangent(top_t)
         _hip.gemm_nt(_hip.ptr(ct, coff), _hip.ptr(self.w_p), _hip.ptr(self.pred_t), B, K * E, H, H, H, K * E, code, a_rpi=1, a_item=cstride)
         # ---- penalty parts of the parameter gradients (pass-1 adjoints are still in the gradient grids)
