@@ -438,6 +438,199 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+
+// ---- 16-byte variants of the four BatchNorm kernels for bf16 tensors (8 channels per thread: one dwordx4 load per tensor and row
+// instead of a dwordx2; C a multiple of 8).  Same sums in the same per-thread order over rows; the reduction over row phases is
+// in fixed order as above.
+struct f32x8 { f32x4 lo, hi; };
+__device__ __forceinline__ f32x8 load8(const bf16_t* src) {
+    const uint4 u = *(const uint4*)src;
+    f32x8 o;
+    o.lo = (f32x4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                   __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    o.hi = (f32x4){__builtin_bit_cast(float, u.z << 16), __builtin_bit_cast(float, u.z & 0xffff0000u),
+                   __builtin_bit_cast(float, u.w << 16), __builtin_bit_cast(float, u.w & 0xffff0000u)};
+    return o;
+}
+__device__ __forceinline__ void store8(bf16_t* dst, const f32x4& lo, const f32x4& hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)lo[e]; o[4 + e] = (bf16_t)hi[e]; }
+    *(bf16x8*)dst = o;
+}
+
+__global__ __launch_bounds__(256) void bn_stats8_kernel(const bf16_t* __restrict__ x, float* __restrict__ slabs, long long rows, int C,
+                                                        long long rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    const int c8n = C / 8;
+    const int cg = threadIdx.x % c8n, rp = threadIdx.x / c8n, nrp = 256 / c8n;
+    f32x4 s1l = {0.f, 0.f, 0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
+    if (rp < nrp) {
+        long long r = r0 + rp;
+        const bf16_t* px = x + cg * 8;
+        for (; r + 3LL * nrp < r1; r += 4LL * nrp) {
+            const f32x8 v0 = load8(px + r * C), v1 = load8(px + (r + nrp) * C), v2 = load8(px + (r + 2LL * nrp) * C),
+                        v3 = load8(px + (r + 3LL * nrp) * C);
+            s1l += v0.lo; s1h += v0.hi; s2l += v0.lo * v0.lo; s2h += v0.hi * v0.hi;
+            s1l += v1.lo; s1h += v1.hi; s2l += v1.lo * v1.lo; s2h += v1.hi * v1.hi;
+            s1l += v2.lo; s1h += v2.hi; s2l += v2.lo * v2.lo; s2h += v2.hi * v2.hi;
+            s1l += v3.lo; s1h += v3.hi; s2l += v3.lo * v3.lo; s2h += v3.hi * v3.hi;
+        }
+        for (; r < r1; r += nrp) {
+            const f32x8 v = load8(px + r * C);
+            s1l += v.lo; s1h += v.hi; s2l += v.lo * v.lo; s2h += v.hi * v.hi;
+        }
+    }
+    __shared__ float red[4096];          // [nrp][2][C]: 256 / (C/8) * 2 * C = 4096 floats for every C
+    if (rp < nrp) {
+        *(f32x4*)(red + (rp * 2 + 0) * C + cg * 8) = s1l; *(f32x4*)(red + (rp * 2 + 0) * C + cg * 8 + 4) = s1h;
+        *(f32x4*)(red + (rp * 2 + 1) * C + cg * 8) = s2l; *(f32x4*)(red + (rp * 2 + 1) * C + cg * 8 + 4) = s2h;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < nrp; ++q) acc += red[q * 2 * C + i];
+        slabs[(long long)blockIdx.x * 2 * C + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict__ x, Grid gx, bf16_t* __restrict__ out, Grid go,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int relu) {
+    const int c8n = gx.C / 8;
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c8 = (int)(idx % c8n);
+        const int h = (int)((idx / c8n) % gx.H);
+        const unsigned col = idx / (unsigned)(c8n * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const f32x8 v = load8(x + grid_off(gx, b, w, h) + c8 * 8);
+        f32x4 o[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c = c8 * 8 + hf * 4;
+            const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + gx.C + c);
+            const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+            const f32x4 vv = hf ? v.hi : v.lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[hf][e] = (vv[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                if (relu) o[hf][e] = relu_f(o[hf][e]);
+            }
+        }
+        store8(out + grid_off(go, b, w, h) + c8 * 8, o[0], o[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, Grid gy,
+                                                             const bf16_t* __restrict__ x, Grid gx, const float* __restrict__ stats,
+                                                             float* __restrict__ slabs, int relu, long long cols_per_block) {
+    const int C = gx.C, c8n = C / 8;
+    const int cg = threadIdx.x % c8n, rp = threadIdx.x / c8n, nrp = 256 / c8n;
+    const long long ncol = (long long)gx.B * gx.W;
+    const long long q0 = (long long)blockIdx.x * cols_per_block, q1 = min(ncol, q0 + cols_per_block);
+    f32x4 s1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (rp < nrp && q0 < q1) {
+        f32x4 mu[2], rs[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            mu[hf] = *(const f32x4*)(stats + cg * 8 + hf * 4);
+            rs[hf] = *(const f32x4*)(stats + C + cg * 8 + hf * 4);
+        }
+        const unsigned rend = (unsigned)(q1 * gx.H);
+        for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < rend; r += 2u * nrp) {
+            f32x8 g8[2], y8[2], x8[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned ru = r + (unsigned)(u * nrp);
+                ok[u] = ru < rend;
+                const unsigned rc = ok[u] ? ru : r;
+                const unsigned q = rc / (unsigned)gx.H;
+                const int h = (int)(rc - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
+                const long long oy = grid_off(gy, b, w, h) + cg * 8;
+                g8[u] = load8(dy + oy);
+                if (relu) y8[u] = load8(y + oy);
+                x8[u] = load8(x + grid_off(gx, b, w, h) + cg * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f32x4 gg = hf ? g8[u].hi : g8[u].lo, yy = hf ? y8[u].hi : y8[u].lo, xx = hf ? x8[u].hi : x8[u].lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = (!relu || yy[e] > 0.f) ? gg[e] : 0.f;
+                        s1[hf][e] += g * (xx[e] - mu[hf][e]) * rs[hf][e];
+                        s2[hf][e] += g;
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float red[4096];
+    if (rp < nrp) {
+        *(f32x4*)(red + (rp * 2 + 0) * C + cg * 8) = s1[0]; *(f32x4*)(red + (rp * 2 + 0) * C + cg * 8 + 4) = s1[1];
+        *(f32x4*)(red + (rp * 2 + 1) * C + cg * 8) = s2[0]; *(f32x4*)(red + (rp * 2 + 1) * C + cg * 8 + 4) = s2[1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < nrp; ++q) acc += red[q * 2 * C + i];
+        slabs[(long long)blockIdx.x * 2 * C + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, Grid gy,
+                                                            const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, Grid gx,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                            float inv_count, int relu, int train) {
+    const int C = gx.C, c8n = C / 8;
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
+    const bool fixed = ((gridDim.x * 256u) % (unsigned)c8n) == 0u;
+    f32x4 k1[2], k2[2], k3[2], mu[2];
+    auto coeffs = [&](int c8) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c8 * 8 + hf * 4 + e;
+                const float rs = stats[C + c], ga = gamma[c];
+                mu[hf][e] = stats[c];
+                k1[hf][e] = ga * rs;
+                k2[hf][e] = train ? ga * rs * dbeta[c] * inv_count : 0.f;
+                k3[hf][e] = train ? ga * rs * rs * dgamma[c] * inv_count : 0.f;
+            }
+    };
+    if (fixed) coeffs((int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)c8n));
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c8 = (int)(idx % c8n);
+        const int h = (int)((idx / c8n) % gx.H);
+        const unsigned col = idx / (unsigned)(c8n * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const long long oy = grid_off(gy, b, w, h) + c8 * 8, ox = grid_off(gx, b, w, h) + c8 * 8;
+        const f32x8 g8 = load8(dy + oy);
+        const f32x8 x8 = load8(x + ox);
+        f32x8 y8;
+        if (relu) y8 = load8(y + oy);
+        if (!fixed) coeffs(c8);
+        f32x4 o[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 gg = hf ? g8.hi : g8.lo, yy = hf ? y8.hi : y8.lo, xx = hf ? x8.hi : x8.lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = (!relu || yy[e] > 0.f) ? gg[e] : 0.f;
+                o[hf][e] = k1[hf][e] * g - k2[hf][e] - k3[hf][e] * (xx[e] - mu[hf][e]);
+            }
+        }
+        store8(dx + ox, o[0], o[1]);
+    }
+}
+
 // MaxPool2d(kernel = stride = p, ceil_mode=True, no padding) on grids (residual branches, scalogram_model.py:434-436).
 template <typename TI, typename T>
 __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TI* __restrict__ in, Grid gi, T* __restrict__ out, Grid go, int p) {
@@ -822,6 +1015,11 @@ int launch_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, 
 int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, hipStream_t st) {
     if (rows <= 0 || !bn_c_ok(C) || nblocks <= 0) return CPC_EINVAL;
     const long long rpb = (rows + nblocks - 1) / nblocks;
+    if (dtype == CPC_DTYPE_BF16 && C % 8 == 0) {
+        hipLaunchKernelGGL(bn_stats8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)x, slabs, rows, C, rpb);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     DISPATCH2(dtype,
               hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)x, slabs, rows, C, rpb),
               hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const float*)x, slabs, rows, C, rpb));
@@ -844,6 +1042,12 @@ int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, cons
                     int relu, int x_f32, int dtype, hipStream_t st) {
     if (!grid_ok(gx) || !grid_ok(go) || !same_shape(gx, go) || gx[5] % 4) return CPC_EINVAL;
     const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
+        const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
+        hipLaunchKernelGGL(bn_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16 && x_f32)
         hipLaunchKernelGGL((bn_apply_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu);
     else
@@ -859,6 +1063,11 @@ int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const voi
     if (!grid_ok(gx) || !grid_ok(gy) || !same_shape(gx, gy) || !bn_c_ok(gx[5]) || nblocks <= 0) return CPC_EINVAL;
     const long long ncol = (long long)gx[0] * gx[1];
     const long long cpb = (ncol + nblocks - 1) / nblocks;
+    if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
+        hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16 && x_f32)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const float*)x, mk(gx), stats, slabs, relu, cpb);
     else
@@ -876,6 +1085,12 @@ int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void
     if (train && (!dgamma || !dbeta)) return CPC_EINVAL;
     const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
     const float inv = (float)(1.0 / count);
+    if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
+        const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
+        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16 && x_f32)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const float*)x, (float*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train);
     else

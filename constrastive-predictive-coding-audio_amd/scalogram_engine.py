@@ -10,6 +10,7 @@ read, so everything downstream is shared with engine.CPCEngine.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -65,9 +66,10 @@ def _col_group(cout, kw=1, stride=(1, 1), pad=0):
     """How many consecutive output rows a tall-kernel GEMM computes per GEMM row: with fewer than 128 output channels the
     128-wide MFMA tile would be mostly empty, so G = 128 / C_out rows are produced side by side (their windows overlap in
     all but G-1 input rows; the weight operand holds G shifted copies of the kernel, +(G-1)/k extra FLOPs)."""
-    if kw != 1 or stride != (1, 1) or pad != 0 or cout >= 128 or 128 % cout:
+    width = int(os.environ.get("CPC_COL_WIDTH", "128"))      # 256: fill the 256 x 256 tile of the large GEMM kernels instead
+    if kw != 1 or stride != (1, 1) or pad != 0 or cout >= width or width % cout:
         return 1
-    return 128 // cout
+    return width // cout
 
 
 def _col_ok(kw, sh, sw, pad, cin, in_f32):
@@ -150,6 +152,10 @@ class _Conv:
                 self.nsplit = max(self.nsplit, min(2048, self.M // 2048))
             self.slab = self.nsplit * self.Kp * self.cout
         self.dy0: Optional[Grid] = None        # set by the owner (may alias another gradient grid)
+        # the train-mode BatchNorm behind this convolution, if any: its input gradient has zero mean per channel BY CONSTRUCTION
+        # (dx = gamma rstd (g - <g> - xhat <g xhat>)), so the bias gradient is exactly zero -- the reference's autograd sums rounding
+        # noise of relative size 1e-7 there.  The column-sum pass over the gradient grid is skipped and zero is written.
+        self.bn_after = None
 
     # ------------------------------------------------------------------
     def prepare(self):
@@ -265,7 +271,11 @@ class _Conv:
         (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
         e, gin, dy0 = self.eng, self.gin, self.dy0
         g, code = e.model._grad, self.code
-        self._wgrad(gin, getattr(self, "col", None), dy0, g[self.wname], g[self.bname] if (self.bname and self.bname in g) else None)
+        gb = g[self.bname] if (self.bname and self.bname in g) else None
+        if gb is not None and self.bn_after is not None and self.bn_after.trained and os.environ.get("CPC_BN_BIAS_COLSUM", "0") != "1":
+            gb.zero_()
+            gb = None
+        self._wgrad(gin, getattr(self, "col", None), dy0, g[self.wname], gb)
         if din is None or not self.need_dgrad:
             return
         if self.mode == 'col' and self.G > 1:
@@ -394,9 +404,8 @@ class _BatchNorm:
         self.C = y0.C
         self.x_f32 = 1 if (y0.dtype == torch.float32 and eng.dt != torch.float32) else 0
         self.stats = torch.zeros(2, self.C, device=eng.device, dtype=torch.float32)
-        self.nb = max(1, min(512, y0.rows // 512))
-        # the backward reduction reads three tensors per element and needs more workgroups in flight to reach the HBM rate; the
-        # forward statistics keep 512 partial sums (their summation order is what the bf16 full-size reference values were taken with)
+        # streaming reductions: enough workgroups in flight to reach the HBM rate (512 left the statistics pass at 2.4 TB/s)
+        self.nb = max(1, min(2048, y0.rows // 256))
         self.nb_bwd = max(1, min(2048, y0.rows // 512))
         self.slab = self.nb_bwd * 2 * self.C
         self.dy0: Optional[Grid] = None
@@ -591,6 +600,7 @@ class _Block:
                 self.a_full = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt)
             self.bn_a = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], ya,
                                    self.a_full if self.pool1 > 1 else self.a_a)
+            (self.conv_a.pw if isinstance(self.conv_a, _SepConv) else self.conv_a).bn_after = self.bn_a
         else:
             self.bn_a = None
             if self.pool1 > 1:
@@ -612,6 +622,7 @@ class _Block:
                 self.main_full = Grid(yb.B, yb.W, yb.H, yb.C, dev, dt)
             self.bn_b = _BatchNorm(eng, f"{pre}main_modules.{blk.index['bn_2']}", mm[blk.index['bn_2']], yb,
                                    self.main_full if self.pool2 > 1 else self.main)
+            (self.conv_b.pw if isinstance(self.conv_b, _SepConv) else self.conv_b).bn_after = self.bn_b
         else:
             self.bn_b = None
             if self.pool2 > 1:
@@ -1082,6 +1093,7 @@ class _ArBlock:
         if batch_norm:
             self.main = Grid(y0.B, 1, y0.H, cout, dev, dt)
             self.bn = _BatchNorm(eng, f"{pre}main_modules.{ci + 1}", blk.main_modules[ci + 1], y0, self.main)
+            self.conv.bn_after = self.bn
         else:
             self.main, self.bn = y0, None
         self.residual = residual
