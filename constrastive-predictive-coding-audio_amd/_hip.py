@@ -94,6 +94,13 @@ _SIGNATURES = {
     "cpc_maxpool2d_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_residual_add": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_residual_add_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_stem_supported": ([_I, _I, _I, _I, _I, _I], _I),
+    "cpc_stem_stats": ([_P, _P, _P, _P, _P, _P, _I, _P], _I),
+    "cpc_stem_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
+    "cpc_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
+    "cpc_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _I, _I, _P], _I),
+    "cpc_stem_residual_add": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_stem_residual_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool2d_select": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_gp_direction": ([_P, _P, _L, _I, _F, _P, _I, _P], _I),
     "cpc_bn_gp_cross": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
@@ -137,7 +144,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 5:
+        if handle.cpc_abi_version() != 6:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -17,7 +17,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 5; }
+int cpc_abi_version(void) { return 6; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -374,6 +374,49 @@ int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void*
                          int ow, int relu, int r_f32, int dtype, void* stream) {
     if (!dout || !da || !dr || (relu && !out)) return CPC_EINVAL;
     return launch_residual_add_bwd(dout, out, go, da, ga, dr, gr, oh, ow, relu, r_f32, dtype, (hipStream_t)stream);
+}
+
+int cpc_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph) { return launch_stem_supported(cin, cout, kh, kw, hin, ph); }
+
+int cpc_stem_stats(const float* x, const int* gx, const float* w, const float* bias, const int* conv, float* slabs, int nblocks,
+                   void* stream) {
+    if (!x || !gx || !w || !conv || !slabs) return CPC_EINVAL;
+    return launch_stem_stats(x, gx, w, bias, conv[0], conv[1], conv[2], conv[3], conv[4], conv[5], conv[6], conv[7], conv[8], slabs, nblocks,
+                             (hipStream_t)stream);
+}
+
+int cpc_stem_apply(const float* x, const int* gx, const float* w, const float* bias, const int* conv, const float* stats,
+                   const float* gamma, const float* beta, void* out, const int* go, int nblocks, int dtype, void* stream) {
+    if (!x || !gx || !w || !conv || !stats || !gamma || !beta || !out || !go) return CPC_EINVAL;
+    return launch_stem_apply(x, gx, w, bias, conv[0], conv[1], conv[2], conv[3], conv[4], conv[5], conv[6], conv[7], conv[8], stats, gamma, beta,
+                             out, go, nblocks, dtype, (hipStream_t)stream);
+}
+
+int cpc_stem_bwd_reduce(const float* x, const int* gx, const float* w, const float* bias, const int* conv, const float* stats,
+                        const void* da, const void* a, const int* ga, float* slabs, int nblocks, int dtype, void* stream) {
+    if (!x || !gx || !w || !conv || !stats || !da || !a || !ga || !slabs) return CPC_EINVAL;
+    return launch_stem_bwd_reduce(x, gx, w, bias, conv[0], conv[1], conv[2], conv[3], conv[4], conv[5], conv[6], conv[7], conv[8], stats, da, a,
+                                  ga, slabs, nblocks, dtype, (hipStream_t)stream);
+}
+
+int cpc_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const float* bias, const int* conv, const float* stats,
+                       const float* gamma, const float* dgamma, const float* dbeta, double count, const void* da, const void* a,
+                       const int* ga, float* slabs, int nblocks, int dtype, void* stream) {
+    if (!x || !gx || !w || !conv || !stats || !gamma || !dgamma || !dbeta || !da || !a || !ga || !slabs) return CPC_EINVAL;
+    return launch_stem_bwd_wgrad(x, gx, w, bias, conv[0], conv[1], conv[2], conv[3], conv[4], conv[5], conv[6], conv[7], conv[8], stats, gamma,
+                                 dgamma, dbeta, count, da, a, ga, slabs, nblocks, dtype, (hipStream_t)stream);
+}
+
+int cpc_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
+                          int oh, int ow, int relu, int dtype, void* stream) {
+    if (!main_ || !gm || !xp || !gp || !wr || !out || !go) return CPC_EINVAL;
+    return launch_stem_residual_add(main_, gm, xp, gp, wr, out, go, oh, ow, relu, dtype, (hipStream_t)stream);
+}
+
+int cpc_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
+                          float* slabs, int oh, int ow, int relu, int nblocks, int dtype, void* stream) {
+    if (!dout || !go || !dmain || !gm || !xp || !gp || !slabs || (relu && !out)) return CPC_EINVAL;
+    return launch_stem_residual_bwd(dout, out, go, dmain, gm, xp, gp, slabs, oh, ow, relu, nblocks, dtype, (hipStream_t)stream);
 }
 
 int cpc_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,

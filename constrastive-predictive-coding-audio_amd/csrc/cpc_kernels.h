@@ -196,3 +196,22 @@ int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
                     float grad_scale, const float* skip, hipStream_t stream);
+
+// first block of the scalogram encoder on the float32 input (stem.hip): the convolution is recomputed, never stored
+int launch_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph);
+int launch_stem_stats(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,
+                      int pw, int Ho, int Wo, float* slabs, int nblocks, hipStream_t stream);
+int launch_stem_apply(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,
+                      int pw, int Ho, int Wo, const float* stats, const float* gamma, const float* beta, void* out, const int* go,
+                      int nblocks, int dtype, hipStream_t stream);
+int launch_stem_bwd_reduce(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw,
+                           int ph, int pw, int Ho, int Wo, const float* stats, const void* da, const void* a, const int* ga, float* slabs,
+                           int nblocks, int dtype, hipStream_t stream);
+int launch_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw,
+                          int ph, int pw, int Ho, int Wo, const float* stats, const float* gamma, const float* dgamma, const float* dbeta,
+                          double count, const void* da, const void* a, const int* ga, float* slabs, int nblocks, int dtype,
+                          hipStream_t stream);
+int launch_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
+                             int oh, int ow, int relu, int dtype, hipStream_t stream);
+int launch_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
+                             float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t stream);

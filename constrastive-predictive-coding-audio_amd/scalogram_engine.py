@@ -66,7 +66,7 @@ def _col_group(cout, kw=1, stride=(1, 1), pad=0):
     """How many consecutive output rows a tall-kernel GEMM computes per GEMM row: with fewer than 128 output channels the
     128-wide MFMA tile would be mostly empty, so G = 128 / C_out rows are produced side by side (their windows overlap in
     all but G-1 input rows; the weight operand holds G shifted copies of the kernel, +(G-1)/k extra FLOPs)."""
-    width = int(os.environ.get("CPC_COL_WIDTH", "128"))      # 256: fill the 256 x 256 tile of the large GEMM kernels instead
+    width = int(os.environ.get("CPC_COL_WIDTH", "256"))      # 256 x 256 tiles of the large GEMM kernels (128: 20.5 -> 22.2 ms per configs[2] step)
     if kw != 1 or stride != (1, 1) or pad != 0 or cout >= width or width % cout:
         return 1
     return width // cout
@@ -550,6 +550,96 @@ class _CastRelu:
         pass          # piecewise linear, no parameters: nothing of second order
 
 
+class _Stem:
+    """First convolution of the encoder + its train-mode BatchNorm + ReLU on the float32 scalogram (scalogram_model.py:392-406 of
+    block 0) through csrc/stem.hip: the convolution's output is recomputed in every pass instead of being stored (DESIGN.md,
+    scalogram family).  Stands where conv_a and bn_a stand in a _Block whose input gradient is not needed."""
+
+    def __init__(self, eng, wname, bname, conv_mod, bn_prefix, bn_mod, gin: Grid, a: Grid, Ho, Wo):
+        self.eng, self.wname, self.bname, self.prefix, self.mod, self.gin, self.a = eng, wname, bname, bn_prefix, bn_mod, gin, a
+        self.C = conv_mod.out_channels
+        kh, kw = conv_mod.kernel_size
+        sh, sw = conv_mod.stride
+        ph, pw = conv_mod.padding
+        self.taps = gin.C * kh * kw
+        self.conv = (C.c_int * 9)(self.C, kh, kw, sh, sw, ph, pw, Ho, Wo)
+        self.count = float(gin.B * Wo * Ho)
+        self.nb = max(1, min(2048, gin.B * Wo))
+        self.slab = self.nb * max(2 * self.C, self.C * self.taps)
+        self.stats = torch.zeros(2, self.C, device=eng.device, dtype=torch.float32)
+        self.zeros = torch.zeros(self.C, device=eng.device, dtype=torch.float32)
+        self.trained = True
+
+    def _args(self):
+        p = self.eng.model._param
+        return (self.gin.ptr(), _desc(self.gin, self.gin.desc), _hip.ptr(p[self.wname]), _hip.ptr(p.get(self.bname)) if self.bname else None,
+                C.cast(self.conv, C.c_void_p))
+
+    def forward(self):
+        e, mod = self.eng, self.mod
+        p = e.model._param
+        self.trained = bool(mod.training or not mod.track_running_stats)
+        if self.trained:
+            _hip.call("cpc_stem_stats", *self._args(), _hip.ptr(e.slabs), self.nb)
+            rm = mod.running_mean if mod.track_running_stats else None
+            rv = mod.running_var if mod.track_running_stats else None
+            momentum = 0.1 if mod.momentum is None else float(mod.momentum)
+            _hip.call("cpc_bn_finalize", _hip.ptr(e.slabs), self.nb, self.C, self.count, float(mod.eps), momentum, _hip.ptr(self.stats),
+                      _hip.ptr(rm), _hip.ptr(rv))
+            if mod.track_running_stats and mod.num_batches_tracked is not None:
+                mod.num_batches_tracked += 1
+        else:
+            self.stats[0].copy_(mod.running_mean)
+            self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
+        _hip.call("cpc_stem_apply", *self._args(), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]),
+                  self.a.ptr(), _desc(self.a, self.a.desc), min(4096, self.gin.B * int(self.conv[8])), e.code)
+
+    def backward(self, da: Grid):
+        """da: gradient of the activation (before its ReLU mask) -> BatchNorm scale / shift gradients and the convolution's weight
+        gradient; the convolution's output gradient is formed inside the weight-gradient kernel and never stored."""
+        e = self.eng
+        p, g = e.model._param, e.model._grad
+        gw, gb = g[self.prefix + ".weight"], g[self.prefix + ".bias"]
+        a = self.a
+        _hip.call("cpc_stem_bwd_reduce", *self._args(), _hip.ptr(self.stats), da.ptr(), a.ptr(), _desc(a, a.desc), _hip.ptr(e.slabs), self.nb,
+                  e.code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb, 2 * self.C, 1, 1, 0, 0)
+        dg, db = (gw, gb) if self.trained else (self.zeros, self.zeros)
+        _hip.call("cpc_stem_bwd_wgrad", *self._args(), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(dg), _hip.ptr(db),
+                  self.count, da.ptr(), a.ptr(), _desc(a, a.desc), _hip.ptr(e.slabs), self.nb, e.code)
+        n = self.C * self.taps
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(g[self.wname]), 1, n, self.nb, n, 1, 1, 0, 0)
+        if self.bname and self.bname in g:
+            if self.trained:          # exactly zero in front of a train-mode BatchNorm (its input gradient has zero mean per channel)
+                g[self.bname].zero_()
+            else:                     # running statistics: dy = gamma rstd g, summed over the positions
+                g[self.bname].copy_(p[self.prefix + ".weight"].detach() * self.stats[1] * gb)
+
+
+class _StemResidual:
+    """Residual branch of block 0 on the float32 input: [MaxPool2d] -> 1x1 Conv2d (no bias, no padding) -> cropped add
+    (scalogram_model.py:434-446, :462-472) with the projection applied inside the add (csrc/stem.hip): neither the projected
+    float32 grid nor its gradient is stored."""
+
+    def __init__(self, eng, wname, xp: Grid, main: Grid, out: Grid, oh, ow, relu):
+        self.eng, self.wname, self.xp, self.main, self.out, self.oh, self.ow, self.relu = eng, wname, xp, main, out, oh, ow, relu
+        self.nb = max(1, min(1024, main.B * main.W))
+        self.n = main.C * xp.C
+        self.slab = self.nb * self.n
+
+    def forward(self):
+        e, m, xp, o = self.eng, self.main, self.xp, self.out
+        _hip.call("cpc_stem_residual_add", m.ptr(), _desc(m, m.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(e.model._param[self.wname]),
+                  o.ptr(), _desc(o, o.desc), self.oh, self.ow, 1 if self.relu else 0, e.code)
+
+    def backward(self, d_out: Grid, d_main: Grid):
+        e, xp, o = self.eng, self.xp, self.out
+        _hip.call("cpc_stem_residual_bwd", d_out.ptr(), o.ptr(), _desc(o, o.desc), d_main.ptr(), _desc(d_main, d_main.desc), xp.ptr(),
+                  _desc(xp, xp.desc), _hip.ptr(e.slabs), self.oh, self.ow, 1 if self.relu else 0, self.nb, e.code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(e.model._grad[self.wname]), 1, self.n, self.nb, self.n, 1, 1, 0, 0)
+
+
 class _Block:
     """One ScalogramEncoderBlock (scalogram_model.py:372-479) on grids."""
 
@@ -589,12 +679,24 @@ class _Block:
         direct = (not has_bn) and (not cast) and self.pool1 == 1 and bool(a_geom['top'] or a_geom['tail'])
         if direct and (cfg.get('separable') or _col_ok(k1[1], s1, s1, p1, cfg['in_channels'], in_f32)):
             direct, cast = False, bool(top2)        # (a missing tail only costs the row grouping of the next GEMM)
-        self.conv_a = _make_conv(eng, f"{pre}main_modules.{i1}", mm[i1], gin, bias, in_f32=in_f32, need_dgrad=not first,
-                                 relu=not has_bn, out_pad=(a_geom['top'], a_geom['tail'], a_geom['guard_rows']) if direct else None)
-        ya = self.conv_a.y0
-        assert (ya.H, ya.W) == (Hc, Wc)
+        # block 0 in a training engine (no input gradient): convolution + BatchNorm + ReLU through the recomputing kernels of csrc/stem.hip
+        self.stem = None
+        if (in_f32 and first and has_bn and self.pool1 == 1 and not cfg.get('separable') and gin.top == 0 and
+                os.environ.get("CPC_STEM", "1") != "0" and
+                _hip.lib().cpc_stem_supported(gin.C, cfg['hidden_channels'], k1[0], k1[1], gin.H, p1) == 1):
+            self.a_a = Grid(gin.B, Wa1, Ha1, cfg['hidden_channels'], dev, dt, **a_geom)
+            self.stem = _Stem(eng, f"{pre}main_modules.{i1}.weight", f"{pre}main_modules.{i1}.bias" if bias else None, mm[i1],
+                              f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], gin, self.a_a, Hc, Wc)
+            self.conv_a = self.bn_a = self.a_full = None
+        else:
+            self.conv_a = _make_conv(eng, f"{pre}main_modules.{i1}", mm[i1], gin, bias, in_f32=in_f32, need_dgrad=not first,
+                                     relu=not has_bn, out_pad=(a_geom['top'], a_geom['tail'], a_geom['guard_rows']) if direct else None)
+        ya = self.conv_a.y0 if self.conv_a is not None else None
+        assert ya is None or (ya.H, ya.W) == (Hc, Wc)
         self.a_full = None
-        if has_bn:
+        if self.stem is not None:
+            pass
+        elif has_bn:
             self.a_a = Grid(ya.B, Wa1, Ha1, ya.C, dev, dt, **a_geom)
             if self.pool1 > 1:
                 self.a_full = Grid(ya.B, ya.W, ya.H, ya.C, dev, dt)
@@ -640,7 +742,14 @@ class _Block:
                 p_ = blk.res_pool
                 self.rp = Grid(gin.B, _ceil_div(gin.W, p_), _ceil_div(gin.H, p_), gin.C, dev, torch.float32 if in_f32 else dt)
                 src, src_f32 = self.rp, in_f32
-            if 'res_conv' in blk.index:
+            self.stem_res = None
+            if ('res_conv' in blk.index and src_f32 and first and blk.residual_modules[blk.index['res_conv']].padding == (0, 0) and
+                    src.C <= 4 and os.environ.get("CPC_STEM", "1") != "0" and cfg['out_channels'] % 4 == 0 and
+                    256 % (cfg['out_channels'] // 4) == 0 and (256 // (cfg['out_channels'] // 4)) * src.C * cfg['out_channels'] <= 4096):
+                ri = blk.index['res_conv']
+                self.stem_res = f"{pre}residual_modules.{ri}.weight"
+                self.res = src                      # 1x1, no padding: the projected grid would have the pooled input's extents
+            elif 'res_conv' in blk.index:
                 ri = blk.index['res_conv']
                 self.res_conv = _Conv(eng, f"{pre}residual_modules.{ri}.weight", None, blk.residual_modules[ri], src, in_f32=src_f32,
                                       need_dgrad=not first)
@@ -657,11 +766,14 @@ class _Block:
                 raise ValueError(f"block {idx}: residual {self.res.H}x{self.res.W} cannot be cropped onto main {m.H}x{m.W}")
             self.out = Grid(m.B, m.W, m.H, m.C, dev, dt, top=next_top)
             self.r_f32 = 1 if (self.res.dtype == torch.float32 and dt != torch.float32) else 0
+            if self.stem_res is not None:
+                self.stem_res = _StemResidual(eng, self.stem_res, self.res, m, self.out, self.oh, self.ow, relu=not last)
         else:
+            self.stem_res = None
             if next_top:
                 raise NotImplementedError("top_padding_1 after a block without residual branch")
             self.out = self.main
-        self.slab = max([c.slab for c in (self.conv_a, self.conv_b, self.res_conv) if c is not None] +
+        self.slab = max([c.slab for c in (self.conv_a, self.conv_b, self.res_conv, self.stem, self.stem_res) if c is not None] +
                         [b.slab for b in (self.bn_a, self.bn_b) if b is not None])
 
     def allocate_grads(self, d_in: Optional[Grid]):
@@ -671,7 +783,7 @@ class _Block:
         self.d_out = self.out.like(dev)
         if self.blk.residual:
             self.d_main = self.main.like(dev, guard_rows=self.conv_b.kh + 16)
-            self.d_res = self.res.like(dev)
+            self.d_res = self.res.like(dev) if self.stem_res is None else None
             self.d_rp = self.rp.like(dev) if (self.rp is not None and self.res_conv is not None) else None
             if self.res_conv is not None:
                 self.res_conv.dy0 = self.d_res
@@ -685,6 +797,9 @@ class _Block:
         else:
             self.conv_b.dy0 = self.d_main_full if self.pool2 > 1 else self.d_main
         self.d_a = self.a_a.like(dev, guard_rows=self.conv_b.kh + 16)
+        if self.stem is not None:
+            self.d_a_full = None
+            return
         self.d_a_full = self.a_full.like(dev, guard_rows=self.conv_a.kh + 16) if self.pool1 > 1 else None
         if self.bn_a is not None:
             self.bn_a.dy0 = self.conv_a.y0.like(dev, guard_rows=self.conv_a.kh + 16)
@@ -699,7 +814,10 @@ class _Block:
 
     def forward(self):
         e, code = self.eng, self.eng.code
-        self.conv_a.forward()
+        if self.stem is not None:
+            self.stem.forward()
+        else:
+            self.conv_a.forward()
         if self.bn_a is not None:
             self.bn_a.forward()
         if self.pool1 > 1:
@@ -717,8 +835,11 @@ class _Block:
                           self.blk.res_pool, 1 if self.in_f32 else 0, self.rp.code)
             if self.res_conv is not None:
                 self.res_conv.forward()
-            _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
-                      self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)
+            if self.stem_res is not None:
+                self.stem_res.forward()
+            else:
+                _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
+                          self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)
 
     # ---- Wasserstein gradient penalty
     def tangent(self):
@@ -767,7 +888,9 @@ class _Block:
     def backward(self):
         e, code = self.eng, self.eng.code
         first = not self.need_input_grad
-        if self.blk.residual:
+        if self.stem_res is not None:
+            self.stem_res.backward(self.d_out, self.d_main)
+        elif self.blk.residual:
             self.d_res.t.zero_()
             _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
                       _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, self.ow,
@@ -788,7 +911,12 @@ class _Block:
             self.bn_b.backward(g_b)
         else:
             _hip.call("cpc_relu_mask", g_b.ptr(), act_b.ptr(), g_b.rows * g_b.C, code)
-        self.conv_b.backward(self.d_a, mask_input=self.bn_a is None and self.pool1 == 1)
+        self.conv_b.backward(self.d_a, mask_input=self.bn_a is None and self.stem is None and self.pool1 == 1)
+        if self.stem is not None:          # (block 0: no input gradient, and its residual branch was handled above)
+            self.stem.backward(self.d_a)
+            if self.blk.residual and self.stem_res is None and self.res_conv is not None:
+                self.res_conv.backward(None)
+            return
         # first convolution
         g_a = self.d_a
         if self.pool1 > 1:
@@ -799,7 +927,7 @@ class _Block:
             self.bn_a.backward(g_a)
         self.conv_a.backward(None if first else self.d_in)
         # residual branch (adds into the block-input gradient after the main branch wrote it)
-        if self.blk.residual:
+        if self.blk.residual and self.stem_res is None:
             if self.res_conv is not None:
                 if self.rp is not None:
                     self.res_conv.backward(None if first else self.d_rp)
@@ -879,7 +1007,7 @@ class ScalogramCPCEngine(CPCEngine):
             self.act, self.dact = [out.t], [self.blocks[-1].d_out.t]
         self.aux = side_stream(self.device)      # side stream, see engine.CPCEngine
         self.ctx = make_context(self, ar) if (self.V + self.K) > 0 else None
-        need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)]
+        need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.a_a.C, b.conv_b.cout) for b in self.blocks)]
         self._alloc_head(need)
 
     supports_prepare_ahead = False     # operand copies are rebuilt at the start of every step (engine.CPCEngine.prepare_ahead)
@@ -1331,7 +1459,7 @@ class ResNetArContext:
         self.c32 = torch.empty(e.B, out.C, device=e.device, dtype=torch.float32)
 
     def slab_floats(self):
-        return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(max(b.conv_a.cout, b.conv_b.cout) for b in self.blocks)
+        return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(max(b.a_a.C, b.conv_b.cout) for b in self.blocks)
 
     def prepare_weights(self):
         for b in self.blocks:

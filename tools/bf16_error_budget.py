@@ -1,0 +1,111 @@
+"""Where does the bf16 loss error of BASELINE configs[2] come from?  The exact-f32 engine is run with ONE group of tensors at a time
+rounded to bf16 (what bf16 storage does to it), and the relative change of the loss is printed per group.
+
+    python tools/bf16_error_budget.py [--batch 128]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cpc_audio_amd import configs  # noqa: E402
+from cpc_audio_amd.audio_model import AudioPredictiveCodingModel, ConvolutionalArModel  # noqa: E402
+from cpc_audio_amd.scalogram_model import PreprocessingModule, ScalogramResidualEncoder, cqt_default_dict  # noqa: E402
+
+
+def rnd(t):
+    t.copy_(t.bfloat16().float())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, V, K = args.batch, 60, 16
+    torch.manual_seed(0)
+    pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+    enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
+                                       visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+    pre, model = pre.to(dev), model.to(dev)
+    wave = (torch.randn(B, 97024, generator=torch.Generator().manual_seed(11)) * 0.1).to(dev)
+    x32 = pre(wave.unsqueeze(1)).clone()
+    pre.cqt.precision = "bf16x3"
+    x3 = pre(wave.unsqueeze(1)).clone()
+    eng = model.engine_for(x32)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run(x=x32):
+        model.load_state_dict(state)
+        eng.forward(x)
+        eng.nce_forward_backward(True, 1.0)
+        return float(eng.nce_out[0])
+
+    base = run()
+    print(f"exact-f32 loss {base:.6f}")
+    print(f"{'bf16x3 CQT':50s} {abs(run(x3) - base) / base:.2e}")
+
+    def with_patch(name, patches):
+        saved = []
+        for obj, attr, post in patches:
+            orig = getattr(obj, attr)
+            saved.append((obj, attr, orig))
+
+            def wrapped(*a, _orig=orig, _post=post, **k):
+                r = _orig(*a, **k)
+                _post()
+                return r
+            setattr(obj, attr, wrapped)
+        try:
+            v = run()
+        finally:
+            for obj, attr, orig in saved:
+                setattr(obj, attr, orig)
+        print(f"{name:50s} {abs(v - base) / base:.2e}   ({v:.5f})")
+
+    blocks = eng.blocks
+    # weights: the operand copies made by prepare()
+    def w_post(c):
+        def f():
+            for n in ("w_fwd", "w_t", "w_dgrad"):
+                t = getattr(c, n, None)
+                if t is not None:
+                    rnd(t)
+        return f
+    convs = [c for b in blocks for c in (b.conv_a, b.conv_b, b.res_conv) if c is not None]
+    with_patch("all encoder conv weights", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32])
+    for i, b in enumerate(blocks):
+        if not b.conv_a.in_f32:
+            with_patch(f"block {i} conv_a output (pre-BN / activation)", [(b.conv_a, "forward", lambda g=b.conv_a.y0: rnd(g.t))])
+        with_patch(f"block {i} conv_b output (pre-BN / activation)", [(b.conv_b, "forward", lambda g=b.conv_b.y0: rnd(g.t))])
+        if b.bn_a is not None:
+            with_patch(f"block {i} BN_a output (activation a)", [(b.bn_a, "forward", lambda g=b.bn_a.a: rnd(g.t))])
+        if b.bn_b is not None:
+            with_patch(f"block {i} BN_b output (main)", [(b.bn_b, "forward", lambda g=b.bn_b.a: rnd(g.t))])
+        if b.res_conv is not None and not b.res_conv.in_f32:
+            with_patch(f"block {i} residual projection output", [(b.res_conv, "forward", lambda g=b.res_conv.y0: rnd(g.t))])
+        with_patch(f"block {i} output (after the residual add)", [(b, "forward", lambda g=b.out: rnd(g.t))])
+    with_patch("all encoder pre-BN conv outputs", [(c, "forward", lambda g=c.y0: rnd(g.t)) for b in blocks for c, bn in ((b.conv_a, b.bn_a), (b.conv_b, b.bn_b)) if bn is not None and not c.in_f32])
+    with_patch("all encoder BN outputs", [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None])
+    ctx = eng.ctx
+    ar_blocks = getattr(ctx, "blocks", [])
+    with_patch("context: all conv outputs", [(b.conv, "forward", lambda g=b.conv.y0: rnd(g.t)) for b in ar_blocks])
+    with_patch("context: all BN outputs", [(b.bn, "forward", lambda g=b.bn.a: rnd(g.t)) for b in ar_blocks if b.bn is not None])
+    with_patch("context: all block outputs", [(b, "forward", lambda g=b.out: rnd(g.t)) for b in ar_blocks])
+    with_patch("context: conv weights", [(c, "prepare", w_post(c)) for b in ar_blocks for c in (b.conv, b.res_conv) if c is not None])
+    with_patch("everything above at once", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] +
+               [(c, "forward", lambda g=c.y0: rnd(g.t)) for c in convs if not c.in_f32] +
+               [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None] +
+               [(b, "forward", lambda g=b.out: rnd(g.t)) for b in blocks] +
+               [(b.conv, "forward", lambda g=b.conv.y0: rnd(g.t)) for b in ar_blocks] +
+               [(b.bn, "forward", lambda g=b.bn.a: rnd(g.t)) for b in ar_blocks if b.bn is not None] +
+               [(b, "forward", lambda g=b.out: rnd(g.t)) for b in ar_blocks])
+
+
+if __name__ == "__main__":
+    main()
