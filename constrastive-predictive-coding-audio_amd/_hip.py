@@ -94,7 +94,7 @@ _SIGNATURES = {
     "cpc_maxpool2d_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_residual_add": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_residual_add_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
-    "cpc_stem_supported": ([_I, _I, _I, _I, _I, _I], _I),
+    "cpc_stem_supported": ([_I, _I, _I, _I, _I, _I, _I], _I),
     "cpc_stem_stats": ([_P, _P, _P, _P, _P, _P, _I, _P], _I),
     "cpc_stem_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),

@@ -376,7 +376,7 @@ int cpc_residual_add_bwd(const void* dout, const void* out, const int* go, void*
     return launch_residual_add_bwd(dout, out, go, da, ga, dr, gr, oh, ow, relu, r_f32, dtype, (hipStream_t)stream);
 }
 
-int cpc_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph) { return launch_stem_supported(cin, cout, kh, kw, hin, ph); }
+int cpc_stem_supported(int cin, int cout, int kh, int kw, int sh, int hin, int ph) { return launch_stem_supported(cin, cout, kh, kw, sh, hin, ph); }
 
 int cpc_stem_stats(const float* x, const int* gx, const float* w, const float* bias, const int* conv, float* slabs, int nblocks,
                    void* stream) {

@@ -198,7 +198,7 @@ int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, f
                     float grad_scale, const float* skip, hipStream_t stream);
 
 // first block of the scalogram encoder on the float32 input (stem.hip): the convolution is recomputed, never stored
-int launch_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph);
+int launch_stem_supported(int cin, int cout, int kh, int kw, int sh, int hin, int ph);
 int launch_stem_stats(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,
                       int pw, int Ho, int Wo, float* slabs, int nblocks, hipStream_t stream);
 int launch_stem_apply(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,

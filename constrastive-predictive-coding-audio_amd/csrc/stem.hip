@@ -33,10 +33,43 @@ struct StemConv {
 };
 
 constexpr int R = 4;              // output rows per lane
-constexpr int MAX_XS = 4096;      // floats of input columns in LDS (kw * (Hin + 2 ph) * Cin)
+constexpr int MAX_XS = 2560;      // floats of ONE buffer of input columns in LDS (kw * (Hin + 2 ph + R * sh) * Cin); two buffers
 constexpr int MAX_WL = 2304;      // floats of weights in LDS (taps * Cout)
+constexpr int MAXPF = 10;         // input-column floats a thread stages per output column (256 threads: kw * (Hin + 2 ph) * Cin <= 2560)
 
-// weights -> LDS as wl[t][co], t = (c*kh + dh)*kw + dw  (so that a lane's 4 output channels are one 16-byte read)
+// Window shape as template parameters (0 = taken from the arguments at run time).  With a compile-time shape the tap loops unroll,
+// the weights of a lane's 4 channels live in registers and a lane's input window is read from LDS once per column of taps.
+template <int CIN_, int KH_, int KW_, int SH_>
+struct Win {
+    static constexpr bool FIXED = CIN_ > 0;
+    static constexpr int T = FIXED ? CIN_ * KH_ * KW_ : 1;
+    static constexpr int WROWS = FIXED ? ((R - 1) * SH_ + KH_) * CIN_ : 1;      // floats of a lane's window in one input column
+    __device__ static __forceinline__ int cin(const StemConv& p) { return FIXED ? CIN_ : p.gx.C; }
+    __device__ static __forceinline__ int kh(const StemConv& p) { return FIXED ? KH_ : p.kh; }
+    __device__ static __forceinline__ int kw(const StemConv& p) { return FIXED ? KW_ : p.kw; }
+    __device__ static __forceinline__ int sh(const StemConv& p) { return FIXED ? SH_ : p.sh; }
+};
+
+// LDS column stride in floats: the padded input height plus R * sh rows of slack (zero), so that the window of a lane whose last
+// rows lie beyond Ho stays inside the buffer
+// (a multiple of 4 floats: a lane's window starts at ho0 * sh * Cin with ho0 a multiple of R = 4, so its reads are 16-byte aligned)
+template <class W>
+__device__ __forceinline__ int col_stride(const StemConv& p) { return ((p.gx.H + 2 * p.ph + R * W::sh(p)) * W::cin(p) + 3) & ~3; }
+
+// a lane's window of one input column: WROWS consecutive floats from a 16-byte aligned LDS address
+template <int N>
+__device__ __forceinline__ void load_window(const float* col, float (&xin)[N]) {
+    const f32x4* c4 = (const f32x4*)__builtin_assume_aligned(col, 16);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const f32x4 v = c4[i];
+        xin[4 * i] = v[0]; xin[4 * i + 1] = v[1]; xin[4 * i + 2] = v[2]; xin[4 * i + 3] = v[3];
+    }
+#pragma unroll
+    for (int i = N / 4 * 4; i < N; ++i) xin[i] = col[i];
+}
+
+// weights -> LDS as wl[t][co], t = (c*kh + dh)*kw + dw  (a lane's 4 output channels are one 16-byte read)
 __device__ __forceinline__ void stage_weights(const StemConv& p, float* wl) {
     const int T = p.gx.C * p.kh * p.kw;
     for (int i = threadIdx.x; i < T * p.Cout; i += 256) {
@@ -45,49 +78,171 @@ __device__ __forceinline__ void stage_weights(const StemConv& p, float* wl) {
     }
 }
 
-// the kw input columns of output column (b, wo) -> LDS as xs[dw][(ph + h) * Cin + c], zero where the window leaves the grid
-__device__ __forceinline__ void stage_columns(const StemConv& p, int b, int wo, float* xs) {
-    const int Cin = p.gx.C, Hp = p.gx.H + 2 * p.ph, colf = Hp * Cin;
-    for (int i = threadIdx.x; i < p.kw * colf; i += 256) {
-        const int dw = i / colf, j = i - dw * colf;
-        const int h = j / Cin - p.ph, c = j - (j / Cin) * Cin;
-        const int w = wo * p.sw - p.pw + dw;
-        float v = 0.f;
-        if (w >= 0 && w < p.gx.W && h >= 0 && h < p.gx.H) v = p.x[grid_off(p.gx, b, w, h) + c];
-        xs[i] = v;
-    }
-}
-
-// acc[r] = bias + sum over taps of w * x for output rows ho0 + r (r < R; rows beyond Ho compute on clamped addresses and are
-// discarded by the caller), channels 4 cq .. 4 cq + 3.  Fixed order: t = (c, dh, dw) ascending.
-__device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, const float* xs, int cq, int ho0, f32x4 acc[R]) {
-    const int Cin = p.gx.C, colf = (p.gx.H + 2 * p.ph) * Cin;
-    const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    int rowbase[R];
+// Staging of the kw input columns of output column (b, wo) as xs[dw][(ph + h) * Cin + c] (zero where the window leaves the grid):
+// every thread owns up to MAXPF floats of a column set; the NEXT column set is loaded into registers while the current one is
+// being convolved, and written to the other LDS buffer afterwards.
+template <class W>
+struct ColumnStage {
+    // per slot: LDS index (12 bits; 0xfff = slot unused) | (offset from the input column's first element + 1) << 12 (0 = padding
+    // row) | dw << 28.  The per-column work is a handful of 32-bit operations per slot and no branch: addresses are clamped into
+    // the grid and the value is selected afterwards.
+    int code[MAXPF];
+    float v[MAXPF];
+    int npf;
+    __device__ __forceinline__ void init(const StemConv& p) {
+        const int Cin = W::cin(p), Hp = p.gx.H + 2 * p.ph, colf = Hp * Cin, cs = col_stride<W>(p), n = W::kw(p) * colf;
+        npf = (n + 255) / 256;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] = b4;
-        rowbase[r] = min(ho0 + r, p.Ho - 1) * p.sh * Cin;
-    }
-    int t = 0;
-    for (int c = 0; c < Cin; ++c)
-        for (int dh = 0; dh < p.kh; ++dh)
-            for (int dw = 0; dw < p.kw; ++dw, ++t) {
-                const f32x4 w4 = *(const f32x4*)(wl + t * p.Cout + cq * 4);
-                const float* col = xs + dw * colf + dh * Cin + c;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float xv = col[rowbase[r]];
-                    acc[r] += w4 * xv;
-                }
+        for (int k = 0; k < MAXPF; ++k) {
+            const int i = threadIdx.x + k * 256;
+            code[k] = 0xfff;
+            if (i < n) {
+                const int dw = i / colf, j = i - dw * colf, h = j / Cin - p.ph, c = j - (j / Cin) * Cin;
+                const int rel1 = (h >= 0 && h < p.gx.H) ? h * Cin + c + 1 : 0;
+                code[k] = (dw * cs + j) | (rel1 << 12) | (dw << 28);
             }
+        }
+    }
+    // (b, wo) are uniform over the workgroup
+    __device__ __forceinline__ void fetch(const StemConv& p, int b, int wo) {
+        const int w0 = wo * p.sw - p.pw, HaC = p.gx.Ha * W::cin(p);
+        const float* xb = p.x + ((long long)b * p.gx.W * p.gx.Ha + p.gx.top) * W::cin(p);
+        // (a predicated load per slot: the value stays in flight until commit(); a branch-free clamp-and-select form made the
+        // compiler wait for the loads right here, and the kernels ran 1.5x slower)
+#pragma unroll
+        for (int k = 0; k < MAXPF; ++k) {
+            const int w = w0 + (int)((unsigned)code[k] >> 28), rel1 = (code[k] >> 12) & 0xffff;
+            v[k] = (k < npf && rel1 > 0 && w >= 0 && w < p.gx.W) ? xb[w * HaC + rel1 - 1] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void commit(float* xs) const {
+#pragma unroll
+        for (int k = 0; k < MAXPF; ++k)
+            if (k < npf && (code[k] & 0xfff) != 0xfff) xs[code[k] & 0xfff] = v[k];
+    }
+};
+
+// output column index -> (b, wo), advanced by a fixed step without divisions
+struct ColIdx {
+    int q, b, wo;
+    __device__ __forceinline__ ColIdx(int q0, int Wo) : q(q0), b(q0 / Wo), wo(q0 % Wo) {}
+    __device__ __forceinline__ void step(int dq, int db, int dwo, int Wo) {
+        q += dq; b += db; wo += dwo;
+        if (wo >= Wo) { wo -= Wo; ++b; }
+    }
+};
+
+// four channels of one position in the storage type, unconverted (half the registers of f32x4 for bf16 while a load is in flight)
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    f32x4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *(const f32x4*)p; }
+    __device__ __forceinline__ f32x4 get() const { return v; }
+};
+template <> struct Raw4<bf16_t> {
+    uint2 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const uint2*)p; }
+    __device__ __forceinline__ f32x4 get() const {
+        return (f32x4){__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                       __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+    }
+};
+
+// acc[r] = bias + sum over taps of w * x for output rows ho0 + r (r < R; rows beyond Ho read the zero slack rows and are discarded
+// by the caller), channels 4 cq .. 4 cq + 3.  One fixed order of summation per window shape: every pass sees identical values.
+template <class W, bool WREG>
+__device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, const f32x4 (&wreg)[W::T], const float* xs, int cq,
+                                          int ho0, f32x4 acc[R]) {
+    const int Cin = W::cin(p), KH = W::kh(p), KW = W::kw(p), SH = W::sh(p), cs = col_stride<W>(p);
+    const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = b4;
+    if constexpr (W::FIXED) {
+#pragma unroll
+        for (int dw = 0; dw < KW; ++dw) {
+            float xin[W::WROWS];
+            load_window<W::WROWS>(xs + dw * cs + ho0 * SH * Cin, xin);
+#pragma unroll
+            for (int c = 0; c < Cin; ++c)
+#pragma unroll
+                for (int dh = 0; dh < KH; ++dh) {
+                    const int t = (c * KH + dh) * KW + dw;
+                    const f32x4 w4 = WREG ? wreg[t] : *(const f32x4*)(wl + t * p.Cout + cq * 4);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] += w4 * xin[(r * SH + dh) * Cin + c];
+                }
+        }
+    } else {
+        for (int dw = 0; dw < KW; ++dw)
+            for (int c = 0; c < Cin; ++c)
+                for (int dh = 0; dh < KH; ++dh) {
+                    const f32x4 w4 = *(const f32x4*)(wl + ((c * KH + dh) * KW + dw) * p.Cout + cq * 4);
+                    const float* col = xs + dw * cs + (ho0 * SH + dh) * Cin + c;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] += w4 * col[r * SH * Cin];
+                }
+    }
 }
 
-// block-wide sum of per-lane f32x4 pairs over the lanes that share a channel quad (fixed order), result by the lanes rg == 0
+// The loop every pass runs: columns q = blockIdx.x, + gridDim.x, ...; double-buffered staging; body(b, wo, ho0, acc) per lane and row group
+// pre(b, wo, ho0): issued BEFORE the convolution of a row group (the global loads of the backward passes, whose latency then
+// runs under the convolution's arithmetic); WREG: weights in registers (false: 16-byte LDS reads, for the kernel that needs the
+// registers for its accumulators).
+template <class W, bool WREG, class Pre, class Body>
+__device__ __forceinline__ void stem_columns(const StemConv& p, float* wl, float* xs2, f32x4 (&wreg)[W::T], int cq, int rg, int nrg, Pre pre,
+                                             Body body) {
+    stage_weights(p, wl);
+    for (int i = threadIdx.x; i < 2 * MAX_XS; i += 256) xs2[i] = 0.f;
+    // Two column sets are in flight in registers (sa: the next column, sb: the one after): a set has the convolution of TWO columns
+    // to arrive in (a load from HBM takes 1-2 us under load, a column's arithmetic 0.5-1 us).
+    ColumnStage<W> sa, sb;
+    sa.init(p);
+    sb.npf = sa.npf;
+#pragma unroll
+    for (int k = 0; k < MAXPF; ++k) sb.code[k] = sa.code[k];
+    const int ncol = p.gx.B * p.Wo, G = gridDim.x, Gb = G / p.Wo, Gw = G % p.Wo;
+    ColIdx cur(blockIdx.x, p.Wo), nxt(blockIdx.x, p.Wo);          // the column being convolved / the newest one requested
+    if (cur.q < ncol) sa.fetch(p, cur.b, cur.wo);
+    __syncthreads();
+    if constexpr (W::FIXED && WREG) {
+#pragma unroll
+        for (int t = 0; t < W::T; ++t) wreg[t] = *(const f32x4*)(wl + t * p.Cout + cq * 4);
+    }
+    if (cur.q < ncol) sa.commit(xs2);
+    nxt.step(G, Gb, Gw, p.Wo);
+    if (nxt.q < ncol) sa.fetch(p, nxt.b, nxt.wo);
+    __syncthreads();
+    auto column = [&](const ColIdx& c, const float* xs) {
+        for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
+            pre(c.b, c.wo, ho0);
+            f32x4 acc[R];
+            conv_rows<W, WREG>(p, wl, wreg, xs, cq, ho0, acc);
+            body(c.b, c.wo, ho0, acc, xs);
+        }
+    };
+    // invariant at the top: LDS buffer 0 holds column cur.q, sa holds (or is loading) column cur.q + G = nxt.q
+    while (cur.q < ncol) {
+        nxt.step(G, Gb, Gw, p.Wo);                                // cur + 2G
+        if (nxt.q < ncol) sb.fetch(p, nxt.b, nxt.wo);
+        column(cur, xs2);
+        if (cur.q + G < ncol) sa.commit(xs2 + MAX_XS);
+        __syncthreads();
+        cur.step(G, Gb, Gw, p.Wo);
+        if (cur.q >= ncol) break;
+        nxt.step(G, Gb, Gw, p.Wo);                                // (old cur) + 3G
+        if (nxt.q < ncol) sa.fetch(p, nxt.b, nxt.wo);
+        column(cur, xs2 + MAX_XS);
+        if (cur.q + G < ncol) sb.commit(xs2);
+        __syncthreads();
+        cur.step(G, Gb, Gw, p.Wo);
+        // (buffer 0 now holds cur.q; sa holds cur.q + G = nxt.q: the invariant again)
+    }
+}
+
+// block-wide sum of per-lane f32x4 values over the lanes that share a channel quad (fixed order), result in the lanes rg == 0
 template <int NV>
 __device__ __forceinline__ void reduce_quads(f32x4 (&v)[NV], float* red, int cqn, int cq, int rg, int nrg) {
-    // red: [nrg][NV][cqn*4] floats
-    const int C = cqn * 4;
+    const int C = cqn * 4;          // red: [nrg][NV][C] floats
 #pragma unroll
     for (int k = 0; k < NV; ++k) *(f32x4*)(red + (rg * NV + k) * C + cq * 4) = v[k];
     __syncthreads();
@@ -102,31 +257,26 @@ __device__ __forceinline__ void reduce_quads(f32x4 (&v)[NV], float* red, int cqn
     __syncthreads();
 }
 
+#define STEM_SHARED                                                    \
+    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];          \
+    __shared__ __attribute__((aligned(16))) float xs2[2 * MAX_XS];     \
+    const int cqn = p.Cout / 4, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn; \
+    f32x4 wreg[W::T];
+
 // ---- pass 1: per-workgroup partial sums of y and y^2 (BatchNorm statistics), slabs[blk][2][Cout]
+template <class W>
 __global__ __launch_bounds__(256) void stem_stats_kernel(StemConv p, float* __restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];
-    __shared__ __attribute__((aligned(16))) float xs[MAX_XS];
+    STEM_SHARED
     __shared__ __attribute__((aligned(16))) float red[2048];
-    const int cqn = p.Cout / 4, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn;
-    stage_weights(p, wl);
     f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const int ncol = p.gx.B * p.Wo;
-    for (int q = blockIdx.x; q < ncol; q += gridDim.x) {
-        __syncthreads();
-        stage_columns(p, q / p.Wo, q % p.Wo, xs);
-        __syncthreads();
-        for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
-            f32x4 acc[R];
-            conv_rows(p, wl, xs, cq, ho0, acc);
+    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int, int, int ho0, f32x4* acc, const float*) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (ho0 + r < p.Ho) {
-                    s[0] += acc[r];
-                    s[1] += acc[r] * acc[r];
-                }
-        }
-    }
-    __syncthreads();
+        for (int r = 0; r < R; ++r)
+            if (ho0 + r < p.Ho) {
+                s[0] += acc[r];
+                s[1] += acc[r] * acc[r];
+            }
+    });
     reduce_quads<2>(s, red, cqn, cq, rg, nrg);
     if (rg == 0) {
         *(f32x4*)(slabs + (long long)blockIdx.x * 2 * p.Cout + cq * 4) = s[0];
@@ -135,77 +285,55 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(StemConv p, float* __re
 }
 
 // ---- pass 2: a = relu((y - mean) * rstd * gamma + beta) into the activation grid (storage dtype, its own row geometry)
-template <typename T>
+template <class W, typename T>
 __global__ __launch_bounds__(256) void stem_apply_kernel(StemConv p, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ out, Grid go) {
-    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];
-    __shared__ __attribute__((aligned(16))) float xs[MAX_XS];
-    const int cqn = p.Cout / 4, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn;
-    stage_weights(p, wl);
+    STEM_SHARED
     const f32x4 mu = *(const f32x4*)(stats + cq * 4), rs = *(const f32x4*)(stats + p.Cout + cq * 4);
     const f32x4 ga = *(const f32x4*)(gamma + cq * 4), be = *(const f32x4*)(beta + cq * 4);
     const f32x4 k = rs * ga;
-    const int ncol = p.gx.B * p.Wo;
-    for (int q = blockIdx.x; q < ncol; q += gridDim.x) {
-        const int b = q / p.Wo, wo = q % p.Wo;
-        __syncthreads();
-        stage_columns(p, b, wo, xs);
-        __syncthreads();
-        for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
-            f32x4 acc[R];
-            conv_rows(p, wl, xs, cq, ho0, acc);
+    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int b, int wo, int ho0, f32x4* acc, const float*) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (ho0 + r < p.Ho) {
-                    f32x4 o = (acc[r] - mu) * k + be;
+        for (int r = 0; r < R; ++r)
+            if (ho0 + r < p.Ho) {
+                f32x4 o = (acc[r] - mu) * k + be;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = relu_f(o[e]);
-                    store4(out + grid_off(go, b, wo, ho0 + r) + cq * 4, o);
-                }
-        }
-    }
+                for (int e = 0; e < 4; ++e) o[e] = relu_f(o[e]);
+                store4(out + grid_off(go, b, wo, ho0 + r) + cq * 4, o);
+            }
+    });
 }
 
 // ---- backward pass 1: partial sums of g * xhat and g, g = da * (a > 0);  slabs[blk][2][Cout]
-template <typename T>
+template <class W, typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(StemConv p, const float* __restrict__ stats, const T* __restrict__ da,
                                                               const T* __restrict__ a, Grid ga_, float* __restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];
-    __shared__ __attribute__((aligned(16))) float xs[MAX_XS];
+    STEM_SHARED
     __shared__ __attribute__((aligned(16))) float red[2048];
-    const int cqn = p.Cout / 4, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn;
-    stage_weights(p, wl);
     const f32x4 mu = *(const f32x4*)(stats + cq * 4), rs = *(const f32x4*)(stats + p.Cout + cq * 4);
     f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const int ncol = p.gx.B * p.Wo;
-    for (int q = blockIdx.x; q < ncol; q += gridDim.x) {
-        const int b = q / p.Wo, wo = q % p.Wo;
-        __syncthreads();
-        stage_columns(p, b, wo, xs);
-        __syncthreads();
-        for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
-            f32x4 g4[R], a4[R];
+    Raw4<T> gr[R], ar[R];
+    auto pre = [&](int b, int wo, int ho0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
-                g4[r] = load4(da + o);
-                a4[r] = load4(a + o);
-            }
-            f32x4 acc[R];
-            conv_rows(p, wl, xs, cq, ho0, acc);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (ho0 + r < p.Ho) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float g = a4[r][e] > 0.f ? g4[r][e] : 0.f;
-                        s[0][e] += g * (acc[r][e] - mu[e]) * rs[e];
-                        s[1][e] += g;
-                    }
-                }
+        for (int r = 0; r < R; ++r) {
+            const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
+            gr[r].load(da + o);
+            ar[r].load(a + o);
         }
-    }
-    __syncthreads();
+    };
+    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, f32x4* acc, const float*) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (ho0 + r < p.Ho) {
+                const f32x4 g4 = gr[r].get(), a4 = ar[r].get();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = a4[e] > 0.f ? g4[e] : 0.f;
+                    s[0][e] += g * (acc[r][e] - mu[e]) * rs[e];
+                    s[1][e] += g;
+                }
+            }
+    });
     reduce_quads<2>(s, red, cqn, cq, rg, nrg);
     if (rg == 0) {
         *(f32x4*)(slabs + (long long)blockIdx.x * 2 * p.Cout + cq * 4) = s[0];
@@ -215,20 +343,17 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(StemConv p, const 
 
 // ---- backward pass 2: dy = gamma rstd (g - dbeta / n - xhat dgamma / n) formed per position and contracted with the input window at
 // once: slabs[blk][co][t] partial sums of dy[co] * x[tap t]  (the convolution's weight gradient in the reference's layout).
-// The Cin * kh * kw accumulators per channel live in registers, so the window shape is a template parameter (the loops over taps
-// unroll and every accumulator has a fixed register).
-template <typename T, int CIN, int KH, int KW>
+// The Cin * kh * kw accumulators per channel live in registers: compile-time window shapes only.
+template <class W, typename T>
 __global__ __launch_bounds__(256) void stem_bwd_wgrad_kernel(StemConv p, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                              float inv_count, const T* __restrict__ da, const T* __restrict__ a, Grid ga_,
                                                              float* __restrict__ slabs) {
-    constexpr int TAPS = CIN * KH * KW;
-    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];
-    __shared__ __attribute__((aligned(16))) float xs[MAX_XS];
+    static_assert(W::FIXED, "the weight-gradient kernel needs a compile-time window shape");
+    constexpr int TAPS = W::T;
+    STEM_SHARED
     __shared__ __attribute__((aligned(16))) float red[4096];          // one chunk of 4 taps at a time: [nrg][4][Cout]
-    const int cqn = p.Cout / 4, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn;
-    const int colf = (p.gx.H + 2 * p.ph) * CIN;
-    stage_weights(p, wl);
+    const int Cin = W::cin(p), KH = W::kh(p), KW = W::kw(p), SH = W::sh(p), cs = col_stride<W>(p);
     const f32x4 mu = *(const f32x4*)(stats + cq * 4), rs = *(const f32x4*)(stats + p.Cout + cq * 4);
     f32x4 k1, k2, k3;
 #pragma unroll
@@ -238,53 +363,47 @@ __global__ __launch_bounds__(256) void stem_bwd_wgrad_kernel(StemConv p, const f
         k2[e] = k1[e] * dbeta[c] * inv_count;
         k3[e] = k1[e] * rs[e] * dgamma[c] * inv_count;
     }
-    f32x4 dw[TAPS];
+    f32x4 dwa[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) dw[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ncol = p.gx.B * p.Wo;
-    for (int q = blockIdx.x; q < ncol; q += gridDim.x) {
-        const int b = q / p.Wo, wo = q % p.Wo;
-        __syncthreads();
-        stage_columns(p, b, wo, xs);
-        __syncthreads();
-        for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
-            f32x4 g4[R], a4[R];
+    for (int t = 0; t < TAPS; ++t) dwa[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Raw4<T> gr[R], ar[R];
+    auto pre = [&](int b, int wo, int ho0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
-                g4[r] = load4(da + o);
-                a4[r] = load4(a + o);
+        for (int r = 0; r < R; ++r) {
+            const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
+            gr[r].load(da + o);
+            ar[r].load(a + o);
+        }
+    };
+    stem_columns<W, false>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, f32x4* acc, const float* xs) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = ho0 + r < p.Ho;
+            const f32x4 g4 = gr[r].get(), a4 = ar[r].get();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = a4[e] > 0.f ? g4[e] : 0.f;
+                acc[r][e] = ok ? k1[e] * g - k2[e] - k3[e] * (acc[r][e] - mu[e]) : 0.f;      // dy
             }
-            f32x4 acc[R];
-            conv_rows(p, wl, xs, cq, ho0, acc);
-            int rowbase[R];
+        }
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
+        for (int dw = 0; dw < KW; ++dw) {
+            float xin[W::WROWS];
+            load_window<W::WROWS>(xs + dw * cs + ho0 * SH * Cin, xin);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g = a4[r][e] > 0.f ? g4[r][e] : 0.f;
-                    acc[r][e] = (ho0 + r < p.Ho) ? k1[e] * g - k2[e] - k3[e] * (acc[r][e] - mu[e]) : 0.f;      // dy
-                }
-                rowbase[r] = min(ho0 + r, p.Ho - 1) * p.sh * CIN;
-            }
-#pragma unroll
-            for (int c = 0; c < CIN; ++c)
+            for (int c = 0; c < Cin; ++c)
 #pragma unroll
                 for (int dh = 0; dh < KH; ++dh)
 #pragma unroll
-                    for (int dwi = 0; dwi < KW; ++dwi) {
-                        const float* col = xs + dwi * colf + dh * CIN + c;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) dw[(c * KH + dh) * KW + dwi] += acc[r] * col[rowbase[r]];
-                    }
+                    for (int r = 0; r < R; ++r) dwa[(c * KH + dh) * KW + dw] += acc[r] * xin[(r * SH + dh) * Cin + c];
         }
-    }
+    });
     // reduction over the row groups, 4 taps at a time (fixed order)
     for (int t0 = 0; t0 < TAPS; t0 += 4) {
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
-            if (t >= t0 && t < t0 + 4) *(f32x4*)(red + (rg * 4 + (t - t0)) * p.Cout + cq * 4) = dw[t];
+            if (t >= t0 && t < t0 + 4) *(f32x4*)(red + (rg * 4 + (t - t0)) * p.Cout + cq * 4) = dwa[t];
         __syncthreads();
         for (int i = threadIdx.x; i < 4 * p.Cout; i += 256) {
             const int u = i / p.Cout, co = i - u * p.Cout;
@@ -297,75 +416,127 @@ __global__ __launch_bounds__(256) void stem_bwd_wgrad_kernel(StemConv p, const f
 }
 
 // ---- residual branch of the first block: out = act(main + W_r xp(w + ow, h + oh)), xp the pooled float32 input (Cin channels),
-// W_r [Cout][Cin] the 1x1 projection (no bias, no padding).
-template <typename T>
+// W_r [Cout][Cin] the 1x1 projection (no bias, no padding).  A thread owns CPT consecutive channels (16 bytes of the storage type)
+// of one position and keeps their Cin weights in registers while it walks the grid (the walk's stride is a multiple of the channel
+// groups per position).
+template <typename T> struct Cpt { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T, int N>
+__device__ __forceinline__ void loadn(const T* src, float (&v)[N]) {
+    if constexpr (sizeof(T) == 2) {
+        const uint4 u = *(const uint4*)src;
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+    } else {
+        const f32x4 f = *(const f32x4*)src;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f[e];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void storen(T* dst, const float (&v)[N]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        *(bf16x8*)dst = o;
+    } else {
+        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <typename T, int CIN>
 __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restrict__ main_, Grid gm, const float* __restrict__ xp, Grid gp,
                                                                 const float* __restrict__ wr, T* __restrict__ out, Grid go, int oh, int ow,
                                                                 int relu) {
-    const int c4n = gm.C / 4, Cin = gp.C;
-    const unsigned total = (unsigned)((long long)gm.B * gm.W * gm.H * c4n);
-    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-        const int c4 = (int)(idx % c4n);
-        const int h = (int)((idx / c4n) % gm.H);
-        const unsigned col = idx / (unsigned)(c4n * gm.H);
-        const int w = (int)(col % gm.W), b = (int)(col / gm.W);
-        f32x4 v = load4(main_ + grid_off(gm, b, w, h) + c4 * 4);
-        const float* xr = xp + grid_off(gp, b, w + ow, h + oh);
-        for (int ci = 0; ci < Cin; ++ci) {
+    constexpr int N = Cpt<T>::N;
+    const int cgn = gm.C / N;
+    const unsigned total = (unsigned)((long long)gm.B * gm.W * gm.H * cgn);
+    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    const int cg = (int)(first % (unsigned)cgn);          // the launcher makes gridDim.x * 256 a multiple of cgn
+    float w[N][CIN];
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) w[e][ci] = wr[(cg * N + e) * CIN + ci];
+    for (unsigned idx = first; idx < total; idx += gridDim.x * 256u) {
+        const unsigned pos = idx / (unsigned)cgn;
+        const int h = (int)(pos % (unsigned)gm.H);
+        const unsigned col = pos / (unsigned)gm.H;
+        const int wq = (int)(col % (unsigned)gm.W), b = (int)(col / (unsigned)gm.W);
+        float v[N];
+        loadn<T, N>(main_ + grid_off(gm, b, wq, h) + cg * N, v);
+        const float* xr = xp + grid_off(gp, b, wq + ow, h + oh);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
             const float xv = xr[ci];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += wr[(c4 * 4 + e) * Cin + ci] * xv;
+            for (int e = 0; e < N; ++e) v[e] += w[e][ci] * xv;
         }
         if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+            for (int e = 0; e < N; ++e) v[e] = relu_f(v[e]);
         }
-        store4(out + grid_off(go, b, w, h) + c4 * 4, v);
+        storen<T, N>(out + grid_off(go, b, wq, h) + cg * N, v);
     }
 }
 
 // backward: g = dout * (out > 0 if relu);  dmain = g;  slabs[blk][co][ci] partial sums of g[co] * xp[ci]  (gradient of W_r)
-template <typename T>
+template <typename T, int CIN>
 __global__ __launch_bounds__(256) void stem_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, Grid go,
                                                                 T* __restrict__ dmain, Grid gm, const float* __restrict__ xp, Grid gp,
                                                                 float* __restrict__ slabs, int oh, int ow, int relu, long long cols_per_block) {
-    __shared__ __attribute__((aligned(16))) float red[4096];
-    const int C = gm.C, c4n = C / 4, Cin = gp.C;          // Cin <= 4
-    const int cg = threadIdx.x % c4n, rp = threadIdx.x / c4n, nrp = 256 / c4n;
+    constexpr int N = Cpt<T>::N;
+    __shared__ __attribute__((aligned(16))) float red[8192];          // [nrp][CIN][C]: 256 / (C/N) * CIN * C <= 8192
+    const int C = gm.C, cgn = C / N;
+    const int cg = threadIdx.x % cgn, rp = threadIdx.x / cgn, nrp = 256 / cgn;
     const long long ncol = (long long)gm.B * gm.W;
     const long long q0 = (long long)blockIdx.x * cols_per_block, q1 = min(ncol, q0 + cols_per_block);
-    f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float s[CIN][N];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[ci][e] = 0.f;
     if (rp < nrp && q0 < q1) {
         const unsigned rend = (unsigned)(q1 * gm.H);
         for (unsigned r = (unsigned)(q0 * gm.H) + rp; r < rend; r += nrp) {
             const unsigned q = r / (unsigned)gm.H;
             const int h = (int)(r - q * gm.H), w = (int)(q % gm.W), b = (int)(q / gm.W);
-            const long long oo = grid_off(go, b, w, h) + cg * 4;
-            f32x4 g = load4(dout + oo);
+            const long long oo = grid_off(go, b, w, h) + cg * N;
+            float g[N];
+            loadn<T, N>(dout + oo, g);
             if (relu) {
-                const f32x4 y = load4(out + oo);
+                float y[N];
+                loadn<T, N>(out + oo, y);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+                for (int e = 0; e < N; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
             }
-            store4(dmain + grid_off(gm, b, w, h) + cg * 4, g);
+            storen<T, N>(dmain + grid_off(gm, b, w, h) + cg * N, g);
             const float* xr = xp + grid_off(gp, b, w + ow, h + oh);
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-                if (ci < Cin) s[ci] += g * xr[ci];
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float xv = xr[ci];
+#pragma unroll
+                for (int e = 0; e < N; ++e) s[ci][e] += g[e] * xv;
+            }
         }
     }
-    // red[rp][ci][C]
     if (rp < nrp) {
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-            if (ci < Cin) *(f32x4*)(red + (rp * Cin + ci) * C + cg * 4) = s[ci];
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int e = 0; e < N; ++e) red[(rp * CIN + ci) * C + cg * N + e] = s[ci][e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < Cin * C; i += 256) {
+    for (int i = threadIdx.x; i < CIN * C; i += 256) {
         const int ci = i / C, co = i - ci * C;
         float acc = 0.f;
-        for (int qg = 0; qg < nrp; ++qg) acc += red[(qg * Cin + ci) * C + co];
-        slabs[(long long)blockIdx.x * C * Cin + co * Cin + ci] = acc;
+        for (int qg = 0; qg < nrp; ++qg) acc += red[(qg * CIN + ci) * C + co];
+        slabs[(long long)blockIdx.x * C * CIN + co * CIN + ci] = acc;
     }
 }
 
@@ -375,12 +546,23 @@ bool grid_ok(const int* g) {
 }
 Grid mk(const int* g) { return Grid{g[0], g[1], g[2], g[3], g[4], g[5]}; }
 
+// window shapes (Cin, kh, kw, stride in h) with kernels
+#define STEM_SHAPES(X) X(2, 3, 3, 2) X(1, 3, 3, 2) X(2, 3, 3, 1) X(1, 3, 3, 1) X(1, 5, 1, 1) X(2, 5, 1, 1) X(1, 2, 2, 1) X(2, 2, 2, 1)
+
+bool shape_ok(int cin, int kh, int kw, int sh) {
+#define X(CI, KH, KW, SH) if (cin == CI && kh == KH && kw == KW && sh == SH) return true;
+    STEM_SHAPES(X)
+#undef X
+    return false;
+}
+
 bool stem_ok(const int* gx, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo) {
     if (!grid_ok(gx) || gx[4] != 0) return false;
-    const int Cin = gx[5], T = Cin * kh * kw;
-    if (Cin > 4 || Cout % 4 || Cout < 4 || Cout > 64 || 256 % (Cout / 4)) return false;
-    if (kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0) return false;
-    if (T * Cout > MAX_WL || kw * (gx[2] + 2 * ph) * Cin > MAX_XS) return false;
+    const int Cin = gx[5];
+    if (!shape_ok(Cin, kh, kw, sh)) return false;
+    if (Cout % 4 || Cout < 4 || Cout > 64 || 256 % (Cout / 4)) return false;
+    if (sw < 1 || ph < 0 || pw < 0) return false;
+    if (Cin * kh * kw * Cout > MAX_WL || kw * (((gx[2] + 2 * ph + R * sh) * Cin + 3) & ~3) > MAX_XS || kw * (gx[2] + 2 * ph) * Cin > MAXPF * 256) return false;
     if (Ho != (gx[2] + 2 * ph - kh) / sh + 1 || Wo != (gx[1] + 2 * pw - kw) / sw + 1 || Ho < 1 || Wo < 1) return false;
     return true;
 }
@@ -395,12 +577,34 @@ StemConv mkconv(const float* x, const int* gx, const float* w, const float* bias
 
 }  // namespace
 
+int launch_stem_supported(int cin, int cout, int kh, int kw, int sh, int hin, int ph) {
+    if (cout % 4 || cout < 4 || cout > 64 || 256 % (cout / 4) || !shape_ok(cin, kh, kw, sh)) return 0;
+    if (cin * kh * kw * cout > MAX_WL || kw * (((hin + 2 * ph + R * sh) * cin + 3) & ~3) > MAX_XS || kw * (hin + 2 * ph) * cin > MAXPF * 256) return 0;
+    return 1;
+}
+
 int launch_stem_stats(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,
                       int pw, int Ho, int Wo, float* slabs, int nblocks, hipStream_t st) {
     if (!stem_ok(gx, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo) || nblocks <= 0) return CPC_EINVAL;
-    hipLaunchKernelGGL(stem_stats_kernel, dim3(nblocks), dim3(256), 0, st, mkconv(x, gx, w, bias, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo), slabs);
+    const StemConv p = mkconv(x, gx, w, bias, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo);
+    const int cin = gx[5];
+#define X(CI, KH, KW, SH)                                                                                                  \
+    if (cin == CI && kh == KH && kw == KW && sh == SH)                                                                     \
+        hipLaunchKernelGGL((stem_stats_kernel<Win<CI, KH, KW, SH>>), dim3(nblocks), dim3(256), 0, st, p, slabs);
+    STEM_SHAPES(X)
+#undef X
     CPC_CHECK_LAUNCH();
     return CPC_OK;
+}
+
+template <typename T>
+static void stem_apply_t(const StemConv& p, int cin, const float* stats, const float* gamma, const float* beta, T* out, const Grid& go,
+                         int nblocks, hipStream_t st) {
+#define X(CI, KH, KW, SH)                                                                                                  \
+    if (cin == CI && p.kh == KH && p.kw == KW && p.sh == SH)                                                               \
+        hipLaunchKernelGGL((stem_apply_kernel<Win<CI, KH, KW, SH>, T>), dim3(nblocks), dim3(256), 0, st, p, stats, gamma, beta, out, go);
+    STEM_SHAPES(X)
+#undef X
 }
 
 int launch_stem_apply(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw, int ph,
@@ -410,13 +614,23 @@ int launch_stem_apply(const float* x, const int* gx, const float* w, const float
     if (go[0] != gx[0] || go[1] != Wo || go[2] != Ho || go[5] != Cout) return CPC_EINVAL;
     const StemConv p = mkconv(x, gx, w, bias, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo);
     if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((stem_apply_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, p, stats, gamma, beta, (bf16_t*)out, mk(go));
+        stem_apply_t<bf16_t>(p, gx[5], stats, gamma, beta, (bf16_t*)out, mk(go), nblocks, st);
     else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((stem_apply_kernel<float>), dim3(nblocks), dim3(256), 0, st, p, stats, gamma, beta, (float*)out, mk(go));
+        stem_apply_t<float>(p, gx[5], stats, gamma, beta, (float*)out, mk(go), nblocks, st);
     else
         return CPC_EINVAL;
     CPC_CHECK_LAUNCH();
     return CPC_OK;
+}
+
+template <typename T>
+static void stem_bwd_reduce_t(const StemConv& p, int cin, const float* stats, const T* da, const T* a, const Grid& ga, float* slabs,
+                              int nblocks, hipStream_t st) {
+#define X(CI, KH, KW, SH)                                                                                                  \
+    if (cin == CI && p.kh == KH && p.kw == KW && p.sh == SH)                                                               \
+        hipLaunchKernelGGL((stem_bwd_reduce_kernel<Win<CI, KH, KW, SH>, T>), dim3(nblocks), dim3(256), 0, st, p, stats, da, a, ga, slabs);
+    STEM_SHAPES(X)
+#undef X
 }
 
 int launch_stem_bwd_reduce(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw,
@@ -426,45 +640,24 @@ int launch_stem_bwd_reduce(const float* x, const int* gx, const float* w, const 
     if (ga[0] != gx[0] || ga[1] != Wo || ga[2] != Ho || ga[5] != Cout) return CPC_EINVAL;
     const StemConv p = mkconv(x, gx, w, bias, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo);
     if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((stem_bwd_reduce_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, p, stats, (const bf16_t*)da, (const bf16_t*)a, mk(ga), slabs);
+        stem_bwd_reduce_t<bf16_t>(p, gx[5], stats, (const bf16_t*)da, (const bf16_t*)a, mk(ga), slabs, nblocks, st);
     else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((stem_bwd_reduce_kernel<float>), dim3(nblocks), dim3(256), 0, st, p, stats, (const float*)da, (const float*)a, mk(ga), slabs);
+        stem_bwd_reduce_t<float>(p, gx[5], stats, (const float*)da, (const float*)a, mk(ga), slabs, nblocks, st);
     else
         return CPC_EINVAL;
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
-// window shapes with a register-resident weight-gradient kernel: (Cin, kh, kw)
-static bool stem_wgrad_shape_ok(int cin, int kh, int kw) {
-    return (cin == 2 && kh == 3 && kw == 3) || (cin == 1 && kh == 3 && kw == 3) || (cin == 1 && kh == 5 && kw == 1) ||
-           (cin == 2 && kh == 5 && kw == 1) || (cin == 1 && kh == 2 && kw == 2) || (cin == 2 && kh == 2 && kw == 2);
-}
-
 template <typename T>
-static int stem_wgrad_dispatch(int cin, int kh, int kw, const StemConv& p, const float* stats, const float* gamma, const float* dgamma,
-                               const float* dbeta, float inv, const T* da, const T* a, const Grid& ga, float* slabs, int nblocks,
-                               hipStream_t st) {
-#define STEM_CASE(CI, KH, KW)                                                                                                          \
-    if (cin == CI && kh == KH && kw == KW) {                                                                                          \
-        hipLaunchKernelGGL((stem_bwd_wgrad_kernel<T, CI, KH, KW>), dim3(nblocks), dim3(256), 0, st, p, stats, gamma, dgamma, dbeta, inv, da, \
-                           a, ga, slabs);                                                                                             \
-        return CPC_OK;                                                                                                                \
-    }
-    STEM_CASE(2, 3, 3)
-    STEM_CASE(1, 3, 3)
-    STEM_CASE(1, 5, 1)
-    STEM_CASE(2, 5, 1)
-    STEM_CASE(1, 2, 2)
-    STEM_CASE(2, 2, 2)
-#undef STEM_CASE
-    return CPC_EINVAL;
-}
-
-int launch_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph) {
-    if (cin < 1 || cin > 4 || cout % 4 || cout < 4 || cout > 64 || 256 % (cout / 4)) return 0;
-    if (cin * kh * kw * cout > MAX_WL || kw * (hin + 2 * ph) * cin > MAX_XS) return 0;
-    return stem_wgrad_shape_ok(cin, kh, kw) ? 1 : 0;
+static void stem_bwd_wgrad_t(const StemConv& p, int cin, const float* stats, const float* gamma, const float* dgamma, const float* dbeta,
+                             float inv, const T* da, const T* a, const Grid& ga, float* slabs, int nblocks, hipStream_t st) {
+#define X(CI, KH, KW, SH)                                                                                                  \
+    if (cin == CI && p.kh == KH && p.kw == KW && p.sh == SH)                                                               \
+        hipLaunchKernelGGL((stem_bwd_wgrad_kernel<Win<CI, KH, KW, SH>, T>), dim3(nblocks), dim3(256), 0, st, p, stats, gamma, dgamma, dbeta, \
+                           inv, da, a, ga, slabs);
+    STEM_SHAPES(X)
+#undef X
 }
 
 int launch_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const float* bias, int Cout, int kh, int kw, int sh, int sw,
@@ -472,54 +665,54 @@ int launch_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const f
                           double count, const void* da, const void* a, const int* ga, float* slabs, int nblocks, int dtype, hipStream_t st) {
     if (!stem_ok(gx, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo) || !grid_ok(ga) || nblocks <= 0 || count <= 0) return CPC_EINVAL;
     if (ga[0] != gx[0] || ga[1] != Wo || ga[2] != Ho || ga[5] != Cout) return CPC_EINVAL;
-    if (!stem_wgrad_shape_ok(gx[5], kh, kw)) return CPC_EINVAL;
     const StemConv p = mkconv(x, gx, w, bias, Cout, kh, kw, sh, sw, ph, pw, Ho, Wo);
     const float inv = (float)(1.0 / count);
-    int rc;
     if (dtype == CPC_DTYPE_BF16)
-        rc = stem_wgrad_dispatch<bf16_t>(gx[5], kh, kw, p, stats, gamma, dgamma, dbeta, inv, (const bf16_t*)da, (const bf16_t*)a, mk(ga), slabs, nblocks, st);
+        stem_bwd_wgrad_t<bf16_t>(p, gx[5], stats, gamma, dgamma, dbeta, inv, (const bf16_t*)da, (const bf16_t*)a, mk(ga), slabs, nblocks, st);
     else if (dtype == CPC_DTYPE_F32)
-        rc = stem_wgrad_dispatch<float>(gx[5], kh, kw, p, stats, gamma, dgamma, dbeta, inv, (const float*)da, (const float*)a, mk(ga), slabs, nblocks, st);
+        stem_bwd_wgrad_t<float>(p, gx[5], stats, gamma, dgamma, dbeta, inv, (const float*)da, (const float*)a, mk(ga), slabs, nblocks, st);
     else
         return CPC_EINVAL;
-    if (rc != CPC_OK) return rc;
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
-static bool residual_ok(const int* gm, const int* gp, const int* go, int oh, int ow) {
+static bool residual_ok(const int* gm, const int* gp, const int* go, int oh, int ow, int dtype) {
     if (!grid_ok(gm) || !grid_ok(gp) || !grid_ok(go)) return false;
     if (gm[0] != go[0] || gm[1] != go[1] || gm[2] != go[2] || gm[5] != go[5] || gp[0] != gm[0]) return false;
-    if (gm[5] % 4 || gm[5] > 1024 || 256 % (gm[5] / 4) || gp[5] > 4 || oh < 0 || ow < 0) return false;
+    const int n = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if (gm[5] % n || gm[5] / n > 256 || 256 % (gm[5] / n) || gp[5] < 1 || gp[5] > 2 || oh < 0 || ow < 0) return false;
     return gm[1] + ow <= gp[1] && gm[2] + oh <= gp[2];
 }
 
 int launch_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                              int oh, int ow, int relu, int dtype, hipStream_t st) {
-    if (!residual_ok(gm, gp, go, oh, ow)) return CPC_EINVAL;
-    const int nb = (int)std::min<long long>(8192, ((long long)gm[0] * gm[1] * gm[2] * (gm[5] / 4) + 255) / 256);
-    if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((stem_residual_add_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)main_, mk(gm), xp, mk(gp), wr, (bf16_t*)out, mk(go), oh, ow, relu);
-    else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((stem_residual_add_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)main_, mk(gm), xp, mk(gp), wr, (float*)out, mk(go), oh, ow, relu);
-    else
-        return CPC_EINVAL;
+    if (!residual_ok(gm, gp, go, oh, ow, dtype)) return CPC_EINVAL;
+    const int n = dtype == CPC_DTYPE_BF16 ? 8 : 4, cgn = gm[5] / n;
+    const long long total = (long long)gm[0] * gm[1] * gm[2] * cgn;
+    // the walk's stride (gridDim.x * 256) is a multiple of cgn (cgn divides 256), so a thread keeps its channel group
+    const int nb = (int)std::min<long long>(8192, (total + 255) / 256);
+#define RES_ADD(T, CI) hipLaunchKernelGGL((stem_residual_add_kernel<T, CI>), dim3(nb), dim3(256), 0, st, (const T*)main_, mk(gm), xp, mk(gp), wr, (T*)out, mk(go), oh, ow, relu)
+    if (dtype == CPC_DTYPE_BF16) { if (gp[5] == 1) RES_ADD(bf16_t, 1); else RES_ADD(bf16_t, 2); }
+    else if (dtype == CPC_DTYPE_F32) { if (gp[5] == 1) RES_ADD(float, 1); else RES_ADD(float, 2); }
+    else return CPC_EINVAL;
+#undef RES_ADD
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
 
 int launch_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
                              float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t st) {
-    if (!residual_ok(gm, gp, go, oh, ow) || nblocks <= 0) return CPC_EINVAL;
-    if (256 / (gm[5] / 4) * gp[5] * gm[5] > 4096) return CPC_EINVAL;
+    if (!residual_ok(gm, gp, go, oh, ow, dtype) || nblocks <= 0) return CPC_EINVAL;
+    const int n = dtype == CPC_DTYPE_BF16 ? 8 : 4;
+    if (256 / (gm[5] / n) * gp[5] * gm[5] > 8192) return CPC_EINVAL;
     const long long ncol = (long long)gm[0] * gm[1];
     const long long cpb = (ncol + nblocks - 1) / nblocks;
-    if (dtype == CPC_DTYPE_BF16)
-        hipLaunchKernelGGL((stem_residual_bwd_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, mk(go), (bf16_t*)dmain, mk(gm), xp, mk(gp), slabs, oh, ow, relu, cpb);
-    else if (dtype == CPC_DTYPE_F32)
-        hipLaunchKernelGGL((stem_residual_bwd_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const float*)dout, (const float*)out, mk(go), (float*)dmain, mk(gm), xp, mk(gp), slabs, oh, ow, relu, cpb);
-    else
-        return CPC_EINVAL;
+#define RES_BWD(T, CI) hipLaunchKernelGGL((stem_residual_bwd_kernel<T, CI>), dim3(nblocks), dim3(256), 0, st, (const T*)dout, (const T*)out, mk(go), (T*)dmain, mk(gm), xp, mk(gp), slabs, oh, ow, relu, cpb)
+    if (dtype == CPC_DTYPE_BF16) { if (gp[5] == 1) RES_BWD(bf16_t, 1); else RES_BWD(bf16_t, 2); }
+    else if (dtype == CPC_DTYPE_F32) { if (gp[5] == 1) RES_BWD(float, 1); else RES_BWD(float, 2); }
+    else return CPC_EINVAL;
+#undef RES_BWD
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

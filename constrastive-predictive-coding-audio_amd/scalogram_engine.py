@@ -564,7 +564,8 @@ class _Stem:
         self.taps = gin.C * kh * kw
         self.conv = (C.c_int * 9)(self.C, kh, kw, sh, sw, ph, pw, Ho, Wo)
         self.count = float(gin.B * Wo * Ho)
-        self.nb = max(1, min(2048, gin.B * Wo))
+        # two workgroups per CU stay resident (registers): one round of them, each walking its share of the output columns
+        self.nb = max(1, min(512, gin.B * Wo))
         self.slab = self.nb * max(2 * self.C, self.C * self.taps)
         self.stats = torch.zeros(2, self.C, device=eng.device, dtype=torch.float32)
         self.zeros = torch.zeros(self.C, device=eng.device, dtype=torch.float32)
@@ -592,7 +593,7 @@ class _Stem:
             self.stats[0].copy_(mod.running_mean)
             self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
         _hip.call("cpc_stem_apply", *self._args(), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]),
-                  self.a.ptr(), _desc(self.a, self.a.desc), min(4096, self.gin.B * int(self.conv[8])), e.code)
+                  self.a.ptr(), _desc(self.a, self.a.desc), self.nb, e.code)
 
     def backward(self, da: Grid):
         """da: gradient of the activation (before its ReLU mask) -> BatchNorm scale / shift gradients and the convolution's weight
@@ -683,7 +684,7 @@ class _Block:
         self.stem = None
         if (in_f32 and first and has_bn and self.pool1 == 1 and not cfg.get('separable') and gin.top == 0 and
                 os.environ.get("CPC_STEM", "1") != "0" and
-                _hip.lib().cpc_stem_supported(gin.C, cfg['hidden_channels'], k1[0], k1[1], gin.H, p1) == 1):
+                _hip.lib().cpc_stem_supported(gin.C, cfg['hidden_channels'], k1[0], k1[1], s1, gin.H, p1) == 1):
             self.a_a = Grid(gin.B, Wa1, Ha1, cfg['hidden_channels'], dev, dt, **a_geom)
             self.stem = _Stem(eng, f"{pre}main_modules.{i1}.weight", f"{pre}main_modules.{i1}.bias" if bias else None, mm[i1],
                               f"{pre}main_modules.{blk.index['bn_1']}", mm[blk.index['bn_1']], gin, self.a_a, Hc, Wc)
@@ -744,8 +745,8 @@ class _Block:
                 src, src_f32 = self.rp, in_f32
             self.stem_res = None
             if ('res_conv' in blk.index and src_f32 and first and blk.residual_modules[blk.index['res_conv']].padding == (0, 0) and
-                    src.C <= 4 and os.environ.get("CPC_STEM", "1") != "0" and cfg['out_channels'] % 4 == 0 and
-                    256 % (cfg['out_channels'] // 4) == 0 and (256 // (cfg['out_channels'] // 4)) * src.C * cfg['out_channels'] <= 4096):
+                    src.C <= 2 and os.environ.get("CPC_STEM", "1") != "0" and cfg['out_channels'] % 8 == 0 and
+                    256 % (cfg['out_channels'] // 8) == 0 and cfg['out_channels'] <= 128):
                 ri = blk.index['res_conv']
                 self.stem_res = f"{pre}residual_modules.{ri}.weight"
                 self.res = src                      # 1x1, no padding: the projected grid would have the pooled input's extents

@@ -315,8 +315,9 @@ int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream);
  * every pass recomputes it from the input columns (bit-identically), so the 32-wide float32 tensor of 5 M positions that im2col + GEMM
  * moved three times per direction never exists.  x f32 grid gx = {B, W, H, Ha, top = 0, Cin}; w f32 [Cout][Cin][kh][kw] and bias
  * f32 [Cout] (or NULL) are the reference's parameters; conv = {Cout, kh, kw, sh, sw, ph, pw, Ho, Wo} (int[9]).
- *   cpc_stem_supported : 1 when the window shape / channel counts have kernels (Cout a multiple of 4 up to 64 dividing 1024,
- *                        (Cin, kh, kw) one of (2,3,3) (1,3,3) (1,5,1) (2,5,1) (1,2,2) (2,2,2)), else 0 (callers take the im2col route)
+ *   cpc_stem_supported : 1 when the window shape / channel counts have kernels (Cout a multiple of 4 up to 64 dividing 1024;
+ *                        (Cin, kh, kw, sh) one of (1|2, 3,3, 1|2), (1|2, 5,1, 1), (1|2, 2,2, 1): compile-time shapes, the weights and a
+ *                        lane's input window live in registers), else 0 (callers take the im2col route)
  *   cpc_stem_stats     : slabs f32 [nblocks][2][Cout] partial (sum y, sum y^2)                       -> cpc_bn_finalize
  *   cpc_stem_apply     : out (T grid go, any row geometry) = relu((y - mean) rstd gamma + beta)
  *   cpc_stem_bwd_reduce: slabs f32 [nblocks][2][Cout] partial (sum g xhat, sum g), g = da * (a > 0) -> cpc_reduce_slabs (dgamma, dbeta)
@@ -324,10 +325,10 @@ int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream);
  *                        formed per position and never stored -> cpc_reduce_slabs gives d loss / d w in the reference's layout.
  *                        (The bias gradient of a convolution in front of a train-mode BatchNorm is exactly zero.)
  * Residual branch of the same block (scalogram_model.py:434-446, :462-472): xp f32 grid gp = the max-pooled input (cpc_maxpool2d_fwd),
- * wr f32 [Cout][Cin] the 1x1 projection (no bias, padding 0):
+ * wr f32 [Cout][Cin] the 1x1 projection (no bias, padding 0; Cin 1 or 2, Cout a multiple of 8 (bf16) / 4 (f32) dividing 2048 / 1024):
  *   cpc_stem_residual_add: out = act(main + wr xp(w + ow, h + oh))
  *   cpc_stem_residual_bwd: g = dout * (out > 0 if relu); dmain = g; slabs f32 [nblocks][Cout][Cin] partial sums of g (x) xp. */
-int cpc_stem_supported(int cin, int cout, int kh, int kw, int hin, int ph);
+int cpc_stem_supported(int cin, int cout, int kh, int kw, int sh, int hin, int ph);
 int cpc_stem_stats(const float* x, const int* gx, const float* w, const float* bias, const int* conv, float* slabs, int nblocks,
                    void* stream);
 int cpc_stem_apply(const float* x, const int* gx, const float* w, const float* bias, const int* conv, const float* stats,
