@@ -128,8 +128,46 @@ def score_gemm_figures(eng, launches=50):
         tf = flops / (us * 1e-6) / 1e12
         out[name] = {"shape": shape, "gflop": round(flops / 1e9, 3), "us_per_launch": round(us, 2), "achieved": round(tf, 1),
                      "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
-    out["note"] = "back-to-back launches (includes the launch-to-launch gap); one launch per train step in the product path"
+    out["note"] = ("back-to-back launches (includes the launch-to-launch gap); one launch per train step in the product path.  The north "
+                   "star's >= 50 % MFMA target is DEFINED on global_8gpu: at B = 256 one launch is 0.8 / 9.7 GFLOP on 256 CUs, i.e. bound by "
+                   "its prologue / epilogue latency, not by the matrix pipe")
+    out["global_8gpu"] = global_score_gemm(eng)
     return out
+
+
+def global_score_gemm(eng, launches=10):
+    """The score contraction at the size BASELINE configs[4] gives it under the reference's DataParallel semantics (global negatives,
+    score_over_all_timesteps=True: 8 ranks x 256 clips x 12 steps = 24 576 predictions against 24 576 targets, E = 512):
+    cpc_gemm_nt on 24 576 x 512 x 24 576, bf16 operands, f32 scores (2.4 GB) -- the launch engine.GlobalNegatives issues on every rank --
+    and the same product with storage-dtype output (what the gradient-side contractions read)."""
+    from cpc_audio_amd import _hip
+    R, E = 8 * eng.B * eng.K, eng.E
+    dev = eng.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = (torch.randn(R, E, generator=g) * 0.5).to(dev).to(eng.dt)
+    b = (torch.randn(R, E, generator=g) * 0.5).to(dev).to(eng.dt)
+    res = {"shape": f"{R} x {E} x {R}", "gflop": round(2.0 * R * R * E / 1e9, 1)}
+    for name, flags, odt in (("f32_scores", _hip.GEMM_OUT_F32, torch.float32), ("bf16_out", 0, eng.dt)):
+        c = torch.empty(R * R, device=dev, dtype=odt)
+        run = lambda: _hip.gemm_nt(_hip.ptr(a), _hip.ptr(b), _hip.ptr(c), R, R, E, E, E, R, eng.code, flags=flags)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        tf = 2.0 * R * R * E / (ms * 1e-3) / 1e12
+        out_gb = R * R * c.element_size() / 1e9
+        res[name] = {"ms_per_launch": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "output_gb": round(out_gb, 2),
+                     "output_tb_per_s": round(out_gb / ms, 2)}
+        del c
+    torch.cuda.empty_cache()
+    return res
 
 
 def trainer_loop_ms(model, B, L, device, steps=60, warmup=10):

@@ -1,6 +1,6 @@
 """Turns the raw rocprofv3 output of tools/collect_profiles.sh into the tracked summaries under profiles/.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r01 [workload]        (workload: cfg1 = default | scalogram | conv_ar | attention)
 
 Writes profiles/<tag>_kernel_stats.csv (copy of the --stats summary), profiles/<tag>_traffic.json (per-kernel HBM bytes
 per launch from the FETCH_SIZE / WRITE_SIZE passes) and profiles/traffic_latest.json (read by bench.py).
@@ -10,8 +10,11 @@ is the 0.956 GB layer-1 gradient: FETCH_SIZE reads 0.488 GB for it."""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload = sys.argv[2] if len(sys.argv) > 2 else "cfg1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+src = os.path.join(root, "gpurun_out", f"prof_{tag}" + ("" if workload == "cfg1" else f"_{workload}"))
+if workload != "cfg1":
+    tag = f"{tag}_{workload}"
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -21,7 +24,12 @@ def newest(pattern):
 
 
 stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
-shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_bench_b256_bf16.csv"))
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_bench_b256_bf16.csv" if workload == "cfg1" else f"{tag}_kernel_stats.csv"))
+try:          # the JSON line bench.py printed under the profiler (HIP-event figures of the same run)
+    line = [ln for ln in open(os.path.join(src, "stats.log")) if ln.startswith("{")][-1]
+    open(os.path.join(dst, f"{tag}_bench_line_under_rocprof.json"), "w").write(line)
+except (IndexError, FileNotFoundError):
+    pass
 
 
 def per_kernel(counter, sub):
@@ -54,6 +62,11 @@ try:
     json.dump(mf, open(os.path.join(dst, f"{tag}_mfma.json"), "w"), indent=1)
 except (ValueError, FileNotFoundError) as e:
     print("no mfma pass:", e)
+if workload != "cfg1":
+    top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:6]
+    for k, v in top:
+        print(f"{k[:110]:110s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch x {v['launches_sampled']}")
+    sys.exit(0)
 # the dominant kernel of bench.py's roofline object = the 256x256 bf16 -> bf16 NT GEMM in both epilogue forms (register epilogue:
 # conv forward; LDS-staged: data gradients), without the fused layer-1 variant (template flag C1, "...Lb1ELb1E...")
 dom = [k for k in out if "gemm_nt_fast_kernel" in k and "Li2ELi4ELi8ELi4E" in k and "DF16bDF16b" in k and "Li8ELi4ELb1ELb1E" not in k]
