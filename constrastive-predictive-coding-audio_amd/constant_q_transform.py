@@ -11,6 +11,7 @@ UNPINNED.  Everything downstream of the coefficients is pinned: pass ``filters=(
 librosa, or load a reference state_dict, and the outputs follow the reference exactly.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -114,21 +115,47 @@ class CQT(nn.Module):
         if self._operands is not None and self._operands[0] == key:
             return self._operands[1]
         ops = []
+        banks = []                  # per octave group: (interleaved (re, im) rows f32 [2n][size], first bin, size)
         for m, rng in zip(self.conv_modules, self.conv_index_ranges):
             w = m.weight.detach().to(device=device, dtype=torch.float32)[:, 0, :]          # (2n, size): real rows, imag rows
             n = len(rng)
-            npad = (2 * n + 3) // 4 * 4
-            inter = torch.zeros(npad, w.shape[1], device=device, dtype=torch.float32)
-            inter[0:2 * n:2] = w[:n]
-            inter[1:2 * n:2] = w[n:]
-            if self.precision == "bf16x3":
-                npad = (2 * n + 7) // 8 * 8
-                full = torch.zeros(npad, w.shape[1], device=device, dtype=torch.float32)
+            inter = torch.zeros(2 * n, w.shape[1], device=device, dtype=torch.float32)
+            inter[0::2] = w[:n]
+            inter[1::2] = w[n:]
+            banks.append((inter, rng.start, w.shape[1]))
+        if self.precision == "bf16x3":
+            # Octave groups are MERGED while their output columns fit one 128-wide GEMM tile: the shorter filters are zero-padded
+            # (centred, exactly as the reference centres every group inside the longest filter, :136-140 / :165-166) to the length
+            # of the first group of the merge.  A 40- or 64-column launch occupies the 128-wide tile as a full one does, so the merged
+            # launch takes the time of its first group alone and the others' launches disappear (configs[2]: 2.2 -> 1.5 ms of CQT).
+            merged, i = [], 0
+            while i < len(banks):
+                rows, start, size = [banks[i][0]], banks[i][1], banks[i][2]
+                count = rows[0].shape[0]
+                j = i + 1
+                while j < len(banks) and count + banks[j][0].shape[0] <= 128 and os.environ.get("CPC_CQT_MERGE", "1") != "0":
+                    wj, _, sj = banks[j]
+                    pad = torch.zeros(wj.shape[0], size, device=device, dtype=torch.float32)
+                    o = (size - sj) // 2
+                    pad[:, o:o + sj] = wj
+                    rows.append(pad)
+                    count += wj.shape[0]
+                    j += 1
+                merged.append((torch.cat(rows, dim=0), start, size))
+                i = j
+            for inter, start, size in merged:
+                npad = (inter.shape[0] + 7) // 8 * 8
+                full = torch.zeros(npad, size, device=device, dtype=torch.float32)
                 full[:inter.shape[0]] = inter
                 wh = full.to(torch.bfloat16)
                 wl = (full - wh.float()).to(torch.bfloat16)
-                inter = torch.stack([wh, wh, wl], dim=-1).reshape(npad, 3 * w.shape[1])
-            ops.append((inter.contiguous(), npad, rng.start))
+                ops.append((torch.stack([wh, wh, wl], dim=-1).reshape(npad, 3 * size).contiguous(), npad, start, size))
+        else:
+            for inter, start, size in banks:
+                npad = (inter.shape[0] + 3) // 4 * 4
+                full = torch.zeros(npad, size, device=device, dtype=torch.float32)
+                full[:inter.shape[0]] = inter
+                ops.append((full.contiguous(), npad, start, size))
         self._operands = (key, ops)
         return ops
 
@@ -151,7 +178,7 @@ class CQT(nn.Module):
         if self.precision == "bf16x3":
             x3 = torch.empty(B, 3 * x.shape[1], device=x.device, dtype=torch.bfloat16)
             _hip.call("cpc_split3_bf16", _hip.ptr(x), _hip.ptr(x3), x.numel())
-            for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
+            for filt, npad, start, size in self._prepare(x.device):
                 offset = (k0 - size) // 2
                 M, K = B * Tn, 3 * size
                 tiles = -(-M // 128)
@@ -171,7 +198,7 @@ class CQT(nn.Module):
             return cq, Tn, ldq
         if self.precision != "fp32":
             raise ValueError("CQT.precision must be 'fp32' or 'bf16x3'")
-        for (filt, npad, start), size in zip(self._prepare(x.device), self.conv_kernel_sizes):
+        for filt, npad, start, size in self._prepare(x.device):
             offset = (k0 - size) // 2
             _hip.gemm_nt(_hip.ptr(x, offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, size, hop, size, ldq, _hip.F32,
                          a_rpi=Tn, a_item=x.shape[1])

@@ -230,35 +230,51 @@ class _Conv:
         if gb is not None:
             with e.side(self._ev[0]):
                 e._colsum_to_grad(dy0.ptr(), gb, dy0.rows, self.cout, code, scratch=self._bscratch)
+        # The weight-gradient GEMM reads the convolution's input and its output gradient, both final at this point, and nothing the
+        # main stream does next depends on it: it goes to the side stream with its slab reduction, beside the data-gradient GEMM and
+        # the HBM-bound BatchNorm / pooling passes of the layer below (the main queue was busy 18.4 of 18.5 ms per configs[2] step
+        # with the side queue idle for 16.8 of them).  CPC_WGRAD_STREAM=0 / a gradient-penalty step: GEMM on the main stream.
+        side_gemm = e.use_aux and getattr(e, "_gp_phase", 0) == 0 and os.environ.get("CPC_WGRAD_STREAM", "1") != "0"
+
+        def staged(gemm, reduce):
+            if side_gemm:
+                with e.side(self._ev[1]):
+                    gemm()
+                    reduce()
+            else:
+                gemm()
+                with e.side(self._ev[1]):
+                    reduce()
+
         if self.mode == 'col' and self.G > 1:
             G = self.G
             Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.M // G
             chunk = e._chunk(Mg, self.nsplit)
-            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
-                         m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32)
-            with e.side(self._ev[1]):
+
+            def reduce():
                 # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
                 S = wslab[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
                 acc = S[0:self.kh, :, 0, :]
                 for dh in range(1, G):
                     acc = acc + S[dh:dh + self.kh, :, dh, :]
                 gw.view(self.cout, self.cin, self.kh).copy_(acc.permute(2, 1, 0))
+
+            staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
+                                        m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32), reduce)
         elif self.mode == 'col':
             chunk = e._chunk(self.M, self.nsplit)
-            _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
-                         nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32)
-            with e.side(self._ev[1]):
-                _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(gw), self.cin, self.cout, self.kh, self.nsplit,
-                          self.K * self.cout)
+            staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
+                                        nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32),
+                   lambda: _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(gw), self.cin, self.cout, self.kh, self.nsplit,
+                                     self.K * self.cout))
         else:
             chunk = e._chunk(self.M, self.nsplit, self.dt)
-            _hip.gemm_tn(_hip.ptr(col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp, self.cout,
-                         self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit, m_chunk=chunk,
-                         slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
             taps = self.kh * self.kw
-            with e.side(self._ev[1]):
-                _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(gw), self.K, self.cout, self.nsplit, self.Kp * self.cout,
-                          self.cin, self.cin * taps, 1, taps)
+            staged(lambda: _hip.gemm_tn(_hip.ptr(col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp,
+                                        self.cout, self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit,
+                                        m_chunk=chunk, slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32),
+                   lambda: _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(gw), self.K, self.cout, self.nsplit, self.Kp * self.cout,
+                                     self.cin, self.cin * taps, 1, taps))
 
     def gp_wgrad(self, gp_grad):
         """Penalty part of the weight gradient: (tangent of the input) x (gradient of the summed scores w.r.t. the output, which
@@ -892,7 +908,8 @@ class _Block:
         if self.stem_res is not None:
             self.stem_res.backward(self.d_out, self.d_main)
         elif self.blk.residual:
-            self.d_res.t.zero_()
+            # (d_res was zeroed when it was allocated: the cropped add's backward overwrites the same interior every step and never
+            # touches the border)
             _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
                       _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, self.ow,
                       0 if self.last else 1, self.r_f32, code)
@@ -975,6 +992,7 @@ class ScalogramCPCEngine(CPCEngine):
         if top0:
             raise NotImplementedError("top_padding_1 on the first scalogram block")
         self.x_grid = Grid(B, Win, Hin, Cin, self.device, torch.float32)
+        self._x_own = self.x_grid.t
         self.blocks: List[_Block] = []
         gin, in_f32 = self.x_grid, True
         for i, blk in enumerate(blocks):
@@ -1028,7 +1046,14 @@ class ScalogramCPCEngine(CPCEngine):
         channels-last grid; any other layout is re-laid out once."""
         self._check_input(x)
         cl = x.detach().permute(0, 3, 2, 1)
-        self.x_grid.t.view(cl.shape).copy_(cl)
+        if cl.is_contiguous() and cl.dtype == torch.float32 and self.x_grid.top == 0 and self.x_grid.Ha == self.x_grid.H:
+            # PreprocessingModule's output IS the channels-last grid: read it in place (every kernel that reads the input grid stays
+            # inside its B x W x H x C elements; the 165 MB copy of a configs[2] batch is gone)
+            self.x_grid.t = cl.reshape(-1)
+        else:
+            if self.x_grid.t.data_ptr() != self._x_own.data_ptr():
+                self.x_grid.t = self._x_own
+            self.x_grid.t.view(cl.shape).copy_(cl)
         for b in self.blocks:
             b.forward()
         if self.top_grid is not None:
