@@ -474,8 +474,9 @@ class _BatchNorm:
         p, code = e.model._param, e.code
         if not self.trained:
             raise NotImplementedError("gradient penalty through an eval-mode BatchNorm")
-        if self.x_f32:
-            raise NotImplementedError("gradient penalty in bf16 mode (float32 first-stage BatchNorm); use compute_dtype='fp32'")
+        # First-stage BatchNorm of a bf16 engine (x_f32): its input grid, that grid's tangent and the tangent y. are all float32, so
+        # the two reductions / the projection run on the float32 kernels; only the step into the (bf16) activation tangent converts.
+        fcode, fx = (_hip.F32, 0) if self.x_f32 else (code, self.x_f32)
         y0, a = self.y0, self.a
         y0_t, a_t = _twin(e, y0), _twin(e, a)
         C_ = self.C
@@ -492,13 +493,13 @@ class _BatchNorm:
             self.inv_gamma_stats = torch.zeros(2 * C_, device=dev, dtype=torch.float32)
         # sums over the batch of a. and xhat a. (no mask: the tangent enters the normalisation itself)
         _hip.call("cpc_bn_bwd_reduce", y0_t.ptr(), None, _desc(y0, y0.desc), y0.ptr(), _desc(y0, y0.desc), _hip.ptr(self.stats),
-                  _hip.ptr(e.slabs), 0, self.nb_bwd, self.x_f32, code)
+                  _hip.ptr(e.slabs), 0, self.nb_bwd, fx, fcode)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(self.t_dgamma), 1, C_, self.nb_bwd, 2 * C_, 1, 1, 0, 0)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, C_), _hip.ptr(self.t_dbeta), 1, C_, self.nb_bwd, 2 * C_, 1, 1, 0, 0)
         # y. = gamma rstd (a. - <a.> - xhat <xhat a.>)
         _hip.call("cpc_bn_bwd_apply", y0_t.ptr(), None, _desc(y0, y0.desc), y0.ptr(), self.yt.ptr(), _desc(y0, y0.desc), _hip.ptr(self.stats),
                   _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(self.t_dgamma), _hip.ptr(self.t_dbeta), float(y0.count), 0, 1,
-                  self.x_f32, code)
+                  fx, fcode)
         # into the activation's geometry (identity "normalisation": mean 0, rstd 1, gamma 1, beta 0, no ReLU), then the primal mask
         _hip.call("cpc_bn_apply", self.yt.ptr(), _desc(y0, y0.desc), a_t.ptr(), _desc(a, a.desc), _hip.ptr(self.ident), _hip.ptr(self.ones),
                   _hip.ptr(self.zeros), 0, self.x_f32, code)
@@ -523,8 +524,10 @@ class _BatchNorm:
         self.coef[:C_].copy_(-(gamma * rstd) * self.s1 / n)                  # on xhat
         self.coef[C_:2 * C_].copy_(-rstd * self.s2 / n)                      # on y. (= gamma a^.)
         self.coef[2 * C_:].copy_(-rstd * self.t_dgamma / n)                  # on delta_in
+        # (first-stage BatchNorm of a bf16 engine: x, y., the adjoint and the result are all float32 grids)
+        fcode, fx = (_hip.F32, 0) if self.x_f32 else (code, self.x_f32)
         _hip.call("cpc_bn_gp_cross", self.y0.ptr(), self.yt.ptr(), self.dy0.ptr(), self.xterm.ptr(), _desc(self.y0, self.y0.desc),
-                  _hip.ptr(self.stats), _hip.ptr(self.coef), self.x_f32, code)
+                  _hip.ptr(self.stats), _hip.ptr(self.coef), fx, fcode)
 
 
 class _CastRelu:
@@ -555,8 +558,6 @@ class _CastRelu:
 
     def tangent(self):
         e = self.eng
-        if self.x_f32:
-            raise NotImplementedError("gradient penalty in bf16 mode (float32 first stage); use compute_dtype='fp32'")
         a_t = _twin(e, self.a)
         _hip.call("cpc_bn_apply", _twin(e, self.y0).ptr(), _desc(self.y0, self.y0.desc), a_t.ptr(), _desc(self.a, self.a.desc),
                   _hip.ptr(self.ident), _hip.ptr(self.ones), _hip.ptr(self.zeros), 0, self.x_f32, e.code)
@@ -951,13 +952,13 @@ class _Block:
                     self.res_conv.backward(None if first else self.d_rp)
                     if not first:
                         _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_rp.ptr(),
-                                  _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, code)
+                                  _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, self.rp.code)
                 else:
                     self.res_conv.backward(None if first else self.d_in, accumulate=True)
             elif not first:
                 if self.rp is not None:
                     _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_res.ptr(),
-                              _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, code)
+                              _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, self.rp.code)
                 else:
                     self.d_in.t.add_(self.d_res.t)
 
@@ -1113,7 +1114,14 @@ class ScalogramCPCEngine(CPCEngine):
         if global_negatives is not None:
             raise NotImplementedError("the gradient penalty is implemented for per-GPU negatives")
         if self.dt != torch.float32:
-            raise NotImplementedError("the gradient penalty runs in the exact-f32 mode (compute_dtype='fp32')")
+            # bf16 storage: tangent grids and penalty weight-gradient GEMMs in bf16 like the primal ones, the float32 first stage kept.
+            # Built for the grid-based context networks (ConvolutionalArModel / ScalogramResidualEncoder contexts: the reference's
+            # e22-e26 and its script default e29) and linear scores (every penalty experiment of the reference).
+            if softplus:
+                raise NotImplementedError("gradient penalty with softplus scores runs in the exact-f32 mode (compute_dtype='fp32')")
+            if not isinstance(self.ctx, (ConvArGridContext, ResNetArContext)):
+                raise NotImplementedError(f"gradient penalty with bf16 storage is built for convolutional context networks; "
+                                          f"{type(self.ctx).__name__} runs it in the exact-f32 mode (compute_dtype='fp32')")
         if not hasattr(self.ctx, "tangent"):
             raise NotImplementedError(f"no gradient-penalty tangent pass for {type(self.ctx).__name__}")
         model, code = self.model, self.code

@@ -380,6 +380,48 @@ def test_gradient_penalty_matches_reference(golden_dir, fixture):
     assert ran >= 3
 
 
+def test_gradient_penalty_bf16_matches_reference(golden_dir):
+    """The Wasserstein gradient penalty with bf16 STORAGE (tangent grids and penalty weight-gradient GEMMs in bf16, float32 first
+    stage kept) against the reference's own penalty runs with a BatchNorm ConvolutionalArModel context (``scalogram_model_gp``:
+    linear scores, both loss branches -- the shape of the reference's e22-e26 / e29 experiments): loss within the north star's 1e-3,
+    every parameter gradient pointing the reference's way (cosine >= 0.99; gradients that are zero up to rounding skipped)."""
+    fixture = "scalogram_model_gp"
+    g = _load(golden_dir, fixture + ".npz")
+    meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
+    B, K, H = meta["B"], meta["K"], meta["H"]
+    data = torch.from_numpy(g["data"])
+    ran = 0
+    for run in meta["runs"]:
+        if run.get("gp") is None or run["steps"] != 1:
+            continue
+        ran += 1
+        pre, model = _build_scalogram_model(g, meta, "bf16")
+        logger = _Logger()
+        tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=logger, device=DEV,
+                                          regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
+                                          score_function=SCORE[run["score"]], prediction_steps=K, ar_size=H, preprocessing=pre,
+                                          wasserstein_gradient_penalty=True, gradient_penalty_factor=run["gp"])
+        tr.verbose = False
+        random.seed(run["python_seed"])
+        tr.train(batch_size=B, epochs=10, lr=run["lr"], num_workers=0, max_steps=1)
+        rel = abs(logger.loss_meter.values[0] - run["loss"][0]) / abs(run["loss"][0])
+        keys = [k for k in g if k.startswith(run["tag"] + "/grad/")]
+        largest = max(float(np.linalg.norm(g[k])) for k in keys)
+        worst = (1.0, None)
+        for k in keys:
+            name = k.split("/grad/")[1]
+            ref = torch.from_numpy(g[k]).double().flatten()
+            if float(ref.norm()) < 1e-5 * largest:
+                continue
+            got = dict(model.named_parameters())[name].grad.double().cpu().flatten()
+            cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-300))
+            worst = min(worst, (cos, name))
+        print(f"bf16 gradient penalty {run['tag']}: loss rel {rel:.2e}, worst gradient cosine {worst[0]:.4f} ({worst[1]})")
+        assert rel <= 1e-3, (run["tag"], logger.loss_meter.values, run["loss"])
+        assert worst[0] >= 0.99, (run["tag"], worst)
+    assert ran >= 2
+
+
 def test_gradient_penalty_plain_conv_context_against_oracle(golden_dir):
     """The penalty with a ConvolutionalArModel WITHOUT BatchNorm (the reference's default context, ar_conv_default_dict: its
     ReLU is fused into the convolution, so the tangent pass masks by the primal output; a gradient-penalty engine routes it to

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--context", default="gru")
     ap.add_argument("--breakdown", action="store_true")
     ap.add_argument("--cqt", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--gp", type=float, default=None, help="Wasserstein gradient penalty factor (linear scores, as the reference's penalty "
+                                                              "experiments; needs --context conv_ar_3 with bf16 storage)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, V, K = args.batch, 60, 16
@@ -43,6 +45,8 @@ def main():
         ar = ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3))
     model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
                                        compute_dtype=args.dtype).to(dev)
+    if args.gp is not None:
+        model.gradient_penalty_engine = True
     L = model.item_length
     print(f"item_length {L}  receptive_field {enc.receptive_field}  downsampling {enc.downsampling_factor}  "
           f"params {model.parameter_count()}", flush=True)
@@ -56,7 +60,10 @@ def main():
         eng = model.engine_for(x)
         if opt is None:
             opt = FusedAdam(model, lr=1e-4)
-        out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        if args.gp is not None:
+            out = eng.loss_and_grads(x, softplus=False, regularization=0.0, all_timesteps=True, gradient_penalty=args.gp)
+        else:
+            out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
         opt.step()
         return out, x
 
