@@ -1111,8 +1111,19 @@ class ScalogramCPCEngine(CPCEngine):
         DESIGN.md section 8 has the derivation; tests compare with the reference's own double backward (tests/golden/scalogram_model_gp)."""
         if not self.gp_capable:
             raise RuntimeError("this engine was built without gradient-penalty support (model.gradient_penalty_engine = True first)")
-        if global_negatives is not None:
-            raise NotImplementedError("the gradient penalty is implemented for per-GPU negatives")
+        gn = global_negatives
+        if gn is not None and softplus:
+            raise NotImplementedError("gradient penalty + global negatives is built for linear scores (the reference's penalty experiments)")
+        world = gn.world if gn is not None else 1
+
+        def over_ranks(t):
+            """Sum of a (small) seed tensor over the ranks: with global negatives the summed scores S run over the GLOBAL batch, so the
+            constant seeds of pass 1 / the tangent seeds of pass 3 are sums over every rank's targets / predictions."""
+            if gn is None:
+                return t
+            f = t.float().contiguous()
+            gn.dist.all_reduce(f)
+            return f.to(t.dtype)
         if self.dt != torch.float32:
             # bf16 storage: tangent grids and penalty weight-gradient GEMMs in bf16 like the primal ones, the float32 first stage kept.
             # Built for the grid-based context networks (ConvolutionalArModel / ScalogramResidualEncoder contexts: the reference's
@@ -1139,11 +1150,11 @@ class ScalogramCPCEngine(CPCEngine):
         pred3 = self.pred.view(B, K, E)
         tg = top[:, T - K:T, :]
         if all_timesteps:
-            seed_p = tg.sum((0, 1), keepdim=True).expand(B, K, E)
-            seed_t = pred3.sum((0, 1), keepdim=True).expand(B, K, E)
+            seed_p = over_ranks(tg.sum((0, 1), keepdim=True)).expand(B, K, E)
+            seed_t = over_ranks(pred3.sum((0, 1), keepdim=True)).expand(B, K, E)
         else:
-            seed_p = tg.sum(0, keepdim=True).expand(B, K, E)
-            seed_t = pred3.sum(0, keepdim=True).expand(B, K, E)
+            seed_p = over_ranks(tg.sum(0, keepdim=True)).expand(B, K, E)
+            seed_t = over_ranks(pred3.sum(0, keepdim=True)).expand(B, K, E)
         self.dact[-1].zero_()
         if softplus:
             # softplus scores: the summed scores are sum softplus(s), the seeds carry W1 = sigmoid(s) (cpc_gp_score_coeff)
@@ -1169,7 +1180,8 @@ class ScalogramCPCEngine(CPCEngine):
         npix = self.x_grid.B * self.x_grid.W * self.x_grid.H
         nb = min(256, max(1, npix // 256))
         self.gp_partial.zero_()
-        _hip.call("cpc_gp_direction", self.d_x.ptr(), x_t.ptr(), C.c_longlong(npix), self.x_grid.C, factor, _hip.ptr(self.gp_partial), nb)
+        # (global negatives: the penalty is the mean over the GLOBAL batch, 1 / world of this rank's mean)
+        _hip.call("cpc_gp_direction", self.d_x.ptr(), x_t.ptr(), C.c_longlong(npix), self.x_grid.C, factor / world, _hip.ptr(self.gp_partial), nb)
         # ---- tangent pass
         self._gp_phase = 2
         for b in self.blocks:
@@ -1214,14 +1226,16 @@ class ScalogramCPCEngine(CPCEngine):
             add_p = sp.pred_a.view(B, K, E) + sp.pred_b.view(B, K, E)
             add_t = sp.top_a.view(B, Ltop, E)[:, T - K:T, :] + sp.top_b.view(B, Ltop, E)[:, T - K:T, :]
         elif all_timesteps:
-            add_p = tg_t.sum((0, 1), keepdim=True).expand(B, K, E)
-            add_t = pred_t3.sum((0, 1), keepdim=True).expand(B, K, E)
+            add_p = over_ranks(tg_t.sum((0, 1), keepdim=True)).expand(B, K, E)
+            add_t = over_ranks(pred_t3.sum((0, 1), keepdim=True)).expand(B, K, E)
         else:
-            add_p = tg_t.sum(0, keepdim=True).expand(B, K, E)
-            add_t = pred_t3.sum(0, keepdim=True).expand(B, K, E)
+            add_p = over_ranks(tg_t.sum(0, keepdim=True)).expand(B, K, E)
+            add_t = over_ranks(pred_t3.sum(0, keepdim=True)).expand(B, K, E)
         add_p, add_t = add_p.clone(), add_t.clone()
         self.dact[-1].zero_()
-        if all_timesteps:
+        if gn is not None:
+            gn.forward_backward(softplus, regularization, all_timesteps)
+        elif all_timesteps:
             self.nce_all_forward_backward(softplus, regularization)
         else:
             self.nce_forward_backward(softplus, regularization)
@@ -1233,7 +1247,10 @@ class ScalogramCPCEngine(CPCEngine):
         self.backward(x)
         self._gp_phase = 0
         model._flat_grad.add_(self.gp_flat)
-        self.nce_out[0:1].add_(self.gp_partial.sum() * (factor / npix))
+        pen = (self.gp_partial.sum() * (factor / (npix * world))).reshape(1)
+        if gn is not None:
+            gn.dist.all_reduce(pen)
+        self.nce_out[0:1].add_(pen)
         return self.nce_out
 
 

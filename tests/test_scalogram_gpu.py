@@ -834,3 +834,69 @@ def test_stem_kernels_equal_the_im2col_route(golden_dir, dtype, fixture, monkeyp
         assert _rel(s1[k], s0[k].numpy()) < (5e-5 if dtype == "fp32" else 2e-2), k
     for a, b in zip(e1, e0):
         assert _rel(a, b.numpy()) < (1e-5 if dtype == "fp32" else 5e-2)
+
+
+_GP_GN_WORKER = r'''
+import json, os, random, sys
+import numpy as np
+import torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import test_scalogram_gpu as T
+from cpc_audio_amd.audio_dataset import TensorAudioDataset
+from cpc_audio_amd.contrastive_estimation_training import ContrastiveEstimationTrainer
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+golden = os.path.join(root, "tests", "golden")
+g = T._load(golden, "scalogram_model_c.npz")
+meta = json.load(open(os.path.join(golden, "scalogram_model_c.json")))
+B, K, H = meta["B"], meta["K"], meta["H"]
+data = torch.from_numpy(g["data"])
+ok = []
+for run in meta["runs"]:
+    if run.get("gp") is None or run["steps"] != 1:
+        continue
+    pre, model = T._build_scalogram_model(g, meta, "fp32")
+    log = T._Logger()
+    tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=T.DEV), logger=log, device=T.DEV,
+                                      regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
+                                      score_function=T.SCORE[run["score"]], prediction_steps=K, ar_size=H, preprocessing=pre,
+                                      wasserstein_gradient_penalty=True, gradient_penalty_factor=run["gp"])
+    tr.verbose, tr.global_negatives = False, True
+    random.seed(run["python_seed"])
+    tr.train(batch_size=B // world, epochs=10, lr=run["lr"], num_workers=0, max_steps=1)
+    loss = log.loss_meter.values[0]
+    assert abs(loss - run["loss"][0]) <= 1e-4 * abs(run["loss"][0]), (run["tag"], loss, run["loss"])
+    keys = [k for k in g if k.startswith(run["tag"] + "/grad/")]
+    worst = 0.0
+    for k in keys:
+        name = k.split("/grad/")[1]
+        ref = torch.from_numpy(g[k]).double()
+        got = model._grad[name].detach().double().cpu()          # after the all-reduce: the sum of the two ranks' gradients
+        worst = max(worst, float((got - ref).norm() / (ref.norm() + 1e-30)))
+    assert worst < 1e-3, (run["tag"], worst)
+    ok.append((run["tag"], loss, worst))
+if rank == 0:
+    assert len(ok) >= 2
+    print("GP-GN-OK", ok)
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_penalty_with_global_negatives_two_ranks_equal_the_reference(tmp_path):
+    """wasserstein_gradient_penalty + trainer.global_negatives (the reference's nn.DataParallel wrap around its penalty
+    experiments, setup_functions.py:112-115 with contrastive_estimation_training.py:144-158): two ranks with two clips each
+    reproduce the REFERENCE's single-process penalty runs on the four-clip batch -- loss (1e-4) and every parameter gradient
+    (the ranks' gradients summed) -- on the fixture without BatchNorm (``scalogram_model_c``; BatchNorm statistics are per
+    replica in the reference too), both loss branches, exact-f32 mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gp_gn_worker.py"
+    script.write_text(_GP_GN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GP-GN-OK" in outs[0]
