@@ -900,3 +900,61 @@ def test_gradient_penalty_with_global_negatives_two_ranks_equal_the_reference(tm
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GP-GN-OK" in outs[0]
+
+
+def test_e29_architectures_at_real_shapes():
+    """The reference's SCRIPT DEFAULT experiment e29 (train_script.py:11; configs/experiment_configs.py:128-137) with its real
+    architectures: cqt_high_res_dict (44.1 kHz, 292 bins, hop 256, longest filter 65 536) -> power scalogram pooled over two frames
+    -> scalogram_resnet_architecture_9 (eight BatchNorm blocks, tall first kernels) -> ar_conv_architecture_5, V = 43, K = 16, linear
+    scores over all time steps, regularisation 0, Wasserstein gradient penalty factor 1; clips of item_length = 367 616 samples.
+    Plain step: exact-f32 loss against the CPU oracle (1e-4), bf16 against the same number (1e-3).  Penalty step: exact-f32 loss
+    against the oracle's double backward (1e-3: the penalty is a mean of squared input-gradient norms of ~1e4), and the bf16 penalty
+    step (bf16 tangent grids, float32 first stage) within 5e-2 of it."""
+    from cpc_audio_amd import configs
+    from cpc_audio_amd.audio_model import ConvolutionalArModel
+    B, V, K = 4, 43, 16
+    wave_cpu, oracle, losses = None, {}, {}
+    for dtype in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        enc_cfg = configs.fresh(configs.scalogram_resnet_architecture_9)
+        pre = PreprocessingModule(cqt_dict=configs.cqt_high_res_dict, phase=enc_cfg['phase'], offset_zero=enc_cfg['scalogram_offset_zero'],
+                                  output_power=enc_cfg['scalogram_output_power'], pooling=enc_cfg['scalogram_pooling'],
+                                  scaling=enc_cfg['scalogram_scaling'])
+        enc = ScalogramResidualEncoder(args_dict=enc_cfg, preprocessing_module=pre)
+        ar_cfg = configs.fresh(configs.ar_conv_architecture_5)
+        model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(dict(ar_cfg)), enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
+                                           compute_dtype=dtype)
+        assert model.item_length == 367616 and enc.receptive_field == 125952 and enc.downsampling_factor == 4096
+        assert pre.cqt.conv_kernel_sizes[0] == 65536 and pre.cqt.n_bins == 292
+        blocks = [dict(b.cfg) for b in enc.blocks]
+        if wave_cpu is None:
+            wave_cpu = torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(5)) * 0.1
+            params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                cq = O.cqt_forward(wave_cpu.unsqueeze(1), [m.weight.detach() for m in pre.cqt.conv_modules], 256)
+                scal = O.preprocessing_forward(cq, None, offset_zero=True, output_power=2.0, scaling=10.0, pooling=[1, 2])
+                assert tuple(scal.shape) == (B, 1, 292, 590)
+                pz, tg, _, _ = O.cpc_forward(scal, {k: v.clone() for k, v in params.items()}, V, K, scalogram=blocks, conv_ar=dict(ar_cfg), training=True)
+                oracle["plain"] = float(O.info_nce_loss(O.linear_scores(pz, tg), True, 0.0)[0])
+            ot = O.OracleTrainer(params, V, K, score="linear", all_timesteps=True, regularization=0.0, lr=1e-5, scalogram=blocks,
+                                 conv_ar=dict(ar_cfg), gradient_penalty_factor=1.0)
+            oracle["gp"] = float(ot.loss_and_grads(scal)[0])
+        pre, model = pre.to(DEV), model.to(DEV)
+        model.gradient_penalty_engine = True
+        pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
+        x = pre(wave_cpu.to(DEV).unsqueeze(1))
+        assert tuple(x.shape) == (B, 1, 292, 590)
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        eng = model.engine_for(x)
+        plain = float(eng.loss_and_grads(x, softplus=False, regularization=0.0, all_timesteps=True)[0])
+        model.load_state_dict(state)              # (the BatchNorm running statistics moved)
+        gp = float(eng.loss_and_grads(x, softplus=False, regularization=0.0, all_timesteps=True, gradient_penalty=1.0)[0])
+        assert torch.isfinite(model._flat_grad).all() and model._flat_grad.abs().max().item() > 0
+        losses[dtype] = (plain, gp)
+        del eng, model, pre, x
+        torch.cuda.empty_cache()
+    print(f"e29 at real shapes: oracle plain {oracle['plain']:.5f} gp {oracle['gp']:.3f}; f32 {losses['fp32']}; bf16 {losses['bf16']}")
+    assert abs(losses["fp32"][0] - oracle["plain"]) <= 1e-4 * abs(oracle["plain"]), (losses, oracle)
+    assert abs(losses["bf16"][0] - oracle["plain"]) <= 1e-3 * abs(oracle["plain"]), (losses, oracle)
+    assert abs(losses["fp32"][1] - oracle["gp"]) <= 1e-3 * abs(oracle["gp"]), (losses, oracle)
+    assert abs(losses["bf16"][1] - oracle["gp"]) <= 5e-2 * abs(oracle["gp"]), (losses, oracle)
