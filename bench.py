@@ -433,6 +433,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trainer-loop", action="store_true", help="skip the extra run through ContrastiveEstimationTrainer.train")
+    ap.add_argument("--no-score-gemm", action="store_true",
+                    help="skip the stand-alone score-GEMM timings (profiling runs: their launches share the dominant kernel's symbol)")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
     ap.add_argument("--graph", action="store_true", help="diagnostic: replay the step from a captured hipGraph (single GPU only)")
     ap.add_argument("--all-timesteps", action="store_true",
@@ -637,7 +639,8 @@ def main():
                 tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
                 print(f"#   {k:58s} {cnt / args.steps:6.1f}/step {kms / args.steps:9.4f} ms/step {tf}", file=sys.stderr)
         if world == 1 and args.dtype == "bf16" and not args.breakdown and not args.all_timesteps:
-            line["score_gemm"] = score_gemm_figures(eng)
+            if not args.no_score_gemm:
+                line["score_gemm"] = score_gemm_figures(eng)
             if graphed is None and not args.no_trainer_loop:
                 ms_t, n_logged = trainer_loop_ms(model, B, L, device)
                 line["trainer_ms_per_step"] = ms_t

@@ -6,7 +6,7 @@ set -e
 TAG=${1:-r01}
 WL=${2:-cfg1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-if [ "$WL" = "cfg1" ]; then OUT=gpurun_out/prof_$TAG; EXTRA="--no-trainer-loop"; else OUT=gpurun_out/prof_${TAG}_$WL; EXTRA="--workload $WL"; fi
+if [ "$WL" = "cfg1" ]; then OUT=gpurun_out/prof_$TAG; EXTRA="--no-trainer-loop --no-score-gemm"; else OUT=gpurun_out/prof_${TAG}_$WL; EXTRA="--workload $WL"; fi
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $EXTRA > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
