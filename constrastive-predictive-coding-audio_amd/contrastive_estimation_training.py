@@ -276,6 +276,7 @@ class ContrastiveEstimationTrainer:
             self.model._flatten_parameters(device)
             graphed = bool(self.use_graph) and world == 1 and self.preprocessing is None
             optimizer = FusedAdam(self.model, lr=lr, device_step=graphed)
+            self.last_optimizer = optimizer          # (inspection only: tests read its step count after a NaN return)
             graph_steps = {}
             glob_neg = {}
             self.model.link_grads()
@@ -331,7 +332,37 @@ class ContrastiveEstimationTrainer:
             del pending[:n]
             return None
 
+        # The host learns of a NaN loss host_sync_lag steps late; the steps launched meanwhile change nothing on the device that Adam
+        # owns (their updates are skipped there), but their forward passes move the BatchNorm running statistics, and the host-side
+        # step count advances.  Both are put back to where the reference leaves them (it returns inside the NaN step, after that step's
+        # forward pass, :124-133): the buffers are snapshotted at the START of every step (one multi-tensor copy) and the snapshot of
+        # step `nan + 1` is restored.  What cannot be taken back: the sampler has handed out the later batches.
+        bn_bufs = [b for n_, b in self.model.named_buffers() if "running_" in n_ or n_.endswith("num_batches_tracked")]
+        snap_ring, snap_pos, snaps = [], [0], {}
+
+        def snapshot(step):
+            if not fused:
+                return
+            depth = self.host_sync_interval + self.host_sync_lag + 2
+            if bn_bufs:
+                while len(snap_ring) < depth:
+                    snap_ring.append([torch.empty_like(b) for b in bn_bufs])
+                dst = snap_ring[snap_pos[0] % depth]
+                snap_pos[0] += 1
+                torch._foreach_copy_(dst, bn_bufs)
+            else:
+                dst = None
+            snaps[step] = (dst, getattr(optimizer, "t", None))
+            for old_step in [k for k in snaps if k < step - depth + 1]:
+                del snaps[old_step]
+
         def nan_return(step):
+            later = snaps.get(step + 1)
+            if later is not None and later[0] is not None:          # statistics as they were after the NaN step's own forward pass
+                torch._foreach_copy_(bn_bufs, later[0])
+            here = snaps.get(step)
+            if here is not None and here[1] is not None and hasattr(optimizer, "t"):
+                optimizer.t = here[1]                               # no update has happened since the start of the NaN step
             self.training_step = step          # the reference leaves train() inside step `step`, before its update (:124-133)
             print("nan loss")
             print("returned with nan loss at step", step)
@@ -344,6 +375,7 @@ class ContrastiveEstimationTrainer:
             ctx = torch.autograd.profiler.profile(use_device="cuda", enabled=profile)
             with ctx as prof_ctx:
                 for batch in self._batches(self.dataset, sampler, device, num_workers, True, rank, world):
+                    snapshot(self.training_step)
                     if fused and graphed:
                         eng = self.model.engine(batch.shape[0], batch.shape[1], device)
                         key = (batch.shape[0], batch.shape[1])

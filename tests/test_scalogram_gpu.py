@@ -961,3 +961,34 @@ def test_e29_architectures_at_real_shapes():
     assert abs(losses["fp32"][1] - oracle["gp"]) <= 1e-3 * abs(oracle["gp"]), (losses, oracle)
     assert abs(losses["bf16"][0] - oracle["plain"]) <= 3e-2 * abs(oracle["plain"]), (losses, oracle)
     assert abs(losses["bf16"][1] - oracle["gp"]) <= 8e-2 * abs(oracle["gp"]), (losses, oracle)
+
+
+def test_nan_return_restores_batchnorm_statistics_and_step_count(golden_dir):
+    """The host learns of a NaN loss one step late and has launched another step by then: that step's
+    update is skipped on the device, and train() puts back what its forward pass moved — the BatchNorm running statistics
+    (num_batches_tracked counts the NaN step's own forward, as in the reference, which returns after it, :124-133, and not the
+    step launched behind it) and Adam's step count (no update since the start of the NaN step)."""
+    from cpc_audio_amd.audio_dataset import FileBatchSampler
+    g = _load(golden_dir, "scalogram_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+    run = meta["runs"][0]
+    data = torch.from_numpy(g["data"]).clone()
+    bad_step = 1
+    random.seed(run["python_seed"])
+    batches = [list(b) for b in FileBatchSampler([data.shape[0]], meta["B"], 1, True, verbose=False)]
+    assert len(batches) > bad_step + 1
+    victim = batches[bad_step][0]
+    assert all(victim not in b for b in batches[:bad_step])
+    data[victim, data.shape[1] // 2] = float("inf")
+    pre, model = _build_scalogram_model(g, meta, "fp32")
+    tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=DEV), logger=_Logger(), device=DEV,
+                                      regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
+                                      score_function=SCORE[run["score"]], prediction_steps=meta["K"], ar_size=meta["H"], preprocessing=pre)
+    tr.verbose = False
+    random.seed(run["python_seed"])
+    ret = tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=bad_step + 3)
+    torch.cuda.synchronize()
+    assert ret is None and tr.training_step == bad_step
+    counts = {k: int(v) for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert counts and all(c == bad_step + 1 for c in counts.values()), counts
+    assert tr.last_optimizer.t == bad_step
