@@ -144,18 +144,28 @@ class CQT(nn.Module):
                 merged.append((torch.cat(rows, dim=0), start, size))
                 i = j
             for inter, start, size in merged:
+                # Only the taps some filter of the bank actually has: a constant-Q filter is its window's length, centred in the
+                # power-of-two frame (the longest of the default bank: 12 060 of 16 384 taps) -- the zero margins are dropped from the
+                # contraction (bounds rounded outwards to multiples of 128 taps: the K-stage, also of a half when K is split; CPC_CQT_TRIM=0: the full frames).
+                lo, hi = 0, size
+                if os.environ.get("CPC_CQT_TRIM", "1") != "0":
+                    nz = (inter != 0).any(dim=0).nonzero()
+                    if nz.numel():
+                        lo = int(nz.min()) // 128 * 128
+                        hi = min(size, (int(nz.max()) + 128) // 128 * 128)
+                inter = inter[:, lo:hi]
                 npad = (inter.shape[0] + 7) // 8 * 8
-                full = torch.zeros(npad, size, device=device, dtype=torch.float32)
+                full = torch.zeros(npad, hi - lo, device=device, dtype=torch.float32)
                 full[:inter.shape[0]] = inter
                 wh = full.to(torch.bfloat16)
                 wl = (full - wh.float()).to(torch.bfloat16)
-                ops.append((torch.stack([wh, wh, wl], dim=-1).reshape(npad, 3 * size).contiguous(), npad, start, size))
+                ops.append((torch.stack([wh, wh, wl], dim=-1).reshape(npad, 3 * (hi - lo)).contiguous(), npad, start, size, lo, hi - lo))
         else:
             for inter, start, size in banks:
                 npad = (inter.shape[0] + 3) // 4 * 4
                 full = torch.zeros(npad, size, device=device, dtype=torch.float32)
                 full[:inter.shape[0]] = inter
-                ops.append((full.contiguous(), npad, start, size))
+                ops.append((full.contiguous(), npad, start, size, 0, size))
         self._operands = (key, ops)
         return ops
 
@@ -178,9 +188,9 @@ class CQT(nn.Module):
         if self.precision == "bf16x3":
             x3 = torch.empty(B, 3 * x.shape[1], device=x.device, dtype=torch.bfloat16)
             _hip.call("cpc_split3_bf16", _hip.ptr(x), _hip.ptr(x3), x.numel())
-            for filt, npad, start, size in self._prepare(x.device):
-                offset = (k0 - size) // 2
-                M, K = B * Tn, 3 * size
+            for filt, npad, start, size, lo, taps in self._prepare(x.device):
+                offset = (k0 - size) // 2 + lo
+                M, K = B * Tn, 3 * taps
                 tiles = -(-M // 128)
                 if K >= 16384 and tiles % 512 and tiles % 512 <= 256:
                     # One 128-row tile per workgroup, two workgroups per CU: 630 tiles would run as one full round plus a
@@ -198,9 +208,9 @@ class CQT(nn.Module):
             return cq, Tn, ldq
         if self.precision != "fp32":
             raise ValueError("CQT.precision must be 'fp32' or 'bf16x3'")
-        for filt, npad, start, size in self._prepare(x.device):
-            offset = (k0 - size) // 2
-            _hip.gemm_nt(_hip.ptr(x, offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, size, hop, size, ldq, _hip.F32,
+        for filt, npad, start, size, lo, taps in self._prepare(x.device):
+            offset = (k0 - size) // 2 + lo
+            _hip.gemm_nt(_hip.ptr(x, offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), B * Tn, npad, taps, hop, taps, ldq, _hip.F32,
                          a_rpi=Tn, a_item=x.shape[1])
         return cq, Tn, ldq
 

@@ -419,6 +419,25 @@ int cpc_stem_residual_bwd(const void* dout, const void* out, const int* go, void
     return launch_stem_residual_bwd(dout, out, go, dmain, gm, xp, gp, slabs, oh, ow, relu, nblocks, dtype, (hipStream_t)stream);
 }
 
+int cpc_bn_apply_bits(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                      int relu, void* out_bits, int dtype, void* stream) {
+    if (!x || !out || !stats || !gamma || !beta || !out_bits) return CPC_EINVAL;
+    return launch_bn_apply(x, gx, out, go, stats, gamma, beta, relu, 0, dtype, (hipStream_t)stream, (unsigned char*)out_bits);
+}
+
+int cpc_bn_bwd_reduce_bits(const void* dy, const void* y_bits, const int* gy, const void* x, const int* gx, const float* stats,
+                           float* slabs, int nblocks, int dtype, void* stream) {
+    if (!dy || !y_bits || !x || !stats || !slabs) return CPC_EINVAL;
+    return launch_bn_bwd_reduce(dy, nullptr, gy, x, gx, stats, slabs, 1, nblocks, 0, dtype, (hipStream_t)stream, (const unsigned char*)y_bits);
+}
+
+int cpc_bn_bwd_apply_bits(const void* dy, const void* y_bits, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                          const float* gamma, const float* dgamma, const float* dbeta, double count, int train, int dtype, void* stream) {
+    if (!dy || !y_bits || !x || !dx || !stats || !gamma) return CPC_EINVAL;
+    return launch_bn_bwd_apply(dy, nullptr, gy, x, dx, gx, stats, gamma, dgamma, dbeta, count, 1, train, 0, dtype, (hipStream_t)stream,
+                               (const unsigned char*)y_bits);
+}
+
 int cpc_maxpool2d_select(const void* in, const void* sel, const int* gi, void* out, const int* go, int p, int in_f32, int dtype,
                          void* stream) {
     if (!in || !sel || !out) return CPC_EINVAL;

@@ -174,12 +174,12 @@ int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblo
 int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
                        float* run_var, hipStream_t stream);
 int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
-                    int relu, int x_f32, int dtype, hipStream_t stream);
+                    int relu, int x_f32, int dtype, hipStream_t stream, unsigned char* bits = nullptr);
 int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
-                         int relu, int nblocks, int x_f32, int dtype, hipStream_t stream);
+                         int relu, int nblocks, int x_f32, int dtype, hipStream_t stream, const unsigned char* ybits = nullptr);
 int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
                         const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
-                        int dtype, hipStream_t stream);
+                        int dtype, hipStream_t stream, const unsigned char* ybits = nullptr);
 int launch_maxpool2d_fwd(const void* in, const int* gi, void* out, const int* go, int p, int in_f32, int dtype, hipStream_t stream);
 int launch_maxpool2d_bwd(const void* in, void* din, const int* gi, const void* dout, const int* go, int p, int accumulate, int dtype,
                          hipStream_t stream);

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void bn_stats8_kernel(const bf16_t* __restrict
 
 __global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict__ x, Grid gx, bf16_t* __restrict__ out, Grid go,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, int relu) {
+                                                        const float* __restrict__ beta, int relu, unsigned char* __restrict__ bits) {
     const int c8n = gx.C / 8;
     const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -519,13 +519,23 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict
                 if (relu) o[hf][e] = relu_f(o[hf][e]);
             }
         }
-        store8(out + grid_off(go, b, w, h) + c8 * 8, o[0], o[1]);
+        const long long oo = grid_off(go, b, w, h) + c8 * 8;
+        store8(out + oo, o[0], o[1]);
+        if (bits) {          // sign-bit mask of the stored activation (bit e = element e of the 8 is > 0): what the backward passes need of it
+            unsigned m = 0u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m |= ((float)(bf16_t)o[hf][e] > 0.f ? 1u : 0u) << (hf * 4 + e);
+            bits[oo >> 3] = (unsigned char)m;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, Grid gy,
                                                              const bf16_t* __restrict__ x, Grid gx, const float* __restrict__ stats,
-                                                             float* __restrict__ slabs, int relu, long long cols_per_block) {
+                                                             float* __restrict__ slabs, int relu, long long cols_per_block,
+                                                             const unsigned char* __restrict__ ybits) {
     const int C = gx.C, c8n = C / 8;
     const int cg = threadIdx.x % c8n, rp = threadIdx.x / c8n, nrp = 256 / c8n;
     const long long ncol = (long long)gx.B * gx.W;
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
         const unsigned rend = (unsigned)(q1 * gx.H);
         for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < rend; r += 2u * nrp) {
             f32x8 g8[2], y8[2], x8[2];
+            unsigned mb[2] = {0xffu, 0xffu};
             bool ok[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -551,7 +562,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
                 const int h = (int)(rc - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
                 const long long oy = grid_off(gy, b, w, h) + cg * 8;
                 g8[u] = load8(dy + oy);
-                if (relu) y8[u] = load8(y + oy);
+                if (relu) {
+                    if (ybits) mb[u] = ybits[oy >> 3];
+                    else y8[u] = load8(y + oy);
+                }
                 x8[u] = load8(x + grid_off(gx, b, w, h) + cg * 8);
             }
 #pragma unroll
@@ -562,7 +576,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
                     const f32x4 gg = hf ? g8[u].hi : g8[u].lo, yy = hf ? y8[u].hi : y8[u].lo, xx = hf ? x8[u].hi : x8[u].lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float g = (!relu || yy[e] > 0.f) ? gg[e] : 0.f;
+                        const bool pos = ybits ? ((mb[u] >> (hf * 4 + e)) & 1u) != 0u : yy[e] > 0.f;
+                        const float g = (!relu || pos) ? gg[e] : 0.f;
                         s1[hf][e] += g * (xx[e] - mu[hf][e]) * rs[hf][e];
                         s2[hf][e] += g;
                     }
@@ -587,7 +602,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, Grid gx,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                            float inv_count, int relu, int train) {
+                                                            float inv_count, int relu, int train, const unsigned char* __restrict__ ybits) {
     const int C = gx.C, c8n = C / 8;
     const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
     const bool fixed = ((gridDim.x * 256u) % (unsigned)c8n) == 0u;
@@ -615,7 +630,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
         const f32x8 g8 = load8(dy + oy);
         const f32x8 x8 = load8(x + ox);
         f32x8 y8;
-        if (relu) y8 = load8(y + oy);
+        unsigned mb = 0xffu;
+        if (relu) {
+            if (ybits) mb = ybits[oy >> 3];
+            else y8 = load8(y + oy);
+        }
         if (!fixed) coeffs(c8);
         f32x4 o[2];
 #pragma unroll
@@ -623,7 +642,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
             const f32x4 gg = hf ? g8.hi : g8.lo, yy = hf ? y8.hi : y8.lo, xx = hf ? x8.hi : x8.lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float g = (!relu || yy[e] > 0.f) ? gg[e] : 0.f;
+                const bool pos = ybits ? ((mb >> (hf * 4 + e)) & 1u) != 0u : yy[e] > 0.f;
+                const float g = (!relu || pos) ? gg[e] : 0.f;
                 o[hf][e] = k1[hf][e] * g - k2[hf][e] - k3[hf][e] * (xx[e] - mu[hf][e]);
             }
         }
@@ -1039,12 +1059,13 @@ int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float
 static bool same_shape(const int* a, const int* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[5] == b[5]; }
 
 int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
-                    int relu, int x_f32, int dtype, hipStream_t st) {
+                    int relu, int x_f32, int dtype, hipStream_t st, unsigned char* bits) {
+    if (bits && !(dtype == CPC_DTYPE_BF16 && !x_f32 && gx && gx[5] % 8 == 0)) return CPC_EINVAL;
     if (!grid_ok(gx) || !grid_ok(go) || !same_shape(gx, go) || gx[5] % 4) return CPC_EINVAL;
     const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
     if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
         const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
-        hipLaunchKernelGGL(bn_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu);
+        hipLaunchKernelGGL(bn_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (bf16_t*)out, mk(go), stats, gamma, beta, relu, bits);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
@@ -1059,12 +1080,13 @@ int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, cons
 }
 
 int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
-                         int relu, int nblocks, int x_f32, int dtype, hipStream_t st) {
+                         int relu, int nblocks, int x_f32, int dtype, hipStream_t st, const unsigned char* ybits) {
+    if (ybits && !(dtype == CPC_DTYPE_BF16 && !x_f32 && gx && gx[5] % 8 == 0)) return CPC_EINVAL;
     if (!grid_ok(gx) || !grid_ok(gy) || !same_shape(gx, gy) || !bn_c_ok(gx[5]) || nblocks <= 0) return CPC_EINVAL;
     const long long ncol = (long long)gx[0] * gx[1];
     const long long cpb = (ncol + nblocks - 1) / nblocks;
     if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
-        hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb);
+        hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb, ybits);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
@@ -1080,14 +1102,15 @@ int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const voi
 
 int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
                         const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
-                        int dtype, hipStream_t st) {
+                        int dtype, hipStream_t st, const unsigned char* ybits) {
+    if (ybits && !(dtype == CPC_DTYPE_BF16 && !x_f32 && gx && gx[5] % 8 == 0)) return CPC_EINVAL;
     if (!grid_ok(gx) || !grid_ok(gy) || !same_shape(gx, gy) || gx[5] % 4 || count <= 0) return CPC_EINVAL;
     if (train && (!dgamma || !dbeta)) return CPC_EINVAL;
     const int nb = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 4));
     const float inv = (float)(1.0 / count);
     if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
         const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
-        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train);
+        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train, ybits);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }

@@ -426,6 +426,13 @@ class _BatchNorm:
         self.slab = self.nb_bwd * 2 * self.C
         self.dy0: Optional[Grid] = None
         self.trained = True
+        # the activation's ReLU mask as sign bits (one byte per 8 channels), written by the normalisation pass and read by the two
+        # backward passes instead of the activation itself: 4 of their 14 bytes per element (bf16 grids; not in gradient-penalty
+        # engines, whose passes call these kernels on other operands)
+        self.abits = None
+        if (eng.dt == torch.bfloat16 and not self.x_f32 and self.C % 8 == 0 and not getattr(eng, "gp_capable", False) and
+                os.environ.get("CPC_BN_BITS", "1") != "0"):
+            self.abits = torch.zeros(a.rows * a.C // 8, device=eng.device, dtype=torch.uint8)
 
     def forward(self):
         e, mod = self.eng, self.mod
@@ -443,20 +450,33 @@ class _BatchNorm:
         else:
             self.stats[0].copy_(mod.running_mean)
             self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
-        _hip.call("cpc_bn_apply", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc), _hip.ptr(self.stats),
-                  _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), 1, self.x_f32, code)
+        if self.abits is not None:
+            _hip.call("cpc_bn_apply_bits", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc),
+                      _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), 1, _hip.ptr(self.abits), code)
+        else:
+            _hip.call("cpc_bn_apply", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc), _hip.ptr(self.stats),
+                      _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), 1, self.x_f32, code)
 
     def backward(self, da: Grid):
         e = self.eng
         p, g, code = e.model._param, e.model._grad, e.code
         gw, gb = g[self.prefix + ".weight"], g[self.prefix + ".bias"]
-        _hip.call("cpc_bn_bwd_reduce", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), _desc(self.y0, self.y0.desc),
-                  _hip.ptr(self.stats), _hip.ptr(e.slabs), 1, self.nb_bwd, self.x_f32, code)
+        if self.abits is not None:
+            _hip.call("cpc_bn_bwd_reduce_bits", da.ptr(), _hip.ptr(self.abits), _desc(self.a, self.a.desc), self.y0.ptr(),
+                      _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(e.slabs), self.nb_bwd, code)
+        else:
+            _hip.call("cpc_bn_bwd_reduce", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), _desc(self.y0, self.y0.desc),
+                      _hip.ptr(self.stats), _hip.ptr(e.slabs), 1, self.nb_bwd, self.x_f32, code)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
         _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
-        _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
-                  _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
-                  float(self.y0.count), 1, 1 if self.trained else 0, self.x_f32, code)
+        if self.abits is not None:
+            _hip.call("cpc_bn_bwd_apply_bits", da.ptr(), _hip.ptr(self.abits), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
+                      _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
+                      float(self.y0.count), 1 if self.trained else 0, code)
+        else:
+            _hip.call("cpc_bn_bwd_apply", da.ptr(), self.a.ptr(), _desc(self.a, self.a.desc), self.y0.ptr(), self.dy0.ptr(),
+                      _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(gw), _hip.ptr(gb),
+                      float(self.y0.count), 1, 1 if self.trained else 0, self.x_f32, code)
         gp = getattr(e, "_gp_phase", 0)
         if gp == 1:          # first backward pass of a gradient-penalty step (seeds: the summed scores): keep sum q xhat
             if getattr(self, "s2", None) is None:

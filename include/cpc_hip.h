@@ -291,6 +291,16 @@ int cpc_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* 
 int cpc_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
                      const float* gamma, const float* dgamma, const float* dbeta, double count, int relu, int train, int x_f32,
                      int dtype, void* stream);
+/* The same three passes with the activation's ReLU mask as SIGN BITS (one byte per 8 channels of a position, bit e = channel 8 i + e
+ * is > 0, indexed by the element offset in the activation grid / 8): cpc_bn_apply_bits also writes them, the two backward passes read
+ * them INSTEAD of the activation (2 bytes per element less in each; a ReLU's backward needs nothing else of it).  bf16 grids with C a
+ * multiple of 8 only (CPC_EINVAL otherwise); relu is implied in the backward passes. */
+int cpc_bn_apply_bits(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
+                      int relu, void* out_bits, int dtype, void* stream);
+int cpc_bn_bwd_reduce_bits(const void* dy, const void* y_bits, const int* gy, const void* x, const int* gx, const float* stats,
+                           float* slabs, int nblocks, int dtype, void* stream);
+int cpc_bn_bwd_apply_bits(const void* dy, const void* y_bits, const int* gy, const void* x, void* dx, const int* gx, const float* stats,
+                          const float* gamma, const float* dgamma, const float* dbeta, double count, int train, int dtype, void* stream);
 /* nn.MaxPool2d(kernel = stride = p): ceil mode (residual branches, scalogram_model.py:434-436; window clipped at the border)
  * or floor mode (main-branch pooling, :401-403; remainder dropped) according to the extents of the output grid; the backward
  * routes dout to the first maximum of each window (+= if accumulate; positions outside every window are not written). */

@@ -184,6 +184,23 @@ def test_batchnorm_grid(dt, train):
               _hip.ptr(dgam), _hip.ptr(dbet), float(gx.count), 1, 1 if train else 0, 0, code)
     assert ((_read(gdx) - x.grad).abs().max() / x.grad.abs().max()).item() < t
     assert gdx.t.view(B, W, gdx.Ha, Cc)[:, :, H:].abs().max().item() == 0
+    if dt == torch.bfloat16:
+        # the sign-bit variants (the activation's ReLU mask as one byte per 8 channels, written by the normalisation pass and read by
+        # the backward passes instead of the activation): bit for bit the results of the calls above
+        bits = torch.zeros(ga.rows * Cc // 8, device=DEV, dtype=torch.uint8)
+        ga2 = ga.like(DEV, dt)
+        _hip.call("cpc_bn_apply_bits", gx.ptr(), _d(gx.desc), ga2.ptr(), _d(ga2.desc), _hip.ptr(stats), _hip.ptr(d_gamma), _hip.ptr(d_beta), 1,
+                  _hip.ptr(bits), code)
+        assert torch.equal(ga2.t, ga.t)
+        want = (ga.t.float().view(-1, 8) > 0).to(torch.uint8)
+        assert torch.equal(bits, (want << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8))
+        slabs2 = torch.zeros_like(slabs)
+        _hip.call("cpc_bn_bwd_reduce_bits", gda.ptr(), _hip.ptr(bits), _d(ga.desc), gx.ptr(), _d(gx.desc), _hip.ptr(stats), _hip.ptr(slabs2), nb, code)
+        assert torch.equal(slabs2, slabs)
+        gdx2 = gx.like(DEV, dt)
+        _hip.call("cpc_bn_bwd_apply_bits", gda.ptr(), _hip.ptr(bits), _d(ga.desc), gx.ptr(), gdx2.ptr(), _d(gx.desc), _hip.ptr(stats),
+                  _hip.ptr(d_gamma), _hip.ptr(dgam), _hip.ptr(dbet), float(gx.count), 1 if train else 0, code)
+        assert torch.equal(gdx2.t, gdx.t)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -24,31 +24,51 @@ def rnd(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--arch", default="7", choices=["7", "9"], help="7: BASELINE configs[2]; 9: the reference's script default e29")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, V, K = args.batch, 60, 16
     torch.manual_seed(0)
-    pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
-    enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
-    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
-                                       visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+    if args.arch == "7":
+        pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+        enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+        ar = ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3))
+        softplus, all_t, reg = True, False, 1.0
+    else:
+        V = 43
+        cfg = configs.fresh(configs.scalogram_resnet_architecture_9)
+        pre = PreprocessingModule(cqt_dict=configs.cqt_high_res_dict, phase=cfg['phase'], offset_zero=cfg['scalogram_offset_zero'],
+                                  output_power=cfg['scalogram_output_power'], pooling=cfg['scalogram_pooling'], scaling=cfg['scalogram_scaling'])
+        enc = ScalogramResidualEncoder(args_dict=cfg, preprocessing_module=pre)
+        ar = ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_5))
+        softplus, all_t, reg = False, True, 0.0
+    model = AudioPredictiveCodingModel(enc, ar, enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K, compute_dtype="fp32")
     pre, model = pre.to(dev), model.to(dev)
-    wave = (torch.randn(B, 97024, generator=torch.Generator().manual_seed(11)) * 0.1).to(dev)
+    wave = (torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(11)) * 0.1).to(dev)
     x32 = pre(wave.unsqueeze(1)).clone()
     pre.cqt.precision = "bf16x3"
     x3 = pre(wave.unsqueeze(1)).clone()
     eng = model.engine_for(x32)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
+    zref = [None]
+
     def run(x=x32):
         model.load_state_dict(state)
         eng.forward(x)
-        eng.nce_forward_backward(True, 1.0)
+        if all_t:
+            eng.nce_all_forward_backward(softplus, reg)
+        else:
+            eng.nce_forward_backward(softplus, reg)
+        z = eng.view_top()[:, :eng.T, :].float().clone()
+        if zref[0] is None:
+            zref[0] = z
+        run.zerr = float((z - zref[0]).norm() / zref[0].norm())
         return float(eng.nce_out[0])
 
     base = run()
-    print(f"exact-f32 loss {base:.6f}")
-    print(f"{'bf16x3 CQT':50s} {abs(run(x3) - base) / base:.2e}")
+    print(f"exact-f32 loss {base:.6f}     (columns: relative loss change, relative L2 change of the encoder output z)")
+    print(f"{'bf16x3 CQT':50s} {abs(run(x3) - base) / base:.2e}   z {run.zerr:.2e}")
 
     def with_patch(name, patches):
         saved = []
@@ -66,7 +86,7 @@ def main():
         finally:
             for obj, attr, orig in saved:
                 setattr(obj, attr, orig)
-        print(f"{name:50s} {abs(v - base) / base:.2e}   ({v:.5f})")
+        print(f"{name:50s} {abs(v - base) / base:.2e}   z {run.zerr:.2e}   ({v:.5f})")
 
     blocks = eng.blocks
     # weights: the operand copies made by prepare()
@@ -77,10 +97,10 @@ def main():
                 if t is not None:
                     rnd(t)
         return f
-    convs = [c for b in blocks for c in (b.conv_a, b.conv_b, b.res_conv) if c is not None]
+    convs = [c for b in blocks for c in (b.conv_a, b.conv_b, b.res_conv) if c is not None]          # (block 0 of a stem engine has neither conv_a nor res_conv)
     with_patch("all encoder conv weights", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32])
     for i, b in enumerate(blocks):
-        if not b.conv_a.in_f32:
+        if b.conv_a is not None and not b.conv_a.in_f32:
             with_patch(f"block {i} conv_a output (pre-BN / activation)", [(b.conv_a, "forward", lambda g=b.conv_a.y0: rnd(g.t))])
         with_patch(f"block {i} conv_b output (pre-BN / activation)", [(b.conv_b, "forward", lambda g=b.conv_b.y0: rnd(g.t))])
         if b.bn_a is not None:
@@ -90,7 +110,7 @@ def main():
         if b.res_conv is not None and not b.res_conv.in_f32:
             with_patch(f"block {i} residual projection output", [(b.res_conv, "forward", lambda g=b.res_conv.y0: rnd(g.t))])
         with_patch(f"block {i} output (after the residual add)", [(b, "forward", lambda g=b.out: rnd(g.t))])
-    with_patch("all encoder pre-BN conv outputs", [(c, "forward", lambda g=c.y0: rnd(g.t)) for b in blocks for c, bn in ((b.conv_a, b.bn_a), (b.conv_b, b.bn_b)) if bn is not None and not c.in_f32])
+    with_patch("all encoder pre-BN conv outputs", [(c, "forward", lambda g=c.y0: rnd(g.t)) for b in blocks for c, bn in ((b.conv_a, b.bn_a), (b.conv_b, b.bn_b)) if bn is not None and c is not None and not c.in_f32])
     with_patch("all encoder BN outputs", [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None])
     ctx = eng.ctx
     ar_blocks = getattr(ctx, "blocks", [])
@@ -98,6 +118,14 @@ def main():
     with_patch("context: all BN outputs", [(b.bn, "forward", lambda g=b.bn.a: rnd(g.t)) for b in ar_blocks if b.bn is not None])
     with_patch("context: all block outputs", [(b, "forward", lambda g=b.out: rnd(g.t)) for b in ar_blocks])
     with_patch("context: conv weights", [(c, "prepare", w_post(c)) for b in ar_blocks for c in (b.conv, b.res_conv) if c is not None])
+    stream = [(b, "forward", lambda g=b.out: rnd(g.t)) for b in blocks[:-1]] + \
+             [(b.res_conv, "forward", lambda g=b.res_conv.y0: rnd(g.t)) for b in blocks if b.res_conv is not None and not b.res_conv.in_f32]
+    rest = [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] + \
+           [(c, "forward", lambda g=c.y0: rnd(g.t)) for b in blocks for c in (b.conv_a, b.conv_b) if c is not None and not c.in_f32] + \
+           [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None] + \
+           [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))]
+    with_patch("ONLY the residual stream (block outputs, projections)", stream)
+    with_patch("everything in the encoder EXCEPT the residual stream", rest)
     with_patch("everything above at once", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] +
                [(c, "forward", lambda g=c.y0: rnd(g.t)) for c in convs if not c.in_f32] +
                [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None] +
