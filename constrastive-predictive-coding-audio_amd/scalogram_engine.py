@@ -1389,7 +1389,7 @@ class _ArBlock:
     def backward(self):
         code = self.eng.code
         if self.residual:
-            self.d_res.t.zero_()
+            # (d_res was zeroed when it was allocated; the cropped add's backward overwrites the same interior every step)
             _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
                       _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, 0, 0, 0, code)
         if self.bn is not None:
@@ -1489,7 +1489,7 @@ class ConvArGridContext:
         e = self.eng
         last = self.blocks[-1]
         d = last.d_out
-        d.t.zero_()
+        # (only the last position carries a gradient; the rest of the grid was zeroed when it was allocated and nothing writes it)
         d.t.view(d.B, d.Ha, d.C)[:, d.top + d.H - 1, :] = dc.to(d.t.dtype)
         for b in reversed(self.blocks):
             b.backward()
@@ -1576,7 +1576,7 @@ class ResNetArContext:
     def backward(self, dc):
         e = self.eng
         d = self.blocks[-1].d_out
-        d.t.zero_()
+        # (only the first time step carries a gradient; the rest of the grid was zeroed when it was allocated and nothing writes it)
         self._first_step(d).copy_(dc)
         for b in reversed(self.blocks):
             b.backward()
