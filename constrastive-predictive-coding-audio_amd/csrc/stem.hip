@@ -23,6 +23,10 @@ struct Grid {
 __device__ __forceinline__ long long grid_off(const Grid& g, int b, int w, int h) {
     return (((long long)b * g.W + w) * g.Ha + g.top + h) * g.C;
 }
+// (grids hold fewer than 2^31 elements, checked by the launchers: 32-bit arithmetic for the per-row accesses of the hot loops)
+__device__ __forceinline__ unsigned grid_off32(const Grid& g, int b, int w, int h) {
+    return (unsigned)(((b * g.W + w) * g.Ha + g.top + h) * g.C);
+}
 
 struct StemConv {
     const float* x;      // input grid, float32
@@ -32,10 +36,13 @@ struct StemConv {
     int Cout, kh, kw, sh, sw, ph, pw, Ho, Wo;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int R = 4;              // output rows per lane
-constexpr int MAX_XS = 2560;      // floats of ONE buffer of input columns in LDS (kw * (Hin + 2 ph + R * sh) * Cin); two buffers
+constexpr int MAX_XS = 1664;      // floats of ONE buffer of input columns in LDS (kw * (Hin + 2 ph + R * sh) * Cin); two buffers
 constexpr int MAX_WL = 2304;      // floats of weights in LDS (taps * Cout)
-constexpr int MAXPF = 10;         // input-column floats a thread stages per output column (256 threads: kw * (Hin + 2 ph) * Cin <= 2560)
+constexpr int MAXPF = 6;          // input-column floats a thread stages per output column (256 threads: kw * (Hin + 2 ph) * Cin <= 1536:
+                                  // three columns of 256 bins x 2 channels; every slot costs a predicated load per column)
 
 // Window shape as template parameters (0 = taken from the arguments at run time).  With a compile-time shape the tap loops unroll,
 // the weights of a lane's 4 channels live in registers and a lane's input window is read from LDS once per column of taps.
@@ -109,6 +116,8 @@ struct ColumnStage {
         const float* xb = p.x + ((long long)b * p.gx.W * p.gx.Ha + p.gx.top) * W::cin(p);
         // (a predicated load per slot: the value stays in flight until commit(); a branch-free clamp-and-select form made the
         // compiler wait for the loads right here, and the kernels ran 1.5x slower)
+        // (and plain, unpredicated loads for the unpadded case were SUNK by the compiler to their use in commit(), behind the column's
+        // arithmetic: no prefetch at all, 1.8x slower.  The branch around each load is what keeps it up here.)
 #pragma unroll
         for (int k = 0; k < MAXPF; ++k) {
             const int w = w0 + (int)((unsigned)code[k] >> 28), rel1 = (code[k] >> 12) & 0xffff;
@@ -148,13 +157,31 @@ template <> struct Raw4<bf16_t> {
     }
 };
 
+// the channels a lane owns (4 as f32x4, or 2 as f32x2 for the kernel whose accumulators fill the register file) in the storage type
+template <typename T, typename VT> struct RawV;
+template <typename T> struct RawV<T, f32x4> : Raw4<T> {};
+template <> struct RawV<float, f32x2> {
+    f32x2 v;
+    __device__ __forceinline__ void load(const float* p) { v = *(const f32x2*)p; }
+    __device__ __forceinline__ f32x2 get() const { return v; }
+};
+template <> struct RawV<bf16_t, f32x2> {
+    unsigned v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const unsigned*)p; }
+    __device__ __forceinline__ f32x2 get() const { return (f32x2){__builtin_bit_cast(float, v << 16), __builtin_bit_cast(float, v & 0xffff0000u)}; }
+};
+template <typename VT> __device__ __forceinline__ VT vzero();
+template <> __device__ __forceinline__ f32x4 vzero<f32x4>() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ f32x2 vzero<f32x2>() { return (f32x2){0.f, 0.f}; }
+
 // acc[r] = bias + sum over taps of w * x for output rows ho0 + r (r < R; rows beyond Ho read the zero slack rows and are discarded
 // by the caller), channels 4 cq .. 4 cq + 3.  One fixed order of summation per window shape: every pass sees identical values.
-template <class W, bool WREG>
-__device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, const f32x4 (&wreg)[W::T], const float* xs, int cq,
-                                          int ho0, f32x4 acc[R]) {
+template <class W, bool WREG, typename VT>
+__device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, const VT (&wreg)[W::T], const float* xs, int cq,
+                                          int ho0, VT acc[R]) {
+    constexpr int CPL = sizeof(VT) / 4;          // channels per lane
     const int Cin = W::cin(p), KH = W::kh(p), KW = W::kw(p), SH = W::sh(p), cs = col_stride<W>(p);
-    const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const VT b4 = p.bias ? *(const VT*)(p.bias + cq * CPL) : vzero<VT>();
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = b4;
     if constexpr (W::FIXED) {
@@ -167,7 +194,7 @@ __device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, co
 #pragma unroll
                 for (int dh = 0; dh < KH; ++dh) {
                     const int t = (c * KH + dh) * KW + dw;
-                    const f32x4 w4 = WREG ? wreg[t] : *(const f32x4*)(wl + t * p.Cout + cq * 4);
+                    const VT w4 = WREG ? wreg[t] : *(const VT*)(wl + t * p.Cout + cq * CPL);
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[r] += w4 * xin[(r * SH + dh) * Cin + c];
                 }
@@ -176,7 +203,7 @@ __device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, co
         for (int dw = 0; dw < KW; ++dw)
             for (int c = 0; c < Cin; ++c)
                 for (int dh = 0; dh < KH; ++dh) {
-                    const f32x4 w4 = *(const f32x4*)(wl + ((c * KH + dh) * KW + dw) * p.Cout + cq * 4);
+                    const VT w4 = *(const VT*)(wl + ((c * KH + dh) * KW + dw) * p.Cout + cq * CPL);
                     const float* col = xs + dw * cs + (ho0 * SH + dh) * Cin + c;
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[r] += w4 * col[r * SH * Cin];
@@ -188,8 +215,8 @@ __device__ __forceinline__ void conv_rows(const StemConv& p, const float* wl, co
 // pre(b, wo, ho0): issued BEFORE the convolution of a row group (the global loads of the backward passes, whose latency then
 // runs under the convolution's arithmetic); WREG: weights in registers (false: 16-byte LDS reads, for the kernel that needs the
 // registers for its accumulators).
-template <class W, bool WREG, class Pre, class Body>
-__device__ __forceinline__ void stem_columns(const StemConv& p, float* wl, float* xs2, f32x4 (&wreg)[W::T], int cq, int rg, int nrg, Pre pre,
+template <class W, bool WREG, typename VT, class Pre, class Body>
+__device__ __forceinline__ void stem_columns(const StemConv& p, float* wl, float* xs2, VT (&wreg)[W::T], int cq, int rg, int nrg, Pre pre,
                                              Body body) {
     stage_weights(p, wl);
     for (int i = threadIdx.x; i < 2 * MAX_XS; i += 256) xs2[i] = 0.f;
@@ -206,7 +233,7 @@ __device__ __forceinline__ void stem_columns(const StemConv& p, float* wl, float
     __syncthreads();
     if constexpr (W::FIXED && WREG) {
 #pragma unroll
-        for (int t = 0; t < W::T; ++t) wreg[t] = *(const f32x4*)(wl + t * p.Cout + cq * 4);
+        for (int t = 0; t < W::T; ++t) wreg[t] = *(const VT*)(wl + t * p.Cout + cq * (int)(sizeof(VT) / 4));
     }
     if (cur.q < ncol) sa.commit(xs2);
     nxt.step(G, Gb, Gw, p.Wo);
@@ -215,8 +242,8 @@ __device__ __forceinline__ void stem_columns(const StemConv& p, float* wl, float
     auto column = [&](const ColIdx& c, const float* xs) {
         for (int ho0 = rg * R; ho0 < p.Ho; ho0 += nrg * R) {
             pre(c.b, c.wo, ho0);
-            f32x4 acc[R];
-            conv_rows<W, WREG>(p, wl, wreg, xs, cq, ho0, acc);
+            VT acc[R];
+            conv_rows<W, WREG, VT>(p, wl, wreg, xs, cq, ho0, acc);
             body(c.b, c.wo, ho0, acc, xs);
         }
     };
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(StemConv p, float* __re
     STEM_SHARED
     __shared__ __attribute__((aligned(16))) float red[2048];
     f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int, int, int ho0, f32x4* acc, const float*) {
+    stem_columns<W, true, f32x4>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int, int, int ho0, f32x4* acc, const float*) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (ho0 + r < p.Ho) {
@@ -292,14 +319,14 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(StemConv p, const float
     const f32x4 mu = *(const f32x4*)(stats + cq * 4), rs = *(const f32x4*)(stats + p.Cout + cq * 4);
     const f32x4 ga = *(const f32x4*)(gamma + cq * 4), be = *(const f32x4*)(beta + cq * 4);
     const f32x4 k = rs * ga;
-    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int b, int wo, int ho0, f32x4* acc, const float*) {
+    stem_columns<W, true, f32x4>(p, wl, xs2, wreg, cq, rg, nrg, [](int, int, int) {}, [&](int b, int wo, int ho0, f32x4* acc, const float*) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (ho0 + r < p.Ho) {
                 f32x4 o = (acc[r] - mu) * k + be;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = relu_f(o[e]);
-                store4(out + grid_off(go, b, wo, ho0 + r) + cq * 4, o);
+                store4(out + (grid_off32(go, b, wo, ho0 + r) + cq * 4), o);
             }
     });
 }
@@ -316,12 +343,12 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(StemConv p, const 
     auto pre = [&](int b, int wo, int ho0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
+            const unsigned o = grid_off32(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
             gr[r].load(da + o);
             ar[r].load(a + o);
         }
     };
-    stem_columns<W, true>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, f32x4* acc, const float*) {
+    stem_columns<W, true, f32x4>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, f32x4* acc, const float*) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (ho0 + r < p.Ho) {
@@ -351,37 +378,43 @@ __global__ __launch_bounds__(256) void stem_bwd_wgrad_kernel(StemConv p, const f
                                                              float* __restrict__ slabs) {
     static_assert(W::FIXED, "the weight-gradient kernel needs a compile-time window shape");
     constexpr int TAPS = W::T;
-    STEM_SHARED
-    __shared__ __attribute__((aligned(16))) float red[4096];          // one chunk of 4 taps at a time: [nrg][4][Cout]
+    // TWO channels per lane here (f32x2: one packed FMA per tap and row): with four, the 18 x 4 accumulators beside the window and the
+    // convolution's own registers left one wave per SIMD and every LDS / global access exposed (0.51 ms at configs[2]).
+    typedef f32x2 VT;
+    __shared__ __attribute__((aligned(16))) float wl[MAX_WL];
+    __shared__ __attribute__((aligned(16))) float xs2[2 * MAX_XS];
+    __shared__ __attribute__((aligned(16))) float red[2048];          // one chunk of 4 taps at a time: [nrg][4][Cout] = 2 048 floats
+    const int cqn = p.Cout / 2, cq = threadIdx.x % cqn, rg = threadIdx.x / cqn, nrg = 256 / cqn;
+    VT wreg[W::T];
     const int Cin = W::cin(p), KH = W::kh(p), KW = W::kw(p), SH = W::sh(p), cs = col_stride<W>(p);
-    const f32x4 mu = *(const f32x4*)(stats + cq * 4), rs = *(const f32x4*)(stats + p.Cout + cq * 4);
-    f32x4 k1, k2, k3;
+    const VT mu = *(const VT*)(stats + cq * 2), rs = *(const VT*)(stats + p.Cout + cq * 2);
+    VT k1, k2, k3;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = cq * 4 + e;
+    for (int e = 0; e < 2; ++e) {
+        const int c = cq * 2 + e;
         k1[e] = gamma[c] * rs[e];
         k2[e] = k1[e] * dbeta[c] * inv_count;
         k3[e] = k1[e] * rs[e] * dgamma[c] * inv_count;
     }
-    f32x4 dwa[TAPS];
+    VT dwa[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) dwa[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Raw4<T> gr[R], ar[R];
+    for (int t = 0; t < TAPS; ++t) dwa[t] = vzero<VT>();
+    RawV<T, VT> gr[R], ar[R];
     auto pre = [&](int b, int wo, int ho0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const long long o = grid_off(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 4;
+            const unsigned o = grid_off32(ga_, b, wo, min(ho0 + r, p.Ho - 1)) + cq * 2;
             gr[r].load(da + o);
             ar[r].load(a + o);
         }
     };
-    stem_columns<W, false>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, f32x4* acc, const float* xs) {
+    stem_columns<W, false, VT>(p, wl, xs2, wreg, cq, rg, nrg, pre, [&](int, int, int ho0, VT* acc, const float* xs) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = ho0 + r < p.Ho;
-            const f32x4 g4 = gr[r].get(), a4 = ar[r].get();
+            const VT g4 = gr[r].get(), a4 = ar[r].get();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
                 const float g = a4[e] > 0.f ? g4[e] : 0.f;
                 acc[r][e] = ok ? k1[e] * g - k2[e] - k3[e] * (acc[r][e] - mu[e]) : 0.f;      // dy
             }
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(256) void stem_bwd_wgrad_kernel(StemConv p, const f
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
-            if (t >= t0 && t < t0 + 4) *(f32x4*)(red + (rg * 4 + (t - t0)) * p.Cout + cq * 4) = dwa[t];
+            if (t >= t0 && t < t0 + 4) *(VT*)(red + (rg * 4 + (t - t0)) * p.Cout + cq * 2) = dwa[t];
         __syncthreads();
         for (int i = threadIdx.x; i < 4 * p.Cout; i += 256) {
             const int u = i / p.Cout, co = i - u * p.Cout;
