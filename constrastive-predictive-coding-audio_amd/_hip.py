@@ -114,6 +114,7 @@ _SIGNATURES = {
     "cpc_prep_frag": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_gru_tape_elems": ([_I, _I, _I, _I], _L),
     "cpc_gru_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "cpc_gru_fwd_h0": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_bwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_gru_gp_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_gru_gp_bwd": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),

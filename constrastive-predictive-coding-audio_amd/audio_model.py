@@ -95,12 +95,12 @@ class AudioEncoder(nn.Module):
 
 class AudioGRUModel(nn.Module):
     """GRU context network; ``forward(input)`` takes (batch, input_size, steps) and returns the last hidden state
-    (reference audio_model.py:47-77).  Only ``reset_hidden=True`` (the reference default) is supported."""
+    (reference audio_model.py:47-77).  ``reset_hidden=False`` carries the last hidden state of one call into the next (``self.hidden``,
+    as in the reference, :69 / :75): forward only -- a call that starts from a carried state cannot be differentiated (the reference's
+    autograd raises there too, the previous call's graph being gone)."""
 
     def __init__(self, input_size, hidden_size, bias=True, reset_hidden=True):
         super().__init__()
-        if not reset_hidden:
-            raise NotImplementedError("reset_hidden=False (state carried across calls) is not part of the HIP path")
         self.input_size, self.hidden_size = input_size, hidden_size
         self.gruCell = _GRUCellParams(input_size, hidden_size, bias)
         self.hidden = None

@@ -493,6 +493,12 @@ int cpc_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall,
     return launch_gru_fwd(Gi, Wfrag, bhh, Hall, tape, c_out, B, V, H, dtype, (hipStream_t)stream);
 }
 
+int cpc_gru_fwd_h0(const void* Gi, const void* Wfrag, const float* bhh, const float* h0, void* Hall, void* tape, float* c_out, int B,
+                   int V, int H, int dtype, void* stream) {
+    if (!Gi || !Wfrag || !Hall || !tape || !c_out) return CPC_EINVAL;
+    return launch_gru_fwd(Gi, Wfrag, bhh, Hall, tape, c_out, B, V, H, dtype, (hipStream_t)stream, h0);
+}
+
 int cpc_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype, void* stream) {
     if (!dc || !tape || !WTfrag || !dG) return CPC_EINVAL;
     return launch_gru_bwd(dc, tape, WTfrag, dG, B, V, H, dtype, (hipStream_t)stream);

@@ -103,7 +103,7 @@ int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int 
                          hipStream_t stream);
 long long gru_tape_elems(int B, int V, int H, int dtype);
 int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B,
-                   int V, int H, int dtype, hipStream_t stream);
+                   int V, int H, int dtype, hipStream_t stream, const float* h0 = nullptr);
 int launch_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* dG, int B, int V, int H, int dtype,
                    hipStream_t stream);
 int launch_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const float* bhh, float* tape, float* ct_out, int B,

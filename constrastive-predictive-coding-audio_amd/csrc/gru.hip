@@ -22,7 +22,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(const T* __restrict__ Gi, const T* __restrict__ Wfrag,
                                                       const float* __restrict__ bhh, T* __restrict__ Hall,
                                                       T* __restrict__ tape, float* __restrict__ c_out, int B, int V,
-                                                      int H) {
+                                                      int H, const float* __restrict__ h0) {
     constexpr int CH = Elem<T>::CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rowb = H * (int)sizeof(T) + 16;             // h tile row stride in bytes (16 B pad)
@@ -39,10 +39,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const T* __restrict__ Gi, 
 
     for (int i = tid; i < 3 * H; i += 256) bsh[i] = bhh ? bhh[i] : 0.f;
     for (int i = tid; i < 16 * rowb / 4; i += 256) ((unsigned int*)hbuf[0])[i] = 0u;    // h_0 = 0
+    __syncthreads();          // (the loop below rewrites the tile with a carried state, by other threads)
     // Hall[:, 0, :] = 0
+    // (h0: the state a reset_hidden=False model carries over from its previous call, audio_model.py:69, :75; NULL = zeros)
     for (int i = tid; i < 16 * H; i += 256) {
         const int rb = i / H, j = i % H;
-        if (b0 + rb < B) Hall[((long long)(b0 + rb) * (V + 1)) * H + j] = from_f32<T>(0.f);
+        const float v = (h0 && b0 + rb < B) ? h0[(long long)(b0 + rb) * H + j] : 0.f;
+        ((T*)(hbuf[0] + rb * rowb))[j] = from_f32<T>(v);
+        if (b0 + rb < B) Hall[((long long)(b0 + rb) * (V + 1)) * H + j] = from_f32<T>(v);
     }
     __syncthreads();
 
@@ -50,7 +54,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const T* __restrict__ Gi, 
 #pragma unroll
     for (int q = 0; q < GRU_MAXJT; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hprev[q][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const int jt = wave + 4 * q;
+            hprev[q][e] = (h0 && b_ok && jt < ntile) ? h0[(long long)b * H + jt * 16 + fg * 4 + e] : 0.f;
+        }
 
     for (int t = 0; t < V; ++t) {
         const unsigned char* hcur = hbuf[t & 1];
@@ -259,7 +266,7 @@ template <int KC>
 __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* __restrict__ Gi, const bf16_t* __restrict__ Wfrag,
                                                                   const float* __restrict__ bhh, bf16_t* __restrict__ Hall,
                                                                   bf16_t* __restrict__ tape, float* __restrict__ c_out, int B,
-                                                                  int V) {
+                                                                  int V, const float* __restrict__ h0) {
     typedef GruCfg<KC> Cfg;
     constexpr int H = Cfg::H, NT = Cfg::NT, NJT = Cfg::NJT, KCL = Cfg::KCL, KCRN = KC - KCL, NW = GRU_NW, NTHR = 64 * NW;
     constexpr bool FULL = Cfg::FULL;
@@ -299,10 +306,17 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* 
     }
     for (int i = tid; i < 3 * H; i += NTHR) bsh[i] = bhh ? bhh[i] : 0.f;
     for (int i = tid; i < 16 * ROWB / 4; i += NTHR) ((unsigned int*)hbuf0)[i] = 0u;
+    if (h0) __syncthreads();          // (uniform: the loop below rewrites the tile with the carried state, by other threads)
     // Hall[:, 0, :] = 0 and the input-projection tile of step 0 (row-contiguous 16-byte chunks)
     for (int i = tid; i < 16 * H / 8; i += NTHR) {
         const int rb = i / (H / 8), cc = i % (H / 8);
-        if (b0 + rb < B) *(uint4*)(Hall + ((long long)(b0 + rb) * (V + 1)) * H + cc * 8) = make_uint4(0, 0, 0, 0);
+        uint4 hv = make_uint4(0, 0, 0, 0);
+        if (h0 && b0 + rb < B) {          // carried state (reset_hidden=False): the bf16 copy the MFMAs read, and Hall[:, 0]
+            const float* hp = h0 + (long long)(b0 + rb) * H + cc * 8;
+            hv = pack8(*(const f32x4*)hp, *(const f32x4*)(hp + 4));
+            *(uint4*)(hbuf0 + rb * ROWB + cc * 16) = hv;
+        }
+        if (b0 + rb < B) *(uint4*)(Hall + ((long long)(b0 + rb) * (V + 1)) * H + cc * 8) = hv;
     }
     uint4 gpre[GPT];
 #pragma unroll
@@ -321,7 +335,10 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* 
 #pragma unroll
     for (int q = 0; q < NJT; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hprev[q][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const int jt = wave + NW * q;
+            hprev[q][e] = (h0 && b_ok && (FULL || jt < NT)) ? h0[(long long)b * H + jt * 16 + fg * 4 + e] : 0.f;
+        }
     const long long tape_bt = (long long)blockIdx.x * V;
 
     for (int t = 0; t < V; ++t) {
@@ -583,7 +600,7 @@ long long gru_tape_elems(int B, int V, int H, int dtype) {
 }
 
 int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B,
-                   int V, int H, int dtype, hipStream_t stream) {
+                   int V, int H, int dtype, hipStream_t stream, const float* h0) {
     if (!gru_ok(B, V, H, dtype)) return CPC_EINVAL;
     const int esz = dtype == CPC_DTYPE_BF16 ? 2 : 4;
     const size_t shm = 2 * 16 * (size_t)(H * esz + 16) + 3 * H * sizeof(float);
@@ -591,7 +608,7 @@ int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Ha
     if (dtype == CPC_DTYPE_BF16 && !g_gru_force_streaming && (H == 32 || H == 64 || H == 128 || H == 256)) {
 #define GRU_F(KC) \
     hipLaunchKernelGGL((gru_fwd_res_kernel<KC>), grid, dim3(64 * GRU_NW), 0, stream, (const bf16_t*)Gi, (const bf16_t*)Wfrag, bhh, \
-                       (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V)
+                       (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V, h0)
         if (H == 256) GRU_F(8); else if (H == 128) GRU_F(4); else if (H == 64) GRU_F(2); else GRU_F(1);
 #undef GRU_F
         CPC_CHECK_LAUNCH();
@@ -599,10 +616,10 @@ int launch_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Ha
     }
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((gru_fwd_kernel<bf16_t>), grid, dim3(256), shm, stream, (const bf16_t*)Gi, (const bf16_t*)Wfrag, bhh,
-                           (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V, H);
+                           (bf16_t*)Hall, (bf16_t*)tape, c_out, B, V, H, h0);
     else
         hipLaunchKernelGGL((gru_fwd_kernel<float>), grid, dim3(256), shm, stream, (const float*)Gi, (const float*)Wfrag, bhh,
-                           (float*)Hall, (float*)tape, c_out, B, V, H);
+                           (float*)Hall, (float*)tape, c_out, B, V, H, h0);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

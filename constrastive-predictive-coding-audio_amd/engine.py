@@ -684,6 +684,7 @@ class GRUContext:
 
     def __init__(self, eng, ar):
         self.eng = eng
+        self.ar = ar
         self.H = int(ar.hidden_size)
         ch = 8 if eng.dt == torch.bfloat16 else 4
         if ar.input_size != eng.E or self.H != eng.H:
@@ -727,8 +728,19 @@ class GRUContext:
         Ltop, t0, top = e.geo.alloc[-1], e.T - K - V, e.act[-1]
         _hip.gemm_nt(_hip.ptr(top, t0 * E), _hip.ptr(self.w_ih), _hip.ptr(self.Gi), B * V, 3 * H, E, E, E, 3 * H, code,
                      bias=_hip.ptr(p.get(self.prefix + "bias_ih")), a_rpi=V, a_item=Ltop * E)
-        _hip.call("cpc_gru_fwd", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get(self.prefix + "bias_hh")),
-                  _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(e.c), B, V, H, code)
+        # reset_hidden=False (audio_model.py:69, :75): the last hidden state of the previous call is this call's initial one
+        carry = not getattr(self.ar, "reset_hidden", True)
+        h0 = self.ar.hidden if carry else None
+        if h0 is not None and (tuple(h0.shape) != (B, H) or h0.device != e.c.device):
+            raise ValueError(f"carried GRU state has shape {tuple(h0.shape)} on {h0.device}, this call needs ({B}, {H}) on {e.c.device}")
+        self.carried = h0 is not None
+        if h0 is not None:
+            _hip.call("cpc_gru_fwd_h0", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get(self.prefix + "bias_hh")),
+                      _hip.ptr(h0.detach().float().contiguous()), _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(e.c), B, V, H, code)
+        else:
+            _hip.call("cpc_gru_fwd", _hip.ptr(self.Gi), _hip.ptr(self.w_hh_frag), _hip.ptr(p.get(self.prefix + "bias_hh")),
+                      _hip.ptr(self.Hall), _hip.ptr(self.tape), _hip.ptr(e.c), B, V, H, code)
+        self.ar.hidden = e.c.detach().clone() if carry else None
 
     def c_operand(self):
         """(tensor, element offset, item stride): storage-dtype rows of c, one per item (h_V inside the hidden-state buffer)."""
@@ -742,6 +754,10 @@ class GRUContext:
         g, code, B, V, E, K = e.model._grad, e.code, e.B, e.V, e.E, e.K
         Ltop, t0, top, dtop = e.geo.alloc[-1], e.T - K - V, e.act[-1], e.dact[-1]
         phase = getattr(e, "_gp_phase", 0)
+        if getattr(self, "carried", False):
+            raise RuntimeError("this GRU call started from a state carried over from the previous call (reset_hidden=False): it cannot be "
+                               "differentiated -- the reference's autograd cannot either (the previous call's graph is gone after its "
+                               "backward()); use reset_hidden=False for inference / streaming, or set model.hidden = None before a train step")
         if phase == 1:               # gradient penalty, pass 1: dc is the adjoint of the summed scores (gp_grads starts from it)
             self._gp_buffers()
             self.gp_dc1.copy_(dc)

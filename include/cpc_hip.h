@@ -396,6 +396,11 @@ int cpc_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int 
 long long cpc_gru_tape_elems(int B, int V, int H, int dtype);
 int cpc_gru_fwd(const void* Gi, const void* Wfrag, const float* bhh, void* Hall, void* tape, float* c_out, int B, int V,
                 int H, int dtype, void* stream);
+/* The same with an initial hidden state h0 f32 [B][H] (NULL = zeros): AudioGRUModel(reset_hidden=False) carries the last hidden state
+ * of one call into the next (audio_model.py:69, :75).  Forward only: the reference's autograd cannot differentiate a second call
+ * through the first one's graph either. */
+int cpc_gru_fwd_h0(const void* Gi, const void* Wfrag, const float* bhh, const float* h0, void* Hall, void* tape, float* c_out, int B,
+                   int V, int H, int dtype, void* stream);
 /* Backward through time: dc f32 [B][H] -> dG T [B][V][4H] = [d r_pre | d z_pre | d n_pre | d n_pre * r]: columns [0,3H) are
  * the gradient w.r.t. the input-projection term, columns [0,2H) and [3H,4H) the gradient w.r.t. h W_hh^T + b_hh.
  * WTfrag = cpc_prep_frag(weight_hh, transpose=1) ([H][3H] logical). */

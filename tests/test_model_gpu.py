@@ -1434,3 +1434,36 @@ def test_operand_copies_prepared_ahead_equal_prepared_at_step_start(context):
     ref_eng.forward(data[2])
     for got, ref in zip(eng.outputs(), ref_eng.outputs()):
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gru_state_carried_across_calls(golden_dir, dtype):
+    """AudioGRUModel(reset_hidden=False) (reference audio_model.py:58-77): the last hidden state of one call is the initial state of
+    the next, so two calls on the two halves of a sequence equal ONE call on the whole sequence (the fixture's 13 steps, against the
+    REFERENCE's own final state from gru.npz), ``model.hidden`` holds that state, and a reset_hidden=True model forgets it.  A call
+    that started from a carried state refuses to be differentiated, as the reference's autograd does."""
+    g = _load(golden_dir, "gru.npz")
+    state = {k[len("param/autoregressive_model."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    z = torch.from_numpy(g["z"]).to(DEV)                         # (7, 32, 13)
+    tol = 1e-4 if dtype == "fp32" else 2e-2
+    gru = AudioGRUModel(input_size=32, hidden_size=64, reset_hidden=False)
+    gru.compute_dtype = torch.float32 if dtype == "fp32" else torch.bfloat16
+    gru.load_state_dict(state)
+    gru = gru.to(DEV)
+    with torch.no_grad():
+        h_a = gru(z[:, :, :6].contiguous())
+        assert gru.hidden is not None and torch.equal(gru.hidden, h_a)
+        h_b = gru(z[:, :, 6:].contiguous())
+    assert _rel(h_b, g["h"]) < tol                                # = one call over all 13 steps, as the reference computed it
+    assert _rel(h_a, g["h"]) > 10 * tol                           # (and not the state after 6 steps)
+    fresh = AudioGRUModel(input_size=32, hidden_size=64)          # reset_hidden=True: every call starts from zeros
+    fresh.compute_dtype = gru.compute_dtype
+    fresh.load_state_dict(state)
+    fresh = fresh.to(DEV)
+    with torch.no_grad():
+        fresh(z[:, :, :6].contiguous())
+        h_c = fresh(z[:, :, 6:].contiguous())
+    assert fresh.hidden is None and _rel(h_c, g["h"]) > 10 * tol
+    zg = z[:, :, 6:].contiguous().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="carried"):
+        gru(zg).sum().backward()
