@@ -1167,7 +1167,18 @@ __device__ __forceinline__ u32x2 lds_read_tr_asm(unsigned addr) {
     return d;
 }
 
-template <typename TO, int WI, int WJ, int TI, int TJ>
+// ROWS: operands addressed as items of rpi rows (the valid rows of each column of a grid); the row -> offset division runs on
+// a float reciprocal with one correction step (8 per lane and stage, beside 64 MFMAs per wave).
+__device__ __forceinline__ long long row_off_rcp(int m, int rpi, float inv, long long item, long long ld) {
+    if (rpi == 0) return (long long)m * ld;
+    int q = (int)(((float)m + 0.5f) * inv);
+    int r = m - q * rpi;
+    if (r < 0) { --q; r += rpi; }
+    else if (r >= rpi) { ++q; r -= rpi; }
+    return (long long)q * item + (long long)r * ld;
+}
+
+template <typename TO, int WI, int WJ, int TI, int TJ, bool ROWS>
 __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_dma_kernel(GemmTN p) {
     typedef bf16_t T;
     constexpr int BKM = 64, NW = WI * WJ;
@@ -1217,6 +1228,15 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_dma_kernel(GemmTN p) {
         typedef __attribute__((address_space(3))) unsigned char lds_byte;
         lds_byte* const lds3 = (lds_byte*)lds;
         const unsigned wdst = wave_u * 4096;
+        const float inva = ROWS && p.a_rpi ? 1.0f / (float)p.a_rpi : 0.f, invb = ROWS && p.b_rpi ? 1.0f / (float)p.b_rpi : 0.f;
+        auto offa = [&](int m) -> long long {
+            if constexpr (ROWS) return row_off_rcp(m, p.a_rpi, inva, p.a_item, p.lda);
+            else return (long long)m * p.lda;
+        };
+        auto offb = [&](int m) -> long long {
+            if constexpr (ROWS) return row_off_rcp(m, p.b_rpi, invb, p.b_item, p.ldb);
+            else return (long long)m * p.ldb;
+        };
 #define TN_DMA1(g, dst)                                                                                          \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                         \
                                      (__attribute__((address_space(3))) void*)(lds3 + (dst)), 16, 0, 0)
@@ -1226,14 +1246,14 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_dma_kernel(GemmTN p) {
         const int mb_ = m_begin + (st) * BKM;                                                                    \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
         switch (idx) {                                                                                           \
-        case 0: TN_DMA1(ga[0] + (long long)min(mb_ + rowa[0], p.M - 1) * p.lda, da); break;                      \
-        case 1: TN_DMA1(gb[0] + (long long)min(mb_ + rowb[0], p.M - 1) * p.ldb, db); break;                      \
-        case 2: TN_DMA1(ga[1] + (long long)min(mb_ + rowa[1], p.M - 1) * p.lda, da + 1024); break;               \
-        case 3: TN_DMA1(gb[1] + (long long)min(mb_ + rowb[1], p.M - 1) * p.ldb, db + 1024); break;               \
-        case 4: TN_DMA1(ga[2] + (long long)min(mb_ + rowa[2], p.M - 1) * p.lda, da + 2048); break;               \
-        case 5: TN_DMA1(gb[2] + (long long)min(mb_ + rowb[2], p.M - 1) * p.ldb, db + 2048); break;               \
-        case 6: TN_DMA1(ga[3] + (long long)min(mb_ + rowa[3], p.M - 1) * p.lda, da + 3072); break;               \
-        case 7: TN_DMA1(gb[3] + (long long)min(mb_ + rowb[3], p.M - 1) * p.ldb, db + 3072); break;               \
+        case 0: TN_DMA1(ga[0] + offa(min(mb_ + rowa[0], p.M - 1)), da); break;                      \
+        case 1: TN_DMA1(gb[0] + offb(min(mb_ + rowb[0], p.M - 1)), db); break;                      \
+        case 2: TN_DMA1(ga[1] + offa(min(mb_ + rowa[1], p.M - 1)), da + 1024); break;               \
+        case 3: TN_DMA1(gb[1] + offb(min(mb_ + rowb[1], p.M - 1)), db + 1024); break;               \
+        case 4: TN_DMA1(ga[2] + offa(min(mb_ + rowa[2], p.M - 1)), da + 2048); break;               \
+        case 5: TN_DMA1(gb[2] + offb(min(mb_ + rowb[2], p.M - 1)), db + 2048); break;               \
+        case 6: TN_DMA1(ga[3] + offa(min(mb_ + rowa[3], p.M - 1)), da + 3072); break;               \
+        case 7: TN_DMA1(gb[3] + offb(min(mb_ + rowb[3], p.M - 1)), db + 3072); break;               \
         default: break;                                                                                          \
         }                                                                                                        \
     } while (0)
@@ -1745,13 +1765,16 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
         q.m_chunk = eff_chunk;
         grid = dim3(nsplit, numI * numJ, batch);
         const bool plain = p.a_rpi == 0 && p.b_rpi == 0;
-        const bool tdma = plain && !(p.flags & GEMM_NO_DMA) && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.I % 8 == 0 && p.J % 8 == 0 &&
+        const bool tdma = (plain || (p.a_item % 8 == 0 && p.b_item % 8 == 0 && p.M < (1 << 22))) && !(p.flags & GEMM_NO_DMA) && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.I % 8 == 0 && p.J % 8 == 0 &&
                           ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.a_batch % 8 == 0 && p.b_batch % 8 == 0;
 #define TN_LAUNCH(WII, WJJ, TII, TJJ, NTH)                                                                               \
     do {                                                                                                                 \
-        if (tdma) {                                                                                                      \
-            if (of32) hipLaunchKernelGGL((gemm_tn_dma_kernel<float, WII, WJJ, TII, TJJ>), grid, dim3(NTH), 0, stream, q); \
-            else hipLaunchKernelGGL((gemm_tn_dma_kernel<bf16_t, WII, WJJ, TII, TJJ>), grid, dim3(NTH), 0, stream, q);    \
+        if (tdma && plain) {                                                                                             \
+            if (of32) hipLaunchKernelGGL((gemm_tn_dma_kernel<float, WII, WJJ, TII, TJJ, false>), grid, dim3(NTH), 0, stream, q);   \
+            else hipLaunchKernelGGL((gemm_tn_dma_kernel<bf16_t, WII, WJJ, TII, TJJ, false>), grid, dim3(NTH), 0, stream, q);      \
+        } else if (tdma) {                                                                                               \
+            if (of32) hipLaunchKernelGGL((gemm_tn_dma_kernel<float, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);    \
+            else hipLaunchKernelGGL((gemm_tn_dma_kernel<bf16_t, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);       \
         } else if (plain) {                                                                                              \
             if (of32) hipLaunchKernelGGL((gemm_tn_fast_kernel<float, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);   \
             else hipLaunchKernelGGL((gemm_tn_fast_kernel<bf16_t, WII, WJJ, TII, TJJ, true>), grid, dim3(NTH), 0, stream, q);      \

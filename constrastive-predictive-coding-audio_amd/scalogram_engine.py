@@ -121,17 +121,29 @@ class _Conv:
                 self.Rd = _ceil_div((self.kh + G - 1) * self.cout, 64) * 64 // self.cout
                 if (self.Rw * self.cin) % 64 or (self.Rd * self.cout) % 64:
                     self.G = 1
+            # Only the rows that exist are computed.  A valid convolution with a tall kernel has Ho = Ha - kh + 1 output rows per column
+            # (127 of 190, 34 of 63, 2 of 16 in scalogram_resnet_architecture_7), and only the rows [top, top + H) of the input carry a
+            # gradient: the GEMMs address "rows per column" (a_rpi / c_rpi) instead of running over every allocated row of the grid
+            # (CPC_COL_VALID=0: all rows, the round-2 form -- 33 ... 47 % more GEMM work on the tall kernels).
+            self.valid_rows = os.environ.get("CPC_COL_VALID", "1") != "0"
+            self.ncol = B * gin.W
+            Gq = self.G
+            self.Hg = _ceil_div(self.Ho, Gq)                                   # output (super-)rows per column
+            self.r0 = gin.top // Gq                                            # first input (super-)row that carries a gradient
+            self.nr = _ceil_div(gin.top + gin.H, Gq) - self.r0                 # ... and how many
             if self.G > 1:
                 G = self.G
                 self.w_fwd = torch.zeros(G, self.cout, self.Rw, self.cin, device=dev, dtype=dt)       # [(dh,co)][(r,c)]
                 self.w_dgrad = torch.zeros(G, self.cin, self.Rd, self.cout, device=dev, dtype=dt)     # [(dr,c)][(q,co)]
                 self.bias_g = torch.zeros(G * self.cout, device=dev, dtype=torch.float32)
-                self.nsplit = eng._pick_split(self.Rw * self.cin, G * self.cout, self.M // G)
+                self.Mw = self.ncol * self.Hg if self.valid_rows else self.M // G          # rows of the weight-gradient reduction
+                self.nsplit = eng._pick_split(self.Rw * self.cin, G * self.cout, self.Mw)
                 self.slab = self.nsplit * self.Rw * self.cin * G * self.cout
             else:
                 self.w_fwd = torch.empty(self.cout * self.K, device=dev, dtype=dt)
                 self.w_dgrad = torch.empty(self.cin * self.kh * self.cout, device=dev, dtype=dt)
-                self.nsplit = eng._pick_split(self.K, self.cout, self.M)
+                self.Mw = self.ncol * self.Hg if self.valid_rows else self.M
+                self.nsplit = eng._pick_split(self.K, self.cout, self.Mw)
                 self.slab = self.nsplit * self.K * self.cout
         else:
             o_top, o_tail, o_guard = out_pad if out_pad is not None else (0, 0, 96)
@@ -199,11 +211,19 @@ class _Conv:
             G = self.G
             Kg, Ng = self.Rw * self.cin, G * self.cout
             Hg = _ceil_div(self.Ho, G)
-            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M // G, Ng, Kg, G * self.cin, Kg, Ng, code,
-                         bias=(_hip.ptr(self.bias_g) if self.bname else None) if not tangent else None, mask=mask,
-                         c_rpi=gin.Ha // G, c_item=y0.Ha * self.cout, c_valid=Hg, flags=flags)
+            bias_g = (_hip.ptr(self.bias_g) if self.bname else None) if not tangent else None
+            if self.valid_rows:
+                _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.ncol * Hg, Ng, Kg, G * self.cin, Kg, Ng, code, bias=bias_g, mask=mask,
+                             a_rpi=Hg, a_item=gin.Ha * self.cin, c_rpi=Hg, c_item=y0.Ha * self.cout, c_valid=Hg, flags=flags)
+            else:
+                _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M // G, Ng, Kg, G * self.cin, Kg, Ng, code, bias=bias_g, mask=mask,
+                             c_rpi=gin.Ha // G, c_item=y0.Ha * self.cout, c_valid=Hg, flags=flags)
             if Hg * G > self.Ho:          # rows of the last super-row beyond the valid output
                 y0.t.view(-1, y0.Ha, self.cout)[:, self.Ho:Hg * G, :] = 0
+        elif self.mode == 'col' and self.valid_rows:
+            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.ncol * self.Ho, self.cout, self.K, self.cin, self.K, self.cout, code,
+                         bias=bias, mask=mask, a_rpi=self.Ho, a_item=gin.Ha * self.cin, c_rpi=self.Ho, c_item=y0.Ha * self.cout,
+                         c_valid=self.Ho, flags=flags)
         elif self.mode == 'col':
             _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M, self.cout, self.K, self.cin, self.K, self.cout, code,
                          bias=bias, mask=mask, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
@@ -248,8 +268,9 @@ class _Conv:
 
         if self.mode == 'col' and self.G > 1:
             G = self.G
-            Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.M // G
+            Kg, Ng, Mg = self.Rw * self.cin, G * self.cout, self.Mw
             chunk = e._chunk(Mg, self.nsplit)
+            rows = dict(a_rpi=self.Hg, a_item=gin.Ha * self.cin, b_rpi=self.Hg, b_item=dy0.Ha * self.cout) if self.valid_rows else {}
 
             def reduce():
                 # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
@@ -260,11 +281,12 @@ class _Conv:
                 gw.view(self.cout, self.cin, self.kh).copy_(acc.permute(2, 1, 0))
 
             staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
-                                        m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32), reduce)
+                                        m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32, **rows), reduce)
         elif self.mode == 'col':
-            chunk = e._chunk(self.M, self.nsplit)
-            staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.M, self.K, self.cout, self.cin, self.cout, self.cout, code,
-                                        nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32),
+            chunk = e._chunk(self.Mw, self.nsplit)
+            rows = dict(a_rpi=self.Ho, a_item=gin.Ha * self.cin, b_rpi=self.Ho, b_item=dy0.Ha * self.cout) if self.valid_rows else {}
+            staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), self.Mw, self.K, self.cout, self.cin, self.cout, self.cout, code,
+                                        nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.K * self.cout, flags=_hip.GEMM_OUT_F32, **rows),
                    lambda: _hip.call("cpc_reduce_conv_w", _hip.ptr(wslab), _hip.ptr(gw), self.cin, self.cout, self.kh, self.nsplit,
                                      self.K * self.cout))
         else:
@@ -303,8 +325,14 @@ class _Conv:
                     self._din_tmp = din.like(e.device, e.dt)
                 dst = self._din_tmp
             Kd = self.Rd * self.cout
-            _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
-                         Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
+            if self.valid_rows:
+                r0, nr = self.r0, self.nr
+                _hip.gemm_nt(dy0.ptr((r0 * G - (self.kh - 1)) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(r0 * G * self.cin), self.ncol * nr,
+                             G * self.cin, Kd, G * self.cout, Kd, G * self.cin, code, mask=gin.ptr(r0 * G * self.cin) if mask_input else None,
+                             a_rpi=nr, a_item=dy0.Ha * self.cout, c_rpi=nr, c_item=dst.Ha * self.cin, c_valid=nr)
+            else:
+                _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
+                             Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
             if accumulate:
                 din.t.add_(dst.t)
         elif self.mode == 'col':
@@ -314,8 +342,14 @@ class _Conv:
                 if getattr(self, "_din_tmp", None) is None:
                     self._din_tmp = din.like(e.device, e.dt)
                 dst = self._din_tmp
-            _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
-                         D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
+            if self.valid_rows:
+                r0, nr = self.r0, self.nr
+                _hip.gemm_nt(dy0.ptr((r0 - (D - 1)) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(r0 * self.cin), self.ncol * nr, self.cin,
+                             D * self.cout, self.cout, D * self.cout, self.cin, code, mask=gin.ptr(r0 * self.cin) if mask_input else None,
+                             a_rpi=nr, a_item=dy0.Ha * self.cout, c_rpi=nr, c_item=dst.Ha * self.cin, c_valid=nr)
+            else:
+                _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
+                             D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
             if accumulate:
                 din.t.add_(dst.t)
         else:
