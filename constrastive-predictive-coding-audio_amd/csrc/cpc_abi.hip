@@ -17,7 +17,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 6; }
+int cpc_abi_version(void) { return 7; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -30,6 +30,8 @@ int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     p.c_rpi = a->c_rpi; p.c_item = a->c_item; p.c_valid = a->c_valid;
     p.a_batch = a->a_batch; p.b_batch = a->b_batch; p.c_batch = a->c_batch;
     p.flags = a->flags;
+    p.a_rpi2 = a->a_rpi2; p.a_item2 = a->a_item2; p.c_rpi2 = a->c_rpi2; p.c_item2 = a->c_item2; p.k_ranges = a->k_ranges;
+    if (a->a_rpi2 && a->a_extent > 0) return CPC_EINVAL;
     if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
     if (a->mask && (p.flags & GEMM_OUT_F32) && a->dtype != CPC_DTYPE_F32) return CPC_EINVAL;
     // Optional extent check (see the over-read contract in cpc_hip.h): the last row of the last batch ends at ..._end elements.

@@ -60,6 +60,13 @@ __device__ __forceinline__ long long row_off(int m, int rpi, long long item, lon
     return (long long)q * item + (long long)(m - q * rpi) * ld;
 }
 
+// ... with a second level: items of rpi rows grouped rpi2 to a band (rpi2 == 0: one level)
+__device__ __forceinline__ long long row_off2(int m, int rpi, long long item, long long ld, int rpi2, long long item2) {
+    if (rpi2 == 0) return row_off(m, rpi, item, ld);
+    const int q = m / rpi, q2 = q / rpi2;
+    return (long long)q2 * item2 + (long long)(q - q2 * rpi2) * item + (long long)(m - q * rpi) * ld;
+}
+
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): a GRU step is
 // latency-bound on 16 workgroups, and libm's expf / tanhf / IEEE division cost more than the step's 96 MFMAs.
 __device__ __forceinline__ float fast_sigmoid(float x) {

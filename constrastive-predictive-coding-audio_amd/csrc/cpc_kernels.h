@@ -40,6 +40,17 @@ struct GemmNT {
     int c_rpi; long long c_item; int c_valid;   // rows with (m % c_rpi) >= c_valid are written as zeros (c_rpi != 0)
     long long a_batch, b_batch, c_batch;
     int flags;
+    // Second row level (fast LDS-DMA kernels): with a_rpi2 != 0 row m of A sits at
+    //   (m / (a_rpi a_rpi2)) * a_item2 + ((m / a_rpi) % a_rpi2) * a_item + (m % a_rpi) * lda,   likewise C (and the mask) with c_*2.
+    // "Bands": the rows of a grid ordered (band of rows, column, row within the band) — every row of a tile then lies in one or two
+    // bands, and k_ranges can cut the K loop to what that band needs.
+    int a_rpi2 = 0; long long a_item2 = 0;
+    int c_rpi2 = 0; long long c_item2 = 0;
+    // k_ranges (device, int pairs, or null): the K stages [lo, hi) (units of 64 bf16 / 32 f32 elements) that are not known zeros for
+    // level-2 index i = m / (a_rpi a_rpi2) (a_rpi2 == 0: item index m / a_rpi), hi > lo.  A tile runs the union of its rows' ranges.
+    // The data gradient of a tall (k,1) convolution reads a window of output-gradient rows of which, near the top and bottom of a
+    // column, most lie outside the column (zeros): 47 % of the MACs of the (30,1) kernel on 63 rows.
+    const int* k_ranges = nullptr;
     int m_off = 0;        // internal: first row of this launch (fast kernels; a launch may cover rows [m_off, M) only)
     // internal, fast kernels: order in which the K axis is visited.  Stage s (BK elements) covers the K offsets
     //   (s / k_taps) * BK + (s % k_taps) * k_tap_stride ... + BK        (k_taps <= 1: plain s * BK)

@@ -394,6 +394,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
+    // GemmNT::k_ranges: the K stages this tile's rows need (the union over the bands / items it touches)
+    int nk_tile = p.K / (8 * Elem<T>::CH);
+    if (p.k_ranges) {
+        const int per = p.a_rpi * (p.a_rpi2 > 0 ? p.a_rpi2 : 1);
+        const int i_lo = m0 / per, i_hi = min(m0 + TBM - 1, p.M - 1) / per;
+        int lo = p.k_ranges[2 * i_lo], hi = p.k_ranges[2 * i_lo + 1];
+        for (int i = i_lo + 1; i <= i_hi; ++i) {
+            lo = min(lo, p.k_ranges[2 * i]);
+            hi = max(hi, p.k_ranges[2 * i + 1]);
+        }
+        Ab += (long long)lo * (8 * Elem<T>::CH);
+        Bb += (long long)lo * (8 * Elem<T>::CH);
+        nk_tile = hi - lo;
+    }
     if constexpr (DMA && TI == 8) {
         // start stagger of the first round of workgroups (GemmNT::stagger)
         if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.z == 0) {
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) offB[kk][j] = ATILE + lds_off(wn * TJ * 16 + j * 16 + frow, kk * 4 + fg);
     }
-    const int nk = p.K / BK;
+    const int nk = nk_tile;
     // K visiting order (GemmNT::k_taps): element offset of stage 1, and of the stage the loop fetches next (kb + kj * tstride)
     const int taps = p.k_taps > 1 ? p.k_taps : 1;
     const long long tstride = p.k_taps > 1 ? p.k_tap_stride : 0;
@@ -427,10 +441,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
         static_assert(NA == 4 && NB == 4, "staging code below is written for 4 chunks per operand per thread");
         const int ch = tid & 7, srow = tid >> 3;
-        const T* ga0 = Ab + row_off(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-        const T* ga1 = Ab + row_off(min(m0 + srow + RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-        const T* ga2 = Ab + row_off(min(m0 + srow + 2 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
-        const T* ga3 = Ab + row_off(min(m0 + srow + 3 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda) + ch * CH;
+        const T* ga0 = Ab + row_off2(min(m0 + srow, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + ch * CH;
+        const T* ga1 = Ab + row_off2(min(m0 + srow + RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + ch * CH;
+        const T* ga2 = Ab + row_off2(min(m0 + srow + 2 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + ch * CH;
+        const T* ga3 = Ab + row_off2(min(m0 + srow + 3 * RSTEP, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + ch * CH;
         const T* gb0 = Bb + row_off(min(n0 + srow, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
         const T* gb1 = Bb + row_off(min(n0 + srow + RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
         const T* gb2 = Bb + row_off(min(n0 + srow + 2 * RSTEP, p.N - 1), p.b_rpi, p.b_item, p.ldb) + ch * CH;
@@ -492,10 +506,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         // 8j + (lane>>3), LDS chunk lane&7, SOURCE chunk (lane&7) ^ (row&7) = (lane&7) ^ (lane>>3)  (swizzle on the source)
         const int srow = lane >> 3, sch = (lane & 7) ^ (lane >> 3);
         const int r0 = (wave_u * 4) * 8 + srow;
-        const T* ga0 = Ab + row_off(min(m0 + r0, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
-        const T* ga1 = Ab + row_off(min(m0 + r0 + 8, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
-        const T* ga2 = Ab + row_off(min(m0 + r0 + 16, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
-        const T* ga3 = Ab + row_off(min(m0 + r0 + 24, p.M - 1), p.a_rpi, p.a_item, p.lda) + sch * CH;
+        const T* ga0 = Ab + row_off2(min(m0 + r0, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + sch * CH;
+        const T* ga1 = Ab + row_off2(min(m0 + r0 + 8, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + sch * CH;
+        const T* ga2 = Ab + row_off2(min(m0 + r0 + 16, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + sch * CH;
+        const T* ga3 = Ab + row_off2(min(m0 + r0 + 24, p.M - 1), p.a_rpi, p.a_item, p.lda, p.a_rpi2, p.a_item2) + sch * CH;
         const int br0 = DIRECT ? direct_b_col(r0) : r0, br1 = DIRECT ? direct_b_col(r0 + 8) : r0 + 8;
         const int br2 = DIRECT ? direct_b_col(r0 + 16) : r0 + 16, br3 = DIRECT ? direct_b_col(r0 + 24) : r0 + 24;
         const T* gb0 = Bb + row_off(min(n0 + br0, p.N - 1), p.b_rpi, p.b_item, p.ldb) + sch * CH;
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 for (int k = 0; k < 4; ++k) {
                     const int r = (wave_u * 4 + k) * 8 + (lane >> 3);
                     const int m = min(m0 + r, p.M - 1);
-                    const unsigned char* src = p.mask_bits + (((long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n0) >> 3) + (lane & 7) * 4;
+                    const unsigned char* src = p.mask_bits + (((long long)blockIdx.z * p.c_batch + row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2) + n0) >> 3) + (lane & 7) * 4;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(lds3 + BITS_OFF + (wave_u * 4 + k) * 256), 4, 0, 0);
                 }
@@ -723,7 +737,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = min(m0 + (wm * TI + i) * 16 + frow, p.M - 1);
-            off[i] = row_off(m, p.c_rpi, p.c_item, p.ldc) + min(nb, p.N - 8);
+            off[i] = row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2) + min(nb, p.N - 8);
             rv[i] = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
         }
         const long long o1 = (nb + 32 < p.N) ? 32 : 0;                  // pair 1 beyond N: any valid address (value unused)
@@ -805,14 +819,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #pragma unroll
                     for (int q = 0; q < NPASS; ++q) {
                         const int m = min(m0 + rr + q * RPP, p.M - 1);
-                        mbits[q] = Mbits[((long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n) >> 3];
+                        mbits[q] = Mbits[((long long)blockIdx.z * p.c_batch + row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2) + n) >> 3];
                     }
                 }
             } else if (Mb && n < p.N) {
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q) {
                     const int m = min(m0 + rr + q * RPP, p.M - 1);
-                    mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off(m, p.c_rpi, p.c_item, p.ldc) + n);
+                    mk[q] = *(const uint4*)(Mb + (long long)blockIdx.z * p.c_batch + row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2) + n);
                 }
             }
 #pragma unroll
@@ -886,7 +900,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                     const int r = rr + q * RPP;
                     const int m = m0 + r;
                     if (m >= p.M) break;
-                    const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
+                    const long long coff = row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2);
                     uint4 v = *(const uint4*)(lds + r * EPI_RS + cc * 16);
                     if (Mbits) {
                         if (!bits_early) {
@@ -978,7 +992,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     for (int i = 0; i < TI; ++i) {
         const int m = m0 + wm * TI * 16 + i * 16 + frow;
         if (m >= p.M) continue;
-        const long long coff = row_off(m, p.c_rpi, p.c_item, p.ldc);
+        const long long coff = row_off2(m, p.c_rpi, p.c_item, p.ldc, p.c_rpi2, p.c_item2);
         const bool row_valid = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -1647,6 +1661,10 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         return CPC_OK;
     }
     const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
+    // two-level rows and K ranges exist in the fast kernels only; a K range needs items to index and the storage K order
+    const bool banded = p.a_rpi2 || p.c_rpi2 || p.k_ranges;
+    if (banded && (!fast || (p.flags & (GEMM_EPI_CONV1 | GEMM_NO_DMA)) || p.m_off || p.k_taps > 1 || p.colsum_slabs)) return CPC_EINVAL;
+    if ((p.a_rpi2 && (!p.a_rpi || p.a_item2 % ch)) || (p.c_rpi2 && (!p.c_rpi || p.c_item2 % 4)) || (p.k_ranges && !p.a_rpi)) return CPC_EINVAL;
     // 256x256 tiles only where they fill the chip: below ~200 of them (e.g. the 3072 x 3072 all-timesteps score matrix: 144)
     // four times as many 128x128 tiles keep more CUs busy
     const long long big_tiles = (long long)((p.M - p.m_off + 255) / 256) * ((p.N + 255) / 256);
@@ -1656,14 +1674,14 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (g_nt_wt == 1) q.flags |= GEMM_WT_AGENT; else if (g_nt_wt == 2) q.flags |= GEMM_WT_SYSTEM;
     // overlapped-row A operand (strided-conv view): visit K tap-innermost, see GemmNT::k_taps
     const int bk = 8 * ch;
-    if (fast && p.k_taps == 0 && p.lda > 0 && p.lda < p.K && p.K % p.lda == 0 && p.lda % bk == 0 && !(p.flags & GEMM_LINEAR_K)) {
+    if (fast && !p.k_ranges && p.k_taps == 0 && p.lda > 0 && p.lda < p.K && p.K % p.lda == 0 && p.lda % bk == 0 && !(p.flags & GEMM_LINEAR_K)) {
         q.k_taps = (int)(p.K / p.lda);
         q.k_tap_stride = p.lda;
     }
     if (g_nt_probe == 32) { q.k_taps = g_nt_probe_taps; q.k_tap_stride = p.K / g_nt_probe_taps; }      // (timing probe: see DBG 32)
     if (q.k_taps > 1 && (!fast || (long long)q.k_taps * q.k_tap_stride != p.K || q.k_tap_stride % bk)) return CPC_EINVAL;
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
-        p.c_item % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
+        p.c_item % 8 == 0 && p.c_item2 % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;
     if (big && g_nt_stagger64 > 0 && (p.mask || p.mask_bits) && big_tiles * batch >= 3 * 256) {
         // a tile takes about nk * 3600 + 20000 cycles; the largest phase (7) starts g_nt_stagger64 / 64 of that late

@@ -145,6 +145,7 @@ class _Conv:
                 self.Mw = self.ncol * self.Hg if self.valid_rows else self.M
                 self.nsplit = eng._pick_split(self.K, self.cout, self.Mw)
                 self.slab = self.nsplit * self.K * self.cout
+            self.bands = self._bands(int(os.environ.get("CPC_DGRAD_BAND", "1"))) if (self.valid_rows and need_dgrad) else None
         else:
             o_top, o_tail, o_guard = out_pad if out_pad is not None else (0, 0, 96)
             self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt, top=o_top, tail=o_tail, guard_rows=o_guard)
@@ -168,6 +169,34 @@ class _Conv:
         # (dx = gamma rstd (g - <g> - xhat <g xhat>)), so the bias gradient is exactly zero -- the reference's autograd sums rounding
         # noise of relative size 1e-7 there.  The column-sum pass over the gradient grid is skipped and zero is written.
         self.bn_after = None
+
+    def _bands(self, RB):
+        """Data gradient of a tall kernel in bands of RB (super-)rows: the GEMM rows are ordered (band, column, row within the band), so
+        that a 256-row tile lies in one band (or two), and every band runs only the part of its window of output-gradient rows that
+        lies inside the column -- input row a receives W[j] dY[a - j] for 0 <= a - j < Ho only, the rest of the window is the zero
+        rows above and below (cpc_gemm_nt_args.k_ranges; (30,1) kernel on 63 rows: 53 % of the MACs of the full windows remain).
+        Returns (first super-row, number of bands, RB, ranges tensor, FLOPs) or None (RB = 0, or the geometry does not fit)."""
+        gin, G, kh = self.gin, self.G, self.kh
+        if RB <= 0:
+            return None
+        rows_alloc = gin.Ha // G
+        nrb = _ceil_div(self.nr, RB) * RB
+        bk = 64 if self.dt == torch.bfloat16 else 32
+        Kd = (self.Rd if G > 1 else kh) * self.cout
+        if nrb > rows_alloc or Kd % bk:
+            return None
+        r0b = min(self.r0, rows_alloc - nrb)
+        nst, ranges, stages = Kd // bk, [], 0
+        for i in range(nrb // RB):
+            first, last = r0b + i * RB, r0b + (i + 1) * RB - 1
+            lo, hi = max(0, (kh - 1) - G * last), min(kh + G - 1, self.Ho + kh - 1 - G * first)      # window rows [lo, hi) of the band
+            lo_s, hi_s = (lo * self.cout // bk, min(nst, _ceil_div(hi * self.cout, bk))) if hi > lo else (0, 1)
+            ranges += [lo_s, hi_s]
+            stages += hi_s - lo_s
+        if stages * 10 > 9 * nst * (nrb // RB) * self.nr // nrb:           # less than 10 % to gain: the plain column order reuses L2 better
+            return None
+        t = torch.tensor(ranges, dtype=torch.int32, device=self.eng.device)
+        return r0b, nrb // RB, RB, t, 2.0 * self.ncol * RB * stages * bk * G * self.cin
 
     # ------------------------------------------------------------------
     def prepare(self):
@@ -304,6 +333,15 @@ class _Conv:
         e = self.eng
         self._wgrad(_twin(e, self.gin), getattr(self, "col_t", None), self.dy0, gp_grad[self.wname], None)
 
+    def _dgrad_bands(self, dy0: Grid, dst: Grid, Kd, mask_input):
+        G, gin = self.G, self.gin
+        r0b, nb, RB, ranges, flops = self.bands
+        _hip.gemm_nt(dy0.ptr((r0b * G - (self.kh - 1)) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(r0b * G * self.cin), nb * self.ncol * RB,
+                     G * self.cin, Kd, G * self.cout, Kd, G * self.cin, self.code, mask=gin.ptr(r0b * G * self.cin) if mask_input else None,
+                     a_rpi=RB, a_item=dy0.Ha * self.cout, a_rpi2=self.ncol, a_item2=RB * G * self.cout,
+                     c_rpi=RB, c_item=dst.Ha * self.cin, c_valid=RB, c_rpi2=self.ncol, c_item2=RB * G * self.cin,
+                     k_ranges=_hip.ptr(ranges), work=flops)
+
     def backward(self, din: Optional[Grid], accumulate=False, mask_input=False):
         """dy0 (gradient of the convolution output) -> bias / weight gradients, and the input gradient into ``din``
         (``mask_input``: multiplied by gin > 0, the ReLU that produced the input)."""
@@ -325,7 +363,9 @@ class _Conv:
                     self._din_tmp = din.like(e.device, e.dt)
                 dst = self._din_tmp
             Kd = self.Rd * self.cout
-            if self.valid_rows:
+            if self.bands is not None:
+                self._dgrad_bands(dy0, dst, Kd, mask_input)
+            elif self.valid_rows:
                 r0, nr = self.r0, self.nr
                 _hip.gemm_nt(dy0.ptr((r0 * G - (self.kh - 1)) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(r0 * G * self.cin), self.ncol * nr,
                              G * self.cin, Kd, G * self.cout, Kd, G * self.cin, code, mask=gin.ptr(r0 * G * self.cin) if mask_input else None,
@@ -342,7 +382,9 @@ class _Conv:
                 if getattr(self, "_din_tmp", None) is None:
                     self._din_tmp = din.like(e.device, e.dt)
                 dst = self._din_tmp
-            if self.valid_rows:
+            if self.bands is not None:
+                self._dgrad_bands(dy0, dst, D * self.cout, mask_input)
+            elif self.valid_rows:
                 r0, nr = self.r0, self.nr
                 _hip.gemm_nt(dy0.ptr((r0 - (D - 1)) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(r0 * self.cin), self.ncol * nr, self.cin,
                              D * self.cout, self.cout, D * self.cout, self.cin, code, mask=gin.ptr(r0 * self.cin) if mask_input else None,

@@ -68,6 +68,15 @@ typedef struct cpc_gemm_nt_args {
      * number of elements readable from A / Bt (all batches); when > 0 the call returns CPC_EINVAL if any row would end beyond
      * it; 0 = not checked, the caller vouches. */
     long long a_extent, b_extent;
+    /* Second row level and K ranges (LDS-DMA kernels, K a multiple of 64 bf16 / 32 f32 elements; CPC_EINVAL elsewhere): with
+     * a_rpi2 != 0 row m of A sits at (m / (a_rpi a_rpi2)) a_item2 + ((m / a_rpi) % a_rpi2) a_item + (m % a_rpi) lda, likewise C and the
+     * mask with c_rpi2 / c_item2: the rows of a grid ordered (band of rows, column, row within the band).  k_ranges: device int
+     * pairs [lo, hi), hi > lo, in stages of 64 bf16 / 32 f32 elements: the part of the K axis that is not known to be zero for the
+     * rows of band i = m / (a_rpi a_rpi2) (a_rpi2 == 0: of item m / a_rpi); a tile runs the union of the ranges of its rows.  The
+     * extent check above does not know the second level: pass a_extent = 0 with a_rpi2.  All zero = off. */
+    int a_rpi2; long long a_item2;
+    int c_rpi2; long long c_item2;
+    const int* k_ranges;
 } cpc_gemm_nt_args;
 int cpc_gemm_nt(const cpc_gemm_nt_args* args, void* stream);
 

@@ -169,6 +169,56 @@ def test_gemm_nt_addressing_mask_batch(dt):
     assert rel_err(S, refS) < tol(dt)
 
 
+@pytest.mark.parametrize("dt,nb,ncol,RB,N,K", [(torch.bfloat16, 3, 100, 2, 72, 256), (torch.float32, 3, 100, 2, 72, 128),
+                                                 (torch.bfloat16, 5, 5100, 2, 256, 512), (torch.bfloat16, 17, 3000, 1, 256, 384)])
+def test_gemm_nt_bands_and_k_ranges(dt, nb, ncol, RB, N, K):
+    """cpc_gemm_nt_args.a_rpi2 / c_rpi2 / k_ranges: rows ordered (band, column, row in band) over a column-major grid, each band
+    summing only its own stage range of K, with a relu-backward mask addressed like C; against an f64 reference.  Outside its band's
+    range a row holds zeros where its tile straddles two bands (the tile runs the union of the ranges) and NaN where the tile lies in
+    one band: a launch that ignored the ranges would produce NaN there.  128- and 256-tile kernels."""
+    g = torch.Generator().manual_seed(nb * 1000 + ncol + K)
+    code, bk = _hip.dtype_code(dt), (64 if dt == torch.bfloat16 else 32)
+    lda = K + 64                               # rows do not overlap: each can carry its own pattern
+    rows_col = nb * RB                         # rows per column that this launch writes
+    a_item = (rows_col + 2) * lda              # column stride of the source grid (a little more than its rows)
+    nst = K // bk
+    lo = torch.randint(0, nst, (nb,), generator=g)
+    hi = torch.minimum(lo + 1 + torch.randint(0, nst, (nb,), generator=g), torch.tensor(nst))
+    ranges = torch.stack([lo, hi], 1).to(torch.int32).contiguous()
+    M = nb * ncol * RB
+    m = torch.arange(M)
+    band, col, rl = m // (ncol * RB), (m // RB) % ncol, m % RB
+    a_off = band * (RB * lda) + col * a_item + rl * lda
+    c_row = col * rows_col + band * RB + rl                            # C as [ncol][rows_col][N]
+    tile = _hip.nt_tile(code, M, N, K, 0, 1)
+    t0 = (m // tile) * tile
+    one_band = (t0 // (ncol * RB)) == (torch.clamp(t0 + tile - 1, max=M - 1) // (ncol * RB))
+    kk = torch.arange(K)
+    inside = (kk[None, :] >= (lo[band] * bk)[:, None]) & (kk[None, :] < (hi[band] * bk)[:, None])
+    vals = torch.randn(M, K, generator=g)
+    rows_ref = torch.where(inside, rounded(vals, dt), torch.zeros(1, dtype=torch.float64))
+    rows_dev = torch.where(inside, vals, torch.where(one_band[:, None], torch.tensor(float("nan")), torch.tensor(0.0)))
+    X = torch.zeros(ncol * a_item + K + 64)
+    X[a_off[:, None] + kk[None, :]] = rows_dev
+    Bt = torch.randn(N, K, generator=g) * 0.2
+    mask = torch.randn(ncol * rows_col, N, generator=g)
+    dX, dB, dM, dR = dev(X, dt), dev(Bt, dt), dev(mask, dt), dev(ranges)
+    out = torch.full((ncol * rows_col, N), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_nt(_hip.ptr(dX), _hip.ptr(dB), _hip.ptr(out), M, N, K, lda, K, N, code, mask=_hip.ptr(dM),
+                 a_rpi=RB, a_item=a_item, a_rpi2=ncol, a_item2=RB * lda, c_rpi=RB, c_item=rows_col * N, c_valid=RB, c_rpi2=ncol, c_item2=RB * N,
+                 k_ranges=_hip.ptr(dR))
+    ref = torch.zeros(ncol * rows_col, N, dtype=torch.float64)
+    ref[c_row] = rows_ref @ rounded(Bt, dt).T
+    ref = torch.where(rounded(mask, dt) > 0, ref, torch.zeros_like(ref))
+    assert one_band.any() and not one_band.all()
+    assert not torch.isnan(out.float()).any()
+    assert rel_err(out, ref) < tol(dt)
+    # the generic kernel has neither: refused, never ignored
+    with pytest.raises(RuntimeError):
+        _hip.gemm_nt(_hip.ptr(dX), _hip.ptr(dB), _hip.ptr(out), M, N, K, lda, K, N, code, a_rpi=RB, a_item=a_item, a_rpi2=ncol, a_item2=RB * lda,
+                     c_rpi=RB, c_item=rows_col * N, c_valid=RB, c_rpi2=ncol, c_item2=RB * N, k_ranges=_hip.ptr(dR), flags=_hip.GEMM_FORCE_GENERIC)
+
+
 # --------------------------------------------------------------------------------------- gemm_tn
 @pytest.mark.parametrize("dt,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, _hip.GEMM_TN_NO_TR)])
 @pytest.mark.parametrize("M,I,J", [(1000, 136, 72), (64, 128, 128), (129, 8, 264)])

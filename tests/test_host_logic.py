@@ -86,7 +86,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert handle.cpc_abi_version() == 6
+    assert handle.cpc_abi_version() == 7
     nm = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cpc_\w+)", nm))
     assert exported == declared
