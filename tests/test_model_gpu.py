@@ -752,6 +752,44 @@ def test_conv_ar_batchnorm_residual_matches_reference(golden_dir, dtype, variant
                 assert l2 < bound, (run["tag"], name, l2)
 
 
+def test_standalone_transformer_layers_forward():
+    """TransformerEncoderLayer.forward / TransformerEncoder.forward called on their own (reference transformer.py:150-170, :254-272, a
+    vendored copy of torch's nn.Transformer): the HIP kernels against torch's own post-norm layers on the CPU in float64 with the same
+    state_dict; causal mask, eval mode.  Other masks and differentiable calls are refused, never approximated."""
+    from cpc_audio_amd.attention_model import TransformerEncoder, TransformerEncoderLayer
+    torch.manual_seed(11)
+    S, B, C, heads, FF, N = 24, 6, 128, 2, 256, 2
+    layer = TransformerEncoderLayer(C, heads, FF, dropout=0.1)
+    enc = TransformerEncoder(layer, N, torch.nn.LayerNorm(C))
+    for p_ in enc.parameters():                     # all layers start as copies of one layer: make them differ
+        p_.data.add_(torch.randn_like(p_) * 0.05)
+    ref_layer = torch.nn.TransformerEncoderLayer(C, heads, FF, dropout=0.1)
+    ref_enc = torch.nn.TransformerEncoder(ref_layer, N, torch.nn.LayerNorm(C), enable_nested_tensor=False)
+    ref_enc.load_state_dict(enc.state_dict())
+    ref_enc = ref_enc.double().eval()
+    src = torch.randn(S, B, C)
+    mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
+    with torch.no_grad():
+        want_enc = ref_enc(src.double(), mask=mask.double())
+        want_layer = ref_enc.layers[1](src.double(), src_mask=mask.double())
+    enc = enc.to(DEV).eval()
+    with torch.no_grad():
+        got_enc = enc(src.to(DEV), mask.to(DEV))
+        got_layer = enc.layers[1](src.to(DEV), mask.to(DEV))
+    assert got_enc.shape == (S, B, C) and got_layer.shape == (S, B, C)
+    assert (got_enc.cpu().double() - want_enc).abs().max().item() < 2e-5
+    assert (got_layer.cpu().double() - want_layer).abs().max().item() < 2e-5
+    with pytest.raises(NotImplementedError):
+        enc(src.to(DEV), None)
+    with pytest.raises(NotImplementedError):
+        enc.layers[0](src.to(DEV).requires_grad_(True), mask.to(DEV))
+    # train mode: dropout masks are drawn (counter-based), the result differs from the eval result and stays finite
+    enc.train()
+    with torch.no_grad():
+        dropped = enc(src.to(DEV), mask.to(DEV))
+    assert torch.isfinite(dropped).all() and (dropped - got_enc).abs().max().item() > 1e-3
+
+
 def test_attention_dropout_against_oracle_with_same_masks(golden_dir):
     """Train-mode dropout (p = 0.2) in the attention context: the device masks are a function of (seed, site, index), so
     they can be materialised (cpc_dropout_mask) and handed to the oracle; forward, loss and all gradients must then agree
