@@ -303,6 +303,7 @@ def run_secondary(args, world, rank, device, dist):
     opt = FusedAdam(model, lr=1e-4)
     sync = GradAllReduce(model, optimizer=None) if world > 1 else None
     opt.skip_flag = eng.nan_flag()
+    opt.after_update = eng.prepare_ahead          # next step's operand copies rebuilt off the critical path (as the trainer sets it)
 
     def step(i):
         out = eng.loss_and_grads(inputs(i), softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,

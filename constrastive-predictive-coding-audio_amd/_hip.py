@@ -64,6 +64,7 @@ _SIGNATURES = {
     "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_w_prep_group": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_relu_row_bwd": ([_P, _P, _P, _I, _I, _L, _L, _I, _P], _I),

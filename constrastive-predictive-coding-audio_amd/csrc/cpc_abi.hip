@@ -188,6 +188,10 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
     return launch_gemm_tn(p, dtype, nsplit, 1, (hipStream_t)stream);
 }
 
+int cpc_conv_w_prep_group(const float* w, const float* bias, void* w_fwd, void* w_dgrad, float* bias_g, int Cout, int Cin, int kh, int G,
+                          int Rw, int Rd, int dtype, void* stream) {
+    return launch_conv_w_prep_group(w, bias, w_fwd, w_dgrad, bias_g, Cout, Cin, kh, G, Rw, Rd, dtype, (hipStream_t)stream);
+}
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype, void* stream) {
     if (!w || (!w_fwd && !w_dgrad)) return CPC_EINVAL;
     return launch_conv_w_prep(w, w_fwd, w_dgrad, Cout, Cin, kw, stride, dtype, (hipStream_t)stream);

@@ -225,6 +225,53 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
     return CPC_OK;
 }
 
+// Operands of a tall (kh,1) convolution computed G output rows per GEMM row (scalogram_engine._col_group): G shifted copies of the kernel
+// in a window of Rw (forward) / Rd (data gradient) rows, zero elsewhere.  W f32 [co][c][kh];
+//   fwd  [dh][co][r][c]  = W[co][c][r - dh]              for dh <= r < dh + kh      (output row G R + dh reads window rows dh .. dh+kh-1)
+//   dgrd [dr][c][q][co]  = W[co][c][kh - 1 - (q - dr)]   for dr <= q < dr + kh      (input row G R + dr receives tap j from dY window row dr + kh-1 - j)
+//   bias_g [dh][co] = bias[co]   (bias may be null)
+// One thread per output element, the fastest index of each layout along the lanes (the weights are a few MB; this replaces 3 G small
+// copy / flip launches per convolution and step).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_w_prep_group_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                                T* __restrict__ fwd, T* __restrict__ dgrd, float* __restrict__ bias_g,
+                                                                int Cout, int Cin, int kh, int G, int Rw, int Rd) {
+    const long long nf = (long long)G * Cout * Rw * Cin, nd = (long long)G * Cin * Rd * Cout;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nf) {
+        const int c = (int)(i % Cin), r = (int)((i / Cin) % Rw), co = (int)((i / ((long long)Cin * Rw)) % Cout), dh = (int)(i / ((long long)Cin * Rw * Cout));
+        const int j = r - dh;
+        fwd[i] = from_f32<T>((j >= 0 && j < kh) ? W[((long long)co * Cin + c) * kh + j] : 0.f);
+    } else if (i < nf + nd) {
+        const long long k = i - nf;
+        const int co = (int)(k % Cout), q = (int)((k / Cout) % Rd), c = (int)((k / ((long long)Cout * Rd)) % Cin), dr = (int)(k / ((long long)Cout * Rd * Cin));
+        const int j = kh - 1 - (q - dr);
+        dgrd[k] = from_f32<T>((j >= 0 && j < kh) ? W[((long long)co * Cin + c) * kh + j] : 0.f);
+    } else if (bias && i < nf + nd + (long long)G * Cout) {
+        const long long k = i - nf - nd;
+        bias_g[k] = bias[k % Cout];
+    }
+}
+
+int launch_conv_w_prep_group(const float* W, const float* bias, void* fwd, void* dgrd, float* bias_g, int Cout, int Cin, int kh, int G,
+                             int Rw, int Rd, int dtype, hipStream_t stream) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || G <= 0 || Rw < kh + G - 1 || Rd < kh + G - 1 || !W || !fwd || !dgrd || (bias && !bias_g))
+        return CPC_EINVAL;
+    const long long n = (long long)G * Cout * Rw * Cin + (long long)G * Cin * Rd * Cout + (long long)G * Cout;
+    const long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return CPC_EINVAL;
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((conv_w_prep_group_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, W, bias, (bf16_t*)fwd, (bf16_t*)dgrd,
+                           bias_g, Cout, Cin, kh, G, Rw, Rd);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((conv_w_prep_group_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, W, bias, (float*)fwd, (float*)dgrd,
+                           bias_g, Cout, Cin, kh, G, Rw, Rd);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,
                        hipStream_t stream) {
     if (Cout <= 0 || Cin <= 0 || kw <= 0 || stride <= 0) return CPC_EINVAL;

@@ -1696,6 +1696,8 @@ class FusedAdam:
         _hip.call("cpc_adam", _hip.ptr(flat), _hip.ptr(grad), _hip.ptr(self.m), _hip.ptr(self.v), C.c_longlong(flat.numel()),
                   C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.t,
                   C.c_float(grad_scale), _hip.ptr(self.skip_flag))
+        if self.after_update is not None:
+            self.after_update(0, flat.numel(), True)
 
 
 class GraphedStep:

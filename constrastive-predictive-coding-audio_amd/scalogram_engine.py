@@ -203,14 +203,11 @@ class _Conv:
         p, code = self.eng.model._param, self.code
         w = p[self.wname]
         if self.mode == 'col' and self.G > 1:
-            wk = w.detach().view(self.cout, self.cin, self.kh)
-            for dh in range(self.G):
-                # forward: output row 4R+dh uses window rows dh .. dh+kh-1;  data gradient: input row 4R+dr receives tap j from
-                # dY window row q = dr + kh-1 - j
-                self.w_fwd[dh, :, dh:dh + self.kh, :].copy_(wk.permute(0, 2, 1))
-                self.w_dgrad[dh, :, dh:dh + self.kh, :].copy_(wk.permute(1, 2, 0).flip(1))
-            if self.bname:
-                self.bias_g.copy_(p[self.bname].detach().repeat(self.G))
+            # forward: output row G R + dh uses window rows dh .. dh+kh-1;  data gradient: input row G R + dr receives tap j from
+            # dY window row q = dr + kh-1 - j   (one launch; 3 G small torch copies before)
+            _hip.call("cpc_conv_w_prep_group", _hip.ptr(w), _hip.ptr(p[self.bname]) if self.bname else None, _hip.ptr(self.w_fwd),
+                      _hip.ptr(self.w_dgrad), _hip.ptr(self.bias_g) if self.bname else None, self.cout, self.cin, self.kh, self.G, self.Rw,
+                      self.Rd, code)
         elif self.mode == 'col':
             _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(self.w_fwd), _hip.ptr(self.w_dgrad), self.cout, self.cin, self.kh, 1, code)
         else:
@@ -1130,7 +1127,34 @@ class ScalogramCPCEngine(CPCEngine):
         need = [b.slab for b in self.blocks] + [self.colsum_blocks * max(max(b.a_a.C, b.conv_b.cout) for b in self.blocks)]
         self._alloc_head(need)
 
-    supports_prepare_ahead = False     # operand copies are rebuilt at the start of every step (engine.CPCEngine.prepare_ahead)
+    # Operand copies for the NEXT step: rebuilt on the side stream right after the step's last Adam launch (FusedAdam.after_update), beside
+    # the next batch's CQT GEMMs, instead of on the main stream in front of the first convolution (0.4 ms of small launches per configs[2]
+    # step).  The next prepare_weights() only waits for their event; any other change of the parameters (load_state_dict, a torch
+    # optimizer, the NaN guard's restore) changes _param_state() and the copies are rebuilt in place as before.  CPC_PREPARE_AHEAD=0: off.
+    supports_prepare_ahead = True
+
+    def prepare_ahead(self, lo, hi, final):
+        if not final or not self.use_aux or self.ctx is None or os.environ.get("CPC_PREPARE_AHEAD", "1") == "0":
+            return
+        if not getattr(self.ctx, "ahead_ok", False):
+            return
+        if getattr(self, "_ahead_ev", None) is None:
+            self._ahead_ev = (torch.cuda.Event(), torch.cuda.Event())
+        with self.side(self._ahead_ev[0]):
+            self._prepare_encoder_weights()
+            self._prepare_head_weights()
+            self._ahead_ev[1].record(self.aux)
+        self._ahead_token = self._param_state()
+
+    def prepare_weights(self):
+        token, self._ahead_token = getattr(self, "_ahead_token", None), None
+        if token is not None and token == self._param_state():
+            torch.cuda.current_stream().wait_event(self._ahead_ev[1])
+            return
+        if getattr(self, "_ahead_ev", None) is not None:
+            torch.cuda.current_stream().wait_event(self._ahead_ev[1])      # a stale ahead-run may still be writing the operand buffers
+        self._prepare_encoder_weights()
+        self._prepare_head_weights()
 
     def _check_input(self, x):
         if not x.is_cuda:
@@ -1497,6 +1521,8 @@ class _ArBlock:
 class ConvArGridContext:
     """ConvolutionalArModel with batch_norm and / or residual (e.g. ar_conv_architecture_2/3) as the context network."""
 
+    ahead_ok = True       # prepare_weights is a pure function of the parameters (ScalogramCPCEngine.prepare_ahead)
+
     def __init__(self, eng, ar):
         self.eng, self.ar = eng, ar
         self.channels = list(ar.channel_count)
@@ -1578,6 +1604,8 @@ class ResNetArContext:
     """ScalogramResidualEncoder used as the autoregressive model (reference configs ar_resnet_architecture_1/2: blocks with
     (1,k) kernels, pooling_1 = 2 with ceil mode, batch norm, residual branches): z (B, E, V) is the grid [B][W = V][H = 1][E];
     the model takes the first remaining time step of the (B, C, T') result (audio_model.py:203-204)."""
+
+    ahead_ok = True       # prepare_weights is a pure function of the parameters (ScalogramCPCEngine.prepare_ahead)
 
     def __init__(self, eng, ar):
         self.eng, self.ar = eng, ar

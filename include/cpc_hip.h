@@ -167,6 +167,13 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
                    int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
                     void* stream);
+/* Operands of a tall (kh,1) nn.Conv2d (scalogram_model.py:393-412, the (64,1) / (30,1) / (15,1) second kernels of the residual blocks)
+ * when G output rows are computed per GEMM row (C_out < 256: G = 256 / C_out rows side by side fill the 256-wide tile): G shifted copies
+ * of the kernel in a window of Rw / Rd >= kh + G - 1 rows, zeros elsewhere.  w f32 [Cout][Cin][kh] (reference layout);
+ *   w_fwd  T [G][Cout][Rw][Cin]: [dh][co][r][c] = w[co][c][r - dh];     w_dgrad T [G][Cin][Rd][Cout]: [dr][c][q][co] = w[co][c][kh-1-(q-dr)];
+ *   bias_g f32 [G][Cout] = bias repeated (bias, bias_g may both be NULL). */
+int cpc_conv_w_prep_group(const float* w, const float* bias, void* w_fwd, void* w_dgrad, float* bias_g, int Cout, int Cin, int kh, int G,
+                          int Rw, int Rd, int dtype, void* stream);
 
 /* ConvolutionalArBlock's MaxPool1d(pool, ceil_mode=True) over positions (audio_model.py:98-99) on channels-last
  * activations [B][L_alloc][C], forward and backward (gradient to the first maximal element of each window). */
