@@ -21,6 +21,14 @@ def rnd(t):
     t.copy_(t.bfloat16().float())
 
 
+def rnd_centred(g):
+    """What storing (value - per-channel mean) in bf16 would do: the candidate fix for the residual stream."""
+    v = g.t.view(-1, g.C)
+    nz = v != 0
+    c = (v.sum(0) / nz.sum(0).clamp(min=1)).unsqueeze(0)
+    v.copy_(torch.where(nz, (v - c).bfloat16().float() + c, v))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
@@ -126,6 +134,12 @@ def main():
            [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))]
     with_patch("ONLY the residual stream (block outputs, projections)", stream)
     with_patch("everything in the encoder EXCEPT the residual stream", rest)
+    stream_c = [(b, "forward", lambda g=b.out: rnd_centred(g)) for b in blocks[:-1]] + \
+               [(b.res_conv, "forward", lambda g=b.res_conv.y0: rnd_centred(g)) for b in blocks if b.res_conv is not None and not b.res_conv.in_f32]
+    with_patch("ONLY the residual stream, stored CENTRED per channel", stream_c)
+    for i, b in enumerate(blocks[:-1]):
+        with_patch(f"block {i} output, stored centred per channel", [(b, "forward", lambda g=b.out: rnd_centred(g))])
+    with_patch("the encoder with a CENTRED residual stream", rest[:-1] + stream_c + [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))])
     with_patch("everything above at once", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] +
                [(c, "forward", lambda g=c.y0: rnd(g.t)) for c in convs if not c.in_f32] +
                [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None] +
