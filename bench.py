@@ -535,9 +535,9 @@ def main():
                                                               "cpc_conv1_fwd"],
                              by_shape=args.breakdown)
     _hip.set_timer(timer)
-    # the dominant kernel's launches are event-timed in every `every`-th step of the timed region (about ten sampled steps):
-    # an event pair costs ~12 us of idle queue per launch, 0.15 ms per step if every launch of every step were bracketed
-    every = 1 if args.breakdown else max(1, args.steps // 10)
+    # the dominant kernel's launches are event-timed in every `every`-th step of the timed region (about five sampled steps, 45 - 50
+    # launches): an event pair costs ~12 us of idle queue per launch, 0.12 - 0.15 ms per bracketed step
+    every = 1 if args.breakdown else max(1, args.steps // 5)
     if graphed is None and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
         opt.after_update = eng.prepare_ahead      # next step's operand copies rebuilt beside the rest of the backward pass
     t0 = time.perf_counter()
