@@ -276,10 +276,25 @@ class CPCEngine:
         prepare_ahead() already rebuilt every operand copy after the last parameter update and nothing has touched the
         parameters since."""
         token, self._ahead_token = getattr(self, "_ahead_token", None), None
+        ev = getattr(self, "_ahead_ev", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev[1])      # a side-stream rebuild (_prepare_all_ahead), current or stale, has finished
         if token is not None and token == self._param_state():
             return
         self._prepare_encoder_weights()
         self._prepare_head_weights()
+
+    def _prepare_all_ahead(self):
+        """Every operand copy of the next step rebuilt on the side stream, behind everything issued so far (the step's last Adam launch):
+        the layout kernels then run beside the head of the next step instead of in front of its first convolution.  prepare_weights()
+        waits for their event."""
+        if getattr(self, "_ahead_ev", None) is None:
+            self._ahead_ev = (torch.cuda.Event(), torch.cuda.Event())
+        with self.side(self._ahead_ev[0]):
+            self._prepare_encoder_weights()
+            self._prepare_head_weights()
+            self._ahead_ev[1].record(self.aux)
+        self._ahead_token = self._param_state()
 
     def _prepare_head_weights(self):
         p, code = self.model._param, self.code
@@ -324,9 +339,13 @@ class CPCEngine:
         side stream; ``final`` False) and from step() for the head of the buffer (``final`` True, main stream, backward
         complete).  In a hook call the lowest updated encoder layer's data-gradient operand is still being read by that
         layer's data-gradient GEMM on the main stream: its next copy is built in a second buffer, swapped in by the final call."""
-        if not self.supports_prepare_ahead or not getattr(self.ctx, "ahead_ok", False):
+        if not self.supports_prepare_ahead or not getattr(self.ctx, "ahead_ok", False) or os.environ.get("CPC_PREPARE_AHEAD", "1") == "0":
             return
         st = getattr(self, "_ahead", None)
+        # (one Adam launch over everything, no gradient-ready pieces: the copies are rebuilt here, on the main stream behind Adam.  Doing that on
+        # the side stream instead -- _prepare_all_ahead, as the scalogram engine does beside its CQT GEMMs -- was measured SLOWER for this
+        # engine: the next step opens with the HBM-bound layer-1 kernel and the layer-2 GEMM, and eleven small high-priority layout kernels
+        # beside them cost more than they save: conv_ar 4.202 against 4.186 ms, attention 4.674 against 4.625, interleaved runs on one box)
         if st is None:
             st = self._ahead = {"conv": set(), "head": False, "swap": []}
         off = self.model._offset
@@ -1035,7 +1054,7 @@ class AttentionContext:
             raise NotImplementedError("AttentionModel sizes must be multiples of 8 (channels <= 2048)")
         self.z_scale = math.sqrt(self.C)
         self.prefix = "autoregressive_model."
-        self.drop_p, self.drop_seed, self._drop_counter = 0.0, 0, 0
+        self.drop_p, self.drop_seed, self._drop_counter, self._l2_scale = 0.0, 0, 0, 1.0
         self.fixed_seed = None          # tests pin the mask seed here
 
     def _lname(self, l, what):
@@ -1111,18 +1130,30 @@ class AttentionContext:
             jobs.append((src, self.w_end_t.data_ptr(), C, H, 1, C))
             self._cast_jobs = (torch.tensor(jobs, dtype=torch.int64, device=e.device), e.model._flat_param, len(jobs))
         _hip.call("cpc_cast2d_batch", _hip.ptr(self._cast_jobs[0]), self._cast_jobs[2], code)
-        # dropout state of this step (prepare_weights runs once per forward, before it)
-        self.drop_p = float(self.ar.dropout) if (self.ar.training and self.ar.dropout > 0.0) else 0.0
-        if self.drop_p > 0.0:
-            if not self.drop_p < 1.0:
+        self._l2_scale = 1.0
+
+    ahead_ok = True       # prepare_weights is a pure function of the parameters (CPCEngine.prepare_ahead); the dropout state is drawn in forward()
+
+    def _begin_forward(self):
+        """Dropout state of this forward pass (train mode, p > 0): a fresh mask seed, and the 1 / (1 - p) of the feed-forward dropout folded
+        into the operand of the feed-forward data-gradient GEMM (d relu(.) dropout = keep / (1 - p): the keep part comes with the ReLU
+        mask of the stored, dropped activation)."""
+        dp = float(self.ar.dropout) if (self.ar.training and self.ar.dropout > 0.0) else 0.0
+        if dp > 0.0:
+            if not dp < 1.0:
                 raise ValueError("dropout probability must be < 1")
             self._drop_counter += 1
             base = torch.initial_seed() if self.fixed_seed is None else int(self.fixed_seed)
             self.drop_seed = (base * 0x9E3779B1 + (0 if self.fixed_seed is not None else self._drop_counter)) & 0x7FFFFFFFFFFFFFFF
-            # d relu(.)·dropout = keep/(1-p): the keep part comes with the ReLU mask of the stored (dropped) activation,
-            # the 1/(1-p) is folded into the operand of the feed-forward data-gradient GEMM
-            for l in range(self.N):
-                self.wt[l]["l2"].mul_(1.0 / (1.0 - self.drop_p))
+        want = 1.0 / (1.0 - dp) if dp > 0.0 else 1.0
+        if want != self._l2_scale:
+            if self._l2_scale != 1.0:          # (train <-> eval without a parameter update in between: rebuild rather than rescale twice)
+                self.prepare_weights()
+            if want != 1.0:
+                for l in range(self.N):
+                    self.wt[l]["l2"].mul_(want)
+            self._l2_scale = want
+        self.drop_p = dp
 
     def _ln(self, a, b, wname, r_out, y, stats, site=None):
         p = self.eng.model._param
@@ -1138,6 +1169,7 @@ class AttentionContext:
         M = B * S
         Ltop, t0 = e.geo.alloc[-1], e.T - e.K - e.V
         P = _hip.ptr
+        self._begin_forward()
         dp, seed = self.drop_p, self.drop_seed
         _hip.call("cpc_pe_scale_fwd", P(e.act[-1], t0 * C), P(self.pe), P(self.X[0]), B, S, C, Ltop * C, self.z_scale, code)
         for l in range(self.N):

@@ -1134,27 +1134,8 @@ class ScalogramCPCEngine(CPCEngine):
     supports_prepare_ahead = True
 
     def prepare_ahead(self, lo, hi, final):
-        if not final or not self.use_aux or self.ctx is None or os.environ.get("CPC_PREPARE_AHEAD", "1") == "0":
-            return
-        if not getattr(self.ctx, "ahead_ok", False):
-            return
-        if getattr(self, "_ahead_ev", None) is None:
-            self._ahead_ev = (torch.cuda.Event(), torch.cuda.Event())
-        with self.side(self._ahead_ev[0]):
-            self._prepare_encoder_weights()
-            self._prepare_head_weights()
-            self._ahead_ev[1].record(self.aux)
-        self._ahead_token = self._param_state()
-
-    def prepare_weights(self):
-        token, self._ahead_token = getattr(self, "_ahead_token", None), None
-        if token is not None and token == self._param_state():
-            torch.cuda.current_stream().wait_event(self._ahead_ev[1])
-            return
-        if getattr(self, "_ahead_ev", None) is not None:
-            torch.cuda.current_stream().wait_event(self._ahead_ev[1])      # a stale ahead-run may still be writing the operand buffers
-        self._prepare_encoder_weights()
-        self._prepare_head_weights()
+        if final and self.ctx is not None and getattr(self.ctx, "ahead_ok", False) and self.use_aux and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
+            self._prepare_all_ahead()
 
     def _check_input(self, x):
         if not x.is_cuda:
