@@ -31,7 +31,8 @@ class GemmNTArgs(C.Structure):
                 ("c_rpi", C.c_int), ("c_item", C.c_longlong), ("c_valid", C.c_int),
                 ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
                 ("flags", C.c_int), ("dtype", C.c_int), ("a_extent", C.c_longlong), ("b_extent", C.c_longlong),
-                ("a_rpi2", C.c_int), ("a_item2", C.c_longlong), ("c_rpi2", C.c_int), ("c_item2", C.c_longlong), ("k_ranges", C.c_void_p)]
+                ("a_rpi2", C.c_int), ("a_item2", C.c_longlong), ("c_rpi2", C.c_int), ("c_item2", C.c_longlong), ("k_ranges", C.c_void_p),
+                ("k_taps", C.c_int), ("k_tap_stride", C.c_longlong), ("k_tap_stride_a", C.c_longlong)]
 
 
 class GemmTNArgs(C.Structure):
@@ -256,11 +257,12 @@ def tn_tile(dtype, M, I, J, nsplit, m_chunk, flags=0):
 # ----------------------------------------------------------------------------- thin call wrappers
 def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None, a_rpi=0, a_item=0, b_rpi=0, b_item=0,
             c_rpi=0, c_item=0, c_valid=0, a_batch=0, b_batch=0, c_batch=0, batch=1, flags=0, a_extent=0, b_extent=0,
-            a_rpi2=0, a_item2=0, c_rpi2=0, c_item2=0, k_ranges=None, work=None):
+            a_rpi2=0, a_item2=0, c_rpi2=0, c_item2=0, k_ranges=None, work=None, k_taps=0, k_tap_stride=0, k_tap_stride_a=0):
     """A, Bt, Cout, bias, mask are ctypes void pointers (see ptr()).  a_extent / b_extent: elements readable from A / Bt
     (0 = unchecked), see the over-read contract in include/cpc_hip.h."""
     args = GemmNTArgs(A, Bt, Cout, bias, mask, M, N, K, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, c_rpi, c_item,
-                      c_valid, a_batch, b_batch, c_batch, batch, flags, dtype, a_extent, b_extent, a_rpi2, a_item2, c_rpi2, c_item2, k_ranges)
+                      c_valid, a_batch, b_batch, c_batch, batch, flags, dtype, a_extent, b_extent, a_rpi2, a_item2, c_rpi2, c_item2, k_ranges,
+                      k_taps, k_tap_stride, k_tap_stride_a)
     if _timer is not None:
         # (work: the FLOPs a launch with k_ranges executes, when the caller knows them)
         _timer.run("gemm_nt" + _variant(dtype, flags, nt_tile(dtype, M, N, K, flags, batch)), work if work is not None else 2.0 * M * N * K * batch,

@@ -32,6 +32,8 @@ int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     p.flags = a->flags;
     p.a_rpi2 = a->a_rpi2; p.a_item2 = a->a_item2; p.c_rpi2 = a->c_rpi2; p.c_item2 = a->c_item2; p.k_ranges = a->k_ranges;
     if (a->a_rpi2 && a->a_extent > 0) return CPC_EINVAL;
+    if (a->k_taps < 0 || a->k_taps == 1 || (a->k_taps > 1 && (a->k_tap_stride <= 0 || a->k_tap_stride_a < 0 || a->a_extent > 0))) return CPC_EINVAL;
+    p.k_taps = a->k_taps; p.k_tap_stride = a->k_taps > 1 ? a->k_tap_stride : 0; p.k_tap_stride_a = a->k_taps > 1 ? a->k_tap_stride_a : 0;
     if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
     if (a->mask && (p.flags & GEMM_OUT_F32) && a->dtype != CPC_DTYPE_F32) return CPC_EINVAL;
     // Optional extent check (see the over-read contract in cpc_hip.h): the last row of the last batch ends at ..._end elements.

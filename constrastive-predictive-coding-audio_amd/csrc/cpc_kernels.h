@@ -59,6 +59,11 @@ struct GemmNT {
     // reads the bytes row m read at tap j+1 ONE stage earlier (an L2 hit) instead of lda / BK stages earlier (by then evicted:
     // every activation byte crossed the fabric K / lda times; profiles/r01h_traffic.json, conv forward 2.16x).
     int k_taps = 0; long long k_tap_stride = 0;
+    // k_tap_stride_a (0 = k_tap_stride): with k_taps > 1 the A operand's tap j starts k_tap_stride_a elements after tap j-1 while the B operand
+    // and the K axis stay dense (K = k_taps * k_tap_stride).  A row of A is then k_taps SEPARATE pieces of k_tap_stride elements: the window
+    // of a 2-D convolution read straight from a channels-last grid (piece = the kh rows x C channels of one kernel column, contiguous in
+    // the grid; the next kernel column is one grid column = Ha * C elements further) — the im2col matrix is never written.
+    long long k_tap_stride_a = 0;
     // internal, 256x256 LDS-DMA kernel: start stagger.  The workgroups of the first round (one per CU) start (phase * stagger)
     // sleeps of 4096 cycles late, phase = (block / 8) % 8, so that the CUs do not all sit in their epilogues (a 32 MB store
     // burst per round of tiles) and prologues at the same time; 0 = off.  Set by the launcher from the tile's K extent.

@@ -435,7 +435,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     // K visiting order (GemmNT::k_taps): element offset of stage 1, and of the stage the loop fetches next (kb + kj * tstride)
     const int taps = p.k_taps > 1 ? p.k_taps : 1;
     const long long tstride = p.k_taps > 1 ? p.k_tap_stride : 0;
+    // (GemmNT::k_tap_stride_a: the A operand's taps lie further apart than the K axis says — rows gathered from a grid, see there)
+    const long long tstride_a = p.k_taps > 1 && p.k_tap_stride_a ? p.k_tap_stride_a : tstride;
     const long long koff1 = taps > 1 ? tstride : (long long)BK;
+    const long long koff1a = taps > 1 ? tstride_a : (long long)BK;
     if constexpr (!DMA) {
         // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
         // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
@@ -452,12 +455,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         // RSTEP is a multiple of 8, so the swizzle term (row & 7) is the same for the 4 rows: one offset + constants
         const int so = lds_off(srow, ch);
         uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define NT_GLOAD(k0)                                                                   \
+#define NT_GLOAD(ka, k0)                                                               \
         do {                                                                               \
-            ra0 = *(const uint4*)(ga0 + (k0)); rb0 = *(const uint4*)(gb0 + (k0));          \
-            ra1 = *(const uint4*)(ga1 + (k0)); rb1 = *(const uint4*)(gb1 + (k0));          \
-            ra2 = *(const uint4*)(ga2 + (k0)); rb2 = *(const uint4*)(gb2 + (k0));          \
-            ra3 = *(const uint4*)(ga3 + (k0)); rb3 = *(const uint4*)(gb3 + (k0));          \
+            ra0 = *(const uint4*)(ga0 + (ka)); rb0 = *(const uint4*)(gb0 + (k0));          \
+            ra1 = *(const uint4*)(ga1 + (ka)); rb1 = *(const uint4*)(gb1 + (k0));          \
+            ra2 = *(const uint4*)(ga2 + (ka)); rb2 = *(const uint4*)(gb2 + (k0));          \
+            ra3 = *(const uint4*)(ga3 + (ka)); rb3 = *(const uint4*)(gb3 + (k0));          \
         } while (0)
 #define NT_LSTORE(base)                                                                \
         do {                                                                               \
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             *(uint4*)(da + 3 * RSTEP * 128) = ra3; *(uint4*)(db + 3 * RSTEP * 128) = rb3;  \
         } while (0)
 
-        NT_GLOAD(0);
+        NT_GLOAD(0, 0);
         NT_LSTORE(lds);
         __syncthreads();
         int kj = 1 % taps;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             const unsigned char* cur = lds + (t & 1) * STAGE;
             const bool more = t + 1 < nk;
             if (more) {
-                NT_GLOAD(kb + kj * tstride);
+                NT_GLOAD(kb + kj * tstride_a, kb + kj * tstride);
                 if (++kj == taps) { kj = 0; kb += BK; }
             }
 #pragma unroll
@@ -527,13 +530,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #define NT_DMA1(g, dst)                                                                                          \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                         \
                                      (__attribute__((address_space(3))) void*)(lds3 + (dst)), 16, 0, 0)
-#define NT_DMA_STAGE(buf, k0)                                                                                    \
+#define NT_DMA_STAGE(buf, ka, k0)                                                                                \
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
-        NT_DMA1(ga0 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da);            \
-        NT_DMA1(ga1 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 1024);     \
-        NT_DMA1(ga2 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 2048);     \
-        NT_DMA1(ga3 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (k0)), da + 3072);     \
+        NT_DMA1(ga0 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (ka)), da);            \
+        NT_DMA1(ga1 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (ka)), da + 1024);     \
+        NT_DMA1(ga2 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (ka)), da + 2048);     \
+        NT_DMA1(ga3 + ((DBG & 32) ? (long long)((buf) / taps) * p.a_item + ((buf) % taps) * 64 : (ka)), da + 3072);     \
         if constexpr (DBG & 64) {                                                                                \
             NT_DMA1(gd0 + (long long)(k0) * 256, db);        NT_DMA1(gd1 + (long long)(k0) * 256, db + 1024);    \
             NT_DMA1(gd2 + (long long)(k0) * 256, db + 2048); NT_DMA1(gd3 + (long long)(k0) * 256, db + 3072);    \
@@ -587,17 +590,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         default: break;                                                                                          \
         }                                                                                                        \
     } while (0)
-#define NT_DMA_PIECE(idx, buf, k0)                                                                               \
+#define NT_DMA_PIECE(idx, buf, ka, k0)                                                                           \
     do {                                                                                                         \
         const unsigned da = (buf) * STAGE + wdst, db = da + ATILE;                                               \
         switch (idx) {                                                                                           \
-        case 0: if constexpr (!(DBG & 16)) NT_DMA1(ga0 + ((DBG & 32) ? kA_ : (k0)), da); break;                                       \
+        case 0: if constexpr (!(DBG & 16)) NT_DMA1(ga0 + ((DBG & 32) ? kA_ : (ka)), da); break;                                       \
         case 1: NT_DMA1(gb0 + (k0), db); break;                                                                  \
-        case 2: if constexpr (!(DBG & 16)) NT_DMA1(ga1 + ((DBG & 32) ? kA_ : (k0)), da + 1024); break;                                \
+        case 2: if constexpr (!(DBG & 16)) NT_DMA1(ga1 + ((DBG & 32) ? kA_ : (ka)), da + 1024); break;                                \
         case 3: NT_DMA1(gb1 + (k0), db + 1024); break;                                                           \
-        case 4: if constexpr (!(DBG & 16)) NT_DMA1(ga2 + ((DBG & 32) ? kA_ : (k0)), da + 2048); break;                                \
+        case 4: if constexpr (!(DBG & 16)) NT_DMA1(ga2 + ((DBG & 32) ? kA_ : (ka)), da + 2048); break;                                \
         case 5: NT_DMA1(gb2 + (k0), db + 2048); break;                                                           \
-        case 6: if constexpr (!(DBG & 16)) NT_DMA1(ga3 + ((DBG & 32) ? kA_ : (k0)), da + 3072); break;                                \
+        case 6: if constexpr (!(DBG & 16)) NT_DMA1(ga3 + ((DBG & 32) ? kA_ : (ka)), da + 3072); break;                                \
         case 7: NT_DMA1(gb3 + (k0), db + 3072); break;                                                           \
         default: break;                                                                                          \
         }                                                                                                        \
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 #define NT_ITER(DO_DMA, DO_READ)                                                                                 \
     do {                                                                                                         \
         const unsigned cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;                                       \
-        const long long k2 = kb + kj * tstride;                                                                  \
+        const long long k2 = kb + kj * tstride, k2a = kb + kj * tstride_a;                                       \
         /* DBG 32: A stored chunk-major, [K / (64 taps)][rows][64]; the taps of a chunk are 64 elements (one row) apart */ \
         const long long kA_ = (long long)((t + 2) / taps) * p.a_item + (long long)((t + 2) % taps) * 64;         \
         (void)kA_;                                                                                               \
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
                 if constexpr (!(DBG & 2)) mfma_chunk<T>(acc[i][j], as_uint4(fb1[j]), as_uint4(fa1[i]));          \
-                if constexpr (!(DBG & 1)) { if (DO_DMA) NT_DMA_PIECE(i * TJ + j, t & 1, k2); }                   \
+                if constexpr (!(DBG & 1)) { if (DO_DMA) NT_DMA_PIECE(i * TJ + j, t & 1, k2a, k2); }                   \
                 if (DO_READ) NT_READ1(i * TJ + j - (DO_DMA ? 8 : 0), fa0, fb0, aA0, aB0, nxt);                   \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }                                                                                                    \
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 }
             }
         }
-        NT_DMA_STAGE(0, 0);
+        NT_DMA_STAGE(0, 0, 0);
         if constexpr (C1) {
             // Fused layer-1 weight gradient: beside the tile image its epilogue needs an image of the waveform windows of the tile's
             // rows.  That image lives BEHIND the K loop's stage buffers, so it is built here, behind the requests of the first stage and before the loop
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (nk > 1) NT_DMA_STAGE(1, koff1);
+        if (nk > 1) NT_DMA_STAGE(1, koff1a, koff1);
         int kj = 2 % taps;
         long long kb = (long long)(2 / taps) * BK;
         u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
@@ -1679,7 +1682,8 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         q.k_tap_stride = p.lda;
     }
     if (g_nt_probe == 32) { q.k_taps = g_nt_probe_taps; q.k_tap_stride = p.K / g_nt_probe_taps; }      // (timing probe: see DBG 32)
-    if (q.k_taps > 1 && (!fast || (long long)q.k_taps * q.k_tap_stride != p.K || q.k_tap_stride % bk)) return CPC_EINVAL;
+    if (q.k_taps > 1 && (!fast || (long long)q.k_taps * q.k_tap_stride != p.K || q.k_tap_stride % bk || q.k_tap_stride_a % ch)) return CPC_EINVAL;
+    if (q.k_tap_stride_a && q.k_taps <= 1) return CPC_EINVAL;
     if (fast && dtype == CPC_DTYPE_BF16 && !of32 && !(p.flags & GEMM_NARROW_EPI) && p.N % 8 == 0 && p.ldc % 8 == 0 &&
         p.c_item % 8 == 0 && p.c_item2 % 8 == 0 && p.c_batch % 8 == 0 && ((uintptr_t)p.C % 16 == 0) && (!p.mask || (uintptr_t)p.mask % 16 == 0))
         q.flags |= GEMM_WIDE_EPI;

@@ -104,6 +104,7 @@ class _Conv:
         if self.Ho < 1 or self.Wo < 1:
             raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
         self.mode = 'col' if _col_ok(self.kw, self.sh, self.sw, self.pad, self.cin, in_f32) else 'win'
+        self.gather = False
         B = gin.B
         if self.cout % 8:
             raise NotImplementedError("scalogram encoder channel counts must be multiples of 8")
@@ -154,6 +155,20 @@ class _Conv:
             kq = 64 if dt == torch.bfloat16 else 32
             self.Kp = _ceil_div(self.K, kq) * kq if self.K > kq // 2 else _ceil_div(self.K, 8) * 8
             self.M = B * self.Wo * self.Ho
+            # Forward without an im2col matrix (CPC_CONV_GATHER=1; OFF by default: measured 13.78 against 13.62 ms per configs[2] step, two
+            # interleaved pairs on one box — the pieces are padded to the stage size (K 384 instead of 320 for the 3x3x32 kernel), a gathered row is
+            # kw separate 256-byte runs instead of one, and the im2col pass the weight gradient still needs only moves to the side stream, where
+            # it competes with the GEMMs): a GEMM row is the window read straight from the grid as kw pieces — piece
+            # dw = the kh rows x C_in channels of kernel column dw, contiguous in the channels-last grid, the next kernel column one grid column
+            # (Ha C_in elements) further (cpc_gemm_nt_args.k_taps / k_tap_stride_a; each piece padded to the stage size with zero weights,
+            # which over-reads into the rows below: zeros or activations, never beyond the grid's guard).  One launch with batch = B.  The
+            # im2col matrix is then built on the side stream right in front of the weight-gradient GEMM, its only reader left.
+            bkq = 64 if dt == torch.bfloat16 else 32
+            self.seg = _ceil_div(self.kh * self.cin, bkq) * bkq
+            self.gather = (self.pad == 0 and not in_f32 and self.cin % 8 == 0 and os.environ.get("CPC_CONV_GATHER", "0") == "1" and
+                           gin.guard_rows * self.cin >= self.seg)
+            if self.gather:
+                self.w_imp = torch.zeros(self.cout, self.kw, self.seg, device=dev, dtype=dt)
             self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
             self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if need_dgrad else None
             self.w_fwd = torch.zeros(self.cout, self.Kp, device=dev, dtype=dt)
@@ -213,7 +228,10 @@ class _Conv:
         else:
             w4 = w.detach().view(self.cout, self.cin, self.kh, self.kw)
             flat = w4.permute(0, 2, 3, 1).reshape(self.cout, self.K)                  # [co][(dh*kw + dw)*C + c]
-            self.w_fwd[:, :self.K].copy_(flat)
+            if self.gather:
+                self.w_imp[:, :, :self.kh * self.cin].copy_(w4.permute(0, 3, 2, 1).reshape(self.cout, self.kw, self.kh * self.cin))   # [co][dw][(dh, c)]
+            else:
+                self.w_fwd[:, :self.K].copy_(flat)
             self.w_t[:self.K, :].copy_(flat.t())
 
     def forward(self, tangent=False):
@@ -226,7 +244,7 @@ class _Conv:
         flags = _hip.GEMM_RELU if self.relu else 0
         col, mask, mask_w = getattr(self, "col", None), None, None
         if tangent:
-            if self.mode == 'win':
+            if self.mode == 'win' and not self.gather:
                 if getattr(self, "col_t", None) is None:
                     self.col_t = torch.empty_like(self.col)     # the primal im2col matrix is still needed by the weight gradient
                 col = self.col_t
@@ -253,6 +271,12 @@ class _Conv:
         elif self.mode == 'col':
             _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_fwd), y0.ptr(), self.M, self.cout, self.K, self.cin, self.K, self.cout, code,
                          bias=bias, mask=mask, c_rpi=gin.Ha, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags)
+        elif self.gather:
+            Kg = self.kw * self.seg
+            taps = dict(k_taps=self.kw, k_tap_stride=self.seg, k_tap_stride_a=gin.Ha * self.cin) if self.kw > 1 else {}
+            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_imp), y0.ptr(y0.top * self.cout), self.Wo * self.Ho, self.cout, Kg, self.sh * self.cin, Kg,
+                         self.cout, code, bias=bias, mask=mask_w, a_rpi=self.Ho, a_item=self.sw * gin.Ha * self.cin, a_batch=gin.W * gin.Ha * self.cin,
+                         c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, c_batch=self.Wo * y0.Ha * self.cout, batch=gin.B, flags=flags, **taps)
         else:
             _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
                       self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if self.in_f32 else 0, code)
@@ -318,9 +342,17 @@ class _Conv:
         else:
             chunk = e._chunk(self.M, self.nsplit, self.dt)
             taps = self.kh * self.kw
-            staged(lambda: _hip.gemm_tn(_hip.ptr(col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp,
-                                        self.cout, self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit,
-                                        m_chunk=chunk, slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32),
+
+            def gemm():
+                cm = col
+                if self.gather:      # the forward pass wrote no im2col matrix: build it here, from the grid this gradient is taken against
+                    cm = self.col
+                    _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(cm), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
+                              self.pad, self.pad, self.Ho, self.Wo, self.Kp, 0, code)
+                _hip.gemm_tn(_hip.ptr(cm), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp,
+                             self.cout, self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit,
+                             m_chunk=chunk, slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
+            staged(gemm,
                    lambda: _hip.call("cpc_reduce_slabs", _hip.ptr(wslab), _hip.ptr(gw), self.K, self.cout, self.nsplit, self.Kp * self.cout,
                                      self.cin, self.cin * taps, 1, taps))
 

@@ -77,6 +77,12 @@ typedef struct cpc_gemm_nt_args {
     int a_rpi2; long long a_item2;
     int c_rpi2; long long c_item2;
     const int* k_ranges;
+    /* Gathered rows (same kernels): with k_taps > 1 the K axis is k_taps pieces of k_tap_stride = K / k_taps elements (a multiple of 64 bf16 /
+     * 32 f32), dense in Bt, while piece j of a row of A starts j * k_tap_stride_a elements after the row address — the window of an nn.Conv2d
+     * read straight from a channels-last grid (piece = kh rows x C channels of one kernel column; k_tap_stride_a = one grid column), no
+     * im2col matrix.  The over-read contract applies to every piece.  k_taps = 0: off (overlapped rows with lda < K are detected by the launcher
+     * and visited tap-innermost on their own). */
+    int k_taps; long long k_tap_stride; long long k_tap_stride_a;
 } cpc_gemm_nt_args;
 int cpc_gemm_nt(const cpc_gemm_nt_args* args, void* stream);
 

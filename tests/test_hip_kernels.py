@@ -219,6 +219,33 @@ def test_gemm_nt_bands_and_k_ranges(dt, nb, ncol, RB, N, K):
                      c_rpi=RB, c_item=rows_col * N, c_valid=RB, c_rpi2=ncol, c_item2=RB * N, k_ranges=_hip.ptr(dR), flags=_hip.GEMM_FORCE_GENERIC)
 
 
+@pytest.mark.parametrize("dt,B,W,H,C,cout,kh,kw,sh,sw", [(torch.bfloat16, 3, 21, 19, 32, 72, 3, 3, 2, 2), (torch.float32, 2, 12, 11, 16, 40, 2, 2, 1, 1),
+                                                           (torch.bfloat16, 48, 80, 63, 32, 256, 3, 3, 2, 2), (torch.bfloat16, 8, 41, 34, 128, 256, 3, 3, 2, 2)])
+def test_gemm_nt_gathered_rows_are_a_conv2d(dt, B, W, H, C, cout, kh, kw, sh, sw):
+    """cpc_gemm_nt_args.k_taps / k_tap_stride / k_tap_stride_a: the window of an nn.Conv2d read straight from a channels-last grid
+    [B][W][Ha][C] (piece j of a GEMM row = the kh rows x C channels of kernel column j, one grid column apart; K padded per piece to the
+    stage size with zero weights) against F.conv2d.  One launch, batch = B; 128- and 256-tile kernels."""
+    g = torch.Generator().manual_seed(B * 100 + W + C)
+    code, bk = _hip.dtype_code(dt), (64 if dt == torch.bfloat16 else 32)
+    Ha = H + 3                                                   # a few allocated rows more than valid ones, as the grids have
+    x = torch.randn(B, W, Ha, C, generator=g)
+    w = torch.randn(cout, C, kh, kw, generator=g) * 0.2
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    seg = (kh * C + bk - 1) // bk * bk
+    Bt = torch.zeros(cout, kw, seg)
+    Bt[:, :, :kh * C] = w.permute(0, 3, 2, 1).reshape(cout, kw, kh * C)          # [co][dw][(dh, c)]
+    guard = torch.zeros(kw * Ha * C + seg)                                        # the last rows' pieces read beyond the grid
+    dX, dB = dev(torch.cat([x.reshape(-1), guard]), dt), dev(Bt, dt)
+    out = torch.full((B, Wo, Ho, cout), float("nan"), device=DEV, dtype=dt)
+    _hip.gemm_nt(_hip.ptr(dX), _hip.ptr(dB), _hip.ptr(out), Wo * Ho, cout, kw * seg, sh * C, kw * seg, cout, code,
+                 a_rpi=Ho, a_item=sw * Ha * C, a_batch=W * Ha * C, c_batch=Wo * Ho * cout, batch=B,
+                 k_taps=kw, k_tap_stride=seg, k_tap_stride_a=Ha * C)
+    xr = rounded(x, dt)[:, :, :H, :].permute(0, 3, 2, 1)                           # (B, C, H, W)
+    ref = F.conv2d(xr, rounded(w, dt), stride=(sh, sw)).permute(0, 3, 2, 1)      # (B, Wo, Ho, cout)
+    assert not torch.isnan(out.float()).any()
+    assert rel_err(out, ref) < tol(dt)
+
+
 # --------------------------------------------------------------------------------------- gemm_tn
 @pytest.mark.parametrize("dt,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, _hip.GEMM_TN_NO_TR)])
 @pytest.mark.parametrize("M,I,J", [(1000, 136, 72), (64, 128, 128), (129, 8, 264)])

@@ -858,6 +858,40 @@ def test_stem_kernels_equal_the_im2col_route(golden_dir, dtype, fixture, monkeyp
         assert _rel(a, b.numpy()) < (1e-5 if dtype == "fp32" else 5e-2)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gathered_window_forward_equals_the_im2col_route(golden_dir, dtype, monkeypatch):
+    """CPC_CONV_GATHER=1 (strided 3x3 / 2x2 convolutions read their windows straight from the grid through cpc_gemm_nt's k_taps /
+    k_tap_stride_a; the im2col matrix is built only for the weight gradient) against the default im2col route: same loss, same
+    gradients, also through a gradient-penalty step (tangent forward and penalty weight gradients take the same path)."""
+    g = _load(golden_dir, "scalogram_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+    scal = torch.from_numpy(g["scalogram"]).to(DEV)
+    res = {}
+    for gather in ("1", "0"):
+        monkeypatch.setenv("CPC_CONV_GATHER", gather)
+        pre, model = _build_scalogram_model(g, meta, dtype)
+        model.gradient_penalty_engine = True
+        eng = model.engine_for(scal)
+        convs = [c for b in eng.blocks for c in (b.conv_a, b.conv_b, b.res_conv) if c is not None]
+        assert any(c.gather for c in convs) == (gather == "1")
+        out = eng.loss_and_grads(scal, softplus=True, regularization=1.0)
+        plain = (float(out[0]), {n: v.detach().double().cpu().clone() for n, v in model._grad.items()})
+        gp = None
+        if dtype == "fp32":
+            out = eng.loss_and_grads(scal, softplus=False, regularization=0.0, all_timesteps=True, gradient_penalty=10.0)
+            gp = (float(out[0]), {n: v.detach().double().cpu().clone() for n, v in model._grad.items()})
+        res[gather] = (plain, gp)
+    for (l1, g1), (l0, g0) in [(res["1"][0], res["0"][0])] + ([(res["1"][1], res["0"][1])] if dtype == "fp32" else []):
+        assert abs(l1 - l0) <= (1e-5 if dtype == "fp32" else 2e-2) * abs(l0), (l1, l0)
+        scale = max(float(v.norm()) for v in g0.values())
+        for n in g0:
+            if float(g0[n].norm()) < 1e-6 * scale:
+                assert float(g1[n].norm()) < 1e-4 * scale, n
+                continue
+            err = float((g1[n] - g0[n]).norm() / g0[n].norm())
+            assert err < (2e-4 if dtype == "fp32" else 0.3), (n, err)
+
+
 _GP_GN_WORKER = r'''
 import json, os, random, sys
 import numpy as np
