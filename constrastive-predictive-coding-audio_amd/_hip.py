@@ -35,6 +35,31 @@ class GemmNTArgs(C.Structure):
                 ("k_taps", C.c_int), ("k_tap_stride", C.c_longlong), ("k_tap_stride_a", C.c_longlong)]
 
 
+class ConvPrepJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("Cout", C.c_int), ("Cin", C.c_int), ("kw", C.c_int),
+                ("stride", C.c_int), ("D", C.c_int), ("tco", C.c_int), ("gx", C.c_int), ("first", C.c_int)]
+
+
+class ConvPrepBatch:
+    """cpc_conv_w_prep for a list of (w, w_fwd, w_dgrad, Cout, Cin, kw, stride) in one launch; the job table is planned on the host and
+    uploaded once (tensor addresses are stable: parameters are views of the model's flat buffer, operands live as long as their engine)."""
+
+    def __init__(self, jobs, device):
+        n = len(jobs)
+        arr = (ConvPrepJob * n)()
+        for q, (w, fwd, dgrd, cout, cin, kw, stride) in zip(arr, jobs):
+            q.w, q.w_fwd, q.w_dgrad, q.Cout, q.Cin, q.kw, q.stride = w.data_ptr(), fwd.data_ptr(), dgrd.data_ptr(), cout, cin, kw, stride
+        tb, lds = C.c_int(0), C.c_int(0)
+        _check(lib().cpc_conv_w_prep_plan(C.cast(arr, C.c_void_p), n, C.cast(C.byref(tb), C.c_void_p), C.cast(C.byref(lds), C.c_void_p)),
+               "cpc_conv_w_prep_plan")
+        self.n, self.blocks, self.lds = n, tb.value, lds.value
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.keep = [t for j in jobs for t in j[:3]]
+
+    def run(self, dtype):
+        call("cpc_conv_w_prep_batch", ptr(self.table), self.n, self.blocks, self.lds, dtype)
+
+
 class GemmTNArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int), ("I", C.c_int), ("J", C.c_int),
@@ -66,6 +91,8 @@ _SIGNATURES = {
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep_group": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "cpc_conv_w_prep_plan": ([_P, _I, _P, _P], _I),
+    "cpc_conv_w_prep_batch": ([_P, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_relu_row_bwd": ([_P, _P, _P, _I, _I, _L, _L, _I, _P], _I),

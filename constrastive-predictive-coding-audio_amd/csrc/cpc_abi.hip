@@ -190,6 +190,13 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
     return launch_gemm_tn(p, dtype, nsplit, 1, (hipStream_t)stream);
 }
 
+static_assert(sizeof(cpc_conv_prep_job) == 56, "cpc_conv_prep_job layout (three pointers + eight ints)");
+int cpc_conv_w_prep_plan(cpc_conv_prep_job* jobs, int njobs, int* total_blocks, int* lds_bytes) {
+    return conv_w_prep_plan(jobs, njobs, total_blocks, lds_bytes);
+}
+int cpc_conv_w_prep_batch(const cpc_conv_prep_job* jobs_dev, int njobs, int total_blocks, int lds_bytes, int dtype, void* stream) {
+    return launch_conv_w_prep_batch(jobs_dev, njobs, total_blocks, lds_bytes, dtype, (hipStream_t)stream);
+}
 int cpc_conv_w_prep_group(const float* w, const float* bias, void* w_fwd, void* w_dgrad, float* bias_g, int Cout, int Cin, int kh, int G,
                           int Rw, int Rd, int dtype, void* stream) {
     return launch_conv_w_prep_group(w, bias, w_fwd, w_dgrad, bias_g, Cout, Cin, kh, G, Rw, Rd, dtype, (hipStream_t)stream);

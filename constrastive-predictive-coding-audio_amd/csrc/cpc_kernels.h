@@ -140,6 +140,8 @@ int launch_nce_eval(const float* S, float* out, float* workspace, int B, int K, 
 int launch_sign_bits(const void* x, unsigned char* bits, long long n, int dtype, hipStream_t stream);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
                 float grad_scale, const float* skip, hipStream_t stream);
+int conv_w_prep_plan(void* jobs_host, int njobs, int* total_blocks, int* lds_bytes);
+int launch_conv_w_prep_batch(const void* jobs_dev, int njobs, int total_blocks, int lds_bytes, int dtype, hipStream_t stream);
 int launch_conv_w_prep_group(const float* W, const float* bias, void* fwd, void* dgrd, float* bias_g, int Cout, int Cin, int kh, int G,
                              int Rw, int Rd, int dtype, hipStream_t stream);
 int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin, int kw, int stride, int dtype,

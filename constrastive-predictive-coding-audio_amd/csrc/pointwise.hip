@@ -2,6 +2,7 @@
 // the f32 master weights (kept in the reference's state_dict shapes) into the storage-dtype GEMM operand layouts.
 #include "cpc_common.h"
 #include "cpc_kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -48,11 +49,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // in 64-byte runs (32 c of one (co, j); 32 co of one (r, c, dd)).  The element-per-thread form (4-byte gathers at a stride of kw
 // floats, 2 048 workgroups) ran 50-100 us per layer on the side stream beside the backward GEMMs.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restrict__ W, T* __restrict__ fwd,
-                                                          T* __restrict__ dgrd, int Cout, int Cin, int kw, int stride, int D, int tco) {
-    extern __shared__ float tile[];                    // [tco][32 * kw + 1], tco = 32 (a smaller power of two for very wide kernels: LDS)
-    const int rs = 32 * kw + 1;
-    const int c0 = blockIdx.x * 32, co0 = blockIdx.y * tco;
+__device__ __forceinline__ void conv_w_prep_tile(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgrd, int Cout, int Cin,
+                                                 int kw, int stride, int D, int tco, int bx, int by, float* tile) {
+    const int rs = 32 * kw + 1;                        // tile [tco][32 * kw + 1], tco = 32 (a smaller power of two for very wide kernels: LDS)
+    const int c0 = bx * 32, co0 = by * tco;
     const int tid = threadIdx.x;
     const int nc = min(32, Cin - c0), nco = min(tco, Cout - co0);
     for (int i = tid; i < tco * 32 * kw; i += 256) {
@@ -76,6 +76,27 @@ __global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restric
                 dgrd[(((long long)r * Cin + c0 + cl) * D + dd) * Cout + co0 + col] = from_f32<T>(tap < kw ? tile[col * rs + cl * kw + tap] : 0.f);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_w_prep_kernel(const float* __restrict__ W, T* __restrict__ fwd,
+                                                          T* __restrict__ dgrd, int Cout, int Cin, int kw, int stride, int D, int tco) {
+    extern __shared__ float tile[];
+    conv_w_prep_tile<T>(W, fwd, dgrd, Cout, Cin, kw, stride, D, tco, blockIdx.x, blockIdx.y, tile);
+}
+
+// The same for a list of convolutions in ONE launch (a context network's eleven kernels of 5 x 512 x 512 took eleven launches of 20 us on
+// the queue in front of the step).  jobs[j] (device) = {W, fwd, dgrd, Cout, Cin, kw, stride, D, tco, gx, first}: the job's workgroups are
+// [first, first + gx * gy) of the grid, (bx, by) = (local % gx, local / gx).
+struct ConvPrepJob { const float* W; void* fwd; void* dgrd; int Cout, Cin, kw, stride, D, tco, gx, first; };
+template <typename T>
+__global__ __launch_bounds__(256) void conv_w_prep_batch_kernel(const ConvPrepJob* __restrict__ jobs, int njobs) {
+    extern __shared__ float tile[];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first) ++j;
+    const ConvPrepJob q = jobs[j];
+    const int local = blockIdx.x - q.first;
+    conv_w_prep_tile<T>(q.W, (T*)q.fwd, (T*)q.dgrd, q.Cout, q.Cin, q.kw, q.stride, q.D, q.tco, local % q.gx, local / q.gx, tile);
 }
 
 // dst[r][c] = (T) src[r * sr + c * sc]   (dst contiguous [R][C])
@@ -266,6 +287,43 @@ int launch_conv_w_prep_group(const float* W, const float* bias, void* fwd, void*
     else if (dtype == CPC_DTYPE_F32)
         hipLaunchKernelGGL((conv_w_prep_group_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, W, bias, (float*)fwd, (float*)dgrd,
                            bias_g, Cout, Cin, kh, G, Rw, Rd);
+    else
+        return CPC_EINVAL;
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+// Host side of the batched form: fills the launch geometry of every job (D, tco, gx, first workgroup) and returns the grid size and the
+// dynamic LDS the launch needs; the caller uploads the table once (operand addresses are stable) and launches with those.
+int conv_w_prep_plan(void* jobs_host, int njobs, int* total_blocks, int* lds_bytes) {
+    if (!jobs_host || njobs <= 0 || njobs > 4096 || !total_blocks || !lds_bytes) return CPC_EINVAL;
+    ConvPrepJob* jobs = (ConvPrepJob*)jobs_host;
+    long long first = 0;
+    size_t lds = 0;
+    for (int j = 0; j < njobs; ++j) {
+        ConvPrepJob& q = jobs[j];
+        if (q.Cout <= 0 || q.Cin <= 0 || q.kw <= 0 || q.stride <= 0 || q.kw > 511 || !q.W || (!q.fwd && !q.dgrd)) return CPC_EINVAL;
+        q.D = (q.kw + q.stride - 1) / q.stride;
+        int tco = 32;
+        while (tco > 1 && (long long)tco * (32 * q.kw + 1) > 16384) tco >>= 1;
+        q.tco = tco;
+        q.gx = (q.Cin + 31) / 32;
+        q.first = (int)first;
+        first += (long long)q.gx * ((q.Cout + tco - 1) / tco);
+        if (first > 0x7fffffffLL) return CPC_EINVAL;
+        lds = std::max(lds, (size_t)tco * (32 * q.kw + 1) * sizeof(float));
+    }
+    *total_blocks = (int)first;
+    *lds_bytes = (int)lds;
+    return CPC_OK;
+}
+
+int launch_conv_w_prep_batch(const void* jobs_dev, int njobs, int total_blocks, int lds_bytes, int dtype, hipStream_t stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || lds_bytes <= 0 || lds_bytes > 65536) return CPC_EINVAL;
+    if (dtype == CPC_DTYPE_BF16)
+        hipLaunchKernelGGL((conv_w_prep_batch_kernel<bf16_t>), dim3(total_blocks), dim3(256), (size_t)lds_bytes, stream, (const ConvPrepJob*)jobs_dev, njobs);
+    else if (dtype == CPC_DTYPE_F32)
+        hipLaunchKernelGGL((conv_w_prep_batch_kernel<float>), dim3(total_blocks), dim3(256), (size_t)lds_bytes, stream, (const ConvPrepJob*)jobs_dev, njobs);
     else
         return CPC_EINVAL;
     CPC_CHECK_LAUNCH();

@@ -77,6 +77,26 @@ def _col_ok(kw, sh, sw, pad, cin, in_f32):
     return kw == 1 and sh == 1 and sw == 1 and pad == 0 and cin % 8 == 0 and not in_f32
 
 
+def _prepare_convs(eng, holder, convs):
+    """prepare() of a list of convolutions (objects with the _Conv interface): the plain overlapped-row ones (mode 'col', one output row per
+    GEMM row) share ONE cpc_conv_w_prep_batch launch — eleven launches of 20 us each for ar_conv_architecture_3 otherwise; the job table is
+    planned once per parameter buffer (``holder`` keeps it)."""
+    batch = [c for c in convs if isinstance(c, _Conv) and c.mode == 'col' and c.G == 1]
+    if len(batch) < 2 or os.environ.get("CPC_PREP_BATCH", "1") == "0":
+        batch = []
+    for c in convs:
+        if c not in batch:
+            c.prepare()
+    if not batch:
+        return
+    key = eng.model._flat_param.data_ptr()
+    st = getattr(holder, "_prep_batch", None)
+    if st is None or st[0] != key:
+        p = eng.model._param
+        st = holder._prep_batch = (key, _hip.ConvPrepBatch([(p[c.wname], c.w_fwd, c.w_dgrad, c.cout, c.cin, c.kh, 1) for c in batch], eng.device))
+    st[1].run(eng.code)
+
+
 class _Conv:
     """One nn.Conv2d of the encoder on grids.  mode 'col': (k,1) kernel, stride 1, no padding -> overlapped-row GEMMs;
     mode 'win': im2col + GEMM (+ col2im for the data gradient)."""
@@ -954,10 +974,12 @@ class _Block:
         else:
             self.conv_a.dy0 = self.d_a_full if self.pool1 > 1 else self.d_a
 
+    def convs(self):
+        return [c for c in (self.conv_a, self.conv_b, self.res_conv) if c is not None]
+
     def prepare(self):
-        for c in (self.conv_a, self.conv_b, self.res_conv):
-            if c is not None:
-                c.prepare()
+        for c in self.convs():
+            c.prepare()
 
     def forward(self):
         e, code = self.eng, self.eng.code
@@ -1176,8 +1198,7 @@ class ScalogramCPCEngine(CPCEngine):
             raise ValueError(f"expected a scalogram batch of shape {self.in_shape}, got {tuple(x.shape)}")
 
     def _prepare_encoder_weights(self):
-        for b in self.blocks:
-            b.prepare()
+        _prepare_convs(self, self, [c for b in self.blocks for c in b.convs()])
 
     def encoder_forward(self, x):
         """x (B, C, bins, frames) float32 — typically PreprocessingModule's permuted view, whose memory already is the
@@ -1454,10 +1475,12 @@ class _ArBlock:
         else:
             self.conv.dy0 = self.d_main
 
+    def convs(self):
+        return [c for c in (self.conv, self.res_conv) if c is not None]
+
     def prepare(self):
-        self.conv.prepare()
-        if self.res_conv is not None:
-            self.res_conv.prepare()
+        for c in self.convs():
+            c.prepare()
 
     def forward(self):
         code = self.eng.code
@@ -1565,8 +1588,7 @@ class ConvArGridContext:
         return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(self.channels)
 
     def prepare_weights(self):
-        for b in self.blocks:
-            b.prepare()
+        _prepare_convs(self.eng, self, [c for b in self.blocks for c in b.convs()])
 
     def _z_rows(self, buf):
         e = self.eng
@@ -1654,8 +1676,7 @@ class ResNetArContext:
         return max(b.slab for b in self.blocks) + self.eng.colsum_blocks * max(max(b.a_a.C, b.conv_b.cout) for b in self.blocks)
 
     def prepare_weights(self):
-        for b in self.blocks:
-            b.prepare()
+        _prepare_convs(self.eng, self, [c for b in self.blocks for c in b.convs()])
 
     def _z_rows(self, buf):
         e = self.eng

@@ -173,6 +173,17 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
                    int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
                     void* stream);
+/* cpc_conv_w_prep for a LIST of convolutions in one launch (a context network's eleven 5 x 512 x 512 kernels: eleven launches of 20 us in
+ * front of every step otherwise).  The caller fills w / w_fwd / w_dgrad (either output may be NULL) / Cout / Cin / kw / stride of every job in
+ * HOST memory; cpc_conv_w_prep_plan fills the launch geometry (D, tco, gx, first) and returns the grid size and dynamic LDS bytes; the table is
+ * then copied to device memory once (the operand addresses are stable) and cpc_conv_w_prep_batch launched with it whenever the weights changed. */
+typedef struct cpc_conv_prep_job {
+    const float* w; void* w_fwd; void* w_dgrad;
+    int Cout, Cin, kw, stride;
+    int D, tco, gx, first;        /* filled by cpc_conv_w_prep_plan */
+} cpc_conv_prep_job;
+int cpc_conv_w_prep_plan(cpc_conv_prep_job* jobs, int njobs, int* total_blocks, int* lds_bytes);
+int cpc_conv_w_prep_batch(const cpc_conv_prep_job* jobs_dev, int njobs, int total_blocks, int lds_bytes, int dtype, void* stream);
 /* Operands of a tall (kh,1) nn.Conv2d (scalogram_model.py:393-412, the (64,1) / (30,1) / (15,1) second kernels of the residual blocks)
  * when G output rows are computed per GEMM row (C_out < 256: G = 256 / C_out rows side by side fill the 256-wide tile): G shifted copies
  * of the kernel in a window of Rw / Rd >= kh + G - 1 rows, zeros elsewhere.  w f32 [Cout][Cin][kh] (reference layout);
