@@ -246,6 +246,45 @@ def test_gemm_nt_gathered_rows_are_a_conv2d(dt, B, W, H, C, cout, kh, kw, sh, sw
     assert rel_err(out, ref) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_w_prep_batch_and_group(dt):
+    """cpc_conv_w_prep_plan / _batch: several convolutions' operand layouts in one launch, bitwise equal to one cpc_conv_w_prep each
+    (different shapes, one without a data-gradient operand).  cpc_conv_w_prep_group: the G shifted kernel copies of a tall (kh,1)
+    convolution computed G rows per GEMM row, against their definition."""
+    g = torch.Generator().manual_seed(5)
+    code = _hip.dtype_code(dt)
+    shapes = [(64, 32, 5, 1), (96, 40, 8, 4), (32, 64, 3, 1), (128, 128, 10, 5)]
+    ws = [torch.randn(co, ci, k, generator=g).to(DEV) for co, ci, k, s_ in shapes]
+    single, batched, jobs = [], [], []
+    for w, (co, ci, k, st) in zip(ws, shapes):
+        D = -(-k // st)
+        f1, d1 = torch.zeros(co * k * ci, device=DEV, dtype=dt), torch.zeros(st * ci * D * co, device=DEV, dtype=dt)
+        f2, d2 = torch.full_like(f1, 3.0), torch.full_like(d1, 3.0)
+        _hip.call("cpc_conv_w_prep", _hip.ptr(w), _hip.ptr(f1), _hip.ptr(d1), co, ci, k, st, code)
+        single.append((f1, d1))
+        batched.append((f2, d2))
+        jobs.append((w, f2, d2, co, ci, k, st))
+    _hip.ConvPrepBatch(jobs, DEV).run(code)
+    for (f1, d1), (f2, d2) in zip(single, batched):
+        assert torch.equal(f1, f2) and torch.equal(d1, d2)
+    # grouped tall kernel
+    cout, cin, kh, G = 32, 16, 7, 4
+    Rw = Rd = kh + G - 1 + 2
+    w = torch.randn(cout, cin, kh, generator=g)
+    bias = torch.randn(cout, generator=g)
+    wf = torch.full((G, cout, Rw, cin), 9.0, device=DEV, dtype=dt)
+    wd = torch.full((G, cin, Rd, cout), 9.0, device=DEV, dtype=dt)
+    bg = torch.full((G * cout,), 9.0, device=DEV)
+    dw_, db_ = w.to(DEV), bias.to(DEV)
+    _hip.call("cpc_conv_w_prep_group", _hip.ptr(dw_), _hip.ptr(db_), _hip.ptr(wf), _hip.ptr(wd), _hip.ptr(bg), cout, cin, kh, G, Rw, Rd, code)
+    rf, rd = torch.zeros(G, cout, Rw, cin), torch.zeros(G, cin, Rd, cout)
+    for dh in range(G):
+        rf[dh, :, dh:dh + kh, :] = w.permute(0, 2, 1)
+        rd[dh, :, dh:dh + kh, :] = w.permute(1, 2, 0).flip(1)
+    assert torch.equal(wf.cpu(), rf.to(dt)) and torch.equal(wd.cpu(), rd.to(dt))
+    assert torch.equal(bg.cpu(), bias.repeat(G))
+
+
 # --------------------------------------------------------------------------------------- gemm_tn
 @pytest.mark.parametrize("dt,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, _hip.GEMM_TN_NO_TR)])
 @pytest.mark.parametrize("M,I,J", [(1000, 136, 72), (64, 128, 128), (129, 8, 264)])
