@@ -34,13 +34,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--scalogram", action="store_true", help="BASELINE configs[2]: CQT + scalogram_resnet_architecture_7 + ar_conv_architecture_3 "
+                                                              "through the trainer's preprocessing hook (use --batch 128)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256, compute_dtype="bf16").to(dev)
-    ds = SyntheticAudioDataset(512, model.item_length, seed=3, scale=0.5, device=dev)
+    pre = None
+    if args.scalogram:
+        from cpc_audio_amd import configs
+        from cpc_audio_amd.audio_model import ConvolutionalArModel
+        from cpc_audio_amd.scalogram_model import PreprocessingModule, ScalogramResidualEncoder, cqt_default_dict
+        pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True).to(dev)
+        pre.cqt.precision = "bf16x3"
+        enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+        model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
+                                           visible_steps=60, prediction_steps=16, compute_dtype="bf16").to(dev)
+        ds = SyntheticAudioDataset(2 * args.batch, model.item_length, seed=3, scale=0.1, device=dev)
+    else:
+        model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256, compute_dtype="bf16").to(dev)
+        ds = SyntheticAudioDataset(512, model.item_length, seed=3, scale=0.5, device=dev)
     logger = Logger()
-    tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=dev, regularization=1.0)
+    tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=dev, regularization=1.0, preprocessing=pre,
+                                      prediction_steps=16 if args.scalogram else 12)
     tr.verbose = False
     t0 = time.perf_counter()
     tr.train(batch_size=args.batch, epochs=10 ** 6, lr=1e-4, num_workers=0, max_steps=args.steps)
