@@ -140,6 +140,14 @@ def main():
     for i, b in enumerate(blocks[:-1]):
         with_patch(f"block {i} output, stored centred per channel", [(b, "forward", lambda g=b.out: rnd_centred(g))])
     with_patch("the encoder with a CENTRED residual stream", rest[:-1] + stream_c + [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))])
+    pre_bn = [(c, bn) for b in blocks for c, bn in ((b.conv_a, b.bn_a), (b.conv_b, b.bn_b)) if bn is not None and c is not None and not c.in_f32]
+    with_patch("all encoder pre-BN conv outputs, stored CENTRED per channel", [(c, "forward", lambda g=c.y0: rnd_centred(g)) for c, _ in pre_bn])
+    rest_c = [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] + \
+             [(c, "forward", (lambda g=c.y0: rnd_centred(g)) if any(c is cc for cc, _ in pre_bn) else (lambda g=c.y0: rnd(g.t)))
+              for b in blocks for c in (b.conv_a, b.conv_b) if c is not None and not c.in_f32] + \
+             [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None]
+    with_patch("the encoder with CENTRED stream AND centred pre-BN outputs", rest_c + stream_c + [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))])
+    with_patch("... and unrounded weights", rest_c[len([c for c in convs if not c.in_f32]):] + stream_c + [(blocks[-1], "forward", lambda g=blocks[-1].out: rnd(g.t))])
     with_patch("everything above at once", [(c, "prepare", w_post(c)) for c in convs if not c.in_f32] +
                [(c, "forward", lambda g=c.y0: rnd(g.t)) for c in convs if not c.in_f32] +
                [(bn, "forward", lambda g=bn.a: rnd(g.t)) for b in blocks for bn in (b.bn_a, b.bn_b) if bn is not None] +
