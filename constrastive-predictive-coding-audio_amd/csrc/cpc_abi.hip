@@ -34,6 +34,7 @@ int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (a->a_rpi2 && a->a_extent > 0) return CPC_EINVAL;
     if (a->k_taps < 0 || a->k_taps == 1 || (a->k_taps > 1 && (a->k_tap_stride <= 0 || a->k_tap_stride_a < 0 || a->a_extent > 0))) return CPC_EINVAL;
     p.k_taps = a->k_taps; p.k_tap_stride = a->k_taps > 1 ? a->k_tap_stride : 0; p.k_tap_stride_a = a->k_taps > 1 ? a->k_tap_stride_a : 0;
+    p.k_taps_linear = a->k_taps > 1;
     if (a->dtype == CPC_DTYPE_F32) p.flags |= GEMM_OUT_F32;
     if (a->mask && (p.flags & GEMM_OUT_F32) && a->dtype != CPC_DTYPE_F32) return CPC_EINVAL;
     // Optional extent check (see the over-read contract in cpc_hip.h): the last row of the last batch ends at ..._end elements.

@@ -64,6 +64,9 @@ struct GemmNT {
     // of a 2-D convolution read straight from a channels-last grid (piece = the kh rows x C channels of one kernel column, contiguous in
     // the grid; the next kernel column is one grid column = Ha * C elements further) — the im2col matrix is never written.
     long long k_tap_stride_a = 0;
+    // internal: the taps were given by the caller (gathered rows): stages are visited in storage order (all of piece 0, then piece 1, ...), the
+    // order k_ranges counts in, instead of tap-innermost (there is no reuse between the pieces of neighbouring rows to win)
+    bool k_taps_linear = false;
     // internal, 256x256 LDS-DMA kernel: start stagger.  The workgroups of the first round (one per CU) start (phase * stagger)
     // sleeps of 4096 cycles late, phase = (block / 8) % 8, so that the CUs do not all sit in their epilogues (a 32 MB store
     // burst per round of tiles) and prologues at the same time; 0 = off.  Set by the launcher from the tile's K extent.

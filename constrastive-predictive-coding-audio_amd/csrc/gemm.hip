@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     const T* Ab = (const T*)p.A + (long long)blockIdx.z * p.a_batch;
     const T* Bb = (const T*)p.Bt + (long long)blockIdx.z * p.b_batch;
     // GemmNT::k_ranges: the K stages this tile's rows need (the union over the bands / items it touches)
-    int nk_tile = p.K / (8 * Elem<T>::CH);
+    int nk_tile = p.K / (8 * Elem<T>::CH), k_lo = 0;
     if (p.k_ranges) {
         const int per = p.a_rpi * (p.a_rpi2 > 0 ? p.a_rpi2 : 1);
         const int i_lo = m0 / per, i_hi = min(m0 + TBM - 1, p.M - 1) / per;
@@ -404,8 +404,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             lo = min(lo, p.k_ranges[2 * i]);
             hi = max(hi, p.k_ranges[2 * i + 1]);
         }
-        Ab += (long long)lo * (8 * Elem<T>::CH);
-        Bb += (long long)lo * (8 * Elem<T>::CH);
+        if (p.k_taps > 1) {
+            k_lo = lo;                            // gathered rows (storage order over the pieces): the loop starts inside piece lo / stages-per-piece
+        } else {
+            Ab += (long long)lo * (8 * Elem<T>::CH);
+            Bb += (long long)lo * (8 * Elem<T>::CH);
+        }
         nk_tile = hi - lo;
     }
     if constexpr (DMA && TI == 8) {
@@ -437,8 +441,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
     const long long tstride = p.k_taps > 1 ? p.k_tap_stride : 0;
     // (GemmNT::k_tap_stride_a: the A operand's taps lie further apart than the K axis says — rows gathered from a grid, see there)
     const long long tstride_a = p.k_taps > 1 && p.k_tap_stride_a ? p.k_tap_stride_a : tstride;
-    const long long koff1 = taps > 1 ? tstride : (long long)BK;
-    const long long koff1a = taps > 1 ? tstride_a : (long long)BK;
+    // Position of the next stage to request: tap kj, offset kb within the tap.  Overlapped rows (launcher-detected) are visited tap-innermost
+    // (kj runs fastest); rows gathered from separate pieces (GemmNT::k_taps_linear, taps given by the caller) in storage order (kb runs
+    // fastest), which is the order k_ranges counts stages in.
+    const bool klin = taps > 1 && p.k_taps_linear;
+    int kj = 0;
+    long long kb = 0;
+    if (klin && k_lo) {
+        const int spp = (int)(tstride / BK);
+        kj = k_lo / spp;
+        kb = (long long)(k_lo % spp) * BK;
+    }
+#define NT_KSTEP()                                                       \
+    do {                                                                 \
+        if (klin) { kb += BK; if (kb == tstride) { kb = 0; ++kj; } }     \
+        else if (++kj == taps) { kj = 0; kb += BK; }                     \
+    } while (0)
+    const long long koff0 = kb + kj * tstride, koff0a = kb + kj * tstride_a;
+    NT_KSTEP();
+    const long long koff1 = kb + kj * tstride, koff1a = kb + kj * tstride_a;
+    NT_KSTEP();
     if constexpr (!DMA) {
         // staging: thread -> chunk tid&7 of tile rows (tid>>3) + RSTEP*i, i = 0..3 (rows clamped into range).  Named scalars
         // on purpose: arrays here end up in scratch / LDS-promoted allocas with hipcc 7.2.
@@ -472,17 +494,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             *(uint4*)(da + 3 * RSTEP * 128) = ra3; *(uint4*)(db + 3 * RSTEP * 128) = rb3;  \
         } while (0)
 
-        NT_GLOAD(0, 0);
+        NT_GLOAD(koff0a, koff0);
         NT_LSTORE(lds);
         __syncthreads();
-        int kj = 1 % taps;
-        long long kb = (long long)(1 / taps) * BK;
         for (int t = 0; t < nk; ++t) {
             const unsigned char* cur = lds + (t & 1) * STAGE;
             const bool more = t + 1 < nk;
             if (more) {
-                NT_GLOAD(kb + kj * tstride_a, kb + kj * tstride);
-                if (++kj == taps) { kj = 0; kb += BK; }
+                if (t == 0) NT_GLOAD(koff1a, koff1);
+                else {
+                    NT_GLOAD(kb + kj * tstride_a, kb + kj * tstride);
+                    NT_KSTEP();
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -628,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         /* DBG 32: A stored chunk-major, [K / (64 taps)][rows][64]; the taps of a chunk are 64 elements (one row) apart */ \
         const long long kA_ = (long long)((t + 2) / taps) * p.a_item + (long long)((t + 2) % taps) * 64;         \
         (void)kA_;                                                                                               \
-        if (DO_DMA) { if (++kj == taps) { kj = 0; kb += BK; } }                                                  \
+        if (DO_DMA) NT_KSTEP();                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j) {                                                     \
                 if constexpr (!(DBG & 2)) mfma_chunk<T>(acc[i][j], as_uint4(fb0[j]), as_uint4(fa0[i]));          \
@@ -664,7 +687,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
                 }
             }
         }
-        NT_DMA_STAGE(0, 0, 0);
+        NT_DMA_STAGE(0, koff0a, koff0);
         if constexpr (C1) {
             // Fused layer-1 weight gradient: beside the tile image its epilogue needs an image of the waveform windows of the tile's
             // rows.  That image lives BEHIND the K loop's stage buffers, so it is built here, behind the requests of the first stage and before the loop
@@ -705,8 +728,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (nk > 1) NT_DMA_STAGE(1, koff1a, koff1);
-        int kj = 2 % taps;
-        long long kb = (long long)(2 / taps) * BK;
         u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
         NT_READ_SET(fa0, fb0, aA0, aB0, 0u);
         NT_WAIT_SET(fa0, fb0);
@@ -718,6 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         }
         NT_ITER(false, false);
 #undef NT_ITER
+#undef NT_KSTEP
 #undef NT_READ1
 #undef NT_DMA_PIECE
 #undef NT_READ_SET
@@ -1666,7 +1688,7 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const bool fast = (p.K % (8 * ch) == 0) && !(p.flags & GEMM_FORCE_GENERIC);
     // two-level rows and K ranges exist in the fast kernels only; a K range needs items to index and the storage K order
     const bool banded = p.a_rpi2 || p.c_rpi2 || p.k_ranges;
-    if (banded && (!fast || (p.flags & (GEMM_EPI_CONV1 | GEMM_NO_DMA)) || p.m_off || p.k_taps > 1 || p.colsum_slabs)) return CPC_EINVAL;
+    if (banded && (!fast || (p.flags & (GEMM_EPI_CONV1 | GEMM_NO_DMA)) || p.m_off || (p.k_taps > 1 && !p.k_taps_linear) || p.colsum_slabs)) return CPC_EINVAL;
     if ((p.a_rpi2 && (!p.a_rpi || p.a_item2 % ch)) || (p.c_rpi2 && (!p.c_rpi || p.c_item2 % 4)) || (p.k_ranges && !p.a_rpi)) return CPC_EINVAL;
     // 256x256 tiles only where they fill the chip: below ~200 of them (e.g. the 3072 x 3072 all-timesteps score matrix: 144)
     // four times as many 128x128 tiles keep more CUs busy

@@ -124,7 +124,7 @@ class _Conv:
         if self.Ho < 1 or self.Wo < 1:
             raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
         self.mode = 'col' if _col_ok(self.kw, self.sh, self.sw, self.pad, self.cin, in_f32) else 'win'
-        self.gather = False
+        self.gather = self.parity = False
         B = gin.B
         if self.cout % 8:
             raise NotImplementedError("scalogram encoder channel counts must be multiples of 8")
@@ -169,7 +169,18 @@ class _Conv:
             self.bands = self._bands(int(os.environ.get("CPC_DGRAD_BAND", "1"))) if (self.valid_rows and need_dgrad) else None
         else:
             o_top, o_tail, o_guard = out_pad if out_pad is not None else (0, 0, 96)
+            # Data gradient of a 3x3 stride-2 convolution WITHOUT the im2col-gradient matrix (_dgrad_parity below; CPC_DGRAD_PARITY=0: off): needs
+            # one zero row below every output column (the row "H_out" that the last input rows' windows reach)
+            self.parity = (need_dgrad and (self.kh, self.kw, self.sh, self.sw, self.pad) == (3, 3, 2, 2, 0) and not in_f32 and
+                           os.environ.get("CPC_DGRAD_PARITY", "1") != "0" and (2 * self.cout) % (64 if dt == torch.bfloat16 else 32) == 0 and
+                           self.cin % 8 == 0 and gin.Ha >= 2 * (self.Ho + 1) and gin.W >= 2 * self.Wo + 1)
+            if self.parity and out_pad is None:
+                o_tail = 1
+            elif self.parity and o_tail < 1:
+                self.parity = False
             self.y0 = Grid(B, self.Wo, self.Ho, self.cout, dev, dt, top=o_top, tail=o_tail, guard_rows=o_guard)
+            if self.parity:
+                self._parity_setup(B, dev, dt)
             self.K = self.kh * self.kw * self.cin
             # K padded so that the fast GEMM paths apply (K-stage of 64 bf16 / 32 f32 elements); tiny K stays at a multiple of 8
             kq = 64 if dt == torch.bfloat16 else 32
@@ -190,7 +201,7 @@ class _Conv:
             if self.gather:
                 self.w_imp = torch.zeros(self.cout, self.kw, self.seg, device=dev, dtype=dt)
             self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
-            self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if need_dgrad else None
+            self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if (need_dgrad and not self.parity) else None
             self.w_fwd = torch.zeros(self.cout, self.Kp, device=dev, dtype=dt)
             self.w_t = torch.zeros(self.Kp, self.cout, device=dev, dtype=dt)
             self.nsplit = eng._pick_split(self.Kp, self.cout, self.M, dt)
@@ -204,6 +215,65 @@ class _Conv:
         # (dx = gamma rstd (g - <g> - xhat <g xhat>)), so the bias gradient is exactly zero -- the reference's autograd sums rounding
         # noise of relative size 1e-7 there.  The column-sum pass over the gradient grid is skipped and zero is written.
         self.bn_after = None
+
+    def _parity_setup(self, B, dev, dt):
+        """Data gradient of a 3x3 stride-2 convolution as two overlapped-row GEMMs on the output-gradient grid (no im2col-gradient matrix, no
+        col2im pass).  With R = a // 2 over the allocated input rows a and dY rows outside [0, H_out) zero:
+            dX[w][2R]   = sum_dw  dY[wo][R] W[0][dw] + dY[wo][R-1] W[2][dw],      dX[w][2R+1] = sum_dw dY[wo][R] W[1][dw],     w = 2 wo + dw
+        so an EVEN input column w = 2 wo' takes dY columns wo'-1 (dw = 2) and wo' (dw = 0), an ODD one w = 2 wo' + 1 only column wo' (dw = 1).
+        Per input column and super-row R the 2 C_in values (rows 2R, 2R+1) are one GEMM row: A = the dY rows (R-1, R) of one column (2 C_out
+        contiguous elements, overlapped rows) — for even columns two such pieces, one grid column apart (cpc_gemm_nt_args.k_taps).  The first
+        and the last even column have only one piece inside their clip: the rows are ordered (column, clip, R) through the second addressing
+        level, so that a tile lies in one column, and k_ranges cuts the missing piece out (a piece outside the clip belongs to the
+        neighbouring clip).  Rows per (column, clip) are padded to a whole number of tiles per column where B * (H_out + 1) is not one."""
+        cin, cout, Ho, Wo = self.cin, self.cout, self.Ho, self.Wo
+        bk = 64 if dt == torch.bfloat16 else 32
+        Hs = Ho + 1
+        Hp = Hs
+        while (B * Hp) % 256 and Hp < Hs + 16:
+            Hp += 1
+        if (B * Hp) % 256 or Hp * 4 > Hs * 5:
+            self.parity = False                         # small batches of odd heights: the im2col route
+            return
+        self.Hs, self.Hp = Hs, Hp
+        spp = 2 * cout // bk
+        r = [0, 2 * spp] * (Wo + 1)
+        r[0], r[1] = spp, 2 * spp                      # column 0: only dY column 0 (piece 1)
+        r[2 * Wo], r[2 * Wo + 1] = 0, spp              # column 2 Wo: only dY column Wo - 1 (piece 0)
+        self.par_ranges = torch.tensor(r, dtype=torch.int32, device=dev)
+        self.w_even = torch.zeros(2, cin, 2, 2, cout, device=dev, dtype=dt)      # [(r, c)][(piece, q, co)]
+        self.w_odd = torch.zeros(2, cin, 2, cout, device=dev, dtype=dt)          # [(r, c)][(q, co)]
+        self.par_work = (2.0 * B * Hs * 2 * cin * ((Wo - 1) * 4 * cout + 2 * 2 * cout), 2.0 * B * Hs * 2 * cin * Wo * 2 * cout)
+
+    def _parity_prepare(self, w4):
+        wt = w4.permute(2, 3, 1, 0)                    # [dh][dw][c][co]
+        for dst, dws in ((self.w_even, (2, 0)), (self.w_odd, (1,))):
+            for pi, dw in enumerate(dws):
+                d = dst[:, :, pi] if dst is self.w_even else dst
+                d[0, :, 0, :].copy_(wt[2, dw])         # row 2R   <- dY[R-1] W[2]
+                d[0, :, 1, :].copy_(wt[0, dw])         # row 2R   <- dY[R]   W[0]
+                d[1, :, 1, :].copy_(wt[1, dw])         # row 2R+1 <- dY[R]   W[1]        (d[1, :, 0] stays zero)
+
+    def _dgrad_parity(self, dy0: Grid, din: Grid, mask_input):
+        gin, cin, cout, Wo, Hs, Hp, code = self.gin, self.cin, self.cout, self.Wo, self.Hs, self.Hp, self.code
+        B, P = gin.B, _hip.ptr
+        if dy0.Ha - dy0.top - self.Ho < 1 or din.Ha != gin.Ha or dy0.W != Wo or dy0.guard_rows < Hp - Hs + 2:
+            raise AssertionError("parity data gradient: the output-gradient grid has no zero row below its columns")
+        col_o, col_i = dy0.Ha * cout, din.Ha * cin
+        a0 = (dy0.top - 1) * cout                      # row R - 1 of R = 0
+        skip = _hip.GEMM_SKIP_PAD_ROWS if Hp > Hs else 0
+        mk = (lambda off: gin.ptr(off)) if mask_input else (lambda off: None)
+        # even input columns 2 wo', wo' = 0 .. Wo: pieces = dY columns wo' - 1 and wo'
+        _hip.gemm_nt(dy0.ptr(a0 - col_o), P(self.w_even), din.ptr(), (Wo + 1) * B * Hp, 2 * cin, 4 * cout, cout, 4 * cout, 2 * cin, code,
+                     mask=mk(0), a_rpi=Hp, a_item=Wo * col_o, a_rpi2=B, a_item2=col_o, c_rpi=Hp, c_item=gin.W * col_i, c_valid=Hs, c_rpi2=B,
+                     c_item2=2 * col_i, k_taps=2, k_tap_stride=2 * cout, k_tap_stride_a=col_o, k_ranges=P(self.par_ranges), flags=skip,
+                     work=self.par_work[0])
+        # odd input columns 2 wo' + 1, wo' = 0 .. Wo - 1: dY column wo'
+        _hip.gemm_nt(dy0.ptr(a0), P(self.w_odd), din.ptr(col_i), B * Wo * Hp, 2 * cin, 2 * cout, cout, 2 * cout, 2 * cin, code, mask=mk(col_i),
+                     a_rpi=Hp, a_item=col_o, a_rpi2=Wo, a_item2=Wo * col_o, c_rpi=Hp, c_item=2 * col_i, c_valid=Hs, c_rpi2=Wo,
+                     c_item2=gin.W * col_i, flags=skip, work=self.par_work[1])
+        if gin.W > 2 * Wo + 1:                          # input columns no window reaches: zero (the residual branch adds into this grid)
+            din.t.view(B, gin.W, col_i)[:, 2 * Wo + 1:, :].zero_()
 
     def _bands(self, RB):
         """Data gradient of a tall kernel in bands of RB (super-)rows: the GEMM rows are ordered (band, column, row within the band), so
@@ -252,7 +322,10 @@ class _Conv:
                 self.w_imp[:, :, :self.kh * self.cin].copy_(w4.permute(0, 3, 2, 1).reshape(self.cout, self.kw, self.kh * self.cin))   # [co][dw][(dh, c)]
             else:
                 self.w_fwd[:, :self.K].copy_(flat)
-            self.w_t[:self.K, :].copy_(flat.t())
+            if self.parity:
+                self._parity_prepare(w4)
+            else:
+                self.w_t[:self.K, :].copy_(flat.t())
 
     def forward(self, tangent=False):
         """tangent=True (gradient-penalty step): the same GEMM on the TANGENT of the input, written to the tangent of the output —
@@ -443,7 +516,11 @@ class _Conv:
                              D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
             if accumulate:
                 din.t.add_(dst.t)
+        elif self.parity and not accumulate:
+            self._dgrad_parity(dy0, din, mask_input)
         else:
+            if self.parity:
+                raise NotImplementedError("accumulating data gradient of a parity-route convolution")
             # (an output-bound launch: with its weight-gradient GEMM beside it the pair moves 2.25 GB in 0.75 ms for block 1 of
             # scalogram_resnet_architecture_7; 128-wide tiles or the LDS-staged epilogue change nothing)
             _hip.gemm_nt(dy0.ptr(dy0.top * self.cout), _hip.ptr(self.w_t), _hip.ptr(self.dcol), self.M, self.Kp, self.cout, self.cout,
@@ -931,7 +1008,8 @@ class _Block:
             self.ow = self.res.W - int(o_w + m.W) if int(o_w) > 0 else 0
             if (int(o_h) <= 0 and self.res.H != m.H) or (int(o_w) <= 0 and self.res.W != m.W):
                 raise ValueError(f"block {idx}: residual {self.res.H}x{self.res.W} cannot be cropped onto main {m.H}x{m.W}")
-            self.out = Grid(m.B, m.W, m.H, m.C, dev, dt, top=next_top)
+            # (an even number of allocated rows: the parity-route data gradient of the next block's 3x3 stride-2 convolution writes row pairs)
+            self.out = Grid(m.B, m.W, m.H, m.C, dev, dt, top=next_top, tail=0 if last else (next_top + m.H) % 2)
             self.r_f32 = 1 if (self.res.dtype == torch.float32 and dt != torch.float32) else 0
             if self.stem_res is not None:
                 self.stem_res = _StemResidual(eng, self.stem_res, self.res, m, self.out, self.oh, self.ow, relu=not last)
