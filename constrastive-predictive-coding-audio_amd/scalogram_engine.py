@@ -229,49 +229,60 @@ class _Conv:
         cin, cout, Ho, Wo = self.cin, self.cout, self.Ho, self.Wo
         bk = 64 if dt == torch.bfloat16 else 32
         Hs = Ho + 1
-        Hp = Hs
-        while (B * Hp) % 256 and Hp < Hs + 16:
+        # G row pairs per GEMM row where 2 C_in columns would leave most of a 128-wide tile empty (C_in = 32: G = 2, the window is then the
+        # three dY rows R-1 .. R+1 per piece): half the tiles, each full — 0.52 -> 0.3x ms for the even columns of block 1 of architecture 7
+        G = 1
+        if os.environ.get("CPC_DGRAD_PARITY_GROUP", "1") != "0":
+            while 2 * cin * G * 2 <= 128 and Hs % (2 * G) == 0:
+                G *= 2
+        Hg = Hs // G
+        tile = 256 if 2 * cin * G >= 256 else 128
+        Hp = Hg
+        while (B * Hp) % tile and Hp < Hg + 16:
             Hp += 1
-        if (B * Hp) % 256 or Hp * 4 > Hs * 5:
+        if (B * Hp) % tile or Hp * 4 > Hg * 5 or ((G + 1) * cout) % bk:
             self.parity = False                         # small batches of odd heights: the im2col route
             return
-        self.Hs, self.Hp = Hs, Hp
-        spp = 2 * cout // bk
+        self.Hs, self.Hp, self.Hg, self.Gp = Hs, Hp, Hg, G
+        spp = (G + 1) * cout // bk
         r = [0, 2 * spp] * (Wo + 1)
         r[0], r[1] = spp, 2 * spp                      # column 0: only dY column 0 (piece 1)
         r[2 * Wo], r[2 * Wo + 1] = 0, spp              # column 2 Wo: only dY column Wo - 1 (piece 0)
         self.par_ranges = torch.tensor(r, dtype=torch.int32, device=dev)
-        self.w_even = torch.zeros(2, cin, 2, 2, cout, device=dev, dtype=dt)      # [(r, c)][(piece, q, co)]
-        self.w_odd = torch.zeros(2, cin, 2, cout, device=dev, dtype=dt)          # [(r, c)][(q, co)]
-        self.par_work = (2.0 * B * Hs * 2 * cin * ((Wo - 1) * 4 * cout + 2 * 2 * cout), 2.0 * B * Hs * 2 * cin * Wo * 2 * cout)
+        self.w_even = torch.zeros(2 * G, cin, 2, G + 1, cout, device=dev, dtype=dt)      # [(g, r, c)][(piece, q, co)]
+        self.w_odd = torch.zeros(2 * G, cin, G + 1, cout, device=dev, dtype=dt)          # [(g, r, c)][(q, co)]
+        n, kp = 2.0 * B * Hg * 2 * G * cin, (G + 1) * cout
+        self.par_work = (n * ((Wo - 1) * 2 * kp + 2 * kp), n * Wo * kp)
 
     def _parity_prepare(self, w4):
         wt = w4.permute(2, 3, 1, 0)                    # [dh][dw][c][co]
         for dst, dws in ((self.w_even, (2, 0)), (self.w_odd, (1,))):
             for pi, dw in enumerate(dws):
                 d = dst[:, :, pi] if dst is self.w_even else dst
-                d[0, :, 0, :].copy_(wt[2, dw])         # row 2R   <- dY[R-1] W[2]
-                d[0, :, 1, :].copy_(wt[0, dw])         # row 2R   <- dY[R]   W[0]
-                d[1, :, 1, :].copy_(wt[1, dw])         # row 2R+1 <- dY[R]   W[1]        (d[1, :, 0] stays zero)
+                for g in range(self.Gp):               # row pair R = G R' + g reads the window rows q = g (dY[R-1]) and g + 1 (dY[R])
+                    d[2 * g, :, g, :].copy_(wt[2, dw])             # row 2R   <- dY[R-1] W[2]
+                    d[2 * g, :, g + 1, :].copy_(wt[0, dw])         # row 2R   <- dY[R]   W[0]
+                    d[2 * g + 1, :, g + 1, :].copy_(wt[1, dw])     # row 2R+1 <- dY[R]   W[1]
 
     def _dgrad_parity(self, dy0: Grid, din: Grid, mask_input):
-        gin, cin, cout, Wo, Hs, Hp, code = self.gin, self.cin, self.cout, self.Wo, self.Hs, self.Hp, self.code
+        gin, cin, cout, Wo, Hg, Hp, G, code = self.gin, self.cin, self.cout, self.Wo, self.Hg, self.Hp, self.Gp, self.code
         B, P = gin.B, _hip.ptr
-        if dy0.Ha - dy0.top - self.Ho < 1 or din.Ha != gin.Ha or dy0.W != Wo or dy0.guard_rows < Hp - Hs + 2:
+        if dy0.Ha - dy0.top - self.Ho < 1 or din.Ha != gin.Ha or dy0.W != Wo or dy0.guard_rows < G * (Hp - Hg) + 2:
             raise AssertionError("parity data gradient: the output-gradient grid has no zero row below its columns")
         col_o, col_i = dy0.Ha * cout, din.Ha * cin
         a0 = (dy0.top - 1) * cout                      # row R - 1 of R = 0
-        skip = _hip.GEMM_SKIP_PAD_ROWS if Hp > Hs else 0
+        N, kp = 2 * G * cin, (G + 1) * cout
+        skip = _hip.GEMM_SKIP_PAD_ROWS if Hp > Hg else 0
         mk = (lambda off: gin.ptr(off)) if mask_input else (lambda off: None)
         # even input columns 2 wo', wo' = 0 .. Wo: pieces = dY columns wo' - 1 and wo'
-        _hip.gemm_nt(dy0.ptr(a0 - col_o), P(self.w_even), din.ptr(), (Wo + 1) * B * Hp, 2 * cin, 4 * cout, cout, 4 * cout, 2 * cin, code,
-                     mask=mk(0), a_rpi=Hp, a_item=Wo * col_o, a_rpi2=B, a_item2=col_o, c_rpi=Hp, c_item=gin.W * col_i, c_valid=Hs, c_rpi2=B,
-                     c_item2=2 * col_i, k_taps=2, k_tap_stride=2 * cout, k_tap_stride_a=col_o, k_ranges=P(self.par_ranges), flags=skip,
+        _hip.gemm_nt(dy0.ptr(a0 - col_o), P(self.w_even), din.ptr(), (Wo + 1) * B * Hp, N, 2 * kp, G * cout, 2 * kp, N, code,
+                     mask=mk(0), a_rpi=Hp, a_item=Wo * col_o, a_rpi2=B, a_item2=col_o, c_rpi=Hp, c_item=gin.W * col_i, c_valid=Hg, c_rpi2=B,
+                     c_item2=2 * col_i, k_taps=2, k_tap_stride=kp, k_tap_stride_a=col_o, k_ranges=P(self.par_ranges), flags=skip,
                      work=self.par_work[0])
         # odd input columns 2 wo' + 1, wo' = 0 .. Wo - 1: dY column wo'
-        _hip.gemm_nt(dy0.ptr(a0), P(self.w_odd), din.ptr(col_i), B * Wo * Hp, 2 * cin, 2 * cout, cout, 2 * cout, 2 * cin, code, mask=mk(col_i),
-                     a_rpi=Hp, a_item=col_o, a_rpi2=Wo, a_item2=Wo * col_o, c_rpi=Hp, c_item=2 * col_i, c_valid=Hs, c_rpi2=Wo,
-                     c_item2=gin.W * col_i, flags=skip, work=self.par_work[1])
+        _hip.gemm_nt(dy0.ptr(a0), P(self.w_odd), din.ptr(col_i), B * Wo * Hp, N, kp, G * cout, kp, N, code, mask=mk(col_i),
+                     a_rpi=Hp, a_item=col_o, a_rpi2=Wo, a_item2=Wo * col_o, c_rpi=Hp, c_item=2 * col_i, c_valid=Hg, c_rpi2=Wo,
+                     c_item2=gin.W * col_i, flags=skip | _hip.GEMM_LINEAR_K, work=self.par_work[1])
         if gin.W > 2 * Wo + 1:                          # input columns no window reaches: zero (the residual branch adds into this grid)
             din.t.view(B, gin.W, col_i)[:, 2 * Wo + 1:, :].zero_()
 
