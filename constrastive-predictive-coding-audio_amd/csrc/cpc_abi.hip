@@ -350,6 +350,11 @@ int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float ep
     return launch_bn_finalize(slabs, nslab, C, count, eps, momentum, stats, run_mean, run_var, (hipStream_t)stream);
 }
 
+int cpc_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
+                          const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
+                          const int* ga, int dtype, void* stream) {
+    return launch_bn_apply_residual(x, gx, res, gr, out, go, stats, gamma, beta, oh, ow, relu_in, relu_out, r_f32, bits, ga, dtype, (hipStream_t)stream);
+}
 int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                  int relu, int x_f32, int dtype, void* stream) {
     if (!x || !out || !stats || !gamma || !beta) return CPC_EINVAL;

@@ -196,6 +196,9 @@ int launch_col2im2d(const void* dcol, void* din, const int* grid, int kh, int kw
 int launch_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, hipStream_t stream);
 int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
                        float* run_var, hipStream_t stream);
+int launch_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
+                             const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
+                             const int* ga, int dtype, hipStream_t st);
 int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                     int relu, int x_f32, int dtype, hipStream_t stream, unsigned char* bits = nullptr);
 int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,

@@ -542,6 +542,54 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict
     }
 }
 
+// out = act_out(act_in(BatchNorm(x)) + res(w + ow, h + oh)): the second BatchNorm + ReLU of a ScalogramEncoderBlock, the cropped residual add and
+// the ReLU between blocks (scalogram_model.py:418-428, :447-472, :525-526) in one pass.  The normalised main branch is never stored: its
+// backward pass needs the BatchNorm's input, its statistics and the SIGN BITS of its output (bits, one byte per 8 elements at the element
+// offsets of the x grid, as cpc_bn_apply_bits writes them).  The normalised value is rounded to bf16 before the add, as the two-pass route
+// stores it: same results bit for bit.  bf16, 8 channels per thread; TR: the residual's type.
+__device__ __forceinline__ f32x8 load8(const float* src) {
+    f32x8 o;
+    o.lo = *(const f32x4*)src;
+    o.hi = *(const f32x4*)(src + 4);
+    return o;
+}
+template <typename TR>
+__global__ __launch_bounds__(256) void bn_apply_residual8_kernel(const bf16_t* __restrict__ x, Grid gx, const TR* __restrict__ r, Grid gr,
+                                                                 bf16_t* __restrict__ out, Grid go, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int oh, int ow,
+                                                                 int relu_in, int relu_out, unsigned char* __restrict__ bits, Grid ga) {
+    const int c8n = gx.C / 8;
+    const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c8 = (int)(idx % c8n);
+        const int h = (int)((idx / c8n) % gx.H);
+        const unsigned col = idx / (unsigned)(c8n * gx.H);
+        const int w = (int)(col % gx.W), b = (int)(col / gx.W);
+        const f32x8 v = load8(x + grid_off(gx, b, w, h) + c8 * 8);
+        const f32x8 rv = load8(r + grid_off(gr, b, w + ow, h + oh) + c8 * 8);
+        f32x4 o[2];
+        unsigned m = 0u;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c = c8 * 8 + hf * 4;
+            const f32x4 mu = *(const f32x4*)(stats + c), rs = *(const f32x4*)(stats + gx.C + c);
+            const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+            const f32x4 vv = hf ? v.hi : v.lo, rr = hf ? rv.hi : rv.lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = (vv[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                if (relu_in) a = relu_f(a);
+                a = (float)(bf16_t)a;
+                m |= (a > 0.f ? 1u : 0u) << (hf * 4 + e);
+                o[hf][e] = a + rr[e];
+                if (relu_out) o[hf][e] = relu_f(o[hf][e]);
+            }
+        }
+        store8(out + grid_off(go, b, w, h) + c8 * 8, o[0], o[1]);
+        if (bits) bits[(grid_off(ga, b, w, h) + c8 * 8) >> 3] = (unsigned char)m;      // (addressed like the activation grid it stands for)
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, Grid gy,
                                                              const bf16_t* __restrict__ x, Grid gx, const float* __restrict__ stats,
                                                              float* __restrict__ slabs, int relu, long long cols_per_block,
@@ -1067,6 +1115,24 @@ int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float
 }
 
 static bool same_shape(const int* a, const int* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[5] == b[5]; }
+
+int launch_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
+                             const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
+                             const int* ga, int dtype, hipStream_t st) {
+    if (bits && (!grid_ok(ga) || !same_shape(gx, ga))) return CPC_EINVAL;
+    if (dtype != CPC_DTYPE_BF16 || !grid_ok(gx) || !grid_ok(gr) || !grid_ok(go) || !same_shape(gx, go) || gx[5] % 8 || gr[5] != gx[5] ||
+        gr[0] != gx[0] || oh < 0 || ow < 0 || gr[2] < gx[2] + oh || gr[1] < gx[1] + ow || !x || !res || !out || !stats || !gamma || !beta)
+        return CPC_EINVAL;
+    const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
+    if (r_f32)
+        hipLaunchKernelGGL((bn_apply_residual8_kernel<float>), dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (const float*)res, mk(gr),
+                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx));
+    else
+        hipLaunchKernelGGL((bn_apply_residual8_kernel<bf16_t>), dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (const bf16_t*)res, mk(gr),
+                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
 
 int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                     int relu, int x_f32, int dtype, hipStream_t st, unsigned char* bits) {

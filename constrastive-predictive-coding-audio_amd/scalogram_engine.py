@@ -651,7 +651,16 @@ class _BatchNorm:
                 os.environ.get("CPC_BN_BITS", "1") != "0"):
             self.abits = torch.zeros(a.rows * a.C // 8, device=eng.device, dtype=torch.uint8)
 
-    def forward(self):
+    def apply_residual(self, res: Grid, out: Grid, oh, ow, relu_out, r_f32):
+        """The apply pass of forward(apply=False), fused with the block's cropped residual add and the ReLU between blocks
+        (cpc_bn_apply_residual): the activation grid ``a`` is not written, only its sign bits."""
+        e = self.eng
+        p = e.model._param
+        _hip.call("cpc_bn_apply_residual", self.y0.ptr(), _desc(self.y0, self.y0.desc), res.ptr(), _desc(res, res.desc), out.ptr(), _desc(out, out.desc),
+                  _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), oh, ow, 1, relu_out, r_f32,
+                  _hip.ptr(self.abits), _desc(self.a, self.a.desc), e.code)
+
+    def forward(self, apply=True):
         e, mod = self.eng, self.mod
         p, code = e.model._param, e.code
         self.trained = bool(mod.training or not mod.track_running_stats)
@@ -667,6 +676,8 @@ class _BatchNorm:
         else:
             self.stats[0].copy_(mod.running_mean)
             self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
+        if not apply:
+            return
         if self.abits is not None:
             _hip.call("cpc_bn_apply_bits", self.y0.ptr(), _desc(self.y0, self.y0.desc), self.a.ptr(), _desc(self.a, self.a.desc),
                       _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), 1, _hip.ptr(self.abits), code)
@@ -1082,8 +1093,12 @@ class _Block:
             _hip.call("cpc_maxpool2d_fwd", self.a_full.ptr(), _desc(self.a_full, self.a_full.desc), self.a_a.ptr(),
                       _desc(self.a_a, self.a_a.desc), self.pool1, 0, code)
         self.conv_b.forward()
+        # second BatchNorm + ReLU, residual add and the ReLU between blocks in one pass where nothing else reads the normalised branch
+        # (CPC_BN_RESIDUAL=0: two passes; the gradient penalty's tangent pass reads it)
+        fuse = (self.bn_b is not None and self.blk.residual and self.stem_res is None and self.pool2 == 1 and self.bn_b.abits is not None and
+                not getattr(e, "gp_capable", False) and self.main.C % 8 == 0 and os.environ.get("CPC_BN_RESIDUAL", "1") != "0")
         if self.bn_b is not None:
-            self.bn_b.forward()
+            self.bn_b.forward(apply=not fuse)
         if self.pool2 > 1:
             _hip.call("cpc_maxpool2d_fwd", self.main_full.ptr(), _desc(self.main_full, self.main_full.desc), self.main.ptr(),
                       _desc(self.main, self.main.desc), self.pool2, 0, code)
@@ -1095,6 +1110,8 @@ class _Block:
                 self.res_conv.forward()
             if self.stem_res is not None:
                 self.stem_res.forward()
+            elif fuse:
+                self.bn_b.apply_residual(self.res, self.out, self.oh, self.ow, 0 if self.last else 1, self.r_f32)
             else:
                 _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
                           self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)

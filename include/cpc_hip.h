@@ -314,6 +314,14 @@ int cpc_dw_bwd_w(const void* col, const void* dy, float* slabs, long long M, int
 int cpc_bn_stats(const void* x, float* slabs, long long rows, int C, int nblocks, int dtype, void* stream);
 int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float eps, float momentum, float* stats, float* run_mean,
                     float* run_var, void* stream);
+/* cpc_bn_apply_residual (bf16, C a multiple of 8): out = act_out(act_in(BatchNorm(x)) + res(w + ow, h + oh)) — the block's second BatchNorm + ReLU,
+ * the cropped residual add (scalogram_model.py:447-472) and the ReLU between blocks (:525-526) in one pass; the normalised branch is not stored,
+ * only its sign bits (bits, may be NULL; addressed by the element offsets of the activation grid ga it stands for, as cpc_bn_apply_bits writes them)
+ * for the BatchNorm's backward pass.  Same results as cpc_bn_apply followed
+ * by cpc_residual_add, bit for bit.  r_f32: res is a float32 grid. */
+int cpc_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
+                          const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
+                          const int* ga, int dtype, void* stream);
 int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                  int relu, int x_f32, int dtype, void* stream);
 /* Backward: g = dy * (y > 0) if relu.  cpc_bn_bwd_reduce: slabs [nblocks][2][C] partials of (sum g*xhat, sum g) = (dgamma,

@@ -203,6 +203,35 @@ def test_batchnorm_grid(dt, train):
         assert torch.equal(gdx2.t, gdx.t)
 
 
+@pytest.mark.parametrize("r_f32", [0, 1])
+def test_bn_apply_residual_equals_the_two_passes(r_f32):
+    """cpc_bn_apply_residual (second BatchNorm + ReLU, cropped residual add, ReLU between blocks in one pass; only the sign bits of the
+    normalised branch are kept) against cpc_bn_apply_bits followed by cpc_residual_add: bitwise equal outputs and sign bits, grids with
+    different row geometries (tail rows on the convolution output, top rows on the block output, a larger residual grid cropped)."""
+    B, Cc, H, W, oh, ow = 3, 16, 5, 7, 2, 1
+    g = torch.Generator().manual_seed(9)
+    bf = torch.bfloat16
+    code = _hip.dtype_code(bf)
+    gx = Grid(B, W, H, Cc, DEV, bf, tail=3)
+    ga = Grid(B, W, H, Cc, DEV, bf, top=1)
+    gr = Grid(B, W + 3, H + 4, Cc, DEV, torch.float32 if r_f32 else bf, tail=1)
+    go1, go2 = Grid(B, W, H, Cc, DEV, bf, top=2, tail=1), Grid(B, W, H, Cc, DEV, bf, top=2, tail=1)
+    _fill(gx, torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.3)
+    _fill(gr, torch.randn(B, Cc, H + 4, W + 3, generator=g))
+    stats = torch.stack([torch.randn(Cc, generator=g) * 0.2, 1 + 0.3 * torch.rand(Cc, generator=g)]).to(DEV)
+    gamma, beta = (1 + 0.3 * torch.randn(Cc, generator=g)).to(DEV), (0.2 * torch.randn(Cc, generator=g)).to(DEV)
+    bits1 = torch.zeros(ga.rows * Cc // 8, device=DEV, dtype=torch.uint8)
+    bits2 = torch.zeros_like(bits1)
+    for relu_out in (1, 0):
+        _hip.call("cpc_bn_apply_bits", gx.ptr(), _d(gx.desc), ga.ptr(), _d(ga.desc), _hip.ptr(stats), _hip.ptr(gamma), _hip.ptr(beta), 1,
+                  _hip.ptr(bits1), code)
+        _hip.call("cpc_residual_add", ga.ptr(), _d(ga.desc), gr.ptr(), _d(gr.desc), go1.ptr(), _d(go1.desc), oh, ow, relu_out, r_f32, code)
+        _hip.call("cpc_bn_apply_residual", gx.ptr(), _d(gx.desc), gr.ptr(), _d(gr.desc), go2.ptr(), _d(go2.desc), _hip.ptr(stats), _hip.ptr(gamma),
+                  _hip.ptr(beta), oh, ow, 1, relu_out, r_f32, _hip.ptr(bits2), _d(ga.desc), code)
+        assert torch.equal(go1.t, go2.t) and torch.equal(bits1, bits2)
+        assert go1.t.abs().max().item() > 0
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_maxpool2d_and_residual_add(dt):
     B, Cc, H, W, p = 2, 8, 7, 9, 2
