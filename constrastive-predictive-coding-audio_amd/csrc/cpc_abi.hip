@@ -428,6 +428,12 @@ int cpc_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const floa
                                  dgamma, dbeta, count, da, a, ga, slabs, nblocks, dtype, (hipStream_t)stream);
 }
 
+int cpc_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh, int ow,
+                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga, int dtype,
+                             void* stream) {
+    if (!y || !xp || !wr || !out) return CPC_EINVAL;
+    return launch_stem_residual_bn_add(y, gy, xp, gp, wr, out, go, oh, ow, relu, stats, gamma, beta, bits, ga, dtype, (hipStream_t)stream);
+}
 int cpc_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                           int oh, int ow, int relu, int dtype, void* stream) {
     if (!main_ || !gm || !xp || !gp || !wr || !out || !go) return CPC_EINVAL;

@@ -482,10 +482,15 @@ __device__ __forceinline__ void storen(T* dst, const float (&v)[N]) {
     }
 }
 
-template <typename T, int CIN>
+// BN (bf16): main_ is the INPUT of the block's second BatchNorm (grid gm); the value added to the projection is relu(BatchNorm(main_)) rounded to
+// bf16 — what cpc_bn_apply would have stored — and only its sign bits are kept (bits, addressed like the activation grid ga; may be null):
+// cpc_bn_apply + this kernel's plain form in one pass, same results bit for bit.
+template <typename T, int CIN, bool BN = false>
 __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restrict__ main_, Grid gm, const float* __restrict__ xp, Grid gp,
                                                                 const float* __restrict__ wr, T* __restrict__ out, Grid go, int oh, int ow,
-                                                                int relu) {
+                                                                int relu, const float* __restrict__ stats = nullptr,
+                                                                const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                                unsigned char* __restrict__ bits = nullptr, Grid ga = Grid()) {
     constexpr int N = Cpt<T>::N;
     const int cgn = gm.C / N;
     const unsigned total = (unsigned)((long long)gm.B * gm.W * gm.H * cgn);
@@ -503,6 +508,16 @@ __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restr
         const int wq = (int)(col % (unsigned)gm.W), b = (int)(col / (unsigned)gm.W);
         float v[N];
         loadn<T, N>(main_ + grid_off(gm, b, wq, h) + cg * N, v);
+        if constexpr (BN) {
+            unsigned m = 0u;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const int c = cg * N + e;
+                v[e] = (float)(bf16_t)relu_f((v[e] - stats[c]) * stats[gm.C + c] * gamma[c] + beta[c]);
+                m |= (v[e] > 0.f ? 1u : 0u) << e;
+            }
+            if (bits) bits[(grid_off(ga, b, wq, h) + cg * N) >> 3] = (unsigned char)m;
+        }
         const float* xr = xp + grid_off(gp, b, wq + ow, h + oh);
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) {
@@ -716,6 +731,21 @@ static bool residual_ok(const int* gm, const int* gp, const int* go, int oh, int
     const int n = dtype == CPC_DTYPE_BF16 ? 8 : 4;
     if (gm[5] % n || gm[5] / n > 256 || 256 % (gm[5] / n) || gp[5] < 1 || gp[5] > 2 || oh < 0 || ow < 0) return false;
     return gm[1] + ow <= gp[1] && gm[2] + oh <= gp[2];
+}
+
+int launch_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh,
+                                int ow, int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga,
+                                int dtype, hipStream_t st) {
+    if (dtype != CPC_DTYPE_BF16 || !residual_ok(gy, gp, go, oh, ow, dtype) || !stats || !gamma || !beta) return CPC_EINVAL;
+    if (bits && (!grid_ok(ga) || ga[0] != gy[0] || ga[1] != gy[1] || ga[2] != gy[2] || ga[5] != gy[5])) return CPC_EINVAL;
+    const int cgn = gy[5] / 8;
+    const long long total = (long long)gy[0] * gy[1] * gy[2] * cgn;
+    const int nb = (int)std::min<long long>(8192, (total + 255) / 256);
+#define RES_BN_ADD(CI) hipLaunchKernelGGL((stem_residual_add_kernel<bf16_t, CI, true>), dim3(nb), dim3(256), 0, st, (const bf16_t*)y, mk(gy), xp, mk(gp), wr, (bf16_t*)out, mk(go), oh, ow, relu, stats, gamma, beta, bits, bits ? mk(ga) : mk(gy))
+    if (gp[5] == 1) RES_BN_ADD(1); else RES_BN_ADD(2);
+#undef RES_BN_ADD
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
 }
 
 int launch_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,

@@ -894,9 +894,17 @@ class _StemResidual:
         self.n = main.C * xp.C
         self.slab = self.nb * self.n
 
-    def forward(self):
+    def forward(self, bn=None):
+        """``bn``: the block's second BatchNorm whose apply pass was left out (forward(apply=False)): normalise + ReLU inside this add
+        (cpc_stem_residual_bn_add), the normalised branch is kept as sign bits only."""
         e, m, xp, o = self.eng, self.main, self.xp, self.out
-        _hip.call("cpc_stem_residual_add", m.ptr(), _desc(m, m.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(e.model._param[self.wname]),
+        p = e.model._param
+        if bn is not None:
+            _hip.call("cpc_stem_residual_bn_add", bn.y0.ptr(), _desc(bn.y0, bn.y0.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(p[self.wname]),
+                      o.ptr(), _desc(o, o.desc), self.oh, self.ow, 1 if self.relu else 0, _hip.ptr(bn.stats), _hip.ptr(p[bn.prefix + ".weight"]),
+                      _hip.ptr(p[bn.prefix + ".bias"]), _hip.ptr(bn.abits), _desc(bn.a, bn.a.desc), e.code)
+            return
+        _hip.call("cpc_stem_residual_add", m.ptr(), _desc(m, m.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(p[self.wname]),
                   o.ptr(), _desc(o, o.desc), self.oh, self.ow, 1 if self.relu else 0, e.code)
 
     def backward(self, d_out: Grid, d_main: Grid):
@@ -1095,7 +1103,7 @@ class _Block:
         self.conv_b.forward()
         # second BatchNorm + ReLU, residual add and the ReLU between blocks in one pass where nothing else reads the normalised branch
         # (CPC_BN_RESIDUAL=0: two passes; the gradient penalty's tangent pass reads it)
-        fuse = (self.bn_b is not None and self.blk.residual and self.stem_res is None and self.pool2 == 1 and self.bn_b.abits is not None and
+        fuse = (self.bn_b is not None and self.blk.residual and self.pool2 == 1 and self.bn_b.abits is not None and
                 not getattr(e, "gp_capable", False) and self.main.C % 8 == 0 and os.environ.get("CPC_BN_RESIDUAL", "1") != "0")
         if self.bn_b is not None:
             self.bn_b.forward(apply=not fuse)
@@ -1109,7 +1117,7 @@ class _Block:
             if self.res_conv is not None:
                 self.res_conv.forward()
             if self.stem_res is not None:
-                self.stem_res.forward()
+                self.stem_res.forward(self.bn_b if fuse else None)
             elif fuse:
                 self.bn_b.apply_residual(self.res, self.out, self.oh, self.ow, 0 if self.last else 1, self.r_f32)
             else:

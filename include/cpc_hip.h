@@ -389,6 +389,12 @@ int cpc_stem_bwd_reduce(const float* x, const int* gx, const float* w, const flo
 int cpc_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const float* bias, const int* conv, const float* stats,
                        const float* gamma, const float* dgamma, const float* dbeta, double count, const void* da, const void* a,
                        const int* ga, float* slabs, int nblocks, int dtype, void* stream);
+/* cpc_stem_residual_bn_add (bf16): cpc_bn_apply (+ReLU) of the block's second BatchNorm and cpc_stem_residual_add in one pass — y is the
+ * BatchNorm's INPUT grid; out = act(bf16(relu(BatchNorm(y))) + wr xp(w + ow, h + oh)); bits (may be NULL): the sign bits of the normalised branch,
+ * addressed like its activation grid ga (what the BatchNorm's backward pass reads).  Bit-identical to the two passes. */
+int cpc_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh, int ow,
+                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga, int dtype,
+                             void* stream);
 int cpc_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                           int oh, int ow, int relu, int dtype, void* stream);
 int cpc_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,

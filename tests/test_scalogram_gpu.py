@@ -927,6 +927,31 @@ def test_stem_kernels_equal_the_im2col_route(golden_dir, dtype, fixture, monkeyp
         assert _rel(a, b.numpy()) < (1e-5 if dtype == "fp32" else 5e-2)
 
 
+@pytest.mark.parametrize("fixture", ["scalogram_model", "scalogram_model_b"])
+def test_fused_batchnorm_residual_pass_is_bit_identical(golden_dir, fixture, monkeypatch):
+    """CPC_BN_RESIDUAL=1 (default: the block's second BatchNorm + ReLU inside the residual add — cpc_bn_apply_residual, and
+    cpc_stem_residual_bn_add for the first block — with the normalised branch kept as sign bits only) against the two-pass route: the
+    same loss and the same gradient buffer BIT FOR BIT (bf16 storage), train and eval mode."""
+    g = _load(golden_dir, fixture + ".npz")
+    meta = json.load(open(os.path.join(golden_dir, fixture + ".json")))
+    scal = torch.from_numpy(g["scalogram"]).to(DEV)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CPC_BN_RESIDUAL", fuse)
+        pre, model = _build_scalogram_model(g, meta, "bf16")
+        eng = model.engine_for(scal)
+        out = eng.loss_and_grads(scal, softplus=True, regularization=1.0)
+        loss, grads = float(out[0]), model._flat_grad.detach().clone()
+        model.eval()
+        with torch.no_grad():
+            ev = [t.detach().clone() for t in model(scal)]
+        res[fuse] = (loss, grads, ev)
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1])
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gathered_window_forward_equals_the_im2col_route(golden_dir, dtype, monkeypatch):
     """CPC_CONV_GATHER=1 (strided 3x3 / 2x2 convolutions read their windows straight from the grid through cpc_gemm_nt's k_taps /
