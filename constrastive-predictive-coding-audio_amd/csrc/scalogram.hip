@@ -5,6 +5,7 @@
 //   * BatchNorm (batch statistics) forward / backward, MaxPool2d(ceil), cropped residual add.
 #include "cpc_common.h"
 #include "cpc_kernels.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -539,6 +540,54 @@ __global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict
                 for (int e = 0; e < 4; ++e) m |= ((float)(bf16_t)o[hf][e] > 0.f ? 1u : 0u) << (hf * 4 + e);
             bits[oo >> 3] = (unsigned char)m;
         }
+    }
+}
+
+// 16-byte (8-channel) forms of the cropped residual add and its backward for bf16 grids (the 8-byte forms ran at half the HBM rate the
+// BatchNorm passes reach on the same tensors); same values.
+__global__ __launch_bounds__(256) void residual_add8_kernel(const bf16_t* __restrict__ a, Grid ga, const bf16_t* __restrict__ r, Grid gr,
+                                                            bf16_t* __restrict__ out, Grid go, int oh, int ow, int relu) {
+    const int c8n = go.C / 8;
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c8 = (int)(idx % c8n);
+        const int h = (int)((idx / c8n) % go.H);
+        const unsigned col = idx / (unsigned)(c8n * go.H);
+        const int w = (int)(col % go.W), b = (int)(col / go.W);
+        const f32x8 x = load8(a + grid_off(ga, b, w, h) + c8 * 8), y = load8(r + grid_off(gr, b, w + ow, h + oh) + c8 * 8);
+        f32x4 lo = x.lo + y.lo, hi = x.hi + y.hi;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = relu_f(lo[e]); hi[e] = relu_f(hi[e]); }
+        }
+        store8(out + grid_off(go, b, w, h) + c8 * 8, lo, hi);
+    }
+}
+__global__ __launch_bounds__(256) void residual_add_bwd8_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, Grid go,
+                                                                bf16_t* __restrict__ da, Grid ga, bf16_t* __restrict__ dr, Grid gr, int oh, int ow,
+                                                                int relu) {
+    const int c8n = go.C / 8;
+    const unsigned total = (unsigned)((long long)go.B * go.W * go.H * c8n);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int c8 = (int)(idx % c8n);
+        const int h = (int)((idx / c8n) % go.H);
+        const unsigned col = idx / (unsigned)(c8n * go.H);
+        const int w = (int)(col % go.W), b = (int)(col / go.W);
+        const long long oo = grid_off(go, b, w, h) + c8 * 8;
+        uint4 g = *(const uint4*)(dout + oo);
+        if (relu) {          // bf16 > 0  <=>  sign bit clear and not zero: the gradient's 16-bit halves are kept or cleared, no conversion
+            const uint4 y = *(const uint4*)(out + oo);
+            const unsigned yw[4] = {y.x, y.y, y.z, y.w};
+            unsigned gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned l16 = yw[e] & 0xffffu, h16 = yw[e] >> 16;
+                gw[e] &= ((l16 != 0u && l16 < 0x8000u) ? 0xffffu : 0u) | ((h16 != 0u && h16 < 0x8000u) ? 0xffff0000u : 0u);
+            }
+            g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+        }
+        *(uint4*)(da + grid_off(ga, b, w, h) + c8 * 8) = g;
+        *(uint4*)(dr + grid_off(gr, b, w + ow, h + oh) + c8 * 8) = g;
     }
 }
 
@@ -1253,10 +1302,22 @@ static bool crop_ok(const int* ga, const int* gr, const int* go, int oh, int ow)
            oh >= 0 && ow >= 0 && oh + go[2] <= gr[2] && ow + go[1] <= gr[1];
 }
 
+static bool res8_enabled() {          // CPC_RES8=0: the 8-byte residual kernels (A/B switch)
+    static const bool on = [] { const char* v = getenv("CPC_RES8"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 int launch_residual_add(const void* a, const int* ga, const void* r, const int* gr, void* out, const int* go, int oh, int ow, int relu,
                         int r_f32, int dtype, hipStream_t st) {
     if (!crop_ok(ga, gr, go, oh, ow)) return CPC_EINVAL;
     const int nb = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && !r_f32 && go[5] % 8 == 0 && res8_enabled()) {
+        const int nb8 = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 8));
+        hipLaunchKernelGGL(residual_add8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)a, mk(ga), (const bf16_t*)r, mk(gr), (bf16_t*)out, mk(go),
+                           oh, ow, relu);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16 && r_f32)
         hipLaunchKernelGGL((residual_add_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)a, mk(ga), (const float*)r, mk(gr), (bf16_t*)out, mk(go), oh, ow, relu);
     else
@@ -1271,6 +1332,13 @@ int launch_residual_add_bwd(const void* dout, const void* out, const int* go, vo
                             int ow, int relu, int r_f32, int dtype, hipStream_t st) {
     if (!crop_ok(ga, gr, go, oh, ow)) return CPC_EINVAL;
     const int nb = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 4));
+    if (dtype == CPC_DTYPE_BF16 && !r_f32 && go[5] % 8 == 0 && res8_enabled()) {
+        const int nb8 = blocks_for((long long)go[0] * go[1] * go[2] * (go[5] / 8));
+        hipLaunchKernelGGL(residual_add_bwd8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, mk(go), (bf16_t*)da, mk(ga),
+                           (bf16_t*)dr, mk(gr), oh, ow, relu);
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16 && r_f32)
         hipLaunchKernelGGL((residual_add_bwd_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, mk(go), (bf16_t*)da, mk(ga), (float*)dr, mk(gr), oh, ow, relu);
     else
