@@ -1602,16 +1602,22 @@ class _ArBlock:
             _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.xp.ptr(), _desc(self.xp, self.xp.desc),
                       self.pool, 0, code)
         self.conv.forward()
+        # BatchNorm1d + ReLU and the residual add in one pass where nothing else reads the normalised branch (see _Block.forward)
+        fuse = (self.bn is not None and self.residual and self.bn.abits is not None and not getattr(self.eng, "gp_capable", False) and
+                self.main.C % 8 == 0 and os.environ.get("CPC_BN_RESIDUAL", "1") != "0")
         if self.bn is not None:
-            self.bn.forward()
+            self.bn.forward(apply=not fuse)
         if self.residual:
             if self.rp is not None and self.rp is not self.xp:
                 _hip.call("cpc_maxpool2d_fwd", self.gin.ptr(), _desc(self.gin, self.gin.desc), self.rp.ptr(), _desc(self.rp, self.rp.desc),
                           self.pool * self.stride, 0, code)
             if self.res_conv is not None:
                 self.res_conv.forward()
-            _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
-                      self.out.ptr(), _desc(self.out, self.out.desc), self.oh, 0, 0, 0, code)
+            if fuse:
+                self.bn.apply_residual(self.res, self.out, self.oh, 0, 0, 0)
+            else:
+                _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
+                          self.out.ptr(), _desc(self.out, self.out.desc), self.oh, 0, 0, 0, code)
 
     def tangent(self):
         e, code = self.eng, self.eng.code
