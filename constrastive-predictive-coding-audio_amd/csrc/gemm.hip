@@ -16,6 +16,7 @@
 #include <algorithm>
 #include "cpc_common.h"
 #include "cpc_kernels.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------- NT
 namespace {
@@ -738,14 +739,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             ++t;
         }
         NT_ITER(false, false);
-#undef NT_ITER
-#undef NT_KSTEP
-#undef NT_READ1
-#undef NT_DMA_PIECE
-#undef NT_READ_SET
-#undef NT_WAIT_SET
-#undef NT_DMA1
-#undef NT_DMA_STAGE
     }
 
 
@@ -1042,6 +1035,196 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
         }
     }
 }
+
+// PERSISTENT form of the 256x256 bf16 LDS-DMA kernel with the register epilogue (no mask, no K ranges, one GEMM per launch): one workgroup
+// per CU walks tiles blockIdx.x, + gridDim.x, ... and the stage stream never drains between them — while the last two K stages of a tile run,
+// their LDS-DMA slots already receive stages 0 and 1 of the NEXT tile (its row pointers replace the current ones as soon as the current
+// tile's last stage has been requested), the next tile's first fragments are read in the last iteration, and the epilogue's stores leave
+// while the next tile's loads are in flight.  What it removes is the fixed cost of a tile (workgroup launch, first-stage latency, drain):
+// 8.9 us of the 20 us a tile of the 24 576 x 512 x 24 576 score contraction takes, a tenth of a K = 2 048 convolution tile.
+// Same sums in the same order as gemm_nt_fast_kernel: bit-identical results.  The macros are that kernel's (same local names).
+template <int DBG>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
+    typedef bf16_t T;
+    typedef bf16_t TO;
+    constexpr int WN = 4, TI = 8, TJ = 4;
+    constexpr int CH = 8, BK = 64, TBM = 256, TBN = 256;
+    constexpr int ATILE = TBM * 128, BTILE = TBN * 128, STAGE = ATILE + BTILE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int numM = (p.M + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
+    const int total = (int)nt_grid_blocks(numM, numN);
+    const int frow = lane & 15, fg = lane >> 4;
+    int offA[2][TI], offB[2][TJ];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) offA[kk][i] = lds_off(wm * TI * 16 + i * 16 + frow, kk * 4 + fg);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) offB[kk][j] = ATILE + lds_off(wn * TJ * 16 + j * 16 + frow, kk * 4 + fg);
+    }
+    const int nk = p.K / BK;
+    const int taps = p.k_taps > 1 ? p.k_taps : 1;
+    const long long tstride = p.k_taps > 1 ? p.k_tap_stride : 0;
+    const long long tstride_a = p.k_taps > 1 && p.k_tap_stride_a ? p.k_tap_stride_a : tstride;
+    const bool klin = taps > 1 && p.k_taps_linear;
+    int kj = 0;
+    long long kb = 0;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int srow = lane >> 3, sch = (lane & 7) ^ (lane >> 3);
+    const int r0 = (wave_u * 4) * 8 + srow;
+    const int br0 = direct_b_col(r0);
+    const T* Ab = (const T*)p.A;
+    const T* Bb = (const T*)p.Bt;
+    // The four rows a lane requests of each operand per stage are a FIXED distance apart (the launcher admits only launches where a 32-row
+    // group of A lies in one item and inside M, and plain B rows with N a multiple of 256): one pointer per operand in registers instead
+    // of four — with eight 64-bit pointers the loop spills (the epilogue's operands now live across it).
+    const T *ga0, *gb0;
+    const long long a8 = 8LL * p.lda, b4 = 4LL * p.ldb, b16 = 16LL * p.ldb;          // (direct_b_col: rows r0 + 8 k sit 0, 16, 4, 20 B rows after r0's)
+#define ga1 (ga0 + a8)
+#define ga2 (ga0 + 2 * a8)
+#define ga3 (ga0 + 3 * a8)
+#define gb1 (gb0 + b16)
+#define gb2 (gb0 + b4)
+#define gb3 (gb0 + b16 + b4)
+    const T *gd0 = Bb, *gd1 = Bb, *gd2 = Bb, *gd3 = Bb;          // (timing-probe operands of the shared macros; never used with DBG = 0)
+    // tile index -> first row / column (false: a padding block of the 8-XCD grid, no tile)
+#define PS_TILE_OF(bid, m0_, n0_, ok_)                                   \
+    do {                                                                 \
+        int mt_, nt_;                                                    \
+        nt_tile_of_block((bid), numM, numN, mt_, nt_);                   \
+        m0_ = mt_ * TBM;                                                 \
+        n0_ = nt_ * TBN;                                                 \
+        ok_ = mt_ < numM;                                                \
+    } while (0)
+#define PS_NEXT_TILE(bid, m0_, n0_)                                      \
+    do {                                                                 \
+        bool ok_ = false;                                                \
+        while ((bid) < total) {                                          \
+            PS_TILE_OF(bid, m0_, n0_, ok_);                              \
+            if (ok_) break;                                              \
+            (bid) += gridDim.x;                                          \
+        }                                                                \
+    } while (0)
+#define PS_SET_ROWS(m0_, n0_)                                                                                    \
+    do {                                                                                                         \
+        ga0 = Ab + row_off(min((m0_) + wave_u * 32, p.M - 32) + srow, p.a_rpi, p.a_item, p.lda) + sch * CH;      \
+        gb0 = Bb + (long long)((n0_) + br0) * p.ldb + sch * CH;                                                  \
+    } while (0)
+    int m0 = 0, n0 = 0;
+    int tile = blockIdx.x;
+    PS_NEXT_TILE(tile, m0, n0);
+    if (tile >= total) return;
+    PS_SET_ROWS(m0, n0);
+    // start stagger (GemmNT::stagger): the workgroups never resynchronise, so a phase shift given here keeps the CUs' store bursts (128 KiB
+    // per tile and CU, 32 MB per round if all CUs finish together) apart for the whole launch
+    if (p.stagger > 0) {
+        const int nsleep = ((blockIdx.x >> 3) & 7) * p.stagger;
+        for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    lds_byte* const lds3 = (lds_byte*)lds;
+    const unsigned wdst = wave_u * 4096;
+    const unsigned lds_u32 = (unsigned)(unsigned long long)(lds3);
+    const unsigned aA0 = lds_u32 + offA[0][0], aA1 = lds_u32 + offA[1][0];
+    const unsigned aB0 = lds_u32 + offB[0][0], aB1 = lds_u32 + offB[1][0];
+    const long long koff0 = 0, koff0a = 0;
+    NT_KSTEP();
+    const long long koff1 = kb + kj * tstride, koff1a = kb + kj * tstride_a;
+    NT_KSTEP();
+    NT_DMA_STAGE(0, koff0a, koff0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    NT_DMA_STAGE(1, koff1a, koff1);
+    u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+    NT_READ_SET(fa0, fb0, aA0, aB0, 0u);
+    NT_WAIT_SET(fa0, fb0);
+    TO* const Cb = (TO*)p.C;
+    const bool relu = p.flags & GEMM_RELU;
+    int t = 0;                                   // running stage count over all tiles of this workgroup: the LDS slot of a stage is its parity
+    for (;;) {
+        int m1 = m0, n1 = n0;
+        int nxt_tile = tile + gridDim.x;
+        PS_NEXT_TILE(nxt_tile, m1, n1);
+        const bool has_next = nxt_tile < total;
+        if (!has_next) { m1 = m0; n1 = n0; }      // the last tile requests its own first stages once more (never used) so that the loop has ONE form
+        for (int s_ = 0; s_ < nk; ++s_, ++t) {
+            if (s_ == nk - 2) {
+                // every request of this tile is out: the row pointers become the next tile's, the K position starts over, and the last two
+                // iterations request its stages 0 and 1 (and read its first fragments) exactly as any other iteration would
+                PS_SET_ROWS(m1, n1);
+                kb = 0;
+                kj = 0;
+            }
+            NT_ITER(true, true);
+        }
+        // register epilogue of gemm_nt_fast_kernel's DIRECT form, without a mask; the accumulators are cleared as they are consumed
+        const int nb = n0 + wn * 64 + 8 * fg;
+        const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int mrow = m0 + (wm * TI + i) * 16 + frow;
+            const int m = min(mrow, p.M - 1);
+            const long long off = row_off(m, p.c_rpi, p.c_item, p.ldc) + min(nb, p.N - 8);
+            const bool rv = (p.c_rpi == 0) || ((m % p.c_rpi) < p.c_valid);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 lo = acc[i][2 * pr], hi = acc[i][2 * pr + 1];
+                acc[i][2 * pr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * pr + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    const int c_ = min(nb + 32 * pr, p.N - 8);
+                    lo += *(const f32x4*)(p.bias + c_);
+                    hi += *(const f32x4*)(p.bias + c_ + 4);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = relu_f(lo[e]); hi[e] = relu_f(hi[e]); }
+                }
+                bf16x4 pl, ph;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pl[e] = (bf16_t)lo[e]; ph[e] = (bf16_t)hi[e]; }
+                const uint2 ul = __builtin_bit_cast(uint2, pl), uh = __builtin_bit_cast(uint2, ph);
+                unsigned vw[4] = {ul.x, ul.y, uh.x, uh.y};
+                if (!rv) {
+                    if (p.flags & GEMM_SKIP_PAD_ROWS) continue;
+                    vw[0] = 0u; vw[1] = 0u; vw[2] = 0u; vw[3] = 0u;
+                }
+                if (full || (mrow < p.M && nb + 32 * pr < p.N))
+                    store_out16((uint4*)(Cb + off + 32 * pr), make_uint4(vw[0], vw[1], vw[2], vw[3]), p.flags);
+            }
+        }
+        if (!has_next) break;
+        tile = nxt_tile;
+        m0 = m1;
+        n0 = n1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last tile's surplus requests land before the LDS is released)
+}
+#undef PS_TILE_OF
+#undef PS_NEXT_TILE
+#undef PS_SET_ROWS
+#undef ga1
+#undef ga2
+#undef ga3
+#undef gb1
+#undef gb2
+#undef gb3
+#undef NT_ITER
+#undef NT_KSTEP
+#undef NT_READ1
+#undef NT_DMA_PIECE
+#undef NT_READ_SET
+#undef NT_WAIT_SET
+#undef NT_DMA1
+#undef NT_DMA_STAGE
 
 // TN fast path (bf16): stage = 64 reduction rows x (tile width) columns per operand, LDS rows padded by 32 B so that the
 // 8 rows a half-wave touches in one transposed read start 8 banks apart, double-buffered, one barrier per stage.
@@ -1666,6 +1849,11 @@ int g_nt_stagger64 = 32;
 int g_nt_probe = 0, g_nt_probe_taps = 1;
 int g_nt_wt = 2;       // output stores of the NT fast kernels: 0 plain, 1 written through at agent scope, 2 at system scope (default)
 
+static bool nt_persist_enabled() {          // CPC_NT_PERSIST=0: one workgroup per tile everywhere (A/B switch)
+    static const bool on = [] { const char* v = getenv("CPC_NT_PERSIST"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return CPC_EINVAL;
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
@@ -1757,6 +1945,16 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
             else if (direct && g_nt_probe == 16) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 16>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 32) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 32>), grid, dim3(512), 0, stream, q);
             else if (direct && g_nt_probe == 64) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true, 64>), grid, dim3(512), 0, stream, q);
+            // (short K only: a tile of up to 16 stages spends a third of its time outside the K loop.  The convolution launches of the train
+            // step, K = 2 048 / 4 096, were measured SLOWER this way — 4.675 against 4.605 ms per configs[1] step, interleaved — the dispatcher's
+            // dynamic tile order balances the CUs better than a fixed walk, and their fixed cost is under a tenth of a tile.)
+            else if (direct && nt_persist_enabled() && !p.mask && !banded && batch == 1 && p.m_off == 0 && p.K / bk >= 2 && p.K / bk <= 16 && blocks > 2 * 256 &&
+                     p.M % 32 == 0 && (p.a_rpi == 0 || p.a_rpi % 32 == 0) && p.b_rpi == 0 && p.N % 256 == 0) {
+                static const int ps = [] { const char* v = getenv("CPC_NT_PERSIST_STAGGER"); return v ? atoi(v) : 64; }();
+                const long long tile_cycles = (long long)(p.K / bk) * 3600 + 20000;
+                q.stagger = ps > 0 ? (int)std::max<long long>(1, tile_cycles * ps / 64 / 7 / 4096) : 0;
+                hipLaunchKernelGGL((gemm_nt_persist_kernel<0>), dim3(256), dim3(512), 0, stream, q);      // one workgroup per CU walks the tiles
+            }
             else if (direct) hipLaunchKernelGGL((gemm_nt_fast_kernel<bf16_t, bf16_t, 2, 4, 8, 4, true, false, true>), grid, dim3(512), 0, stream, q);
             else NT_LAUNCH(bf16_t, bf16_t, 2, 4, 8, 4, 512, q);
         } else if (fast) {

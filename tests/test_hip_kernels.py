@@ -86,7 +86,11 @@ def test_gemm_nt_tile_variants_agree(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,lda,rpi", [(256 * 80, 1024, 256, 256, 0), (256 * 79 + 100, 1000, 512, 256, 0),
-                                             (256 * 60 + 8, 1024, 512, 128, 97), (256 * 130, 512, 1024, 512, 640)])
+                                             (256 * 60 + 8, 1024, 512, 128, 97), (256 * 130, 512, 1024, 512, 640),
+                                             # more than 512 tiles, M % 32 == 0, N % 256 == 0: the unmasked launches take the PERSISTENT kernel
+                                             # (gemm_nt_persist_kernel: one workgroup per CU walks the tiles), incl. a ragged last M tile,
+                                             # overlapped rows (tap-innermost K order) and pad-row handling
+                                             (256 * 140, 1024, 512, 512, 0), (256 * 150 + 96, 1024, 1024, 256, 0), (256 * 300, 512, 128, 128, 320)])
 def test_gemm_nt_register_epilogue_agrees(M, N, K, lda, rpi):
     """The register epilogue of the 256x256 kernel (16-byte stores straight from the accumulators, permuted B rows) against
     the LDS-staged epilogue (CPC_GEMM_NO_PERS) and the f64 reference: bias + relu, relu-backward mask, pad-row zeroing /
