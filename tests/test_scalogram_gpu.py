@@ -817,43 +817,47 @@ def test_no_batchnorm_architectures_at_real_shapes():
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_parity_route_data_gradient_equals_the_im2col_route(dtype, monkeypatch):
+def test_parity_route_data_gradient_is_the_transposed_convolution(dtype):
     """The data gradient of the 3x3 stride-2 convolutions as two overlapped-row GEMMs on the output-gradient grid (_Conv._dgrad_parity: second
-    addressing level, gathered pieces, K ranges at the clip borders) against the im2col-gradient GEMM + col2im route (CPC_DGRAD_PARITY=0), at
-    the REAL shapes of scalogram_resnet_architecture_7 (odd heights 127 / 63 / 31: the last row pair reaches into the zero tail row) with
-    4 clips: same loss, same gradient for every parameter (everything below those convolutions depends on their input gradient)."""
+    addressing level, gathered pieces, K ranges at the clip borders, row-pair grouping, padded rows per column) at the REAL shapes of
+    scalogram_resnet_architecture_7 (odd heights 127 / 34: the last row pair reaches into the zero tail row) with 64 clips, where both
+    convolutions qualify (block 2 with 256-wide tiles): each launch pair on the step's own output gradient against torch's
+    conv_transpose2d of the same tensor.  (Whole-model gradients of the two routes cannot be compared at this size: at random initialisation
+    a 1e-7 relative change of the input moves the gradient at the encoder output by 1e-2 in exact-f32 mode -- tools/bf16_error_budget.py.)"""
     from cpc_audio_amd import configs
     from cpc_audio_amd.audio_model import ConvolutionalArModel
     from cpc_audio_amd.scalogram_model import cqt_default_dict
-    V, K, B = 60, 16, 4
-    res = {}
-    for parity in ("1", "0"):
-        monkeypatch.setenv("CPC_DGRAD_PARITY", parity)
-        torch.manual_seed(0)
-        pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
-        enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
-        model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
-                                           visible_steps=V, prediction_steps=K, compute_dtype=dtype)
-        wave = torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(5)) * 0.1
-        pre, model = pre.to(DEV), model.to(DEV)
-        pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
-        x = pre(wave.to(DEV).unsqueeze(1))
-        eng = model.engine_for(x)
-        convs = [c for b in eng.blocks for c in b.convs() if getattr(c, "mode", "") == "win"]
-        assert any(c.parity for c in convs) == (parity == "1")
-        out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
-        res[parity] = (float(out[0]), {n: v.detach().double().cpu().clone() for n, v in model._grad.items()})
-        del eng, model, pre, x
-        torch.cuda.empty_cache()
-    (l1, g1), (l0, g0) = res["1"], res["0"]
-    assert abs(l1 - l0) <= (1e-5 if dtype == "fp32" else 1e-3) * abs(l0), (l1, l0)      # (the grids differ by a tail row: other summation order)
-    scale = max(float(v.norm()) for v in g0.values())
-    for n in g0:
-        if float(g0[n].norm()) < 1e-6 * scale:
-            assert float(g1[n].norm()) < 1e-4 * scale, n
-            continue
-        err = float((g1[n] - g0[n]).norm() / g0[n].norm())
-        assert err < (1e-4 if dtype == "fp32" else 0.15), (n, err)
+    V, K, B = 60, 16, 64
+    torch.manual_seed(0)
+    pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+    enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
+                                       visible_steps=V, prediction_steps=K, compute_dtype=dtype)
+    wave = torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(5)) * 0.1
+    pre, model = pre.to(DEV), model.to(DEV)
+    pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
+    x = pre(wave.to(DEV).unsqueeze(1))
+    eng = model.engine_for(x)
+    convs = [c for b in eng.blocks for c in b.convs() if getattr(c, "parity", False)]
+    assert len(convs) == 2 and sorted(c.Gp for c in convs) == [1, 2]
+    eng.loss_and_grads(x, softplus=True, regularization=1.0)
+    for c in convs:
+        gin, dy0 = c.gin, c.dy0
+        scratch = gin.like(DEV)
+        scratch.t.fill_(7.0)                                  # every element the route is responsible for must be overwritten
+        c._dgrad_parity(dy0, scratch, False)
+        got = scratch.t.view(gin.B, gin.W, gin.Ha, gin.C).float()
+        dy = dy0.t.view(dy0.B, dy0.W, dy0.Ha, dy0.C)[:, :, dy0.top:dy0.top + c.Ho, :].float().permute(0, 3, 2, 1)      # (B, C_out, Ho, Wo)
+        w = model._param[c.wname].detach().float()
+        if dtype == "bf16":
+            w = w.bfloat16().float()
+        ref = F.conv_transpose2d(dy.double(), w.double(), stride=2).permute(0, 3, 2, 1)                                 # (B, 2Wo+1, 2Ho+1, C_in)
+        hin, win = 2 * c.Ho + 1, 2 * c.Wo + 1
+        err = (got[:, :win, :hin, :].double().cpu() - ref.cpu()).abs().max().item() / ref.abs().max().item()
+        assert err < (2e-6 if dtype == "fp32" else 6e-3), (c.wname, err)
+        if gin.W > win:                                       # columns no window reaches are cleared
+            assert (got[:, win:, :, :] == 0).all()
+        assert (got[:, :win, hin:2 * c.Hs, :] == 0).all()     # rows of the last pair beyond the input: zero contributions
 
 
 def test_scalogram_encoder_with_batchnorm_conv_context_forward(golden_dir):
