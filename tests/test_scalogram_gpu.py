@@ -860,6 +860,58 @@ def test_parity_route_data_gradient_is_the_transposed_convolution(dtype):
         assert (got[:, :win, hin:2 * c.Hs, :] == 0).all()     # rows of the last pair beyond the input: zero contributions
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tall_kernel_convolutions_at_real_shapes_against_torch(dtype):
+    """The (64,1) / (30,1) / (15,1) second kernels of scalogram_resnet_architecture_7 at their real shapes (16 clips): the overlapped-row
+    GEMMs over the valid rows only, G output rows per GEMM row (bf16: G = 8 / 2 / 1), the data gradient in bands with K ranges and the
+    grouped weight-gradient reduction — forward output, data gradient and weight gradient of each convolution, taken from the step's own
+    tensors, against torch's conv2d / conv_transpose2d / conv2d_weight on the same operands."""
+    from cpc_audio_amd import configs
+    from cpc_audio_amd.audio_model import ConvolutionalArModel
+    from cpc_audio_amd.scalogram_model import cqt_default_dict
+    V, K, B = 60, 16, 16
+    torch.manual_seed(0)
+    pre = PreprocessingModule(cqt_dict=cqt_default_dict, phase=True)
+    enc = ScalogramResidualEncoder(args_dict=configs.fresh(configs.scalogram_resnet_architecture_7), preprocessing_module=pre)
+    model = AudioPredictiveCodingModel(enc, ConvolutionalArModel(configs.fresh(configs.ar_conv_architecture_3)), enc_size=512, ar_size=256,
+                                       visible_steps=V, prediction_steps=K, compute_dtype=dtype)
+    wave = torch.randn(B, model.item_length, generator=torch.Generator().manual_seed(5)) * 0.1
+    pre, model = pre.to(DEV), model.to(DEV)
+    pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
+    x = pre(wave.to(DEV).unsqueeze(1))
+    eng = model.engine_for(x)
+    eng.loss_and_grads(x, softplus=True, regularization=1.0)
+    tall = [b.conv_b for b in eng.blocks[:3]]
+    assert [c.kh for c in tall] == [64, 30, 15] and all(c.mode == "col" for c in tall)
+    if dtype == "bf16":
+        assert [c.G for c in tall] == [8, 2, 1] and all(c.valid_rows for c in tall) and tall[0].bands is not None and tall[1].bands is not None
+    tol = 2e-5 if dtype == "fp32" else 1.5e-2
+    rnd = (lambda t: t) if dtype == "fp32" else (lambda t: t.bfloat16().float())
+
+    def nchw(g, rows):               # allocated rows [0, rows) of a grid as (B, C, rows, W) float64
+        return g.t.view(g.B, g.W, g.Ha, g.C)[:, :, :rows, :].float().permute(0, 3, 2, 1).double()
+
+    for c in tall:
+        gin, y0, dy0 = c.gin, c.y0, c.dy0
+        hin = gin.top + gin.H
+        a = nchw(gin, hin)                                                   # input incl. its zero top padding rows
+        w = rnd(model._param[c.wname].detach().float()).double()
+        bias = model._param[c.bname].detach().double() if c.bname else None
+        want_y = F.conv2d(a, w, bias)
+        got_y = nchw(y0, c.Ho)
+        assert ((got_y - want_y).abs().max() / want_y.abs().max()).item() < tol, c.wname
+        dy = nchw(dy0, c.Ho)
+        want_dx = F.conv_transpose2d(dy, w)                                  # (B, C_in, hin, W)
+        scratch = gin.like(DEV, guard_rows=gin.guard_rows)
+        c.backward(scratch)                                                  # (recomputes the same weight gradient, writes the data gradient here)
+        got_dx = nchw(scratch, hin)
+        lo = gin.top                                                         # rows above are padding: their gradient is not formed in full
+        assert ((got_dx[:, :, lo:] - want_dx[:, :, lo:]).abs().max() / want_dx.abs().max()).item() < tol, c.wname
+        want_dw = torch.nn.grad.conv2d_weight(a, w.shape, dy)
+        got_dw = model._grad[c.wname].detach().double()
+        assert ((got_dw - want_dw).abs().max() / want_dw.abs().max()).item() < tol, c.wname
+
+
 def test_scalogram_encoder_with_batchnorm_conv_context_forward(golden_dir):
     """The model shape of the reference's gradient-penalty experiments (scalogram encoder + BatchNorm ConvolutionalArModel):
     forward in eval and train mode against the reference (the fixture's training runs all carry the gradient penalty, which
