@@ -881,6 +881,18 @@ def test_tall_kernel_convolutions_at_real_shapes_against_torch(dtype):
     x = pre(wave.to(DEV).unsqueeze(1))
     eng = model.engine_for(x)
     eng.loss_and_grads(x, softplus=True, regularization=1.0)
+    # block 0's first convolution + train-mode BatchNorm + ReLU, recomputed from the float32 scalogram by the stem kernels: the activation the
+    # tall kernel reads, against torch on the same input
+    b0 = eng.blocks[0]
+    assert b0.stem is not None
+    p0 = {k: model._param[f"encoder.blocks.0.main_modules.{i}.{k}"].detach().double() for i, k in ((0, "weight"),)}
+    conv0 = F.conv2d(x.double(), p0["weight"], model._param["encoder.blocks.0.main_modules.0.bias"].detach().double(), stride=2)
+    want_a = torch.relu(F.batch_norm(conv0, None, None, model._param["encoder.blocks.0.main_modules.1.weight"].detach().double(),
+                                     model._param["encoder.blocks.0.main_modules.1.bias"].detach().double(), training=True, eps=1e-5))
+    ga = b0.a_a
+    got_a = ga.t.view(ga.B, ga.W, ga.Ha, ga.C)[:, :, ga.top:ga.top + ga.H, :].float().permute(0, 3, 2, 1).double()
+    assert ((got_a - want_a).abs().max() / want_a.abs().max()).item() < (2e-5 if dtype == "fp32" else 6e-3)
+    assert (ga.t.view(ga.B, ga.W, ga.Ha, ga.C)[:, :, :ga.top, :] == 0).all()           # the tall kernel's top padding rows
     tall = [b.conv_b for b in eng.blocks[:3]]
     assert [c.kh for c in tall] == [64, 30, 15] and all(c.mode == "col" for c in tall)
     if dtype == "bf16":
