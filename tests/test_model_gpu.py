@@ -10,6 +10,7 @@ import random
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -462,6 +463,50 @@ def test_full_size_properties_b256():
     for n, g32 in grads["fp32"].items():
         cos = torch.dot(g32, grads["bf16"][n]) / (g32.norm() * grads["bf16"][n].norm() + 1e-30)
         assert cos.item() > 0.995, (n, cos.item())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_waveform_encoder_backward_at_the_headline_size_against_torch(dtype):
+    """BASELINE configs[1] at its stated size (256 clips of 20 480 samples): the encoder's activations and — given the SAME gradient at the
+    encoder output, taken from the step — every encoder parameter's gradient against torch's conv1d autograd on the GPU (float32): the strided
+    convolutions as overlapped-row GEMMs, the masked data gradients, the fused layer-2 data gradient / layer-1 weight gradient launch and the
+    split weight-gradient reductions, all at the shapes the benchmark runs.  (Whole-step gradients cannot be compared across routes at this
+    size, see test_scalogram_gpu.py; the encoder alone is piecewise linear in its input gradient.)"""
+    B, L, V, K = 256, 20480, 100, 12
+    torch.manual_seed(0)
+    model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256, visible_steps=V, prediction_steps=K,
+                                       compute_dtype=dtype).to(DEV)
+    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    eng = model.engine(B, L)
+    eng.loss_and_grads(x, softplus=True, regularization=1.0)
+    n, T = eng.n, eng.T
+    ws = [model._param[f"encoder.layers.{l}.weight"].detach().float().clone().requires_grad_(True) for l in range(n)]
+    bs = [model._param[f"encoder.layers.{l}.bias"].detach().float().clone().requires_grad_(True) for l in range(n)]
+    strides = eng.geo.strides
+    # (the engine encodes only the samples the last T frames see)
+    xs = x[:, eng.x_off:eng.x_off + (eng.geo.valid[0] - 1) * strides[0] + eng.geo.kernels[0]]
+    h = xs.unsqueeze(1)
+    acts = []
+    for l in range(n):
+        h = F.conv1d(h, ws[l], bs[l], stride=strides[l])
+        if l < n - 1:
+            h = torch.relu(h)
+        acts.append(h)
+    tol_a = 2e-5 if dtype == "fp32" else 2e-2
+    for l in (0, 1, n - 1):
+        La, Lv, C_ = eng.geo.alloc[l], eng.geo.valid[l], eng.channels[l]
+        got = eng.act[l].view(B, La, C_)[:, :Lv, :].float().transpose(1, 2)
+        assert ((got - acts[l].detach()).abs().max() / acts[l].detach().abs().max()).item() < tol_a, l
+    Ltop = eng.geo.alloc[-1]
+    assert eng.geo.valid[-1] == T == acts[-1].shape[2]
+    dtop = eng.dact[-1].view(B, Ltop, eng.E)[:, :T, :].float().transpose(1, 2).contiguous()       # (B, E, T): the gradient the step put there
+    acts[-1].backward(dtop)
+XX
+    for l in range(n):
+        for name, ref in ((f"encoder.layers.{l}.weight", ws[l].grad), (f"encoder.layers.{l}.bias", bs[l].grad)):
+            got = model._grad[name].detach().float()
+            err = ((got - ref).norm() / ref.norm()).item()
+            assert err < tol_g, (name, err)
 
 
 @pytest.mark.parametrize("context", ["ar_conv_architecture_3", "attention_architecture_1", "ar_conv_default_dict"])
