@@ -68,7 +68,7 @@ class GemmTNArgs(C.Structure):
                 ("b_rpi", C.c_int), ("b_item", C.c_longlong),
                 ("a_batch", C.c_longlong), ("b_batch", C.c_longlong), ("c_batch", C.c_longlong), ("batch", C.c_int),
                 ("nsplit", C.c_int), ("m_chunk", C.c_int), ("slab_stride", C.c_longlong),
-                ("flags", C.c_int), ("dtype", C.c_int), ("c_rpi", C.c_int), ("c_item", C.c_longlong)]
+                ("flags", C.c_int), ("dtype", C.c_int), ("c_rpi", C.c_int), ("c_item", C.c_longlong), ("a_rpi2", C.c_int), ("a_item2", C.c_longlong)]
 
 
 _P, _I, _L, _F, _D, _U64, _U32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_ulonglong, C.c_uint
@@ -301,9 +301,9 @@ def gemm_nt(A, Bt, Cout, M, N, K, lda, ldb, ldc, dtype, *, bias=None, mask=None,
 
 
 def gemm_tn(A, B, Cout, M, I, J, lda, ldb, ldc, dtype, *, a_rpi=0, a_item=0, b_rpi=0, b_item=0, a_batch=0, b_batch=0,
-            c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0, c_rpi=0, c_item=0):
+            c_batch=0, batch=1, nsplit=1, m_chunk=0, slab_stride=0, flags=0, c_rpi=0, c_item=0, a_rpi2=0, a_item2=0):
     args = GemmTNArgs(A, B, Cout, M, I, J, lda, ldb, ldc, a_rpi, a_item, b_rpi, b_item, a_batch, b_batch, c_batch, batch,
-                      nsplit, m_chunk, slab_stride, flags, dtype, c_rpi, c_item)
+                      nsplit, m_chunk, slab_stride, flags, dtype, c_rpi, c_item, a_rpi2, a_item2)
     if _timer is not None:
         _timer.run("gemm_tn" + _variant(dtype, flags if nsplit == 1 else flags | GEMM_OUT_F32,
                                         tn_tile(dtype, M, I, J, nsplit, m_chunk, flags)), 2.0 * M * I * J * batch,

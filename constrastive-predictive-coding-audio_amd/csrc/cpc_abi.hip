@@ -62,6 +62,7 @@ int cpc_gemm_tn(const cpc_gemm_tn_args* a, void* stream) {
     p.b_rpi = a->b_rpi; p.b_item = a->b_item;
     p.a_batch = a->a_batch; p.b_batch = a->b_batch; p.c_batch = a->c_batch;
     p.c_rpi = a->c_rpi; p.c_item = a->c_item;
+    p.a_rpi2 = a->a_rpi2; p.a_item2 = a->a_item2;
     const int nsplit = a->nsplit > 0 ? a->nsplit : 1;
     p.m_chunk = nsplit > 1 ? a->m_chunk : a->M;
     p.slab_stride = a->slab_stride;

@@ -89,6 +89,9 @@ struct GemmTN {
     int b_rpi; long long b_item;
     long long a_batch, b_batch, c_batch;
     int c_rpi; long long c_item;      // output row i at row_off(i, c_rpi, c_item, ldc)  (c_rpi == 0: plain i * ldc)
+    // second row level of the A operand (LDS-DMA kernel): row m at (m / (a_rpi a_rpi2)) a_item2 + ((m / a_rpi) % a_rpi2) a_item + (m % a_rpi) lda —
+    // the windows of a strided 2-D convolution read straight from a channels-last grid (clip, output column, output row), no im2col matrix
+    int a_rpi2 = 0; long long a_item2 = 0;
     int m_chunk;          // reduction rows per split
     long long slab_stride;
     int flags;

@@ -1391,13 +1391,21 @@ __device__ __forceinline__ u32x2 lds_read_tr_asm(unsigned addr) {
 
 // ROWS: operands addressed as items of rpi rows (the valid rows of each column of a grid); the row -> offset division runs on
 // a float reciprocal with one correction step (8 per lane and stage, beside 64 MFMAs per wave).
-__device__ __forceinline__ long long row_off_rcp(int m, int rpi, float inv, long long item, long long ld) {
+__device__ __forceinline__ void divmod_rcp(int m, int d, float inv, int& q, int& r) {
+    q = (int)(((float)m + 0.5f) * inv);
+    r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+__device__ __forceinline__ long long row_off_rcp(int m, int rpi, float inv, long long item, long long ld, int rpi2 = 0, float inv2 = 0.f,
+                                                 long long item2 = 0) {
     if (rpi == 0) return (long long)m * ld;
-    int q = (int)(((float)m + 0.5f) * inv);
-    int r = m - q * rpi;
-    if (r < 0) { --q; r += rpi; }
-    else if (r >= rpi) { ++q; r -= rpi; }
-    return (long long)q * item + (long long)r * ld;
+    int q, r;
+    divmod_rcp(m, rpi, inv, q, r);
+    if (rpi2 == 0) return (long long)q * item + (long long)r * ld;
+    int q2, r2;
+    divmod_rcp(q, rpi2, inv2, q2, r2);
+    return (long long)q2 * item2 + (long long)r2 * item + (long long)r * ld;
 }
 
 template <typename TO, int WI, int WJ, int TI, int TJ, bool ROWS>
@@ -1451,8 +1459,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void gemm_tn_dma_kernel(GemmTN p) {
         lds_byte* const lds3 = (lds_byte*)lds;
         const unsigned wdst = wave_u * 4096;
         const float inva = ROWS && p.a_rpi ? 1.0f / (float)p.a_rpi : 0.f, invb = ROWS && p.b_rpi ? 1.0f / (float)p.b_rpi : 0.f;
+        const float inva2 = ROWS && p.a_rpi2 ? 1.0f / (float)p.a_rpi2 : 0.f;
         auto offa = [&](int m) -> long long {
-            if constexpr (ROWS) return row_off_rcp(m, p.a_rpi, inva, p.a_item, p.lda);
+            if constexpr (ROWS) return row_off_rcp(m, p.a_rpi, inva, p.a_item, p.lda, p.a_rpi2, inva2, p.a_item2);
             else return (long long)m * p.lda;
         };
         auto offb = [&](int m) -> long long {
@@ -1987,6 +1996,7 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
     if (nsplit > 1 && !(p.flags & GEMM_OUT_F32)) return CPC_EINVAL;   // slabs are f32
     if (p.c_rpi && (p.c_item % 4 || nsplit > 1)) return CPC_EINVAL;
     const bool of32 = p.flags & GEMM_OUT_F32;
+    if (p.a_rpi2 && (!p.a_rpi || p.a_item2 % ch)) return CPC_EINVAL;
     const int eff_chunk = nsplit > 1 ? p.m_chunk : p.M;
     if (dtype == CPC_DTYPE_F32 && batch == 1 && p.I <= 32 && p.J <= 64 && p.I * (p.J / 4) <= 256 && p.c_rpi == 0 &&
         p.lda >= (p.I + 3) / 4 * 4 && !(p.flags & GEMM_FORCE_GENERIC)) {
@@ -2009,6 +2019,7 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
         const bool plain = p.a_rpi == 0 && p.b_rpi == 0;
         const bool tdma = (plain || (p.a_item % 8 == 0 && p.b_item % 8 == 0 && p.M < (1 << 22))) && !(p.flags & GEMM_NO_DMA) && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.I % 8 == 0 && p.J % 8 == 0 &&
                           ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.a_batch % 8 == 0 && p.b_batch % 8 == 0;
+        if (p.a_rpi2 && !tdma) return CPC_EINVAL;          // the second row level exists in the LDS-DMA kernel only
 #define TN_LAUNCH(WII, WJJ, TII, TJJ, NTH)                                                                               \
     do {                                                                                                                 \
         if (tdma && plain) {                                                                                             \
@@ -2031,6 +2042,8 @@ int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_
             TN_LAUNCH(2, 2, 4, 4, 256);
         }
 #undef TN_LAUNCH
+    } else if (p.a_rpi2) {
+        return CPC_EINVAL;
     } else if (dtype == CPC_DTYPE_BF16) {
         if (of32) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);

@@ -124,7 +124,7 @@ class _Conv:
         if self.Ho < 1 or self.Wo < 1:
             raise ValueError(f"{wname}: input {hin} x {gin.W} is smaller than the kernel")
         self.mode = 'col' if _col_ok(self.kw, self.sh, self.sw, self.pad, self.cin, in_f32) else 'win'
-        self.gather = self.parity = False
+        self.gather = self.gather_w = self.parity = False
         B = gin.B
         if self.cout % 8:
             raise NotImplementedError("scalogram encoder channel counts must be multiples of 8")
@@ -186,21 +186,22 @@ class _Conv:
             kq = 64 if dt == torch.bfloat16 else 32
             self.Kp = _ceil_div(self.K, kq) * kq if self.K > kq // 2 else _ceil_div(self.K, 8) * 8
             self.M = B * self.Wo * self.Ho
-            # Forward without an im2col matrix (CPC_CONV_GATHER=1; OFF by default: measured 13.78 against 13.62 ms per configs[2] step, two
-            # interleaved pairs on one box — the pieces are padded to the stage size (K 384 instead of 320 for the 3x3x32 kernel), a gathered row is
-            # kw separate 256-byte runs instead of one, and the im2col pass the weight gradient still needs only moves to the side stream, where
-            # it competes with the GEMMs): a GEMM row is the window read straight from the grid as kw pieces — piece
-            # dw = the kh rows x C_in channels of kernel column dw, contiguous in the channels-last grid, the next kernel column one grid column
-            # (Ha C_in elements) further (cpc_gemm_nt_args.k_taps / k_tap_stride_a; each piece padded to the stage size with zero weights,
-            # which over-reads into the rows below: zeros or activations, never beyond the grid's guard).  One launch with batch = B.  The
-            # im2col matrix is then built on the side stream right in front of the weight-gradient GEMM, its only reader left.
+            # Forward and weight gradient without an im2col matrix (bf16; CPC_CONV_GATHER=0: off, =1: also the float32 forward): a GEMM row is the
+            # window read straight from the grid as kw pieces — piece dw = the kh rows x C_in channels of kernel column dw, contiguous in the
+            # channels-last grid, the next kernel column one grid column (Ha C_in elements) further (cpc_gemm_nt_args.k_taps / k_tap_stride_a;
+            # each piece padded to the stage size with zero weights, which over-reads into the rows below: zeros or activations, never beyond
+            # the grid's guard), one launch with batch = B; the weight gradient is a TN GEMM whose reduction rows are the same windows
+            # (cpc_gemm_tn_args.a_rpi2, one batch entry per kernel column).  12.67 -> 12.38 ms per configs[2] step.  The forward half alone
+            # (the im2col pass kept for the weight gradient, on the side stream) had measured 13.78 against 13.62.
             bkq = 64 if dt == torch.bfloat16 else 32
             self.seg = _ceil_div(self.kh * self.cin, bkq) * bkq
-            self.gather = (self.pad == 0 and not in_f32 and self.cin % 8 == 0 and os.environ.get("CPC_CONV_GATHER", "0") == "1" and
+            self.gather = (self.pad == 0 and not in_f32 and self.cin % 8 == 0 and (os.environ.get("CPC_CONV_GATHER", "") == "1" or (dt == torch.bfloat16 and os.environ.get("CPC_CONV_GATHER", "1") != "0")) and
                            gin.guard_rows * self.cin >= self.seg)
             if self.gather:
                 self.w_imp = torch.zeros(self.cout, self.kw, self.seg, device=dev, dtype=dt)
-            self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt)
+            self.gather_w = self.gather and dt == torch.bfloat16          # (the two-level TN kernel is the bf16 LDS-DMA one)
+            # (neither matrix exists where the forward and the weight gradient read the grid directly and the data gradient takes the parity route)
+            self.col = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if not self.gather_w else None
             self.dcol = torch.empty(self.M * self.Kp, device=dev, dtype=dt) if (need_dgrad and not self.parity) else None
             self.w_fwd = torch.zeros(self.cout, self.Kp, device=dev, dtype=dt)
             self.w_t = torch.zeros(self.Kp, self.cout, device=dev, dtype=dt)
@@ -447,13 +448,28 @@ class _Conv:
             chunk = e._chunk(self.M, self.nsplit, self.dt)
             taps = self.kh * self.kw
 
+            if self.gather_w:
+                # the forward pass wrote no im2col matrix, and none is needed here: the rows of the reduction are the windows read straight
+                # from the grid (clip, output column, output row: cpc_gemm_tn_args.a_rpi2), one batch entry per kernel column
+                I, kc = self.kh * self.cin, self.kh * self.cin * self.cout
+
+                def gemm_g():
+                    _hip.gemm_tn(gin.ptr(), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, I, self.cout, self.sh * self.cin, self.cout,
+                                 self.cout, code, a_rpi=self.Ho, a_item=self.sw * gin.Ha * self.cin, a_rpi2=self.Wo,
+                                 a_item2=gin.W * gin.Ha * self.cin, a_batch=gin.Ha * self.cin, b_rpi=self.Ho, b_item=dy0.Ha * self.cout,
+                                 c_batch=kc, batch=self.kw, nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.kw * kc, flags=_hip.GEMM_OUT_F32)
+
+                def reduce_g():
+                    S = wslab[:self.nsplit * self.kw * kc].view(self.nsplit, self.kw, self.kh, self.cin, self.cout).sum(0)      # [dw][dh][c][co]
+                    gw.view(self.cout, self.cin, self.kh, self.kw).copy_(S.permute(3, 2, 1, 0))
+                staged(gemm_g, reduce_g)
+                return
+
             def gemm():
-                cm = col
-                if self.gather:      # the forward pass wrote no im2col matrix: build it here, from the grid this gradient is taken against
-                    cm = self.col
-                    _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(cm), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
+                if self.gather:      # (float32: the forward pass wrote no im2col matrix; build it here, from the grid this gradient is taken against)
+                    _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(self.col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
                               self.pad, self.pad, self.Ho, self.Wo, self.Kp, 0, code)
-                _hip.gemm_tn(_hip.ptr(cm), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp,
+                _hip.gemm_tn(_hip.ptr(self.col if self.gather else col), dy0.ptr(dy0.top * self.cout), _hip.ptr(wslab), self.M, self.Kp, self.cout, self.Kp,
                              self.cout, self.cout, code, b_rpi=self.Ho, b_item=dy0.Ha * self.cout, nsplit=self.nsplit,
                              m_chunk=chunk, slab_stride=self.Kp * self.cout, flags=_hip.GEMM_OUT_F32)
             staged(gemm,

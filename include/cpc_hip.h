@@ -103,6 +103,10 @@ typedef struct cpc_gemm_tn_args {
     int nsplit; int m_chunk; long long slab_stride;
     int flags; int dtype;
     int c_rpi; long long c_item;          /* output row i at the item address (nsplit == 1 only); 0 = plain i*ldc */
+    /* second row level of A (bf16 LDS-DMA kernel; CPC_EINVAL elsewhere): row m at (m / (a_rpi a_rpi2)) a_item2 + ((m / a_rpi) % a_rpi2) a_item
+     * + (m % a_rpi) lda — with a_batch stepping over the kernel columns, the windows of a strided nn.Conv2d read straight from a channels-last grid
+     * (rows = clip, output column, output row): the weight gradient without an im2col matrix.  0 = one level. */
+    int a_rpi2; long long a_item2;
 } cpc_gemm_tn_args;
 int cpc_gemm_tn(const cpc_gemm_tn_args* args, void* stream);
 

@@ -289,6 +289,33 @@ def test_conv_w_prep_batch_and_group(dt):
     assert torch.equal(bg.cpu(), bias.repeat(G))
 
 
+@pytest.mark.parametrize("B,W,H,C,cout,kh,kw,sh,sw,nsplit", [(3, 21, 19, 32, 72, 3, 3, 2, 2, 1), (6, 41, 34, 32, 128, 3, 3, 2, 2, 4), (4, 12, 9, 128, 256, 2, 2, 1, 1, 2)])
+def test_gemm_tn_two_level_rows_are_a_conv2d_weight_gradient(B, W, H, C, cout, kh, kw, sh, sw, nsplit):
+    """cpc_gemm_tn_args.a_rpi2 / a_item2 (bf16 LDS-DMA kernel): the reduction rows of the A operand are the windows of an nn.Conv2d read
+    straight from a channels-last grid [B][W][Ha][C] — (clip, output column, output row), one batch entry per kernel column — against
+    torch's conv2d_weight; split slabs included."""
+    g = torch.Generator().manual_seed(B * 10 + W)
+    bf = torch.bfloat16
+    Ha = H + 2
+    x = torch.randn(B, W, Ha, C, generator=g)
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    dy = torch.randn(B, Wo, Ho + 1, cout, generator=g)               # one spare row per column, as the gradient grids have
+    M, I = B * Wo * Ho, kh * C
+    chunk = -(-(-(-M // nsplit)) // 64) * 64
+    dX = dev(torch.cat([x.reshape(-1), torch.zeros(kw * Ha * C + I)]), bf)
+    dY = dev(dy, bf)
+    slabs = torch.full((nsplit, kw, I, cout), float("nan"), device=DEV)
+    _hip.gemm_tn(_hip.ptr(dX), _hip.ptr(dY), _hip.ptr(slabs), M, I, cout, sh * C, cout, cout, _hip.BF16, a_rpi=Ho, a_item=sw * Ha * C, a_rpi2=Wo,
+                 a_item2=W * Ha * C, a_batch=Ha * C, b_rpi=Ho, b_item=(Ho + 1) * cout, c_batch=I * cout, batch=kw, nsplit=nsplit, m_chunk=chunk,
+                 slab_stride=kw * I * cout, flags=_hip.GEMM_OUT_F32)
+    got = slabs.sum(0).view(kw, kh, C, cout).permute(3, 2, 1, 0).double().cpu()          # [co][c][dh][dw]
+    xr = rounded(x, bf)[:, :, :H, :].permute(0, 3, 2, 1)                                  # (B, C, H, W)
+    dyr = rounded(dy, bf)[:, :, :Ho, :].permute(0, 3, 2, 1)                                # (B, cout, Ho, Wo)
+    ref = torch.nn.grad.conv2d_weight(xr, (cout, C, kh, kw), dyr, stride=(sh, sw))
+    assert not torch.isnan(got).any()
+    assert rel_err(got, ref) < 1e-4
+
+
 # --------------------------------------------------------------------------------------- gemm_tn
 @pytest.mark.parametrize("dt,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, _hip.GEMM_TN_NO_TR)])
 @pytest.mark.parametrize("M,I,J", [(1000, 136, 72), (64, 128, 128), (129, 8, 264)])

@@ -893,6 +893,23 @@ def test_tall_kernel_convolutions_at_real_shapes_against_torch(dtype):
     got_a = ga.t.view(ga.B, ga.W, ga.Ha, ga.C)[:, :, ga.top:ga.top + ga.H, :].float().permute(0, 3, 2, 1).double()
     assert ((got_a - want_a).abs().max() / want_a.abs().max()).item() < (2e-5 if dtype == "fp32" else 6e-3)
     assert (ga.t.view(ga.B, ga.W, ga.Ha, ga.C)[:, :, :ga.top, :] == 0).all()           # the tall kernel's top padding rows
+    # the strided 3x3 first convolutions of blocks 1 and 2 (bf16: windows gathered from the grid, no im2col matrix): output and weight gradient
+    for blk in eng.blocks[1:3]:
+        c = blk.conv_a
+        assert c.mode == "win" and c.gather_w == (dtype == "bf16")
+        gin = c.gin
+        a = gin.t.view(gin.B, gin.W, gin.Ha, gin.C)[:, :, :gin.top + gin.H, :].float().permute(0, 3, 2, 1).double()
+        w = model._param[c.wname].detach().float()
+        w = (w if dtype == "fp32" else w.bfloat16().float()).double()
+        want = F.conv2d(a, w, model._param[c.bname].detach().double() if c.bname else None, stride=2)
+        y0 = c.y0
+        got = y0.t.view(y0.B, y0.W, y0.Ha, y0.C)[:, :, y0.top:y0.top + c.Ho, :].float().permute(0, 3, 2, 1).double()
+        assert ((got - want).abs().max() / want.abs().max()).item() < (2e-5 if dtype == "fp32" else 1.5e-2), c.wname
+        d0 = c.dy0
+        dy = d0.t.view(d0.B, d0.W, d0.Ha, d0.C)[:, :, d0.top:d0.top + c.Ho, :].float().permute(0, 3, 2, 1).double()
+        want_dw = torch.nn.grad.conv2d_weight(a, w.shape, dy, stride=2)
+        got_dw = model._grad[c.wname].detach().double()
+        assert ((got_dw - want_dw).abs().max() / want_dw.abs().max()).item() < (2e-5 if dtype == "fp32" else 1.5e-2), c.wname
     tall = [b.conv_b for b in eng.blocks[:3]]
     assert [c.kh for c in tall] == [64, 30, 15] and all(c.mode == "col" for c in tall)
     if dtype == "bf16":
