@@ -379,9 +379,11 @@ class _Conv:
         elif self.gather:
             Kg = self.kw * self.seg
             taps = dict(k_taps=self.kw, k_tap_stride=self.seg, k_tap_stride_a=gin.Ha * self.cin) if self.kw > 1 else {}
-            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_imp), y0.ptr(y0.top * self.cout), self.Wo * self.Ho, self.cout, Kg, self.sh * self.cin, Kg,
-                         self.cout, code, bias=bias, mask=mask_w, a_rpi=self.Ho, a_item=self.sw * gin.Ha * self.cin, a_batch=gin.W * gin.Ha * self.cin,
-                         c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, c_batch=self.Wo * y0.Ha * self.cout, batch=gin.B, flags=flags, **taps)
+            # rows (clip, output column, output row) in ONE launch through the second row level (a launch per clip, batch = B, left the last
+            # blocks' tiles nearly empty: 76 rows per clip in block 3 of architecture 7)
+            _hip.gemm_nt(gin.ptr(), _hip.ptr(self.w_imp), y0.ptr(y0.top * self.cout), gin.B * self.Wo * self.Ho, self.cout, Kg, self.sh * self.cin, Kg,
+                         self.cout, code, bias=bias, mask=mask_w, a_rpi=self.Ho, a_item=self.sw * gin.Ha * self.cin, a_rpi2=self.Wo,
+                         a_item2=gin.W * gin.Ha * self.cin, c_rpi=self.Ho, c_item=y0.Ha * self.cout, c_valid=self.Ho, flags=flags, **taps)
         else:
             _hip.call("cpc_im2col2d", gin.ptr(), _hip.ptr(col), _desc(gin, gin.padded_desc), self.kh, self.kw, self.sh, self.sw,
                       self.pad, self.pad, self.Ho, self.Wo, self.Kp, 1 if self.in_f32 else 0, code)
