@@ -233,9 +233,9 @@ class _Conv:
         # G row pairs per GEMM row where 2 C_in columns would leave most of a 128-wide tile empty (C_in = 32: G = 2, the window is then the
         # three dY rows R-1 .. R+1 per piece): half the tiles, each full — 0.52 -> 0.3x ms for the even columns of block 1 of architecture 7
         G = 1
-        if os.environ.get("CPC_DGRAD_PARITY_GROUP", "1") != "0":
-            while 2 * cin * G * 2 <= 128 and Hs % (2 * G) == 0:
-                G *= 2
+        width = int(os.environ.get("CPC_DGRAD_PARITY_GROUP", "128"))          # 0: no grouping; 256: up to the 256-wide tile
+        while width and 2 * cin * G * 2 <= width and Hs % (2 * G) == 0:
+            G *= 2
         Hg = Hs // G
         tile = 256 if 2 * cin * G >= 256 else 128
         Hp = Hg
