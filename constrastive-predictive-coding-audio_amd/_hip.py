@@ -121,7 +121,9 @@ _SIGNATURES = {
     "cpc_bn_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_bn_bwd_apply": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _I, _I, _I, _I, _P], _I),
     "cpc_bn_apply_bits": ([_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P], _I),
-    "cpc_bn_apply_residual": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
+    "cpc_bn_apply_residual": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], _I),
+    "cpc_bn_bwd_reduce_res": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
+    "cpc_bn_bwd_apply_res": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _I, _P, _P, _I, _I, _I, _P], _I),
     "cpc_bn_bwd_reduce_bits": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_bn_bwd_apply_bits": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _I, _I, _P], _I),
     "cpc_maxpool2d_fwd": ([_P, _P, _P, _P, _I, _I, _I, _P], _I),

@@ -353,8 +353,19 @@ int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float ep
 
 int cpc_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
                           const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
-                          const int* ga, int dtype, void* stream) {
-    return launch_bn_apply_residual(x, gx, res, gr, out, go, stats, gamma, beta, oh, ow, relu_in, relu_out, r_f32, bits, ga, dtype, (hipStream_t)stream);
+                          const int* ga, unsigned char* obits, int dtype, void* stream) {
+    return launch_bn_apply_residual(x, gx, res, gr, out, go, stats, gamma, beta, oh, ow, relu_in, relu_out, r_f32, bits, ga, dtype, (hipStream_t)stream,
+                                    obits);
+}
+int cpc_bn_bwd_reduce_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                          const int* gx, const float* stats, float* slabs, int nblocks, int dtype, void* stream) {
+    return launch_bn_bwd_reduce_res(dout, gd, obits, abits, ga, x, gx, stats, slabs, nblocks, dtype, (hipStream_t)stream);
+}
+int cpc_bn_bwd_apply_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                         void* dx, const int* gx, const float* stats, const float* gamma, const float* dgamma, const float* dbeta, double count,
+                         int train, void* dres, const int* gr, int oh, int ow, int dtype, void* stream) {
+    return launch_bn_bwd_apply_res(dout, gd, obits, abits, ga, x, dx, gx, stats, gamma, dgamma, dbeta, count, train, dres, gr, oh, ow, dtype,
+                                   (hipStream_t)stream);
 }
 int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                  int relu, int x_f32, int dtype, void* stream) {

@@ -201,7 +201,12 @@ int launch_bn_finalize(const float* slabs, int nslab, int C, double count, float
                        float* run_var, hipStream_t stream);
 int launch_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
                              const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
-                             const int* ga, int dtype, hipStream_t st);
+                             const int* ga, int dtype, hipStream_t st, unsigned char* obits = nullptr);
+int launch_bn_bwd_reduce_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga,
+                             const void* x, const int* gx, const float* stats, float* slabs, int nblocks, int dtype, hipStream_t st);
+int launch_bn_bwd_apply_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                            void* dx, const int* gx, const float* stats, const float* gamma, const float* dgamma, const float* dbeta,
+                            double count, int train, void* dres, const int* gr, int oh, int ow, int dtype, hipStream_t st);
 int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                     int relu, int x_f32, int dtype, hipStream_t stream, unsigned char* bits = nullptr);
 int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,

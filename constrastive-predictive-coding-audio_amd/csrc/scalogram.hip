@@ -606,7 +606,8 @@ template <typename TR>
 __global__ __launch_bounds__(256) void bn_apply_residual8_kernel(const bf16_t* __restrict__ x, Grid gx, const TR* __restrict__ r, Grid gr,
                                                                  bf16_t* __restrict__ out, Grid go, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int oh, int ow,
-                                                                 int relu_in, int relu_out, unsigned char* __restrict__ bits, Grid ga) {
+                                                                 int relu_in, int relu_out, unsigned char* __restrict__ bits, Grid ga,
+                                                                 unsigned char* __restrict__ obits) {
     const int c8n = gx.C / 8;
     const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -634,15 +635,27 @@ __global__ __launch_bounds__(256) void bn_apply_residual8_kernel(const bf16_t* _
                 if (relu_out) o[hf][e] = relu_f(o[hf][e]);
             }
         }
-        store8(out + grid_off(go, b, w, h) + c8 * 8, o[0], o[1]);
+        const long long oo = grid_off(go, b, w, h) + c8 * 8;
+        store8(out + oo, o[0], o[1]);
         if (bits) bits[(grid_off(ga, b, w, h) + c8 * 8) >> 3] = (unsigned char)m;      // (addressed like the activation grid it stands for)
+        if (obits) {          // sign bits of the block output (the ReLU between blocks), addressed like out: what the fused backward passes read
+            unsigned mo = 0u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mo |= ((float)(bf16_t)o[hf][e] > 0.f ? 1u : 0u) << (hf * 4 + e);
+            obits[oo >> 3] = (unsigned char)mo;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, Grid gy,
                                                              const bf16_t* __restrict__ x, Grid gx, const float* __restrict__ stats,
                                                              float* __restrict__ slabs, int relu, long long cols_per_block,
-                                                             const unsigned char* __restrict__ ybits) {
+                                                             const unsigned char* __restrict__ ybits, Grid gd,
+                                                             const unsigned char* __restrict__ obits) {
+    // gd: the grid dy lives on (the activation grid gy, or — the block's residual add folded in — the block-output grid, whose ReLU mask
+    // comes as sign bits obits addressed like dy: g = dy [out > 0] [y > 0])
     const int C = gx.C, c8n = C / 8;
     const int cg = threadIdx.x % c8n, rp = threadIdx.x / c8n, nrp = 256 / c8n;
     const long long ncol = (long long)gx.B * gx.W;
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
         const unsigned rend = (unsigned)(q1 * gx.H);
         for (unsigned r = (unsigned)(q0 * gx.H) + rp; r < rend; r += 2u * nrp) {
             f32x8 g8[2], y8[2], x8[2];
-            unsigned mb[2] = {0xffu, 0xffu};
+            unsigned mb[2] = {0xffu, 0xffu}, mo[2] = {0xffu, 0xffu};
             bool ok[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -667,8 +680,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
                 const unsigned rc = ok[u] ? ru : r;
                 const unsigned q = rc / (unsigned)gx.H;
                 const int h = (int)(rc - q * gx.H), w = (int)(q % gx.W), b = (int)(q / gx.W);
-                const long long oy = grid_off(gy, b, w, h) + cg * 8;
-                g8[u] = load8(dy + oy);
+                const long long oy = grid_off(gy, b, w, h) + cg * 8, od = grid_off(gd, b, w, h) + cg * 8;
+                g8[u] = load8(dy + od);
+                if (obits) mo[u] = obits[od >> 3];
                 if (relu) {
                     if (ybits) mb[u] = ybits[oy >> 3];
                     else y8[u] = load8(y + oy);
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce8_kernel(const bf16_t* __res
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool pos = ybits ? ((mb[u] >> (hf * 4 + e)) & 1u) != 0u : yy[e] > 0.f;
-                        const float g = (!relu || pos) ? gg[e] : 0.f;
+                        const float g = ((!relu || pos) && ((mo[u] >> (hf * 4 + e)) & 1u)) ? gg[e] : 0.f;
                         s1[hf][e] += g * (xx[e] - mu[hf][e]) * rs[hf][e];
                         s2[hf][e] += g;
                     }
@@ -709,7 +723,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, Grid gx,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                            float inv_count, int relu, int train, const unsigned char* __restrict__ ybits) {
+                                                            float inv_count, int relu, int train, const unsigned char* __restrict__ ybits, Grid gd,
+                                                            const unsigned char* __restrict__ obits, bf16_t* __restrict__ dres, Grid gr, int oh,
+                                                            int ow) {
+    // gd / obits as in bn_bwd_reduce8_kernel; dres (may be null): the gradient of the cropped residual operand, dy [out > 0] at (w + ow, h + oh)
     const int C = gx.C, c8n = C / 8;
     const unsigned total = (unsigned)((long long)gx.B * gx.W * gx.H * c8n);
     const bool fixed = ((gridDim.x * 256u) % (unsigned)c8n) == 0u;
@@ -733,8 +750,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
         const int h = (int)((idx / c8n) % gx.H);
         const unsigned col = idx / (unsigned)(c8n * gx.H);
         const int w = (int)(col % gx.W), b = (int)(col / gx.W);
-        const long long oy = grid_off(gy, b, w, h) + c8 * 8, ox = grid_off(gx, b, w, h) + c8 * 8;
-        const f32x8 g8 = load8(dy + oy);
+        const long long oy = grid_off(gy, b, w, h) + c8 * 8, ox = grid_off(gx, b, w, h) + c8 * 8, od = grid_off(gd, b, w, h) + c8 * 8;
+        uint4 graw = *(const uint4*)(dy + od);
+        unsigned mo = 0xffu;
+        if (obits) {
+            mo = obits[od >> 3];
+            unsigned gw[4] = {graw.x, graw.y, graw.z, graw.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gw[e] &= ((mo >> (2 * e)) & 1u ? 0xffffu : 0u) | ((mo >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+            graw = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+        }
+        if (dres) *(uint4*)(dres + grid_off(gr, b, w + ow, h + oh) + c8 * 8) = graw;
+        f32x8 g8;
+        g8.lo = (f32x4){__builtin_bit_cast(float, graw.x << 16), __builtin_bit_cast(float, graw.x & 0xffff0000u),
+                        __builtin_bit_cast(float, graw.y << 16), __builtin_bit_cast(float, graw.y & 0xffff0000u)};
+        g8.hi = (f32x4){__builtin_bit_cast(float, graw.z << 16), __builtin_bit_cast(float, graw.z & 0xffff0000u),
+                        __builtin_bit_cast(float, graw.w << 16), __builtin_bit_cast(float, graw.w & 0xffff0000u)};
         const f32x8 x8 = load8(x + ox);
         f32x8 y8;
         unsigned mb = 0xffu;
@@ -1167,7 +1198,7 @@ static bool same_shape(const int* a, const int* b) { return a[0] == b[0] && a[1]
 
 int launch_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
                              const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
-                             const int* ga, int dtype, hipStream_t st) {
+                             const int* ga, int dtype, hipStream_t st, unsigned char* obits) {
     if (bits && (!grid_ok(ga) || !same_shape(gx, ga))) return CPC_EINVAL;
     if (dtype != CPC_DTYPE_BF16 || !grid_ok(gx) || !grid_ok(gr) || !grid_ok(go) || !same_shape(gx, go) || gx[5] % 8 || gr[5] != gx[5] ||
         gr[0] != gx[0] || oh < 0 || ow < 0 || gr[2] < gx[2] + oh || gr[1] < gx[1] + ow || !x || !res || !out || !stats || !gamma || !beta)
@@ -1175,10 +1206,10 @@ int launch_bn_apply_residual(const void* x, const int* gx, const void* res, cons
     const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
     if (r_f32)
         hipLaunchKernelGGL((bn_apply_residual8_kernel<float>), dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (const float*)res, mk(gr),
-                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx));
+                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx), obits);
     else
         hipLaunchKernelGGL((bn_apply_residual8_kernel<bf16_t>), dim3(nb8), dim3(256), 0, st, (const bf16_t*)x, mk(gx), (const bf16_t*)res, mk(gr),
-                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx));
+                           (bf16_t*)out, mk(go), stats, gamma, beta, oh, ow, relu_in, relu_out, bits, bits ? mk(ga) : mk(gx), obits);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }
@@ -1204,6 +1235,37 @@ int launch_bn_apply(const void* x, const int* gx, void* out, const int* go, cons
     return CPC_OK;
 }
 
+// The block's residual add folded into its second BatchNorm's backward passes (bf16, sign-bit masks): dout lives on the block-output grid
+// gd, obits (may be null: no ReLU behind the add) are the sign bits of the block output addressed like dout, abits those of the normalised
+// branch addressed like its activation grid ga.  The apply pass also writes the residual operand's gradient dres (cropped at (ow, oh) of gr).
+int launch_bn_bwd_reduce_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga,
+                             const void* x, const int* gx, const float* stats, float* slabs, int nblocks, int dtype, hipStream_t st) {
+    if (dtype != CPC_DTYPE_BF16 || !abits || !grid_ok(gx) || !grid_ok(ga) || !grid_ok(gd) || !same_shape(gx, ga) || !same_shape(gx, gd) ||
+        gx[5] % 8 || !bn_c_ok(gx[5]) || nblocks <= 0 || !dout || !x || !stats || !slabs)
+        return CPC_EINVAL;
+    const long long ncol = (long long)gx[0] * gx[1];
+    const long long cpb = (ncol + nblocks - 1) / nblocks;
+    hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)nullptr, mk(ga), (const bf16_t*)x,
+                       mk(gx), stats, slabs, 1, cpb, abits, mk(gd), obits);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_bn_bwd_apply_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                            void* dx, const int* gx, const float* stats, const float* gamma, const float* dgamma, const float* dbeta,
+                            double count, int train, void* dres, const int* gr, int oh, int ow, int dtype, hipStream_t st) {
+    if (dtype != CPC_DTYPE_BF16 || !abits || !grid_ok(gx) || !grid_ok(ga) || !grid_ok(gd) || !same_shape(gx, ga) || !same_shape(gx, gd) ||
+        gx[5] % 8 || !bn_c_ok(gx[5]) || count <= 0 || !dout || !x || !dx || !stats || !gamma || !dgamma || !dbeta)
+        return CPC_EINVAL;
+    if (dres && (!grid_ok(gr) || gr[0] != gx[0] || gr[5] != gx[5] || oh < 0 || ow < 0 || gr[2] < gx[2] + oh || gr[1] < gx[1] + ow)) return CPC_EINVAL;
+    const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
+    hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)nullptr, mk(ga), (const bf16_t*)x,
+                       (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, (float)(1.0 / count), 1, train, abits, mk(gd), obits, (bf16_t*)dres,
+                       dres ? mk(gr) : mk(gx), oh, ow);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
 int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const void* x, const int* gx, const float* stats, float* slabs,
                          int relu, int nblocks, int x_f32, int dtype, hipStream_t st, const unsigned char* ybits) {
     if (ybits && !(dtype == CPC_DTYPE_BF16 && !x_f32 && gx && gx[5] % 8 == 0)) return CPC_EINVAL;
@@ -1211,7 +1273,7 @@ int launch_bn_bwd_reduce(const void* dy, const void* y, const int* gy, const voi
     const long long ncol = (long long)gx[0] * gx[1];
     const long long cpb = (ncol + nblocks - 1) / nblocks;
     if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
-        hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb, ybits);
+        hipLaunchKernelGGL(bn_bwd_reduce8_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, mk(gx), stats, slabs, relu, cpb, ybits, mk(gy), nullptr);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }
@@ -1235,7 +1297,7 @@ int launch_bn_bwd_apply(const void* dy, const void* y, const int* gy, const void
     const float inv = (float)(1.0 / count);
     if (dtype == CPC_DTYPE_BF16 && !x_f32 && gx[5] % 8 == 0) {
         const int nb8 = blocks_for((long long)gx[0] * gx[1] * gx[2] * (gx[5] / 8));
-        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train, ybits);
+        hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(nb8), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, mk(gy), (const bf16_t*)x, (bf16_t*)dx, mk(gx), stats, gamma, dgamma, dbeta, inv, relu, train, ybits, mk(gy), nullptr, nullptr, mk(gy), 0, 0);
         CPC_CHECK_LAUNCH();
         return CPC_OK;
     }

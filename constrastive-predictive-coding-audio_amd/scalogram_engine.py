@@ -669,14 +669,29 @@ class _BatchNorm:
                 os.environ.get("CPC_BN_BITS", "1") != "0"):
             self.abits = torch.zeros(a.rows * a.C // 8, device=eng.device, dtype=torch.uint8)
 
-    def apply_residual(self, res: Grid, out: Grid, oh, ow, relu_out, r_f32):
+    def apply_residual(self, res: Grid, out: Grid, oh, ow, relu_out, r_f32, obits=None):
         """The apply pass of forward(apply=False), fused with the block's cropped residual add and the ReLU between blocks
-        (cpc_bn_apply_residual): the activation grid ``a`` is not written, only its sign bits."""
+        (cpc_bn_apply_residual): the activation grid ``a`` is not written, only its sign bits (and, ``obits``, those of the block output)."""
         e = self.eng
         p = e.model._param
         _hip.call("cpc_bn_apply_residual", self.y0.ptr(), _desc(self.y0, self.y0.desc), res.ptr(), _desc(res, res.desc), out.ptr(), _desc(out, out.desc),
                   _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]), _hip.ptr(p[self.prefix + ".bias"]), oh, ow, 1, relu_out, r_f32,
-                  _hip.ptr(self.abits), _desc(self.a, self.a.desc), e.code)
+                  _hip.ptr(self.abits), _desc(self.a, self.a.desc), _hip.ptr(obits), e.code)
+
+    def backward_res(self, d_out: Grid, obits, d_res: Optional[Grid], oh, ow):
+        """backward() with the block's residual add folded in (cpc_bn_bwd_reduce_res / _apply_res): the gradient of the block output d_out,
+        masked by the output's sign bits, is what both passes read; the apply pass also writes the residual operand's gradient."""
+        e = self.eng
+        p, g, code = e.model._param, e.model._grad, e.code
+        gw, gb = g[self.prefix + ".weight"], g[self.prefix + ".bias"]
+        _hip.call("cpc_bn_bwd_reduce_res", d_out.ptr(), _desc(d_out, d_out.desc), _hip.ptr(obits), _hip.ptr(self.abits), _desc(self.a, self.a.desc),
+                  self.y0.ptr(), _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(e.slabs), self.nb_bwd, code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(gw), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs, self.C), _hip.ptr(gb), 1, self.C, self.nb_bwd, 2 * self.C, 1, 1, 0, 0)
+        _hip.call("cpc_bn_bwd_apply_res", d_out.ptr(), _desc(d_out, d_out.desc), _hip.ptr(obits), _hip.ptr(self.abits), _desc(self.a, self.a.desc),
+                  self.y0.ptr(), self.dy0.ptr(), _desc(self.y0, self.y0.desc), _hip.ptr(self.stats), _hip.ptr(p[self.prefix + ".weight"]),
+                  _hip.ptr(gw), _hip.ptr(gb), float(self.y0.count), 1 if self.trained else 0, d_res.ptr() if d_res is not None else None,
+                  _desc(d_res, d_res.desc) if d_res is not None else None, oh, ow, code)
 
     def forward(self, apply=True):
         e, mod = self.eng, self.mod
@@ -1123,6 +1138,7 @@ class _Block:
         # (CPC_BN_RESIDUAL=0: two passes; the gradient penalty's tangent pass reads it)
         fuse = (self.bn_b is not None and self.blk.residual and self.pool2 == 1 and self.bn_b.abits is not None and
                 not getattr(e, "gp_capable", False) and self.main.C % 8 == 0 and os.environ.get("CPC_BN_RESIDUAL", "1") != "0")
+        self._fused_bwd = False
         if self.bn_b is not None:
             self.bn_b.forward(apply=not fuse)
         if self.pool2 > 1:
@@ -1137,7 +1153,13 @@ class _Block:
             if self.stem_res is not None:
                 self.stem_res.forward(self.bn_b if fuse else None)
             elif fuse:
-                self.bn_b.apply_residual(self.res, self.out, self.oh, self.ow, 0 if self.last else 1, self.r_f32)
+                # (the backward pass folds the residual add into the BatchNorm's passes where the residual operand is a bf16 grid: it then
+                # needs the sign bits of the block output in place of the output itself)
+                self._fused_bwd = (not self.r_f32) and os.environ.get("CPC_BN_RESIDUAL_BWD", "1") != "0"
+                if self._fused_bwd and not self.last and getattr(self, "obits", None) is None:
+                    self.obits = torch.zeros(self.out.rows * self.out.C // 8, device=e.device, dtype=torch.uint8)
+                self.bn_b.apply_residual(self.res, self.out, self.oh, self.ow, 0 if self.last else 1, self.r_f32,
+                                         self.obits if (self._fused_bwd and not self.last) else None)
             else:
                 _hip.call("cpc_residual_add", self.main.ptr(), _desc(self.main, self.main.desc), self.res.ptr(), _desc(self.res, self.res.desc),
                           self.out.ptr(), _desc(self.out, self.out.desc), self.oh, self.ow, 0 if self.last else 1, self.r_f32, code)
@@ -1189,8 +1211,11 @@ class _Block:
     def backward(self):
         e, code = self.eng, self.eng.code
         first = not self.need_input_grad
+        fused_bwd = getattr(self, "_fused_bwd", False) and self.stem_res is None
         if self.stem_res is not None:
             self.stem_res.backward(self.d_out, self.d_main)
+        elif fused_bwd:
+            pass          # (the residual add's backward runs inside the second BatchNorm's passes below)
         elif self.blk.residual:
             # (d_res was zeroed when it was allocated: the cropped add's backward overwrites the same interior every step and never
             # touches the border)
@@ -1209,7 +1234,9 @@ class _Block:
         g_b, act_b = self.d_main, self.main
         if self.pool2 > 1:
             g_b, act_b = unpool(self.main_full, self.d_main_full, self.main, self.d_main, self.pool2), self.main_full
-        if self.bn_b is not None:
+        if fused_bwd:
+            self.bn_b.backward_res(self.d_out, None if self.last else self.obits, self.d_res, self.oh, self.ow)
+        elif self.bn_b is not None:
             self.bn_b.backward(g_b)
         else:
             _hip.call("cpc_relu_mask", g_b.ptr(), act_b.ptr(), g_b.rows * g_b.C, code)

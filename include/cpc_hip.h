@@ -324,11 +324,22 @@ int cpc_bn_finalize(const float* slabs, int nslab, int C, double count, float ep
 /* cpc_bn_apply_residual (bf16, C a multiple of 8): out = act_out(act_in(BatchNorm(x)) + res(w + ow, h + oh)) — the block's second BatchNorm + ReLU,
  * the cropped residual add (scalogram_model.py:447-472) and the ReLU between blocks (:525-526) in one pass; the normalised branch is not stored,
  * only its sign bits (bits, may be NULL; addressed by the element offsets of the activation grid ga it stands for, as cpc_bn_apply_bits writes them)
- * for the BatchNorm's backward pass.  Same results as cpc_bn_apply followed
+ * for the BatchNorm's backward pass; obits (may be NULL): the sign bits of out, addressed like out, for cpc_bn_bwd_*_res.  Same results as cpc_bn_apply followed
  * by cpc_residual_add, bit for bit.  r_f32: res is a float32 grid. */
 int cpc_bn_apply_residual(const void* x, const int* gx, const void* res, const int* gr, void* out, const int* go, const float* stats,
                           const float* gamma, const float* beta, int oh, int ow, int relu_in, int relu_out, int r_f32, unsigned char* bits,
-                          const int* ga, int dtype, void* stream);
+                          const int* ga, unsigned char* obits, int dtype, void* stream);
+/* ... and its backward: the cropped residual add's backward (scalogram_model.py:462-472 under autograd) folded into the second BatchNorm's two
+ * backward passes.  dout: gradient of the block output on grid gd; obits (may be NULL: no ReLU behind the add): sign bits of the block output,
+ * written by cpc_bn_apply_residual, addressed like dout; abits: sign bits of the normalised branch addressed like its activation grid ga.
+ * g = dout [out > 0] [bn_out > 0].  cpc_bn_bwd_reduce_res: slabs as cpc_bn_bwd_reduce.  cpc_bn_bwd_apply_res: dx as cpc_bn_bwd_apply, and
+ * dres (may be NULL) = dout [out > 0] at (w + ow, h + oh) of grid gr: the residual operand's gradient.  Neither the masked gradient of the main
+ * branch nor a separate residual-add backward pass exists.  bf16, C a multiple of 8. */
+int cpc_bn_bwd_reduce_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                          const int* gx, const float* stats, float* slabs, int nblocks, int dtype, void* stream);
+int cpc_bn_bwd_apply_res(const void* dout, const int* gd, const unsigned char* obits, const unsigned char* abits, const int* ga, const void* x,
+                         void* dx, const int* gx, const float* stats, const float* gamma, const float* dgamma, const float* dbeta, double count,
+                         int train, void* dres, const int* gr, int oh, int ow, int dtype, void* stream);
 int cpc_bn_apply(const void* x, const int* gx, void* out, const int* go, const float* stats, const float* gamma, const float* beta,
                  int relu, int x_f32, int dtype, void* stream);
 /* Backward: g = dy * (y > 0) if relu.  cpc_bn_bwd_reduce: slabs [nblocks][2][C] partials of (sum g*xhat, sum g) = (dgamma,

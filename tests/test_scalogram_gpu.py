@@ -206,8 +206,10 @@ def test_batchnorm_grid(dt, train):
 @pytest.mark.parametrize("r_f32", [0, 1])
 def test_bn_apply_residual_equals_the_two_passes(r_f32):
     """cpc_bn_apply_residual (second BatchNorm + ReLU, cropped residual add, ReLU between blocks in one pass; only the sign bits of the
-    normalised branch are kept) against cpc_bn_apply_bits followed by cpc_residual_add: bitwise equal outputs and sign bits, grids with
-    different row geometries (tail rows on the convolution output, top rows on the block output, a larger residual grid cropped)."""
+    normalised branch and of the block output are kept) against cpc_bn_apply_bits followed by cpc_residual_add: bitwise equal outputs and
+    sign bits, grids with different row geometries (tail rows on the convolution output, top rows on the block output, a larger residual
+    grid cropped).  And back: cpc_bn_bwd_reduce_res / _apply_res (the residual add's backward folded into the BatchNorm's two passes)
+    against cpc_residual_add_bwd followed by cpc_bn_bwd_reduce_bits / _apply_bits: the same slabs, input gradient and residual gradient."""
     B, Cc, H, W, oh, ow = 3, 16, 5, 7, 2, 1
     g = torch.Generator().manual_seed(9)
     bf = torch.bfloat16
@@ -222,14 +224,36 @@ def test_bn_apply_residual_equals_the_two_passes(r_f32):
     gamma, beta = (1 + 0.3 * torch.randn(Cc, generator=g)).to(DEV), (0.2 * torch.randn(Cc, generator=g)).to(DEV)
     bits1 = torch.zeros(ga.rows * Cc // 8, device=DEV, dtype=torch.uint8)
     bits2 = torch.zeros_like(bits1)
+    obits = torch.zeros(go2.rows * Cc // 8, device=DEV, dtype=torch.uint8)
     for relu_out in (1, 0):
         _hip.call("cpc_bn_apply_bits", gx.ptr(), _d(gx.desc), ga.ptr(), _d(ga.desc), _hip.ptr(stats), _hip.ptr(gamma), _hip.ptr(beta), 1,
                   _hip.ptr(bits1), code)
         _hip.call("cpc_residual_add", ga.ptr(), _d(ga.desc), gr.ptr(), _d(gr.desc), go1.ptr(), _d(go1.desc), oh, ow, relu_out, r_f32, code)
         _hip.call("cpc_bn_apply_residual", gx.ptr(), _d(gx.desc), gr.ptr(), _d(gr.desc), go2.ptr(), _d(go2.desc), _hip.ptr(stats), _hip.ptr(gamma),
-                  _hip.ptr(beta), oh, ow, 1, relu_out, r_f32, _hip.ptr(bits2), _d(ga.desc), code)
+                  _hip.ptr(beta), oh, ow, 1, relu_out, r_f32, _hip.ptr(bits2), _d(ga.desc), _hip.ptr(obits) if relu_out else None, code)
         assert torch.equal(go1.t, go2.t) and torch.equal(bits1, bits2)
         assert go1.t.abs().max().item() > 0
+        if r_f32:
+            continue
+        # backward: the two routes on the same output gradient
+        gdo = Grid(B, W, H, Cc, DEV, bf, top=2, tail=1)
+        _fill(gdo, torch.randn(B, Cc, H, W, generator=g))
+        gdm, gdr1, gdr2 = ga.like(DEV), gr.like(DEV), gr.like(DEV)
+        dx1, dx2 = gx.like(DEV), gx.like(DEV)
+        nb = 4
+        sl1, sl2 = torch.zeros(nb * 2 * Cc, device=DEV), torch.zeros(nb * 2 * Cc, device=DEV)
+        dg, db = torch.randn(Cc, generator=g).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+        _hip.call("cpc_residual_add_bwd", gdo.ptr(), go1.ptr(), _d(go1.desc), gdm.ptr(), _d(gdm.desc), gdr1.ptr(), _d(gdr1.desc), oh, ow, relu_out, 0, code)
+        _hip.call("cpc_bn_bwd_reduce_bits", gdm.ptr(), _hip.ptr(bits1), _d(ga.desc), gx.ptr(), _d(gx.desc), _hip.ptr(stats), _hip.ptr(sl1), nb, code)
+        _hip.call("cpc_bn_bwd_apply_bits", gdm.ptr(), _hip.ptr(bits1), _d(ga.desc), gx.ptr(), dx1.ptr(), _d(gx.desc), _hip.ptr(stats), _hip.ptr(gamma),
+                  _hip.ptr(dg), _hip.ptr(db), float(B * H * W), 1, code)
+        ob = _hip.ptr(obits) if relu_out else None
+        _hip.call("cpc_bn_bwd_reduce_res", gdo.ptr(), _d(gdo.desc), ob, _hip.ptr(bits2), _d(ga.desc), gx.ptr(), _d(gx.desc), _hip.ptr(stats),
+                  _hip.ptr(sl2), nb, code)
+        _hip.call("cpc_bn_bwd_apply_res", gdo.ptr(), _d(gdo.desc), ob, _hip.ptr(bits2), _d(ga.desc), gx.ptr(), dx2.ptr(), _d(gx.desc), _hip.ptr(stats),
+                  _hip.ptr(gamma), _hip.ptr(dg), _hip.ptr(db), float(B * H * W), 1, gdr2.ptr(), _d(gdr2.desc), oh, ow, code)
+        assert torch.equal(sl1, sl2) and torch.equal(dx1.t, dx2.t) and torch.equal(gdr1.t, gdr2.t)
+        assert dx1.t.abs().max().item() > 0 and gdr1.t.abs().max().item() > 0
 
 
 @pytest.mark.parametrize("dt", DTYPES)
