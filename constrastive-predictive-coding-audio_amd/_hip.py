@@ -136,7 +136,8 @@ _SIGNATURES = {
     "cpc_stem_bwd_reduce": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_stem_bwd_wgrad": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_stem_residual_add": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    "cpc_stem_residual_bn_add": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P], _I),
+    "cpc_stem_residual_bn_add": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P], _I),
+    "cpc_stem_residual_wgrad_bits": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_stem_residual_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_maxpool2d_select": ([_P, _P, _P, _P, _P, _I, _I, _I, _P], _I),
     "cpc_gp_direction": ([_P, _P, _L, _I, _F, _P, _I, _P], _I),

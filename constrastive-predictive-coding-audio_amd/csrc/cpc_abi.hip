@@ -441,10 +441,15 @@ int cpc_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const floa
 }
 
 int cpc_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh, int ow,
-                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga, int dtype,
-                             void* stream) {
+                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga,
+                             unsigned char* obits, int dtype, void* stream) {
     if (!y || !xp || !wr || !out) return CPC_EINVAL;
-    return launch_stem_residual_bn_add(y, gy, xp, gp, wr, out, go, oh, ow, relu, stats, gamma, beta, bits, ga, dtype, (hipStream_t)stream);
+    return launch_stem_residual_bn_add(y, gy, xp, gp, wr, out, go, oh, ow, relu, stats, gamma, beta, bits, ga, dtype, (hipStream_t)stream, obits);
+}
+int cpc_stem_residual_wgrad_bits(const void* dout, const unsigned char* obits, const int* go, const int* gm, const float* xp, const int* gp,
+                                 float* slabs, int oh, int ow, int nblocks, int dtype, void* stream) {
+    if (!dout || !obits || !go || !gm || !xp || !gp || !slabs) return CPC_EINVAL;
+    return launch_stem_residual_bwd(dout, nullptr, go, nullptr, gm, xp, gp, slabs, oh, ow, 1, nblocks, dtype, (hipStream_t)stream, obits);
 }
 int cpc_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                           int oh, int ow, int relu, int dtype, void* stream) {

@@ -247,8 +247,8 @@ int launch_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const f
                           hipStream_t stream);
 int launch_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh,
                                 int ow, int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga,
-                                int dtype, hipStream_t st);
+                                int dtype, hipStream_t st, unsigned char* obits = nullptr);
 int launch_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                              int oh, int ow, int relu, int dtype, hipStream_t stream);
 int launch_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
-                             float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t stream);
+                             float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t stream, const unsigned char* obits = nullptr);

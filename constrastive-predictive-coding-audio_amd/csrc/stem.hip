@@ -490,7 +490,8 @@ __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restr
                                                                 const float* __restrict__ wr, T* __restrict__ out, Grid go, int oh, int ow,
                                                                 int relu, const float* __restrict__ stats = nullptr,
                                                                 const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
-                                                                unsigned char* __restrict__ bits = nullptr, Grid ga = Grid()) {
+                                                                unsigned char* __restrict__ bits = nullptr, Grid ga = Grid(),
+                                                                unsigned char* __restrict__ obits = nullptr) {
     constexpr int N = Cpt<T>::N;
     const int cgn = gm.C / N;
     const unsigned total = (unsigned)((long long)gm.B * gm.W * gm.H * cgn);
@@ -529,7 +530,16 @@ __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restr
 #pragma unroll
             for (int e = 0; e < N; ++e) v[e] = relu_f(v[e]);
         }
-        storen<T, N>(out + grid_off(go, b, wq, h) + cg * N, v);
+        const long long oo = grid_off(go, b, wq, h) + cg * N;
+        storen<T, N>(out + oo, v);
+        if constexpr (BN) {
+            if (obits) {          // sign bits of the stored block output (for the backward passes that read them instead of out)
+                unsigned mo = 0u;
+#pragma unroll
+                for (int e = 0; e < N; ++e) mo |= ((float)(bf16_t)v[e] > 0.f ? 1u : 0u) << e;
+                obits[oo >> 3] = (unsigned char)mo;
+            }
+        }
     }
 }
 
@@ -537,7 +547,10 @@ __global__ __launch_bounds__(256) void stem_residual_add_kernel(const T* __restr
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void stem_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, Grid go,
                                                                 T* __restrict__ dmain, Grid gm, const float* __restrict__ xp, Grid gp,
-                                                                float* __restrict__ slabs, int oh, int ow, int relu, long long cols_per_block) {
+                                                                float* __restrict__ slabs, int oh, int ow, int relu, long long cols_per_block,
+                                                                const unsigned char* __restrict__ obits = nullptr) {
+    // obits (bf16, N = 8): the ReLU mask as the sign bits of out (addressed like out) instead of out itself; dmain may then be null — the
+    // masked gradient is not stored (cpc_bn_bwd_*_res read dout and the same bits) and the pass only gathers the projection's gradient
     constexpr int N = Cpt<T>::N;
     __shared__ __attribute__((aligned(16))) float red[8192];          // [nrp][CIN][C]: 256 / (C/N) * CIN * C <= 8192
     const int C = gm.C, cgn = C / N;
@@ -558,12 +571,18 @@ __global__ __launch_bounds__(256) void stem_residual_bwd_kernel(const T* __restr
             float g[N];
             loadn<T, N>(dout + oo, g);
             if (relu) {
-                float y[N];
-                loadn<T, N>(out + oo, y);
+                if (obits) {
+                    const unsigned mo = obits[oo >> 3];
 #pragma unroll
-                for (int e = 0; e < N; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < N; ++e) g[e] = ((mo >> e) & 1u) ? g[e] : 0.f;
+                } else {
+                    float y[N];
+                    loadn<T, N>(out + oo, y);
+#pragma unroll
+                    for (int e = 0; e < N; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+                }
             }
-            storen<T, N>(dmain + grid_off(gm, b, w, h) + cg * N, g);
+            if (dmain) storen<T, N>(dmain + grid_off(gm, b, w, h) + cg * N, g);
             const float* xr = xp + grid_off(gp, b, w + ow, h + oh);
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
@@ -735,13 +754,13 @@ static bool residual_ok(const int* gm, const int* gp, const int* go, int oh, int
 
 int launch_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh,
                                 int ow, int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga,
-                                int dtype, hipStream_t st) {
+                                int dtype, hipStream_t st, unsigned char* obits) {
     if (dtype != CPC_DTYPE_BF16 || !residual_ok(gy, gp, go, oh, ow, dtype) || !stats || !gamma || !beta) return CPC_EINVAL;
     if (bits && (!grid_ok(ga) || ga[0] != gy[0] || ga[1] != gy[1] || ga[2] != gy[2] || ga[5] != gy[5])) return CPC_EINVAL;
     const int cgn = gy[5] / 8;
     const long long total = (long long)gy[0] * gy[1] * gy[2] * cgn;
     const int nb = (int)std::min<long long>(8192, (total + 255) / 256);
-#define RES_BN_ADD(CI) hipLaunchKernelGGL((stem_residual_add_kernel<bf16_t, CI, true>), dim3(nb), dim3(256), 0, st, (const bf16_t*)y, mk(gy), xp, mk(gp), wr, (bf16_t*)out, mk(go), oh, ow, relu, stats, gamma, beta, bits, bits ? mk(ga) : mk(gy))
+#define RES_BN_ADD(CI) hipLaunchKernelGGL((stem_residual_add_kernel<bf16_t, CI, true>), dim3(nb), dim3(256), 0, st, (const bf16_t*)y, mk(gy), xp, mk(gp), wr, (bf16_t*)out, mk(go), oh, ow, relu, stats, gamma, beta, bits, bits ? mk(ga) : mk(gy), obits)
     if (gp[5] == 1) RES_BN_ADD(1); else RES_BN_ADD(2);
 #undef RES_BN_ADD
     CPC_CHECK_LAUNCH();
@@ -765,13 +784,14 @@ int launch_stem_residual_add(const void* main_, const int* gm, const float* xp, 
 }
 
 int launch_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
-                             float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t st) {
+                             float* slabs, int oh, int ow, int relu, int nblocks, int dtype, hipStream_t st, const unsigned char* obits) {
     if (!residual_ok(gm, gp, go, oh, ow, dtype) || nblocks <= 0) return CPC_EINVAL;
+    if ((obits && dtype != CPC_DTYPE_BF16) || (!obits && (!out || !dmain))) return CPC_EINVAL;
     const int n = dtype == CPC_DTYPE_BF16 ? 8 : 4;
     if (256 / (gm[5] / n) * gp[5] * gm[5] > 8192) return CPC_EINVAL;
     const long long ncol = (long long)gm[0] * gm[1];
     const long long cpb = (ncol + nblocks - 1) / nblocks;
-#define RES_BWD(T, CI) hipLaunchKernelGGL((stem_residual_bwd_kernel<T, CI>), dim3(nblocks), dim3(256), 0, st, (const T*)dout, (const T*)out, mk(go), (T*)dmain, mk(gm), xp, mk(gp), slabs, oh, ow, relu, cpb)
+#define RES_BWD(T, CI) hipLaunchKernelGGL((stem_residual_bwd_kernel<T, CI>), dim3(nblocks), dim3(256), 0, st, (const T*)dout, (const T*)out, mk(go), (T*)dmain, mk(gm), xp, mk(gp), slabs, oh, ow, relu, cpb, obits)
     if (dtype == CPC_DTYPE_BF16) { if (gp[5] == 1) RES_BWD(bf16_t, 1); else RES_BWD(bf16_t, 2); }
     else if (dtype == CPC_DTYPE_F32) { if (gp[5] == 1) RES_BWD(float, 1); else RES_BWD(float, 2); }
     else return CPC_EINVAL;

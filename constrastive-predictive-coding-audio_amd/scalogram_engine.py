@@ -927,18 +927,26 @@ class _StemResidual:
         self.n = main.C * xp.C
         self.slab = self.nb * self.n
 
-    def forward(self, bn=None):
+    def forward(self, bn=None, obits=None):
         """``bn``: the block's second BatchNorm whose apply pass was left out (forward(apply=False)): normalise + ReLU inside this add
-        (cpc_stem_residual_bn_add), the normalised branch is kept as sign bits only."""
+        (cpc_stem_residual_bn_add), the normalised branch is kept as sign bits only (``obits``: and the block output's sign bits)."""
         e, m, xp, o = self.eng, self.main, self.xp, self.out
         p = e.model._param
         if bn is not None:
             _hip.call("cpc_stem_residual_bn_add", bn.y0.ptr(), _desc(bn.y0, bn.y0.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(p[self.wname]),
                       o.ptr(), _desc(o, o.desc), self.oh, self.ow, 1 if self.relu else 0, _hip.ptr(bn.stats), _hip.ptr(p[bn.prefix + ".weight"]),
-                      _hip.ptr(p[bn.prefix + ".bias"]), _hip.ptr(bn.abits), _desc(bn.a, bn.a.desc), e.code)
+                      _hip.ptr(p[bn.prefix + ".bias"]), _hip.ptr(bn.abits), _desc(bn.a, bn.a.desc), _hip.ptr(obits), e.code)
             return
         _hip.call("cpc_stem_residual_add", m.ptr(), _desc(m, m.desc), xp.ptr(), _desc(xp, xp.desc), _hip.ptr(p[self.wname]),
                   o.ptr(), _desc(o, o.desc), self.oh, self.ow, 1 if self.relu else 0, e.code)
+
+    def backward_bits(self, d_out: Grid, obits):
+        """The projection's weight gradient alone, the ReLU mask from the output's sign bits (cpc_stem_residual_wgrad_bits): the masked
+        gradient of the main branch is not stored — the second BatchNorm's fused backward passes read d_out and the same bits."""
+        e, xp, o, m = self.eng, self.xp, self.out, self.main
+        _hip.call("cpc_stem_residual_wgrad_bits", d_out.ptr(), _hip.ptr(obits), _desc(o, o.desc), _desc(m, m.desc), xp.ptr(), _desc(xp, xp.desc),
+                  _hip.ptr(e.slabs), self.oh, self.ow, self.nb, e.code)
+        _hip.call("cpc_reduce_slabs", _hip.ptr(e.slabs), _hip.ptr(e.model._grad[self.wname]), 1, self.n, self.nb, self.n, 1, 1, 0, 0)
 
     def backward(self, d_out: Grid, d_main: Grid):
         e, xp, o = self.eng, self.xp, self.out
@@ -1151,7 +1159,11 @@ class _Block:
             if self.res_conv is not None:
                 self.res_conv.forward()
             if self.stem_res is not None:
-                self.stem_res.forward(self.bn_b if fuse else None)
+                # (fused backward for the first block: needs the ReLU behind the add, i.e. a block that is not the last one)
+                self._fused_bwd = fuse and self.stem_res.relu and os.environ.get("CPC_BN_RESIDUAL_BWD", "1") != "0"
+                if self._fused_bwd and getattr(self, "obits", None) is None:
+                    self.obits = torch.zeros(self.out.rows * self.out.C // 8, device=e.device, dtype=torch.uint8)
+                self.stem_res.forward(self.bn_b if fuse else None, self.obits if self._fused_bwd else None)
             elif fuse:
                 # (the backward pass folds the residual add into the BatchNorm's passes where the residual operand is a bf16 grid: it then
                 # needs the sign bits of the block output in place of the output itself)
@@ -1211,8 +1223,10 @@ class _Block:
     def backward(self):
         e, code = self.eng, self.eng.code
         first = not self.need_input_grad
-        fused_bwd = getattr(self, "_fused_bwd", False) and self.stem_res is None
-        if self.stem_res is not None:
+        fused_bwd = getattr(self, "_fused_bwd", False)
+        if self.stem_res is not None and fused_bwd:
+            self.stem_res.backward_bits(self.d_out, self.obits)
+        elif self.stem_res is not None:
             self.stem_res.backward(self.d_out, self.d_main)
         elif fused_bwd:
             pass          # (the residual add's backward runs inside the second BatchNorm's passes below)
@@ -1235,7 +1249,7 @@ class _Block:
         if self.pool2 > 1:
             g_b, act_b = unpool(self.main_full, self.d_main_full, self.main, self.d_main, self.pool2), self.main_full
         if fused_bwd:
-            self.bn_b.backward_res(self.d_out, None if self.last else self.obits, self.d_res, self.oh, self.ow)
+            self.bn_b.backward_res(self.d_out, None if self.last else self.obits, self.d_res if self.stem_res is None else None, self.oh, self.ow)
         elif self.bn_b is not None:
             self.bn_b.backward(g_b)
         else:

@@ -409,10 +409,16 @@ int cpc_stem_bwd_wgrad(const float* x, const int* gx, const float* w, const floa
                        const int* ga, float* slabs, int nblocks, int dtype, void* stream);
 /* cpc_stem_residual_bn_add (bf16): cpc_bn_apply (+ReLU) of the block's second BatchNorm and cpc_stem_residual_add in one pass — y is the
  * BatchNorm's INPUT grid; out = act(bf16(relu(BatchNorm(y))) + wr xp(w + ow, h + oh)); bits (may be NULL): the sign bits of the normalised branch,
- * addressed like its activation grid ga (what the BatchNorm's backward pass reads).  Bit-identical to the two passes. */
+ * addressed like its activation grid ga (what the BatchNorm's backward pass reads); obits (may be NULL): the sign bits of out, addressed like out.
+ * Bit-identical to the two passes. */
 int cpc_stem_residual_bn_add(const void* y, const int* gy, const float* xp, const int* gp, const float* wr, void* out, const int* go, int oh, int ow,
-                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga, int dtype,
-                             void* stream);
+                             int relu, const float* stats, const float* gamma, const float* beta, unsigned char* bits, const int* ga,
+                             unsigned char* obits, int dtype, void* stream);
+/* cpc_stem_residual_wgrad_bits (bf16): the projection's weight-gradient slabs of cpc_stem_residual_bwd with the ReLU mask taken from obits (the
+ * sign bits of out that cpc_stem_residual_bn_add wrote, addressed like out) and WITHOUT storing the masked gradient: cpc_bn_bwd_*_res read dout
+ * and the same bits.  gm: the main branch's grid (geometry only). */
+int cpc_stem_residual_wgrad_bits(const void* dout, const unsigned char* obits, const int* go, const int* gm, const float* xp, const int* gp,
+                                 float* slabs, int oh, int ow, int nblocks, int dtype, void* stream);
 int cpc_stem_residual_add(const void* main_, const int* gm, const float* xp, const int* gp, const float* wr, void* out, const int* go,
                           int oh, int ow, int relu, int dtype, void* stream);
 int cpc_stem_residual_bwd(const void* dout, const void* out, const int* go, void* dmain, const int* gm, const float* xp, const int* gp,
