@@ -37,7 +37,8 @@ extern "C" {
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
 /* 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
- * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_stem_residual_bn_add.
+ * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
+ * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
  * 6: the stem kernels (cpc_stem_*), sign-bit BatchNorm passes (cpc_bn_*_bits), cpc_gru_fwd_h0.
  * 5 since the gradient-penalty entry points (cpc_gru_gp_*, cpc_ln_tangent / cpc_ln_gp, cpc_attn_tangent / cpc_attn_gp,
  * cpc_gp_score_coeff) were added; 4: per-tile column sums of the data gradients; 3: sign-bit masks; 2: over-read contract. */
