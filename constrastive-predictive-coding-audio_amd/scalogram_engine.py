@@ -1672,6 +1672,7 @@ class _ArBlock:
                           self.pool * self.stride, 0, code)
             if self.res_conv is not None:
                 self.res_conv.forward()
+            self._fused_bwd = fuse and os.environ.get("CPC_BN_RESIDUAL_BWD", "1") != "0"
             if fuse:
                 self.bn.apply_residual(self.res, self.out, self.oh, 0, 0, 0)
             else:
@@ -1705,11 +1706,14 @@ class _ArBlock:
 
     def backward(self):
         code = self.eng.code
-        if self.residual:
+        fused_bwd = self.residual and getattr(self, "_fused_bwd", False)
+        if self.residual and not fused_bwd:
             # (d_res was zeroed when it was allocated; the cropped add's backward overwrites the same interior every step)
             _hip.call("cpc_residual_add_bwd", self.d_out.ptr(), self.out.ptr(), _desc(self.out, self.out.desc), self.d_main.ptr(),
                       _desc(self.d_main, self.d_main.desc), self.d_res.ptr(), _desc(self.d_res, self.d_res.desc), self.oh, 0, 0, 0, code)
-        if self.bn is not None:
+        if fused_bwd:      # the add's backward inside the BatchNorm's passes (no ReLU behind the add in a ConvolutionalArBlock: no output mask)
+            self.bn.backward_res(self.d_out, None, self.d_res, self.oh, 0)
+        elif self.bn is not None:
             self.bn.backward(self.d_main)
         else:
             _hip.call("cpc_relu_mask", self.d_main.ptr(), self.main.ptr(), self.d_main.rows * self.d_main.C, code)
