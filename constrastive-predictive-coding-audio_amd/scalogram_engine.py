@@ -166,7 +166,8 @@ class _Conv:
                 self.Mw = self.ncol * self.Hg if self.valid_rows else self.M
                 self.nsplit = eng._pick_split(self.K, self.cout, self.Mw)
                 self.slab = self.nsplit * self.K * self.cout
-            self.bands = self._bands(int(os.environ.get("CPC_DGRAD_BAND", "1"))) if (self.valid_rows and need_dgrad) else None
+            rb = int(os.environ.get(f"CPC_DGRAD_BAND_K{self.kh}", os.environ.get("CPC_DGRAD_BAND", "1")))      # (per kernel height for A/B runs)
+            self.bands = self._bands(rb) if (self.valid_rows and need_dgrad) else None
         else:
             o_top, o_tail, o_guard = out_pad if out_pad is not None else (0, 0, 96)
             # Data gradient of a 3x3 stride-2 convolution WITHOUT the im2col-gradient matrix (_dgrad_parity below; CPC_DGRAD_PARITY=0: off): needs
