@@ -34,6 +34,16 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   cpu_baseline  the CPU oracle (oracle/cpc_oracle.py, kind "port") timed on this host: CPU model, core count, 3 warm-up + median
                 of 10 steps, and the same under autograd anomaly detection (how the reference's train() runs).
   n_ranks_seen  (N > 1) ranks that took part in the run's collectives.
+  ms_per_step_median / _max / first_timed_step_ms / slowest_timed_step    the K timed steps one by one: one HIP event per step boundary
+                (device-side interval between consecutive boundaries) — a single stall shows up here, the mean hides it.
+  secondary     (default run, N = 1) BASELINE configs[2] / configs[3] — scalogram, conv_ar, attention — each with the same W / K protocol in
+                this process after the headline region: {ms_per_step, clips_per_s, roofline.frac, loss_last_step, ...}.
+  data_parallel (N > 1) what a poor scaling number would need explained: per-rank ms_per_step, the main stream's exposed wait for the
+                gradient all-reduce (HIP events around GradAllReduce.finish() on the sampled steps), the bucket plan and its bytes.
+
+Timed region = exactly K steps.  Everything a timed step does has run before it: the optimizer's prepare_ahead callback and the kernel
+timer are installed BEFORE the warm-up, the last warm-up step is a sampled (event-bracketed) step, and the per-step events exist before
+t0 (round 3's driver run lost 41 ms once, at the head of the timed loop, to first-use work that only the timed region did).
 """
 import argparse
 import json
@@ -49,6 +59,66 @@ if ROOT not in sys.path:
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 DOMINANT = "gemm_nt<bf16,bf16,256>"      # = gemm_nt_fast_kernel<bf16, bf16, 2, 4, 8, 4> (256x256 tile)
+
+
+
+class StepClock:
+    """One host timestamp and one HIP event per step boundary (n steps -> n + 1 marks; the events are created up front)."""
+
+    def __init__(self, n):
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        self.host = [0.0] * (n + 1)
+        self.i = 0
+
+    def mark(self):
+        self.host[self.i] = time.perf_counter()
+        self.ev[self.i].record()
+        self.i += 1
+
+    def stats(self):
+        """Call after a synchronize.  Device-side interval between consecutive step boundaries + the host's enqueue time per step."""
+        n = self.i - 1
+        if n <= 0:
+            return {}
+        dev = [self.ev[i].elapsed_time(self.ev[i + 1]) for i in range(n)]
+        host = [(self.host[i + 1] - self.host[i]) * 1e3 for i in range(n)]
+        srt = sorted(dev)
+        med = 0.5 * (srt[(n - 1) // 2] + srt[n // 2])
+        worst = max(range(n), key=lambda i: dev[i])
+        return {"ms_per_step_median": round(med, 3), "ms_per_step_max": round(dev[worst], 3), "slowest_timed_step": worst,
+                "first_timed_step_ms": round(dev[0], 3), "ms_per_step_min": round(srt[0], 3),
+                "host_enqueue_ms_max": round(max(host), 3), "host_enqueue_ms_first": round(host[0], 3)}
+
+
+def timed_run(step, steps, warmup, timer, every, fence):
+    """The driver's protocol: `warmup` untimed steps, then exactly `steps` timed ones between two fences.  The warm-up runs the SAME code as
+    the timed loop — step clock marks, and its last step with the kernel timer active — so that no allocation, event kind, library page or
+    Python path is used for the first time inside the timed region.  Returns (out, elapsed_s, host_enqueue_s, clock)."""
+    wclock = StepClock(warmup)
+    wclock.mark()
+    for i in range(warmup):
+        timer.active = (i == warmup - 1)
+        step(i)
+        wclock.mark()
+    fence()
+    if warmup:
+        wclock.stats()
+    timer.reset()
+    clock = StepClock(steps)
+    sample_at = every // 2
+    out = None
+    fence()
+    t0 = time.perf_counter()
+    clock.mark()
+    for i in range(steps):
+        timer.active = (i % every == sample_at)
+        out = step(i)
+        clock.mark()
+    host_enqueue = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.active = False
+    return out, elapsed, host_enqueue, clock
 
 
 def build_model(dtype, device, seed=0):
@@ -282,12 +352,13 @@ def cpu_baseline_secondary(name, wl):
                       f"threads, {med * 1e3:.0f} ms/step"}
 
 
-def run_secondary(args, world, rank, device, dist):
-    """--workload scalogram / conv_ar / attention: the same protocol and JSON line as the headline workload."""
+def measure_secondary(name, args, world, rank, device, dist, brief=False):
+    """One of --workload scalogram / conv_ar / attention under the headline's protocol; returns the JSON line as a dict (rank 0; None on
+    the other ranks).  brief: without the per-kernel pass and the CPU baseline — the form the default run carries under `secondary`."""
     from cpc_audio_amd import _hip
     from cpc_audio_amd.engine import FusedAdam, GradAllReduce
-    B = args.batch
-    wl = secondary_workload(args.workload, args.dtype, device, B)
+    B = args.batch if name == args.workload and args.batch else (128 if name == "scalogram" else 256)
+    wl = secondary_workload(name, args.dtype, device, B)
     model = wl.model
     gen = torch.Generator().manual_seed(1000 + rank)
     pool = [(torch.randn(B, wl.L, generator=gen) * wl.amp).to(device) for _ in range(2)]
@@ -318,35 +389,27 @@ def run_secondary(args, world, rank, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.prewarm + args.warmup):
-        step(i)
-    fence()
     # In the timed region only the launches of the dominant GEMM symbol are bracketed with HIP events, in about four sampled steps (an
     # event pair costs ~12 us of idle queue: bracketing all ~290 launches of a configs[2] step made the sampled steps 3 - 5 ms longer and
     # the reported step 0.8 ms).  The per-kernel table (`kernels`, --breakdown) comes from three extra steps AFTER the timed region.
     dom_name = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"
     timer = _hip.KernelTimer(only=[dom_name])
+    timer.active = False
     _hip.set_timer(timer)
     every = max(1, args.steps // 4)
-    sampled = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.active = (i % every == 0)
-        sampled += 1 if timer.active else 0
-        out = step(i)
-    host_enqueue = time.perf_counter() - t0          # the host's share: how long issuing the K steps took (no device wait inside)
-    fence()
-    elapsed = time.perf_counter() - t0
+    out, elapsed, host_enqueue, clock = timed_run(step, args.steps, args.prewarm + args.warmup, timer, every, fence)
+    sampled = len([i for i in range(args.steps) if i % every == every // 2])
     _hip.set_timer(None)
     loss = float(out[0])
     dom_summary = timer.summary().get(dom_name)
+    full_steps = 0 if brief else 3
     full = _hip.KernelTimer(only=None, by_shape=args.breakdown)
-    _hip.set_timer(full)
-    full_steps = 3
-    for i in range(full_steps):
-        step(args.steps + i)
-    fence()
-    _hip.set_timer(None)
+    if full_steps:
+        _hip.set_timer(full)
+        for i in range(full_steps):
+            step(args.steps + i)
+        fence()
+        _hip.set_timer(None)
     n_ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -356,8 +419,8 @@ def run_secondary(args, world, rank, device, dist):
         dist.all_reduce(ones)
         n_ranks_seen = int(ones.item())
     if rank != 0:
-        return
-    summary = full.summary()
+        return None
+    summary = full.summary() if full_steps else {}
     rows = sorted(summary.items(), key=lambda kv: -kv[1][1])
     total_ms = sum(v[1] for _, v in rows)
     gemms = [(k.split(" ")[0], v) for k, v in rows if v[2] > 0 and k.startswith("gemm_")]
@@ -373,6 +436,7 @@ def run_secondary(args, world, rank, device, dist):
         "warmup": args.warmup,
         "prewarm_steps": args.prewarm,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        **clock.stats(),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -388,26 +452,62 @@ def run_secondary(args, world, rank, device, dist):
         line["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                             "traffic": None, "kernel": dom_key, "launches": cnt, "avg_launch_ms": round(ms / cnt, 4),
                             "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
-                            "ms_per_step": round(ms / sampled, 4),
+                            "ms_per_step": round(ms / max(sampled, 1), 4),
                             "note": "HIP events around the launches of this symbol in the sampled steps of the timed region (executed FLOPs "
-                                    "booked per launch); it is the GEMM symbol with the largest summed time in the per-kernel pass"
-                                    + ("" if largest == dom_key or args.breakdown else f" -- NOT so in this run: {largest}")}
-    line["kernels"] = [{"kernel": k, "launches_per_step": round(v[0] / full_steps, 1), "ms_per_step": round(v[1] / full_steps, 4),
-                        **({"tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} if v[2] > 0 and v[1] > 0 else {})}
-                       for k, v in rows if v[1] >= 0.02 * total_ms]
-    line["kernels_note"] = (f"every launch of {full_steps} extra steps AFTER the timed region bracketed with HIP events (not part of ms_per_step; the "
-                            "brackets stretch those steps, the kernel durations are the step's)")
-    line["event_timed_ms_per_step"] = round(total_ms / full_steps, 3)
+                                    "booked per launch)"
+                                    + ("" if (brief or largest == dom_key or args.breakdown) else
+                                       f"; the GEMM symbol with the largest summed time in the per-kernel pass is {largest}")}
     line["host_enqueue_ms_per_step"] = round(host_enqueue / args.steps * 1e3, 3)
+    if full_steps:
+        line["kernels"] = [{"kernel": k, "launches_per_step": round(v[0] / full_steps, 1), "ms_per_step": round(v[1] / full_steps, 4),
+                            **({"tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} if v[2] > 0 and v[1] > 0 else {})}
+                           for k, v in rows if v[1] >= 0.02 * total_ms]
+        line["kernels_note"] = (f"every launch of {full_steps} extra steps AFTER the timed region bracketed with HIP events (not part of ms_per_step; "
+                                "the brackets stretch those steps, the kernel durations are the step's)")
+        line["event_timed_ms_per_step"] = round(total_ms / full_steps, 3)
     if args.breakdown:
         for k, (cnt, kms, w) in rows:
             tf = f"{w / (kms * 1e-3) / 1e12:8.1f} TF/s" if w > 0 and kms > 0 else ""
             print(f"#   {k:70s} {cnt / full_steps:6.1f}/step {kms / full_steps:9.4f} ms/step {tf}", file=sys.stderr)
     if world > 1:
         line["n_ranks_seen"] = n_ranks_seen
-    if not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline_secondary(args.workload, wl)
-    print(json.dumps(line), flush=True)
+    if not brief and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_secondary(name, wl)
+    return line
+
+
+def run_secondary(args, world, rank, device, dist):
+    """--workload scalogram / conv_ar / attention: the same protocol and JSON line as the headline workload."""
+    line = measure_secondary(args.workload, args, world, rank, device, dist)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def secondary_block(args, device):
+    """`secondary` of the default line: BASELINE configs[2] / configs[3] with the same W / K protocol, one after the other in this process
+    (fresh engines; the allocator's cache is emptied in between).  A failure is reported in place, it never takes the headline down."""
+    import gc
+    out = {}
+    for name in ("scalogram", "conv_ar", "attention"):
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            t0 = time.perf_counter()
+            ln = measure_secondary(name, args, 1, 0, device, None, brief=True)
+            cfg = ln["config"]
+            out[name] = {"workload": cfg["workload"], "ms_per_step": ln["ms_per_step"], "ms_per_step_median": ln.get("ms_per_step_median"),
+                         "ms_per_step_max": ln.get("ms_per_step_max"), "first_timed_step_ms": ln.get("first_timed_step_ms"),
+                         "frames_per_s": ln["value"], "clips_per_s": cfg["clips_per_s"], "global_batch": cfg["global_batch"],
+                         "clip_samples": cfg["clip_samples"], "loss_last_step": cfg["loss_last_step"],
+                         "host_enqueue_ms_per_step": ln["host_enqueue_ms_per_step"],
+                         "roofline": {k: ln["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches",
+                                                                       "avg_launch_ms", "ms_per_step")} if "roofline" in ln else None,
+                         "steps": ln["steps"], "warmup": ln["warmup"], "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:          # noqa: BLE001 -- reported, not raised
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_command(n, argv, port=None):
@@ -452,6 +552,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trainer-loop", action="store_true", help="skip the extra run through ContrastiveEstimationTrainer.train")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[2] / configs[3] workloads the default N = 1 run measures after the headline region")
     ap.add_argument("--no-score-gemm", action="store_true",
                     help="skip the stand-alone score-GEMM timings (profiling runs: their launches share the dominant kernel's symbol)")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel (diagnostic run; not the headline number)")
@@ -506,8 +608,23 @@ def main():
 
     sync = GradAllReduce(model, optimizer=opt) if world > 1 else None      # Adam follows each reduced piece of the gradient
     opt.skip_flag = eng.nan_flag()          # the trainer's device-side NaN guard is part of the measured step
-
     graphed = GraphedStep(eng, opt, True, 1.0, args.all_timesteps) if use_graph else None
+    if graphed is None and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
+        opt.after_update = eng.prepare_ahead      # next step's operand copies rebuilt beside the rest of the backward pass; installed
+        #                                           BEFORE the warm-up, as the trainer does: its buffers and side-stream launches are warm
+
+    # event-timed kernels: the dominant MFMA kernel (`roofline`: the 256 x 256 bf16 NT GEMM in its three epilogue forms -- register epilogue
+    # (conv forward), LDS-staged masked epilogue (data gradients) and the fused layer-2 data gradient / layer-1 weight gradient) and the
+    # HBM-bound layer-1 forward (`hbm_kernel`)
+    dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"
+    dom_keys = [dom, dom.replace("gemm_nt<", "gemm_nt_conv1<")]
+    timer = _hip.KernelTimer(only=None if args.breakdown else dom_keys + ["cpc_conv1_fwd"], by_shape=args.breakdown)
+    timer.active = False
+    _hip.set_timer(timer)
+    # in sampled steps of the timed region (one in `every`, about five) the dominant launches are bracketed with HIP events: an event pair
+    # costs ~12 us of idle queue per launch, 0.12 - 0.15 ms per bracketed step.  N > 1: the same steps also bracket GradAllReduce.finish().
+    every = 1 if args.breakdown else max(1, args.steps // 5)
+    exposed = []
 
     def step(i):
         if graphed is not None:
@@ -516,7 +633,14 @@ def main():
                                  grad_ready_hook=sync.hook if sync is not None else opt.hook,
                                  after_loss=sync.reduce_flag if sync is not None else None)
         if sync is not None:
-            sync.finish()                       # RCCL all-reduce (sum) of the flat gradient buffer: overlapped pieces + the head
+            if timer.active:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sync.finish()                   # RCCL all-reduce (sum) of the flat gradient buffer: overlapped pieces + the head
+                e1.record()
+                exposed.append((e0, e1))
+            else:
+                sync.finish()
         opt.step(grad_scale=1.0 / world)
         return out
 
@@ -525,41 +649,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.prewarm):             # clock ramp (see --prewarm); not part of W, not timed, reported in the JSON line
-        step(i)
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    # event-timed kernels: the dominant MFMA kernel (`roofline`) and the HBM-bound layer-1 forward (`hbm_kernel`)
-    timer = _hip.KernelTimer(only=None if args.breakdown else [DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>",
-                                                              "cpc_conv1_fwd"],
-                             by_shape=args.breakdown)
-    _hip.set_timer(timer)
-    # the dominant kernel's launches are event-timed in every `every`-th step of the timed region (about five sampled steps, 45 - 50
-    # launches): an event pair costs ~12 us of idle queue per launch, 0.12 - 0.15 ms per bracketed step
-    every = 1 if args.breakdown else max(1, args.steps // 5)
-    if graphed is None and os.environ.get("CPC_PREPARE_AHEAD", "1") != "0":
-        opt.after_update = eng.prepare_ahead      # next step's operand copies rebuilt beside the rest of the backward pass
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.active = (i % every == 0)
-        out = step(i)
-    host_enqueue = time.perf_counter() - t0          # the host's share: how long issuing the K steps took (no device wait inside)
-    fence()
-    elapsed = time.perf_counter() - t0
+    out, elapsed, host_enqueue, clock = timed_run(step, args.steps, args.prewarm + args.warmup, timer, every, fence)
+    if sync is not None and args.prewarm + args.warmup:
+        exposed = exposed[1:]                   # the first pair belongs to the sampled warm-up step
     _hip.set_timer(None)
     loss = float(out[0])
+    step_stats = clock.stats()
     # The encoder's weight-gradient GEMMs run on a second stream beside the dominant kernel's launches (engine.py,
     # CPC_WGRAD_STREAM), so a launch's duration in the step includes the share of the chip it gives up.  A short extra pass AFTER
     # the timed region, with everything on one stream, gives the same kernel's figures alone (`roofline.alone`).
-    alone = None
-    if graphed is None and args.dtype == "bf16" and os.environ.get("CPC_WGRAD_STREAM", "1") != "0":
+    alone, step_gemm_flops = None, 0.0
+    if graphed is None and args.dtype == "bf16" and os.environ.get("CPC_WGRAD_STREAM", "1") != "0" and not args.breakdown:
         prev = os.environ.get("CPC_WGRAD_STREAM")
         os.environ["CPC_WGRAD_STREAM"] = "0"
         try:
             for i in range(3):
                 step(i)
-            t_alone = _hip.KernelTimer(only=[DOMINANT])
+            t_alone = _hip.KernelTimer(only=dom_keys)
             _hip.set_timer(t_alone)
             t_alone.active = True
             for i in range(6):
@@ -567,9 +673,17 @@ def main():
             fence()
             _hip.set_timer(None)
             sa = t_alone.summary()
-            na = sum(v[0] for k, v in sa.items() if k.startswith(DOMINANT))
-            msa = sum(v[1] for k, v in sa.items() if k.startswith(DOMINANT))
-            fla = sum(v[2] for k, v in sa.items() if k.startswith(DOMINANT))
+            # one more step with every launch booked: the FLOPs of ALL GEMM launches of a step (NT forward / data gradients, TN weight
+            # gradients, GRU and predictor products) -> `whole_step` = those FLOPs over the timed region's ms_per_step
+            t_all = _hip.KernelTimer(only=None)
+            _hip.set_timer(t_all)
+            step(0)
+            fence()
+            _hip.set_timer(None)
+            step_gemm_flops = sum(v[2] for k, v in t_all.summary().items() if k.startswith("gemm_"))
+            na = sum(v[0] for k, v in sa.items() if k in dom_keys)
+            msa = sum(v[1] for k, v in sa.items() if k in dom_keys)
+            fla = sum(v[2] for k, v in sa.items() if k in dom_keys)
             if na and msa > 0:
                 alone = {"achieved": round(fla / (msa * 1e-3) / 1e12, 2), "avg_launch_ms": round(msa / na, 4), "launches": na}
         finally:
@@ -578,23 +692,37 @@ def main():
             else:
                 os.environ["CPC_WGRAD_STREAM"] = prev
     n_ranks_seen = 1
+    dp = None
     if world > 1:
+        mine = elapsed
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                     # how many ranks actually took part in the collectives of this run
         n_ranks_seen = int(ones.item())
+        torch.cuda.synchronize()
+        exp_ms = [a.elapsed_time(b) for a, b in exposed]
+        # one row per rank: [ms_per_step (this rank's own clock between its fences), median step (HIP events), slowest step, host enqueue,
+        #                    exposed all-reduce wait on the sampled steps]
+        row = torch.tensor([mine / args.steps * 1e3, step_stats.get("ms_per_step_median", 0.0), step_stats.get("ms_per_step_max", 0.0),
+                            host_enqueue / args.steps * 1e3, sum(exp_ms) / len(exp_ms) if exp_ms else -1.0], device=device, dtype=torch.float64)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        rows = [r.tolist() for r in rows]
+        dp = data_parallel_report(sync, rows, len(exp_ms))
 
     summary = timer.summary()
     if rank == 0:
         frames = B * T * world * args.steps
-        dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"
-        n = sum(v[0] for k, v in summary.items() if k.startswith(dom))
-        ms = sum(v[1] for k, v in summary.items() if k.startswith(dom))
-        flops = sum(v[2] for k, v in summary.items() if k.startswith(dom))
+        per_key = {k: summary[k] for k in dom_keys if k in summary} if not args.breakdown else \
+            {k: v for k, v in summary.items() if k.split(" ")[0] in dom_keys}
+        n = sum(v[0] for v in per_key.values())
+        ms = sum(v[1] for v in per_key.values())
+        flops = sum(v[2] for v in per_key.values())
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        sampled = len([i for i in range(args.steps) if i % every == every // 2])
         # HBM-side bytes per launch of the dominant kernel: NOT a quantity of this run — PMC counters need their own rocprofv3
         # passes (MI355X_MICROARCH.md, HBM section); the committed summary of the latest such pass is quoted and labelled
         traffic, traffic_source = None, None
@@ -615,6 +743,7 @@ def main():
             "warmup": args.warmup,
             "prewarm_steps": args.prewarm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            **step_stats,
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
@@ -629,16 +758,29 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "kernel": "gemm_nt_fast_kernel<bf16,bf16,2,4,8,4>" if args.dtype == "bf16" else "gemm_nt_fast_kernel<f32,f32,2,2,4,4>",
+                         "kernel": ("gemm_nt_fast_kernel<bf16,bf16,2,4,8,4,...> (all three epilogue forms: conv forward, masked data gradients, "
+                                    "fused layer-2 data gradient + layer-1 weight gradient)") if args.dtype == "bf16"
+                         else "gemm_nt_fast_kernel<f32,f32,2,2,4,4>",
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
-                         "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None},
+                         "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3) if n else None,
+                         "ms_per_step": round(ms / max(sampled, 1), 4),
+                         "frac_of_step_time": round(ms / max(sampled, 1) / (elapsed / args.steps * 1e3), 3),
+                         "symbols": {k: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 4), "gflop_per_launch": round(v[2] / v[0] / 1e9, 2),
+                                         "achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 4)}
+                                     for k, v in per_key.items() if v[0] and v[1] > 0}},
         }
         if alone is not None:
             alone["frac"] = round(alone["achieved"] / peak, 4)
             line["roofline"]["alone"] = alone
             line["roofline"]["note"] = ("achieved / frac: the launches as they run in the timed step, beside the weight-gradient GEMMs on a "
-                                        "second stream; alone: the same kernel with everything on one stream (6 untimed steps after the "
+                                        "second stream; alone: the same kernels with everything on one stream (6 untimed steps after the "
                                         "timed region, CPC_WGRAD_STREAM=0)")
+        if step_gemm_flops > 0:
+            tf = step_gemm_flops / (elapsed / args.steps) / 1e12
+            line["whole_step"] = {"gemm_tflop_per_step": round(step_gemm_flops / 1e12, 3), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                                  "peak": peak, "frac": round(tf / peak, 4),
+                                  "note": "executed FLOPs of every GEMM launch of one step (NT and TN forms) over ms_per_step: the matrix pipe's "
+                                          "share of the whole step, GRU recurrence / layer 1 / loss / Adam time included in the denominator"}
         c1 = [v for k, v in summary.items() if k.startswith("cpc_conv1_fwd")]
         if c1 and sum(v[1] for v in c1) > 0:
             # encoder layer 1 (C_in = 1): writes its [B][L_alloc][512] output once, reads 4 B per input sample
@@ -669,12 +811,32 @@ def main():
                                         f"{n_logged} logged steps (first 10 discarded)")
         if world > 1:
             line["n_ranks_seen"] = n_ranks_seen
+            line["data_parallel"] = dp
+        if world == 1 and args.dtype == "bf16" and not args.no_secondary and not args.breakdown and not args.all_timesteps and graphed is None:
+            # BASELINE configs[2] / configs[3] under the same W / K protocol, in this process, after the headline region
+            del graphed, sync, opt, eng, model, pool
+            line["secondary"] = secondary_block(args, device)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def data_parallel_report(sync, rows, n_sampled):
+    """`data_parallel` of an N > 1 line: one entry per rank (its own ms per step, median / slowest step by HIP events, host enqueue time,
+    exposed all-reduce wait) and the bucket plan of engine.GradAllReduce (flat-gradient ranges in the order their reductions are issued)."""
+    plan = sync.describe()
+    return {"per_rank_ms_per_step": [round(r[0], 3) for r in rows],
+            "per_rank_ms_per_step_median": [round(r[1], 3) for r in rows],
+            "per_rank_ms_per_step_max": [round(r[2], 3) for r in rows],
+            "per_rank_host_enqueue_ms_per_step": [round(r[3], 3) for r in rows],
+            "allreduce_exposed_ms_per_step": [round(r[4], 4) for r in rows],
+            "allreduce_exposed_note": (f"main-stream time of GradAllReduce.finish() on {n_sampled} sampled steps (HIP events): the wait for the last "
+                                       "overlapped bucket + the reduction of the head of the buffer + Adam on the buckets finished there; "
+                                       "everything else travels under the backward pass"),
+            **plan}
 
 
 if __name__ == "__main__":

@@ -1618,6 +1618,21 @@ class GradAllReduce:
         # gradients (default), 1 where the shard gradients add up (global negatives).
         self.optimizer = optimizer
         self.grad_scale = (1.0 / self.world) if grad_scale is None else float(grad_scale)
+        self._plan, self.last_plan = [], []       # flat-gradient ranges in the order their reductions were issued (this step / last finished step)
+
+    def describe(self):
+        """The bucket plan of the last finished step, for a run's report (bench.py `data_parallel`): every range of the flat gradient buffer
+        with its bytes and where its reduction is issued; ``covers_once`` says that the ranges tile the buffer exactly once."""
+        flat = self.model._flat_grad
+        esz, total = flat.element_size(), flat.numel()
+        plan = list(self.last_plan)
+        edges, ok = 0, True
+        for lo, hi, _ in sorted(plan):
+            ok = ok and lo == edges and hi > lo
+            edges = hi
+        return {"grad_bytes": total * esz, "world": self.world,
+                "buckets": [{"lo": lo, "hi": hi, "bytes": (hi - lo) * esz, "issued": where} for lo, hi, where in plan],
+                "covers_once": bool(ok and edges == total)}
 
     def reduce_flag(self, nce_out):
         """Pass as ``after_loss``: the sticky NaN flag (nce_out[6]) becomes the MAXIMUM over the ranks (and the step's indicator
@@ -1643,6 +1658,7 @@ class GradAllReduce:
         if self.optimizer is not None:
             self._apply_finished()          # pieces issued at earlier hook calls (reduced while the backward pass went on)
         self.split = lo if self.split is None else min(self.split, lo)
+        self._plan.append((lo, hi, "backward hook (overlapped)"))
         self.pending.append((self.dist.all_reduce(self.model._flat_grad[lo:hi], async_op=True), lo, hi))
 
     def finish(self):
@@ -1652,8 +1668,10 @@ class GradAllReduce:
         rest = flat if self.split is None else flat[:self.split]
         self._apply_finished()
         if rest.numel():
+            self._plan.append((0, rest.numel(), "finish() (after the backward pass)"))
             self.dist.all_reduce(rest, async_op=True).wait()
         self.split = None
+        self.last_plan, self._plan = self._plan, []
 
 
 class FusedAdam:

@@ -236,12 +236,25 @@ for step in range(3):
     assert torch.equal(m._flat_grad, torch.full((100,), total))        # head [0, 20) reduced by finish(); step() updates it
     assert sync.pending == [] and sync.split is None
     assert nce_out[5:7].tolist() == ([1.0, 1.0] if step == 1 else [0.0, 0.0])
+    # the bucket plan a data-parallel bench line reports (bench.py `data_parallel`): every range once, nothing twice
+    d = sync.describe()
+    assert [(b["lo"], b["hi"]) for b in d["buckets"]] == [(60, 100), (20, 60), (0, 20)] and d["covers_once"], d
+    assert d["grad_bytes"] == 400 and sum(b["bytes"] for b in d["buckets"]) == 400 and d["world"] == world
 # without an optimizer: plain overlapped reduction
 m._flat_grad = torch.full((100,), float(rank + 1))
 sync = GradAllReduce(m)
 sync.hook(50, 100)
 sync.finish()
 assert torch.equal(m._flat_grad, torch.full((100,), total))
+assert sync.describe()["covers_once"]
+# the report bench.py builds from it: one entry per rank and the plan
+sys.path.insert(0, sys.argv[1])
+import bench
+rep = bench.data_parallel_report(sync, [[5.0, 4.9, 6.0, 0.8, 0.05]] * world, 4)
+for key in ("per_rank_ms_per_step", "per_rank_ms_per_step_median", "per_rank_ms_per_step_max", "per_rank_host_enqueue_ms_per_step",
+            "allreduce_exposed_ms_per_step"):
+    assert len(rep[key]) == world, key
+assert rep["grad_bytes"] == 400 and rep["covers_once"] and len(rep["buckets"]) == 2
 if rank == 0:
     print("PIECES-OK")
 dist.destroy_process_group()
