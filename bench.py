@@ -87,13 +87,22 @@ class StepClock:
         worst = max(range(n), key=lambda i: dev[i])
         return {"ms_per_step_median": round(med, 3), "ms_per_step_max": round(dev[worst], 3), "slowest_timed_step": worst,
                 "first_timed_step_ms": round(dev[0], 3), "ms_per_step_min": round(srt[0], 3),
-                "host_enqueue_ms_max": round(max(host), 3), "host_enqueue_ms_first": round(host[0], 3)}
+                "host_enqueue_ms_max": round(max(host), 3), "host_enqueue_slowest_step": max(range(n), key=lambda i: host[i]),
+                "host_enqueue_ms_median": round(sorted(host)[n // 2], 3), "host_enqueue_ms_first": round(host[0], 3)}
 
 
 def timed_run(step, steps, warmup, timer, every, fence):
     """The driver's protocol: `warmup` untimed steps, then exactly `steps` timed ones between two fences.  The warm-up runs the SAME code as
     the timed loop — step clock marks, and its last step with the kernel timer active — so that no allocation, event kind, library page or
     Python path is used for the first time inside the timed region.  Returns (out, elapsed_s, host_enqueue_s, clock)."""
+    # Python's cyclic garbage collector: a full (generation 2) collection walks every tracked object of the process — 38 - 43 ms here, with
+    # torch's module trees alive — and lands wherever the allocation count happens to cross its threshold.  It is what round 3's driver run
+    # lost at the head of its timed loop, and what runs with other allocation histories lost (or did not) elsewhere.  Everything alive now
+    # is long-lived: collect once, BEFORE the warm-up (the GPU is idle anyway), and move it to the permanent generation, so that later
+    # collections only look at what the steps allocate.  The trainer's own loop does the same (ContrastiveEstimationTrainer.train).
+    import gc
+    gc.collect()
+    gc.freeze()
     wclock = StepClock(warmup)
     wclock.mark()
     for i in range(warmup):
@@ -104,6 +113,7 @@ def timed_run(step, steps, warmup, timer, every, fence):
     if warmup:
         wclock.stats()
     timer.reset()
+    gc.freeze()          # (what the warm-up created — events, timer records — joins the permanent generation: no walk, no pause)
     clock = StepClock(steps)
     sample_at = every // 2
     out = None
@@ -178,6 +188,16 @@ def cpu_baseline():
                       f"set_detect_anomaly(True), as the reference's train() runs"}
 
 
+def _hip_call(*a, **k):
+    from cpc_audio_amd import _hip
+    return _hip.call(*a, **k)
+
+
+def _hip_ptr(t):
+    from cpc_audio_amd import _hip
+    return _hip.ptr(t)
+
+
 def score_gemm_figures(eng, launches=50):
     """HIP-event time of the InfoNCE score contraction (contrastive_estimation_training.py:12-22) on the engine's own buffers:
     the equal-step form the default branch runs (K batched B x E x B products) and the full (B K) x E x (B K) form of
@@ -198,6 +218,30 @@ def score_gemm_figures(eng, launches=50):
         tf = flops / (us * 1e-6) / 1e12
         out[name] = {"shape": shape, "gflop": round(flops / 1e9, 3), "us_per_launch": round(us, 2), "achieved": round(tf, 1),
                      "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+    if eng.fused_scores_ok():
+        # the all-timesteps contraction as the train step runs it since round 4: column log-sum-exp pairs + diagonal + bf16 scores from one launch
+        import ctypes as C
+        R, E = eng.B * eng.K, eng.E
+        fs = lambda n, dt=torch.float32: torch.empty(n, device=eng.device, dtype=dt)
+        pm, ps, valid, sb = fs(R // 256 * R), fs(R // 256 * R), fs(R), fs(R * R)
+        tg = fs(R * E, eng.dt).normal_()
+        run = lambda: _hip_call("cpc_score_lse", _hip_ptr(eng.pred), _hip_ptr(tg), _hip_ptr(sb), _hip_ptr(pm), _hip_ptr(ps), _hip_ptr(valid), R, R, E,
+                                C.c_longlong(E), C.c_longlong(E), C.c_longlong(R), 0)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / launches
+        tf = 2.0 * R * R * E / (us * 1e-6) / 1e12
+        out["all_timesteps_fused"] = {"shape": f"{R} x {E} x {R} + column log-sum-exp pairs + f32 scores", "gflop": round(2.0 * R * R * E / 1e9, 3),
+                                      "us_per_launch": round(us, 2), "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS,
+                                      "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                      "note": "replaces two f32-output score GEMMs and the split column pass of the unfused path"}
     out["note"] = ("back-to-back launches (includes the launch-to-launch gap); one launch per train step in the product path.  The north "
                    "star's >= 50 % MFMA target is DEFINED on global_8gpu: at B = 256 one launch is 0.8 / 9.7 GFLOP on 256 CUs, i.e. bound by "
                    "its prologue / epilogue latency, not by the matrix pipe")
@@ -236,6 +280,43 @@ def global_score_gemm(eng, launches=10):
                      "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "output_gb": round(out_gb, 2),
                      "output_tb_per_s": round(out_gb / ms, 2)}
         del c
+    # the same contraction with the column log-sum-exp pairs taken in the GEMM's epilogue (cpc_score_lse, what the all-timesteps loss runs
+    # on since round 4): ONE f32 score matrix instead of two (or none, 'no_scores': the rate of GEMM + column pairs alone).  And what ONE RANK of an
+    # 8-GPU global-negatives step computes since the strips (engine.GlobalNegatives._all_timesteps_strips): 1 / 8 of the columns.
+    import ctypes as C
+    P, L = _hip.ptr, C.c_longlong
+    pm = torch.empty(R // 256, R, device=dev)
+    ps = torch.empty(R // 256, R, device=dev)
+    valid = torch.zeros(R, device=dev)
+
+    def timed(run, n=launches):
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    for name, keep in (("fused_lse_f32_scores", True), ("fused_lse_no_scores", False)):
+        sb = torch.empty(R * R, device=dev, dtype=torch.float32) if keep else None
+        ms = timed(lambda: _hip.call("cpc_score_lse", P(a), P(b), P(sb), P(pm), P(ps), P(valid), R, R, E, L(E), L(E), L(R), 0))
+        tf = 2.0 * R * R * E / (ms * 1e-3) / 1e12
+        res[name] = {"ms_per_launch": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "output_gb": round((R * R * 4 if keep else 0) / 1e9 + 2 * pm.numel() * 4 / 1e9, 3)}
+        del sb
+    Rl = R // 8
+    sb = torch.empty(R * Rl, device=dev, dtype=torch.float32)
+    ms = timed(lambda: _hip.call("cpc_score_lse", P(a), P(b), P(sb), P(pm), P(ps), P(valid), R, Rl, E, L(E), L(E), L(Rl), 0))
+    tf = 2.0 * R * Rl * E / (ms * 1e-3) / 1e12
+    res["one_rank_column_strip"] = {"shape": f"{R} x {E} x {Rl}", "gflop": round(2.0 * R * Rl * E / 1e9, 1), "ms_per_launch": round(ms, 4),
+                                    "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                    "note": "what a rank of an 8-GPU global-negatives step runs: all predictions x its own targets (and a "
+                                            "second strip of the same size for its own predictions), not the whole matrix"}
+    del sb, pm, ps
     torch.cuda.empty_cache()
     return res
 

@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA, GEMM_SKIP_PAD_ROWS = 1, 2, 4, 8, 16, 32, 64, 128
-GEMM_LINEAR_K, GEMM_NO_PERS, GEMM_DIRECT_MASK = 256, 512, 1024
+GEMM_LINEAR_K, GEMM_NO_PERS, GEMM_DIRECT_MASK, GEMM_KRANGE_EXACT = 256, 512, 1024, 2048
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpc_hip.so")
@@ -159,6 +159,11 @@ _SIGNATURES = {
     "cpc_nce_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "cpc_nce_all_workspace_floats": ([_I, _I], _L),
     "cpc_nce_loss_all": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
+    "cpc_score_lse": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P], _I),
+    "cpc_nce_lse_merge": ([_P, _P, _I, _I, _I, _F, _P, _P, _P], _I),
+    "cpc_nce_fused_grad_blocks": ([_I, _I], _L),
+    "cpc_nce_fused_grad": ([_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _I, _I, _F, _F, _F, _P], _I),
+    "cpc_nce_fused_finalize": ([_P, _I, _P, _I, _P, _I, _P, _I, _F, _F, _I, _F, _I, _P, _P], _I),
     "cpc_gp_score_coeff": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_nce_eval_workspace_floats": ([_I, _I], _L),
     "cpc_nce_eval": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
@@ -183,7 +188,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        if handle.cpc_abi_version() != 7:
+        if handle.cpc_abi_version() != 8:
             raise HipLibraryMissing("libcpc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -339,13 +339,15 @@ class ContrastiveEstimationTrainer:
         # step `nan + 1` is restored.  What cannot be taken back: the sampler has handed out the later batches.
         bn_bufs = [b for n_, b in self.model.named_buffers() if "running_" in n_ or n_.endswith("num_batches_tracked")]
         snap_ring, snap_pos, snaps = [], [0], {}
+        if fused and bn_bufs:          # the ring exists before the loop: no allocation inside the hot loop; models without BatchNorm keep none
+            snap_ring = [[torch.empty_like(b) for b in bn_bufs] for _ in range(self.host_sync_interval + self.host_sync_lag + 2)]
 
         def snapshot(step):
             if not fused:
                 return
             depth = self.host_sync_interval + self.host_sync_lag + 2
             if bn_bufs:
-                while len(snap_ring) < depth:
+                while len(snap_ring) < depth:          # (host_sync_interval / host_sync_lag raised while training)
                     snap_ring.append([torch.empty_like(b) for b in bn_bufs])
                 dst = snap_ring[snap_pos[0] % depth]
                 snap_pos[0] += 1
@@ -368,6 +370,13 @@ class ContrastiveEstimationTrainer:
             print("returned with nan loss at step", step)
             return None
 
+        # A full collection of Python's cyclic garbage collector walks every tracked object of the process (38 - 43 ms with the module
+        # trees of a model alive) and lands in whichever step crosses its allocation threshold — a GPU that is only a few steps of work
+        # ahead of the host idles through it.  What is alive now stays alive for the whole run: collect once and freeze it, later
+        # collections only look at what the steps allocate (bench.py, round 4: this is the 41 ms the round-3 driver run lost once).
+        import gc
+        gc.collect()
+        gc.freeze()
         prof = None
         for current_epoch in range(epochs):
             if self.verbose:

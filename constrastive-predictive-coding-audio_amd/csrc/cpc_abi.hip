@@ -17,7 +17,7 @@ static inline int esize(int dtype) { return dtype == CPC_DTYPE_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int cpc_abi_version(void) { return 7; }
+int cpc_abi_version(void) { return 8; }
 
 int cpc_gemm_nt(const cpc_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->Bt || !a->C) return CPC_EINVAL;
@@ -612,6 +612,30 @@ int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float
                      int softplus, float regularization, int dtype, void* stream) {
     if (!S || !ST || !dS || !dST || !out || !workspace) return CPC_EINVAL;
     return launch_nce_all(S, ST, dS, dST, out, workspace, B, K, ld, softplus, regularization, dtype, (hipStream_t)stream);
+}
+
+int cpc_score_lse(const void* P, const void* T, float* S, float* pm, float* ps, float* valid, int M, int N, int E, long long ldp,
+                  long long ldt, long long lds, int diag_off, void* stream) {
+    return launch_score_lse(P, T, S, pm, ps, valid, M, N, E, ldp, ldt, lds, diag_off, (hipStream_t)stream);
+}
+
+int cpc_nce_lse_merge(const float* pm, const float* ps, int nparts, int ncols, int softplus, float nrows_total, float* lse, float* colp,
+                      void* stream) {
+    return launch_nce_lse_merge(pm, ps, nparts, ncols, softplus, nrows_total, lse, colp, (hipStream_t)stream);
+}
+
+long long cpc_nce_fused_grad_blocks(int items, int ncols) { return nce_fused_grad_blocks(items, ncols); }
+
+int cpc_nce_fused_grad(const float* S, const float* lse, void* dS, void* dST, float* gradp, int items, int K, int ncols, long long ld,
+                       long long ldT, int diag_off, int softplus, float regularization, float n_rows_total, float n_items_total, void* stream) {
+    return launch_nce_fused_grad(S, lse, dS, dST, gradp, items, K, ncols, ld, ldT, diag_off, softplus, regularization, n_rows_total,
+                                 n_items_total, (hipStream_t)stream);
+}
+
+int cpc_nce_fused_finalize(const float* colp, int ncolp, const float* valid, int nvalid, const float* gradp, int ngrad, float* sums, int mode,
+                           float n_rows_total, float n_items_total, int K, float regularization, int softplus, float* out, void* stream) {
+    return launch_nce_fused_finalize(colp, ncolp, valid, nvalid, gradp, ngrad, sums, mode, n_rows_total, n_items_total, K, regularization,
+                                     softplus, out, (hipStream_t)stream);
 }
 
 long long cpc_nce_eval_workspace_floats(int B, int K) { return nce_eval_workspace_floats(B, K); }

@@ -14,6 +14,8 @@
 #define GEMM_SKIP_PAD_ROWS 128  // NT: rows with (m % c_rpi) >= c_valid are not stored at all (default: stored as zeros)
 #define GEMM_NO_PERS 512        // NT/bf16: LDS-staged epilogue instead of the register epilogue (A-B check; see DIRECT in gemm.hip)
 #define GEMM_DIRECT_MASK 1024   // NT/bf16: register epilogue also for masked launches (A-B check)
+#define GEMM_KRANGE_EXACT 2048  // NT fast path with k_ranges: the ranges cut out pieces that are NOT zero (a neighbouring item's data), so a tile must lie in ONE
+                                // range index: the launch is refused unless a_rpi * max(a_rpi2, 1) is a multiple of the tile height the launcher picks
 #define GEMM_LINEAR_K 256       // NT fast path: visit K in storage order even for overlapped-row operands (A-B check, see GemmNT::k_taps)
 #define GEMM_WT_AGENT 0x40000   // internal (cpc_debug_set key 6): output stores of the NT fast kernels write through at agent scope (sc1)
 #define GEMM_WT_SYSTEM 0x80000  // ... at system scope (sc0 sc1): the default
@@ -77,6 +79,9 @@ struct GemmNT {
     // with t = q*c1_sub + r (rows with t >= c1_valid contribute nothing); tile = mt * numN + nt, 256 columns per tile.
     const float* c1_x = nullptr; long long c1_ldx = 0; float* c1_slabs = nullptr;
     int c1_rpi = 0, c1_sub = 0, c1_stride = 0, c1_kw = 0, c1_valid = 0;
+    // internal, launch_score_lse (persistent 256x256 bf16 kernel, LSE epilogue): per M tile and column the pair (max, sum exp(s - max)) over
+    // the tile's rows -> lse_pm / lse_ps [M / 256][N]; lse_valid[r] = s[r][r + lse_diag_off] where that column exists (or null)
+    float* lse_pm = nullptr; float* lse_ps = nullptr; float* lse_valid = nullptr; int lse_diag_off = 0;
 };
 
 struct GemmTN {
@@ -103,6 +108,8 @@ extern int g_nt_probe_taps;     // key 5: taps of the chunk-major A operand of p
 extern int g_nt_wt;             // key 6: output stores of the NT fast kernels written through the L2 (1: sc1, 2: sc0 sc1)
 extern int g_nt_probe;          // key 4: timing probes of the 256x256 NT kernel (DBG in gemm.hip; the results are garbage)
 int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream);
+int launch_score_lse(const void* P, const void* Tg, void* Sb, float* pm, float* ps, float* valid, int M, int N, int E, long long ldp,
+                     long long ldt, long long lds_, int diag_off, hipStream_t stream);
 int launch_gemm_tn(const GemmTN& p, int dtype, int nsplit, int batch, hipStream_t stream);
 int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, long long slab_stride, int cdiv,
                         long long s_j, long long s_hi, long long s_lo, hipStream_t stream);
@@ -132,6 +139,13 @@ int launch_gru_gp_fwd(const float* Gi, const float* GiT, const float* WT, const 
                       int V, int H, hipStream_t stream);
 int launch_gru_gp_bwd(const float* dc, const float* tape, const float* W, float* dA, int B, int V, int H, hipStream_t stream);
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream);
+int launch_nce_lse_merge(const float* pm, const float* ps, int nparts, int ncols, int softplus, float nrows, float* lse, float* colp,
+                         hipStream_t stream);
+long long nce_fused_grad_blocks(int items, int ncols);
+int launch_nce_fused_grad(const void* Sb, const float* lse, void* dS, void* dST, float* gradp, int items, int K, int ncols, long long ld,
+                          long long ldT, int diag_off, int softplus, float reg, float n_rows, float n_items, hipStream_t stream);
+int launch_nce_fused_finalize(const float* colp, int ncolp, const float* valid, int nvalid, const float* gradp, int ngrad, float* sums, int mode,
+                              float n_rows, float n_items, int K, float reg, int softplus, float* out, hipStream_t stream);
 long long nce_workspace_floats(int B, int K);
 long long nce_all_workspace_floats(int B, int K);
 int launch_nce_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,

@@ -1043,14 +1043,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 // while the next tile's loads are in flight.  What it removes is the fixed cost of a tile (workgroup launch, first-stage latency, drain):
 // 8.9 us of the 20 us a tile of the 24 576 x 512 x 24 576 score contraction takes, a tenth of a K = 2 048 convolution tile.
 // Same sums in the same order as gemm_nt_fast_kernel: bit-identical results.  The macros are that kernel's (same local names).
-template <int DBG>
+// LSE = true: the InfoNCE score contraction with its column pass fused into the epilogue (GemmNT::lse_*): besides (or instead of) the bf16
+// scores the tile leaves, for each of its 256 columns, the online log-sum-exp pair (max, sum exp(s - max)) over its 256 rows, taken from the
+// f32 accumulators, and the diagonal scores s[r][r + lse_diag_off]; cpc_nce_lse_merge combines the pairs of a column over the M tiles.  The
+// scores themselves are stored as f32 (optional): ONE matrix instead of the unfused path's two (scores and transposed scores).
+template <int DBG, bool LSE = false>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
     typedef bf16_t T;
     typedef bf16_t TO;
     constexpr int WN = 4, TI = 8, TJ = 4;
     constexpr int CH = 8, BK = 64, TBM = 256, TBN = 256;
     constexpr int ATILE = TBM * 128, BTILE = TBN * 128, STAGE = ATILE + BTILE;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE + (LSE ? 2 * TBN * 8 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int numM = (p.M + TBM - 1) / TBM, numN = (p.N + TBN - 1) / TBN;
@@ -1074,7 +1078,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int srow = lane >> 3, sch = (lane & 7) ^ (lane >> 3);
     const int r0 = (wave_u * 4) * 8 + srow;
-    const int br0 = direct_b_col(r0);
+    // (LSE: f32 output — the plain column order, in which the four lanes of a row group store 64 contiguous bytes per row; the 8-column
+    // permutation of the bf16 register epilogue would leave every 32-byte sector half written by each store instruction: 1.68 instead of
+    // 1.1 ms for the 2.4 GB of the 24 576^2 score matrix)
+    const int br0 = LSE ? r0 : direct_b_col(r0);
     const T* Ab = (const T*)p.A;
     const T* Bb = (const T*)p.Bt;
     // The four rows a lane requests of each operand per stage are a FIXED distance apart (the launcher admits only launches where a 32-row
@@ -1085,9 +1092,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
 #define ga1 (ga0 + a8)
 #define ga2 (ga0 + 2 * a8)
 #define ga3 (ga0 + 3 * a8)
-#define gb1 (gb0 + b16)
-#define gb2 (gb0 + b4)
-#define gb3 (gb0 + b16 + b4)
+    const long long bo1 = LSE ? 8LL * p.ldb : b16, bo2 = LSE ? 16LL * p.ldb : b4, bo3 = LSE ? 24LL * p.ldb : b16 + b4;
+#define gb1 (gb0 + bo1)
+#define gb2 (gb0 + bo2)
+#define gb3 (gb0 + bo3)
     const T *gd0 = Bb, *gd1 = Bb, *gd2 = Bb, *gd3 = Bb;          // (timing-probe operands of the shared macros; never used with DBG = 0)
     // tile index -> first row / column (false: a padding block of the 8-XCD grid, no tile)
 #define PS_TILE_OF(bid, m0_, n0_, ok_)                                   \
@@ -1168,8 +1176,79 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
         // register epilogue of gemm_nt_fast_kernel's DIRECT form, without a mask; the accumulators are cleared as they are consumed
         const int nb = n0 + wn * 64 + 8 * fg;
         const bool full = (m0 + TBM <= p.M) && (n0 + TBN <= p.N);
+        if constexpr (LSE) {
+            // Column q = 4 j + e of this lane is tile column wn 64 + 16 j + 4 fg + e (acc[i][j][e]; plain column order, see br0); its rows are
+            // (wm 8 + i) 16 + frow.  Pass 1: the column maxima over the lane's 8 rows, then over the 16 lanes of the row group (lanes that
+            // differ in frow only); pass 2: sum of exp(s - max) the same way; the two wm halves meet in LDS.
+            float cm[16], cs[16];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+            for (int q = 0; q < 16; ++q) { cm[q] = -INFINITY; cs[q] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cm[q] = fmaxf(cm[q], acc[i][q >> 2][q & 3]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) cm[q] = fmaxf(cm[q], __shfl_xor(cm[q], o, 64));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cs[q] += __expf(acc[i][q >> 2][q & 3] - cm[q]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+            float* red = (float*)(lds + 2 * STAGE);
+            if (frow == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int col = wn * 64 + 16 * (q >> 2) + 4 * fg + (q & 3);
+                    red[(wm * TBN + col) * 2] = cm[q];
+                    red[(wm * TBN + col) * 2 + 1] = cs[q];
+                }
+            }
+            // the scores a prediction gives its own target (the "valid" scores of the loss): rows whose column r + lse_diag_off is in this tile
+            if (p.lse_valid != nullptr && m0 + p.lse_diag_off < n0 + TBN && m0 + TBM + p.lse_diag_off > n0) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int r = m0 + (wm * TI + i) * 16 + frow;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = n0 + wn * 64 + 16 * (q >> 2) + 4 * fg + (q & 3);
+                        if (c == r + p.lse_diag_off) p.lse_valid[r] = acc[i][q >> 2][q & 3];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < TBN) {
+                const float ma = red[tid * 2], sa = red[tid * 2 + 1], mb = red[(TBN + tid) * 2], sb = red[(TBN + tid) * 2 + 1];
+                const float mm = fmaxf(ma, mb);
+                const long long o = (long long)(m0 / TBM) * p.N + n0 + tid;
+                p.lse_pm[o] = mm;
+                p.lse_ps[o] = sa * __expf(ma - mm) + sb * __expf(mb - mm);
+            }
+            // (the next tile's K loop has barriers between this read of `red` and the next tile's writes to it)
+        }
+        if constexpr (LSE) {
+            // the scores themselves, f32 (the gradient pass takes exp(score - lse): a bf16 copy of a score of 100 is off by up to 0.4, i.e.
+            // its softmax weight by half): 16 bytes per lane, the four lanes of a row group write 64 contiguous bytes
+            if (Cb != nullptr) {
+                float* const Cf = (float*)p.C;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const long long off = (long long)(m0 + (wm * TI + i) * 16 + frow) * p.ldc + n0 + wn * 64 + 4 * fg;
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) store_out16((uint4*)(Cf + off + 16 * j), __builtin_bit_cast(uint4, acc[i][j]), p.flags);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < (LSE ? 0 : TI); ++i) {
             const int mrow = m0 + (wm * TI + i) * 16 + frow;
             const int m = min(mrow, p.M - 1);
             const long long off = row_off(m, p.c_rpi, p.c_item, p.ldc) + min(nb, p.N - 8);
@@ -1915,6 +1994,10 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     const int numM = (p.M - p.m_off + tbm - 1) / tbm;
     const int numN = (p.N + tbn - 1) / tbn;
     if (!fast && p.m_off) return CPC_EINVAL;
+    if ((p.flags & GEMM_KRANGE_EXACT) && p.k_ranges) {
+        const long long per = (long long)p.a_rpi * (p.a_rpi2 > 0 ? p.a_rpi2 : 1);
+        if (per <= 0 || per % tbm) return CPC_EINVAL;         // a tile would straddle two range indices (see the flag)
+    }
     const long long blocks = nt_grid_blocks(numM, numN);
     if (blocks > 0x7fffffffLL) return CPC_EINVAL;
     dim3 grid((unsigned)blocks, 1, batch);
@@ -1981,6 +2064,29 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
         return CPC_EINVAL;
     }
 #undef NT_LAUNCH
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+// Score contraction with the column log-sum-exp partials fused into its epilogue (bf16; include/cpc_hip.h, cpc_score_lse).
+int launch_score_lse(const void* P, const void* Tg, void* Sb, float* pm, float* ps, float* valid, int M, int N, int E, long long ldp,
+                     long long ldt, long long lds_, int diag_off, hipStream_t stream) {
+    if (!P || !Tg || !pm || !ps || M <= 0 || N <= 0 || E < 128) return CPC_EINVAL;
+    if (M % 256 || N % 256 || E % 64 || ldp % 8 || ldt % 8 || ldp < E || ldt < E) return CPC_EINVAL;
+    if ((uintptr_t)P % 16 || (uintptr_t)Tg % 16) return CPC_EINVAL;
+    if (Sb && (lds_ % 4 || lds_ < N || (uintptr_t)Sb % 16)) return CPC_EINVAL;
+    GemmNT q = {};
+    q.A = P; q.Bt = Tg; q.C = Sb;
+    q.M = M; q.N = N; q.K = E;
+    q.lda = ldp; q.ldb = ldt; q.ldc = Sb ? lds_ : N;
+    q.lse_pm = pm; q.lse_ps = ps; q.lse_valid = valid; q.lse_diag_off = diag_off;
+    if (g_nt_wt == 1) q.flags |= GEMM_WT_AGENT; else if (g_nt_wt == 2) q.flags |= GEMM_WT_SYSTEM;
+    const long long blocks = nt_grid_blocks(M / 256, N / 256);
+    if (blocks > 0x7fffffffLL) return CPC_EINVAL;
+    static const int ps_ = [] { const char* v = getenv("CPC_NT_PERSIST_STAGGER"); return v ? atoi(v) : 64; }();
+    const long long tile_cycles = (long long)(E / 64) * 3600 + 20000;
+    q.stagger = (ps_ > 0 && blocks > 2 * 256) ? (int)std::max<long long>(1, tile_cycles * ps_ / 64 / 7 / 4096) : 0;
+    hipLaunchKernelGGL((gemm_nt_persist_kernel<0, true>), dim3((unsigned)std::min<long long>(256, blocks)), dim3(512), 0, stream, q);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -481,7 +481,224 @@ __global__ __launch_bounds__(256) void nce_eval_finalize_kernel(const float* __r
     }
 }
 
+// ---- score_over_all_timesteps = True with the column pass fused into the score GEMM (bf16; launch_score_lse in gemm.hip) ----
+// The GEMM leaves, per M tile and column, the online log-sum-exp pair (pm, ps) = (max, sum exp(s - max)) of the LINEAR scores s over
+// the tile's 256 rows.  For softplus scores exp(softplus(s)) = 1 + exp(s) (torch's threshold 20 changes that by < e^-20), so
+//   lse[c] = log( [softplus] * nrows + sum_tiles ps * exp(pm) )
+// needs no softplus at all.  colp[block] = {sum of the block's lse, max of its pm}.
+__global__ __launch_bounds__(256) void nce_lse_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps, int nparts, int ncols,
+                                                            int softplus, float nrows, float* __restrict__ lse, float* __restrict__ colp) {
+    __shared__ float red[2][256];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f, mx = -INFINITY;
+    if (c < ncols) {
+        for (int i = 0; i < nparts; ++i) mx = fmaxf(mx, pm[(long long)i * ncols + c]);
+        const float ref = softplus ? fmaxf(mx, 0.f) : mx;
+        float tot = softplus ? nrows * expf(-ref) : 0.f;
+        for (int i = 0; i < nparts; ++i) tot += ps[(long long)i * ncols + c] * expf(pm[(long long)i * ncols + c] - ref);
+        l = ref + logf(tot);
+        lse[c] = l;
+    }
+    red[0][threadIdx.x] = l;
+    red[1][threadIdx.x] = mx;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        colp[blockIdx.x * 2] = red[0][0];
+        colp[blockIdx.x * 2 + 1] = red[1][0];
+    }
+}
+
+// d loss / d linear score from the f32 scores the fused GEMM stored, and its transpose: Sb [items K][ld] (row (b, k) = a prediction, column
+// c = a target), lse [ncols]:
+//   dS[r][c] = score'(s) * ( (exp(sp - lse[c]) - [c == r + diag_off]) / n_rows + 2 reg / (n_items^2 K^2) * m[b][c] ),   m = mean_k sp[(b,k)][c]
+// (n_rows / n_items: of the WHOLE problem — a rank of a data-parallel run holds a strip of it).  Workgroup = 16 items x 64 columns, 128 threads:
+// thread = (item, 8 columns), 16-byte loads / stores along the rows; the transposed copy goes through an LDS image [64][16 K] and leaves
+// as 16 K contiguous elements per column.  gradp[block] = sum of m^2 over the block's (item, column) pairs (the regulariser's value).
+constexpr int NFG_IT = 16, NFG_CW = 64;
+// KT > 0: K as a compile-time constant — the K rows of a thread are loaded once, all loads in flight (with a run-time K the rows are read
+// twice, one dependent load after the other: 117 us instead of 3x us for the 38 MB of B = 256, K = 12).
+template <int KT>
+__global__ __launch_bounds__(256) void nce_fused_grad_kernel(const float* __restrict__ Sb, const float* __restrict__ lse, bf16_t* __restrict__ dS,
+                                                             bf16_t* __restrict__ dST, float* __restrict__ gradp, int items, int K_rt, int ncols,
+                                                             long long ld, long long ldT, int diag_off, int softplus, float inv_r, float reg_c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    __shared__ float red[256];
+    const int K = KT > 0 ? KT : K_rt;
+    const int rs = NFG_IT * K * 2 + 16;                       // LDS image row stride (bytes): one column's 16 K gradients + pad
+    const int tid = threadIdx.x, cg = tid & 15, it = tid >> 4;          // thread = (item, 4 columns)
+    const int c0 = blockIdx.x * NFG_CW + cg * 4, item = blockIdx.y * NFG_IT + it;
+    const bool on = item < items && c0 < ncols;
+    float msq = 0.f;
+    if (on) {
+        const f32x4 l4 = *(const f32x4*)(lse + c0);
+        f32x4 m4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* src = Sb + (long long)item * K * ld + c0;
+        bf16_t* dst = dS + (long long)item * K * ld + c0;
+        const int r0 = item * K + diag_off;                    // the column of row (item, 0)'s own target
+        f32x4 v[KT > 0 ? KT : 1];
+        if constexpr (KT > 0) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) v[k] = *(const f32x4*)(src + (long long)k * ld);
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m4[e] += score_tf(v[k][e], softplus);
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const f32x4 x = *(const f32x4*)(src + (long long)k * ld);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m4[e] += score_tf(x[e], softplus);
+            }
+        }
+        const float inv_k = 1.f / (float)K;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { m4[e] *= inv_k; msq += m4[e] * m4[e]; }
+        auto grad4 = [&](const f32x4& x, int k) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = __expf(score_tf(x[e], softplus) - l4[e]) * inv_r + reg_c * m4[e];
+                if (c0 + e == r0 + k) d -= inv_r;
+                o[e] = (bf16_t)(d * score_grad(x[e], softplus));
+            }
+            return o;
+        };
+        auto pair = [&](const f32x4& xa, const f32x4& xb, int k) {
+            const bf16x4 oa = grad4(xa, k), ob = grad4(xb, k + 1);
+            *(bf16x4*)(dst + (long long)k * ld) = oa;
+            *(bf16x4*)(dst + (long long)(k + 1) * ld) = ob;
+            if (dST != nullptr) {
+                // (element e of row k in the low half, of row k + 1 in the high half; taken from the packed words: hipcc 7.2 gave element 0
+                // for every e when the elements were bit-cast one by one — tools/dbg_grad.py, three columns of four wrong)
+                const uint2 ua = __builtin_bit_cast(uint2, oa), ub = __builtin_bit_cast(uint2, ob);
+                const unsigned wa[2] = {ua.x, ua.y}, wb[2] = {ub.x, ub.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned lo = (wa[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (wb[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                    *(unsigned*)(tsm + (cg * 4 + e) * rs + (it * K + k) * 2) = lo | (hi << 16);          // image[column][row pair]
+                }
+            }
+        };
+        if constexpr (KT > 0) {
+#pragma unroll
+            for (int k = 0; k < KT; k += 2) pair(v[k], v[k + 1], k);
+        } else {
+            for (int k = 0; k < K; k += 2)
+                pair(*(const f32x4*)(src + (long long)k * ld), *(const f32x4*)(src + (long long)(k + 1) * ld), k);
+        }
+    }
+    if (dST != nullptr) {
+        __syncthreads();
+        // column cl of the tile: NFG_IT K contiguous elements of row c of dS^T, starting at element blockIdx.y NFG_IT K
+        const int cpr = NFG_IT * K / 8;                       // 16-byte chunks per column
+        const int rows_here = min(NFG_IT, items - (int)blockIdx.y * NFG_IT) * K;
+        for (int q = tid; q < NFG_CW * cpr; q += 256) {
+            const int cl = q / cpr, ch = q % cpr;
+            const int c = blockIdx.x * NFG_CW + cl;
+            if (c < ncols && ch * 8 < rows_here)
+                *(uint4*)(dST + (long long)c * ldT + (long long)blockIdx.y * NFG_IT * K + ch * 8) = *(const uint4*)(tsm + cl * rs + ch * 16);
+        }
+    }
+    red[tid] = msq;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0 && gradp != nullptr) gradp[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+// Loss scalars of the fused path.  mode 0: reduce the partials and write out[0..6] (single process); mode 1: reduce only ->
+// sums[0..3] = {sum of the valid scores, sum of lse, sum of m^2, max linear score} (a rank's share: all-reduce them, SUM / SUM / SUM / MAX);
+// mode 2: out[0..6] from sums.  out as cpc_nce_loss_all writes it.
+__global__ __launch_bounds__(256) void nce_fused_finalize_kernel(const float* __restrict__ colp, int ncolp, const float* __restrict__ valid, int nvalid,
+                                                                 const float* __restrict__ gradp, int ngrad, float* __restrict__ sums, int mode,
+                                                                 float n_rows, float n_items, int K, float reg, int softplus,
+                                                                 float* __restrict__ out) {
+    __shared__ float red[4][256];
+    float sv = 0.f, sl = 0.f, sm = 0.f, mx = -INFINITY;
+    if (mode != 2) {
+        for (int i = threadIdx.x; i < nvalid; i += 256) sv += score_tf(valid[i], softplus);
+        for (int i = threadIdx.x; i < ncolp; i += 256) { sl += colp[2 * i]; mx = fmaxf(mx, colp[2 * i + 1]); }
+        for (int i = threadIdx.x; i < ngrad; i += 256) sm += gradp[i];
+        red[0][threadIdx.x] = sv; red[1][threadIdx.x] = sl; red[2][threadIdx.x] = sm; red[3][threadIdx.x] = mx;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (threadIdx.x < s2) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + s2];
+                red[1][threadIdx.x] += red[1][threadIdx.x + s2];
+                red[2][threadIdx.x] += red[2][threadIdx.x + s2];
+                red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + s2]);
+            }
+            __syncthreads();
+        }
+        sv = red[0][0]; sl = red[1][0]; sm = red[2][0]; mx = red[3][0];
+    } else {
+        sv = sums[0]; sl = sums[1]; sm = sums[2]; mx = sums[3];
+    }
+    if (threadIdx.x != 0) return;
+    if (mode == 1) {
+        sums[0] = sv; sums[1] = sl; sums[2] = sm; sums[3] = mx;
+        return;
+    }
+    const float t_valid = -sv / n_rows, t_lse = sl / n_rows, t_reg = reg * sm / (n_items * n_rows);
+    out[0] = t_valid + t_lse + t_reg;
+    out[1] = score_tf(mx, softplus);
+    out[2] = t_valid;
+    out[3] = t_lse;
+    out[4] = t_reg;
+    const float lb = t_valid + t_lse;             // the reference's NaN guard tests the loss before the regulariser (:124)
+    const float bad = (lb != lb) ? 1.f : 0.f;
+    out[5] = bad;
+    if (bad != 0.f) out[6] = 1.f;
+}
+
 }  // namespace
+
+int launch_nce_lse_merge(const float* pm, const float* ps, int nparts, int ncols, int softplus, float nrows, float* lse, float* colp,
+                         hipStream_t stream) {
+    if (!pm || !ps || !lse || !colp || nparts <= 0 || ncols <= 0) return CPC_EINVAL;
+    hipLaunchKernelGGL(nce_lse_merge_kernel, dim3((ncols + 255) / 256), dim3(256), 0, stream, pm, ps, nparts, ncols, softplus, nrows, lse, colp);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+long long nce_fused_grad_blocks(int items, int ncols) {
+    return (long long)((ncols + NFG_CW - 1) / NFG_CW) * ((items + NFG_IT - 1) / NFG_IT);
+}
+
+int launch_nce_fused_grad(const void* Sb, const float* lse, void* dS, void* dST, float* gradp, int items, int K, int ncols, long long ld,
+                          long long ldT, int diag_off, int softplus, float reg, float n_rows, float n_items, hipStream_t stream) {
+    if (!Sb || !lse || !dS || items <= 0 || K < 2 || K % 2 || K > 24 || ncols <= 0 || ncols % 4 || ld % 8 || ld < ncols) return CPC_EINVAL;
+    if (dST && (ldT % 8 || ldT < (long long)items * K)) return CPC_EINVAL;
+    if ((uintptr_t)Sb % 16 || (uintptr_t)dS % 16 || (uintptr_t)dST % 16 || (uintptr_t)lse % 16) return CPC_EINVAL;
+    const dim3 grid((ncols + NFG_CW - 1) / NFG_CW, (items + NFG_IT - 1) / NFG_IT);
+    const size_t lds_bytes = dST ? (size_t)NFG_CW * (NFG_IT * K * 2 + 16) : 0;
+    const float inv_r = 1.f / n_rows, reg_c = 2.f * reg / (n_items * n_items * (float)K * (float)K);
+#define NFG_LAUNCH(KT) \
+    hipLaunchKernelGGL(nce_fused_grad_kernel<KT>, grid, dim3(256), lds_bytes, stream, (const float*)Sb, lse, (bf16_t*)dS, (bf16_t*)dST, gradp, items, K, \
+                       ncols, ld, ldT, diag_off, softplus, inv_r, reg_c)
+    if (K == 12) NFG_LAUNCH(12); else if (K == 16) NFG_LAUNCH(16); else if (K == 8) NFG_LAUNCH(8); else NFG_LAUNCH(0);
+#undef NFG_LAUNCH
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_nce_fused_finalize(const float* colp, int ncolp, const float* valid, int nvalid, const float* gradp, int ngrad, float* sums, int mode,
+                              float n_rows, float n_items, int K, float reg, int softplus, float* out, hipStream_t stream) {
+    if (mode < 0 || mode > 2 || (mode != 2 && (!colp || !valid || !gradp)) || (mode != 0 && !sums) || (mode != 1 && !out)) return CPC_EINVAL;
+    hipLaunchKernelGGL(nce_fused_finalize_kernel, dim3(1), dim3(256), 0, stream, colp, ncolp, valid, nvalid, gradp, ngrad, sums, mode, n_rows, n_items,
+                       K, reg, softplus, out);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
 
 // workspace: lse [K*B] + col partials [ceil(K*B/256)] + grad partials [3 * ceil(B/32)^2]   (f32)
 // workspace: lse [K][B] + column partials [K * ceil(B/32)] + pair partials [3 * ceil(B*B/256)] + pair means [B][ld <= B + 7]

@@ -468,10 +468,51 @@ class CPCEngine:
         _hip.gemm_tn(_hip.ptr(W), _hip.ptr(pred), _hip.ptr(out_top, (T - K) * E), B, B, E, ld, K * E, Ltop * E, code,
                      a_batch=B * ld, b_batch=E, c_batch=E, batch=K)
 
+    # ---- score_over_all_timesteps=True with the column pass fused into the score GEMM (bf16; include/cpc_hip.h, cpc_score_lse) ----
+    def fused_scores_ok(self, rows=None, cols=None):
+        """The fused path needs bf16 storage, 256-row / 256-column tiles, E a multiple of 64 and an even K <= 24
+        (CPC_FUSED_SCORE=0: the unfused kernels, A/B)."""
+        R = self.B * self.K
+        rows, cols = (R if rows is None else rows), (R if cols is None else cols)
+        return (self.dt == torch.bfloat16 and os.environ.get("CPC_FUSED_SCORE", "1") != "0" and rows % 256 == 0 and cols % 256 == 0
+                and self.E % 64 == 0 and self.E >= 128 and self.K % 2 == 0 and self.K <= 24)
+
+    def _nce_all_fused(self, softplus: bool, regularization: float):
+        """One persistent MFMA launch forms the (B K) x (B K) scores tile by tile and leaves the f32 scores + per-tile column
+        (max, sum-exp) pairs + the diagonal; a merge, one gradient pass (dS and its transpose) and the loss scalars follow.  Replaces: the second (transposed) score GEMM, two f32 score matrices, the 16-way split column pass and the
+        two element-wise gradient passes of nce_all_forward_backward."""
+        code, B, E, K = self.code, self.B, self.E, self.K
+        Ltop, T = self.geo.alloc[-1], self.T
+        top, dtop = self.act[-1], self.dact[-1]
+        R = B * K
+        f = getattr(self, "_fs", None)
+        if f is None:
+            dev, f32 = self.device, torch.float32
+            f = self._fs = SimpleNamespace(
+                targ=torch.empty(R, E, device=dev, dtype=self.dt), Sb=torch.empty(R, R, device=dev, dtype=f32),
+                pm=torch.empty(R // 256, R, device=dev, dtype=f32), ps=torch.empty(R // 256, R, device=dev, dtype=f32),
+                valid=torch.zeros(R, device=dev, dtype=f32), lse=torch.empty(R, device=dev, dtype=f32),
+                colp=torch.empty(_ceil_div(R, 256), 2, device=dev, dtype=f32),
+                gradp=torch.empty(int(_hip.lib().cpc_nce_fused_grad_blocks(B, R)), device=dev, dtype=f32),
+                dS=torch.empty(R, R, device=dev, dtype=self.dt), dST=torch.empty(R, R, device=dev, dtype=self.dt))
+        P = _hip.ptr
+        f.targ.view(B, K, E).copy_(top.view(B, Ltop, E)[:, T - K:T, :])
+        _hip.call("cpc_score_lse", P(self.pred), P(f.targ), P(f.Sb), P(f.pm), P(f.ps), P(f.valid), R, R, E, C.c_longlong(E), C.c_longlong(E),
+                  C.c_longlong(R), 0, key="score_lse<bf16,256>", work=2.0 * R * R * E)
+        _hip.call("cpc_nce_lse_merge", P(f.pm), P(f.ps), R // 256, R, 1 if softplus else 0, C.c_float(R), P(f.lse), P(f.colp))
+        _hip.call("cpc_nce_fused_grad", P(f.Sb), P(f.lse), P(f.dS), P(f.dST), P(f.gradp), B, K, R, C.c_longlong(R), C.c_longlong(R), 0,
+                  1 if softplus else 0, C.c_float(regularization), C.c_float(R), C.c_float(B))
+        _hip.call("cpc_nce_fused_finalize", P(f.colp), f.colp.shape[0], P(f.valid), R, P(f.gradp), f.gradp.numel(), None, 0, C.c_float(R),
+                  C.c_float(B), K, C.c_float(regularization), 1 if softplus else 0, P(self.nce_out))
+        self._score_grads_all(f.dS, f.dST, self.pred, top, self.dpred, dtop)
+
     def nce_all_forward_backward(self, softplus: bool, regularization: float):
         """score_over_all_timesteps=True (contrastive_estimation_training.py:108-114, :141): the full (B K) x (B K) score
         matrix (and its transpose, as a second tiny GEMM, so that both gradient layouts are written coalesced), the
-        log-sum-exp over ALL predictions for every (target item, step), and d loss / d (predicted_z, targets)."""
+        log-sum-exp over ALL predictions for every (target item, step), and d loss / d (predicted_z, targets).
+        bf16 storage and tile-sized problems take the fused route (_nce_all_fused) instead."""
+        if self.fused_scores_ok():
+            return self._nce_all_fused(softplus, regularization)
         code, B, E, K = self.code, self.B, self.E, self.K
         Ltop, T = self.geo.alloc[-1], self.T
         top, dtop = self.act[-1], self.dact[-1]
@@ -1569,6 +1610,58 @@ class GlobalNegatives:
         _hip.gemm_nt(P(self.dS_all), P(self.targT), P(self.dpred_all), R, E, ld, ld, ld, E, code)
         _hip.gemm_nt(P(self.dST_all), P(self.predT), P(self.dtarg_all), R, E, ld, ld, ld, E, code)
 
+    def _all_timesteps_strips(self, softplus: bool, regularization: float):
+        """The all-timesteps loss over the global batch WITHOUT the global score matrix on every rank: rank r forms two strips of it,
+        (all predictions) x (its own targets) and (its own predictions) x (all targets) — 2 / world of the matrix instead of all of it.
+        The column strip holds every row of its columns, so the column log-sum-exps, the regulariser's pair means and this rank's part of
+        the loss are complete there (three partial sums + a maximum are all-reduced); its gradient gives d loss / d (own targets).  The row
+        strip needs the log-sum-exps of ALL columns (one all-gather of R floats) and gives d loss / d (own predictions).  Fused kernels
+        (cpc_score_lse / cpc_nce_fused_*): no f32 score matrix, no second (transposed) GEMM.  At 8 x 256 clips x 12 steps a rank computes
+        4 x 77 GFLOP instead of 4 x 618."""
+        e, dist = self.eng, self.dist
+        code, E, K, B, GB, W = e.code, e.E, e.K, e.B, self.GB, self.world
+        Rl, Rg = B * K, GB * K
+        lo = self.rank * Rl
+        s = getattr(self, "_strips", None)
+        if s is None:
+            dev, dt, f32 = e.device, e.dt, torch.float32
+            s = self._strips = SimpleNamespace(
+                Sc=torch.empty(Rg, Rl, device=dev, dtype=f32), dSc=torch.empty(Rg, Rl, device=dev, dtype=dt),
+                dScT=torch.empty(Rl, Rg, device=dev, dtype=dt), Sr=torch.empty(Rl, Rg, device=dev, dtype=f32),
+                dSr=torch.empty(Rl, Rg, device=dev, dtype=dt),
+                pm=torch.empty(Rg // 256, Rl, device=dev, dtype=f32), ps=torch.empty(Rg // 256, Rl, device=dev, dtype=f32),
+                pm2=torch.empty(Rl // 256, Rg, device=dev, dtype=f32), ps2=torch.empty(Rl // 256, Rg, device=dev, dtype=f32),
+                valid=torch.zeros(Rg, device=dev, dtype=f32), lse_loc=torch.empty(Rl, device=dev, dtype=f32),
+                lse_all=torch.empty(Rg, device=dev, dtype=f32), colp=torch.empty(_ceil_div(Rl, 256), 2, device=dev, dtype=f32),
+                gradp=torch.empty(int(_hip.lib().cpc_nce_fused_grad_blocks(GB, Rl)), device=dev, dtype=f32),
+                sums=torch.zeros(4, device=dev, dtype=f32),
+                targT=torch.zeros(E, Rg, device=dev, dtype=dt), predT=torch.zeros(E, Rg, device=dev, dtype=dt))
+        P, L, F = _hip.ptr, C.c_longlong, C.c_float
+        sp = 1 if softplus else 0
+        pred_all, targ_all = self.pred_all.view(Rg, E), self.targ_all.view(Rg, E)
+        # column strip: every prediction against this rank's targets
+        _hip.call("cpc_score_lse", P(pred_all), P(targ_all, lo * E), P(s.Sc), P(s.pm), P(s.ps), P(s.valid), Rg, Rl, E, L(E), L(E), L(Rl), -lo,
+                  key="score_lse<bf16,256>", work=2.0 * Rg * Rl * E)
+        _hip.call("cpc_nce_lse_merge", P(s.pm), P(s.ps), Rg // 256, Rl, sp, F(Rg), P(s.lse_loc), P(s.colp))
+        _hip.call("cpc_nce_fused_grad", P(s.Sc), P(s.lse_loc), P(s.dSc), P(s.dScT), P(s.gradp), GB, K, Rl, L(Rl), L(Rg), -lo, sp,
+                  F(regularization), F(Rg), F(GB))
+        _hip.call("cpc_nce_fused_finalize", P(s.colp), s.colp.shape[0], P(s.valid, lo), Rl, P(s.gradp), s.gradp.numel(), P(s.sums), 1, F(Rg),
+                  F(GB), K, F(regularization), sp, None)
+        dist.all_reduce(s.sums[0:3])
+        dist.all_reduce(s.sums[3:4], op=dist.ReduceOp.MAX)
+        _hip.call("cpc_nce_fused_finalize", None, 0, None, 0, None, 0, P(s.sums), 2, F(Rg), F(GB), K, F(regularization), sp, P(self.out))
+        dist.all_gather([s.lse_all[r * Rl:(r + 1) * Rl] for r in range(W)], s.lse_loc)
+        # d loss / d own targets [c][:] = sum over ALL predictions r of dS[r][c] pred[r][:]
+        s.predT.copy_(pred_all.t())
+        _hip.gemm_nt(P(s.dScT), P(s.predT), P(self.dtarg_all, lo * E), Rl, E, Rg, Rg, Rg, E, code)
+        # row strip: this rank's predictions against every target (the same kernel: identical accumulators; its column pairs are not used)
+        _hip.call("cpc_score_lse", P(pred_all, lo * E), P(targ_all), P(s.Sr), P(s.pm2), P(s.ps2), None, Rl, Rg, E, L(E), L(E), L(Rg), lo,
+                  key="score_lse<bf16,256>", work=2.0 * Rl * Rg * E)
+        _hip.call("cpc_nce_fused_grad", P(s.Sr), P(s.lse_all), P(s.dSr), None, None, B, K, Rg, L(Rg), L(0), lo, sp, F(regularization), F(Rg),
+                  F(GB))
+        s.targT.copy_(targ_all.t())
+        _hip.gemm_nt(P(s.dSr), P(s.targT), P(self.dpred_all, lo * E), Rl, E, Rg, Rg, Rg, E, code)
+
     def forward_backward(self, softplus: bool, regularization: float, all_timesteps: bool = False):
         e, dist = self.eng, self.dist
         code, B, E, K, GB, ld = e.code, e.B, e.E, e.K, self.GB, self.ld
@@ -1580,7 +1673,10 @@ class GlobalNegatives:
         dist.all_gather([self.targ_all[r * n:(r + 1) * n] for r in range(self.world)], self.local_targ)
         P = _hip.ptr
         if all_timesteps:
-            self._all_timesteps(softplus, regularization)
+            if e.fused_scores_ok(rows=B * K, cols=B * K) and os.environ.get("CPC_SCORE_STRIPS", "1") != "0":
+                self._all_timesteps_strips(softplus, regularization)
+            else:
+                self._all_timesteps(softplus, regularization)
             lo = self.rank * n
             e.dpred.copy_(self.dpred_all[lo:lo + n])
             dtop[:, T - K:T, :].copy_(self.dtarg_all[lo:lo + n].view(B, K, E))

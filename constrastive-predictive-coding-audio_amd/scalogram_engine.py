@@ -23,19 +23,26 @@ from .engine import CPCEngine, _ceil_div, make_context, side_stream
 class Grid:
     """Zero-initialised [B][W][Ha][C] buffer with guard rows on both ends; valid rows are [top, top + H) of every column."""
 
-    def __init__(self, B, W, H, C_, device, dtype, top=0, tail=0, guard_rows=96):
+    def __init__(self, B, W, H, C_, device, dtype, top=0, tail=0, guard_rows=96, lazy=False):
         self.B, self.W, self.H, self.C, self.top = int(B), int(W), int(H), int(C_), int(top)
         self.Ha = self.top + self.H + int(tail)
         self.guard_rows = int(guard_rows)
         self.dtype = dtype
         self.code = _hip.dtype_code(dtype)
         self.rows = self.B * self.W * self.Ha
-        guard = int(guard_rows) * self.C
-        self.full = torch.zeros(guard + self.rows * self.C + guard, device=device, dtype=dtype)
-        self.t = self.full[guard:guard + self.rows * self.C]
+        self.device = device
+        self.full = self.t = None
+        if not lazy:          # (lazy: a grid that normally aliases the caller's memory gets its own only when allocate() is called)
+            self.allocate()
         self.desc = (C.c_int * 6)(self.B, self.W, self.H, self.Ha, self.top, self.C)
         # the same memory seen as a grid whose top padding rows are ordinary (zero) data rows
         self.padded_desc = (C.c_int * 6)(self.B, self.W, self.top + self.H, self.Ha, 0, self.C)
+
+    def allocate(self):
+        guard = self.guard_rows * self.C
+        self.full = torch.zeros(guard + self.rows * self.C + guard, device=self.device, dtype=self.dtype)
+        self.t = self.full[guard:guard + self.rows * self.C]
+        return self.t
 
     def ptr(self, offset_elems=0):
         return _hip.ptr(self.t, offset_elems)
@@ -279,7 +286,8 @@ class _Conv:
         # even input columns 2 wo', wo' = 0 .. Wo: pieces = dY columns wo' - 1 and wo'
         _hip.gemm_nt(dy0.ptr(a0 - col_o), P(self.w_even), din.ptr(), (Wo + 1) * B * Hp, N, 2 * kp, G * cout, 2 * kp, N, code,
                      mask=mk(0), a_rpi=Hp, a_item=Wo * col_o, a_rpi2=B, a_item2=col_o, c_rpi=Hp, c_item=gin.W * col_i, c_valid=Hg, c_rpi2=B,
-                     c_item2=2 * col_i, k_taps=2, k_tap_stride=kp, k_tap_stride_a=col_o, k_ranges=P(self.par_ranges), flags=skip,
+                     c_item2=2 * col_i, k_taps=2, k_tap_stride=kp, k_tap_stride_a=col_o, k_ranges=P(self.par_ranges),
+                     flags=skip | _hip.GEMM_KRANGE_EXACT,          # the cut-out piece is the neighbouring clip's data, not zeros: no tile may straddle two columns
                      work=self.par_work[0])
         # odd input columns 2 wo' + 1, wo' = 0 .. Wo - 1: dY column wo'
         _hip.gemm_nt(dy0.ptr(a0), P(self.w_odd), din.ptr(col_i), B * Wo * Hp, N, kp, G * cout, kp, N, code, mask=mk(col_i),
@@ -1317,8 +1325,9 @@ class ScalogramCPCEngine(CPCEngine):
         top0 = blocks[0].cfg['top_padding_1'] or 0
         if top0:
             raise NotImplementedError("top_padding_1 on the first scalogram block")
-        self.x_grid = Grid(B, Win, Hin, Cin, self.device, torch.float32)
-        self._x_own = self.x_grid.t
+        # (its own 165 MB at configs[2] only if a batch ever arrives in another layout: PreprocessingModule's output is read in place)
+        self.x_grid = Grid(B, Win, Hin, Cin, self.device, torch.float32, lazy=True)
+        self._x_own = None
         self.blocks: List[_Block] = []
         gin, in_f32 = self.x_grid, True
         for i, blk in enumerate(blocks):
@@ -1383,9 +1392,14 @@ class ScalogramCPCEngine(CPCEngine):
             # PreprocessingModule's output IS the channels-last grid: read it in place (every kernel that reads the input grid stays
             # inside its B x W x H x C elements; the 165 MB copy of a configs[2] batch is gone)
             self.x_grid.t = cl.reshape(-1)
+            # the backward pass recomputes block 0 from this memory (stem kernels, residual weight gradient): an in-place write to the
+            # caller's tensor between forward and backward would silently change the gradients -- its version counter is checked there
+            self._x_alias = (x, x._version)
         else:
-            if self.x_grid.t.data_ptr() != self._x_own.data_ptr():
-                self.x_grid.t = self._x_own
+            self._x_alias = None
+            if self._x_own is None:
+                self._x_own = self.x_grid.allocate()
+            self.x_grid.t = self._x_own
             self.x_grid.t.view(cl.shape).copy_(cl)
         for b in self.blocks:
             b.forward()
@@ -1406,6 +1420,10 @@ class ScalogramCPCEngine(CPCEngine):
         return top_t.t
 
     def _backward_encoder(self, x, grad_ready_hook=None):
+        alias = getattr(self, "_x_alias", None)
+        if alias is not None and alias[0]._version != alias[1]:
+            raise RuntimeError("the scalogram batch was modified in place between the forward and the backward pass: the engine reads it in "
+                               "place (no copy) and recomputes its first block from it — pass a tensor you do not write to, or a clone")
         if self.top_grid is not None:
             d_out = self.blocks[-1].d_out
             d_out.t.zero_()

@@ -34,9 +34,13 @@ extern "C" {
                                     K % lda == 0 is tap-innermost: identical sums in a different order, each input byte fetched once) */
 #define CPC_GEMM_NO_PERS 512      /* NT/bf16: LDS-staged epilogue instead of the register epilogue (A/B check) */
 #define CPC_GEMM_DIRECT_MASK 1024 /* NT/bf16: register epilogue also for launches with a mask (A/B check; default: LDS-staged there) */
+#define CPC_GEMM_KRANGE_EXACT 2048 /* with k_ranges: the ranges cut out pieces that are NOT zero, so no tile may straddle two range indices — the
+                                    * launch returns CPC_EINVAL unless a_rpi * max(a_rpi2, 1) is a multiple of the tile height (128 / 256) the
+                                    * launcher picks.  Without the flag a tile runs the union of its rows' ranges (correct for known-zero cuts only). */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
-/* 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
+/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize).
+ * 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
  * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
  * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
  * 6: the stem kernels (cpc_stem_*), sign-bit BatchNorm passes (cpc_bn_*_bits), cpc_gru_fwd_h0.
@@ -530,6 +534,38 @@ int cpc_gp_score_coeff(const float* S, const float* St1, const float* St2, float
 long long cpc_nce_all_workspace_floats(int B, int K);
 int cpc_nce_loss_all(const float* S, const float* ST, void* dS, void* dST, float* out, float* workspace, int B, int K, int ld,
                      int softplus, float regularization, int dtype, void* stream);
+
+/* score_over_all_timesteps=True with the column pass FUSED into the score contraction (bf16 storage; ABI 8).  The reference forms the
+ * (B K) x (B K) score tensor (contrastive_estimation_training.py:12-22) and takes logsumexp over its first two axes (:109-110); here the
+ * f32 score matrix is never written:
+ *   cpc_score_lse      scores s[r][c] = <P[r][:], T[c][:]> (P [M][ldp], T [N][ldt] bf16, E a multiple of 64 and >= 128, M and N multiples of
+ *                      256) on 256 x 256 tiles of a persistent MFMA kernel whose epilogue leaves, per M tile and column, the online pair
+ *                      pm / ps [M / 256][N] = (max, sum exp(s - max)) over the tile's rows, taken from the f32 accumulators; valid[r] =
+ *                      s[r][r + diag_off] where that column exists (a prediction's own target; may be NULL); S [M][lds] f32 = the scores,
+ *                      for cpc_nce_fused_grad (NULL: not stored) — f32 because that pass takes exp(score - lse): a bf16 copy of a
+ *                      score of 100 is off by up to 0.4, its softmax weight by half (measured: gradient cosine 0.48).
+ *   cpc_nce_lse_merge  lse[c] = log( sum over ALL rows of exp(score(s[r][c])) ) from the pairs: for softplus scores exp(softplus(s)) =
+ *                      1 + exp(s), so lse = log(nrows_total + sum ps exp(pm)) — no softplus is evaluated; colp [ceil(ncols / 256)][2] =
+ *                      {sum of the block's lse, max of its pm}.
+ *   cpc_nce_fused_grad d loss / d linear score (bf16, dS [items K][ld]; and its transpose, dST [ncols][ldT], or NULL) from S and lse, as cpc_nce_loss_all forms it:
+ *                      (exp(sp - lse[c]) - [c == r + diag_off]) / n_rows_total + 2 reg / (n_items_total^2 K^2) mean_k sp[(b,k)][c], times the score
+ *                      function's derivative; rows r = (item, k), items K of them, K even and <= 24, ncols a multiple of 8; gradp
+ *                      [cpc_nce_fused_grad_blocks(items, ncols)] = partial sums of (mean_k sp)^2 (the regulariser :141).
+ *   cpc_nce_fused_finalize   the eight values cpc_nce_loss_all writes to `out`.  mode 0: from the partials (colp, valid, gradp); mode 1:
+ *                      the partials reduced to sums[4] = {sum valid, sum lse, sum m^2, max s} only — a rank that holds a strip of the
+ *                      global score matrix all-reduces them (SUM, SUM, SUM, MAX) — and mode 2: out from sums.  n_rows_total /
+ *                      n_items_total: rows (predictions) and items of the WHOLE score matrix.
+ * Rectangular problems (M != N, diag_off != 0) are the strips of engine.GlobalNegatives: a rank computes all predictions x its own
+ * targets and its own predictions x all targets instead of the whole global matrix. */
+int cpc_score_lse(const void* P, const void* T, float* S, float* pm, float* ps, float* valid, int M, int N, int E, long long ldp,
+                  long long ldt, long long lds, int diag_off, void* stream);
+int cpc_nce_lse_merge(const float* pm, const float* ps, int nparts, int ncols, int softplus, float nrows_total, float* lse, float* colp,
+                      void* stream);
+long long cpc_nce_fused_grad_blocks(int items, int ncols);
+int cpc_nce_fused_grad(const float* S, const float* lse, void* dS, void* dST, float* gradp, int items, int K, int ncols, long long ld,
+                       long long ldT, int diag_off, int softplus, float regularization, float n_rows_total, float n_items_total, void* stream);
+int cpc_nce_fused_finalize(const float* colp, int ncolp, const float* valid, int nvalid, const float* gradp, int ngrad, float* sums, int mode,
+                           float n_rows_total, float n_items_total, int K, float regularization, int softplus, float* out, void* stream);
 
 /* The per-batch quantities of ContrastiveEstimationTrainer.validate (contrastive_estimation_training.py:227-247) from the same
  * score matrices the train step uses (S of cpc_nce_loss when all_timesteps == 0, S of cpc_nce_loss_all otherwise; softplus as

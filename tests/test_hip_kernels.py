@@ -5,6 +5,7 @@ bf16 mode 1e-2 (inputs rounded to 8 significant bits, f32 accumulation).
 """
 import ctypes as C
 import math
+from types import SimpleNamespace
 
 import pytest
 import torch
@@ -746,6 +747,120 @@ def test_nce_loss_all_timesteps(dt, softplus, B, K, reg):
     t = 2e-5 if dt == torch.float32 else 1e-2
     assert rel_err(dSp[:, :R], lin.grad) < t
     assert rel_err(dSTp[:, :R], lin.grad.T) < t
+
+
+def _fused_scores(Pm, Tm, softplus, reg, K, diag_off, n_rows_total, n_items_total, lse_in=None, want_T=True):
+    """cpc_score_lse -> cpc_nce_lse_merge -> cpc_nce_fused_grad on device copies of Pm [M][E] / Tm [N][E] (bf16)."""
+    M, E = Pm.shape
+    N = Tm.shape[0]
+    bf = torch.bfloat16
+    dP, dT = dev(Pm, bf), dev(Tm, bf)
+    Sb = torch.full((M, N), float("nan"), device=DEV)
+    pm = torch.full((M // 256, N), float("nan"), device=DEV)
+    ps = torch.full((M // 256, N), float("nan"), device=DEV)
+    valid = torch.zeros(M, device=DEV)
+    L_, F_ = C.c_longlong, C.c_float
+    _hip.call("cpc_score_lse", _hip.ptr(dP), _hip.ptr(dT), _hip.ptr(Sb), _hip.ptr(pm), _hip.ptr(ps), _hip.ptr(valid), M, N, E, L_(E), L_(E), L_(N),
+              diag_off)
+    lse = torch.full((N,), float("nan"), device=DEV)
+    colp = torch.full(((N + 255) // 256, 2), float("nan"), device=DEV)
+    _hip.call("cpc_nce_lse_merge", _hip.ptr(pm), _hip.ptr(ps), M // 256, N, softplus, F_(n_rows_total), _hip.ptr(lse), _hip.ptr(colp))
+    use = lse if lse_in is None else dev(lse_in.float())
+    items = M // K
+    dS = torch.full((M, N), float("nan"), device=DEV, dtype=bf)
+    dST = torch.full((N, M), float("nan"), device=DEV, dtype=bf) if want_T else None
+    gradp = torch.full((int(_hip.lib().cpc_nce_fused_grad_blocks(items, N)),), float("nan"), device=DEV)
+    _hip.call("cpc_nce_fused_grad", _hip.ptr(Sb), _hip.ptr(use), _hip.ptr(dS), _hip.ptr(dST), _hip.ptr(gradp), items, K, N, L_(N), L_(M), diag_off,
+              softplus, F_(reg), F_(n_rows_total), F_(n_items_total))
+    torch.cuda.synchronize()
+    return SimpleNamespace(Sb=Sb, pm=pm, ps=ps, valid=valid, lse=lse, colp=colp, dS=dS, dST=dST, gradp=gradp)
+
+
+@pytest.mark.parametrize("softplus", [0, 1])
+@pytest.mark.parametrize("items,K,E,reg", [(64, 8, 128, 1.0), (32, 16, 192, 0.01), (64, 12, 512, 0.5)])
+def test_fused_all_timesteps_score_path(softplus, items, K, E, reg):
+    """score_over_all_timesteps=True through the fused kernels (bf16): the score GEMM whose epilogue leaves the column log-sum-exp
+    pairs, the merge, the gradient pass on the bf16 scores and the loss scalars — against the oracle's loss on the same (bf16-rounded)
+    operands and autograd's gradient (contrastive_estimation_training.py:12-22, :108-114, :141)."""
+    R = items * K
+    g = torch.Generator().manual_seed(items + K + E)
+    bf = torch.bfloat16
+    Pm = (torch.randn(R, E, generator=g) * (2.0 / math.sqrt(E))).to(bf)
+    Tm = (torch.randn(R, E, generator=g) * 2.0).to(bf)
+    Pm[0] = Tm[0] * 0.25                                  # one large own-target score (softplus threshold branch, the column maximum)
+    r = _fused_scores(Pm.float(), Tm.float(), softplus, reg, K, 0, R, items)
+    lin = (Pm.double() @ Tm.double().T).requires_grad_(True)
+    sc = lin.view(items, K, items, K)
+    sc = F.softplus(sc) if softplus else sc
+    loss, smax = O.info_nce_loss(sc, all_timesteps=True, regularization=reg)
+    loss.backward()
+    # the scores as stored (f32), their diagonal and the column log-sum-exps (taken from the f32 accumulators)
+    assert rel_err(r.Sb, lin) < 2e-6
+    assert (r.valid.double().cpu() - torch.diagonal(lin.detach())).abs().max().item() < 1e-4 * lin.detach().abs().max().item()
+    ref_lse = torch.logsumexp(sc.detach().reshape(R, R), dim=0)
+    assert (r.lse.double().cpu() - ref_lse).abs().max().item() < 2e-5 * max(1.0, ref_lse.abs().max().item())
+    out = torch.full((8,), float("nan"), device=DEV)
+    out[6] = 0.0
+    F_ = C.c_float
+    _hip.call("cpc_nce_fused_finalize", _hip.ptr(r.colp), r.colp.shape[0], _hip.ptr(r.valid), R, _hip.ptr(r.gradp), r.gradp.numel(), None, 0,
+              F_(R), F_(items), K, F_(reg), softplus, _hip.ptr(out))
+    assert abs(out[0].item() - loss.item()) < 2e-4 * max(1.0, abs(loss.item())), (out[0].item(), loss.item())
+    assert abs(out[1].item() - smax.item()) < 1e-5 * max(1.0, abs(smax.item()))
+    assert out[5].item() == 0.0 and out[6].item() == 0.0
+    assert rel_err(r.dS, lin.grad) < 1.5e-2
+    assert torch.equal(r.dST, r.dS.T.contiguous())      # the transposed copy is the same numbers
+    # the two-stage form a rank of a data-parallel run uses: partial sums, then the scalars from the (all-reduced) sums
+    sums = torch.zeros(4, device=DEV)
+    out2 = torch.full((8,), float("nan"), device=DEV)
+    out2[6] = 0.0
+    _hip.call("cpc_nce_fused_finalize", _hip.ptr(r.colp), r.colp.shape[0], _hip.ptr(r.valid), R, _hip.ptr(r.gradp), r.gradp.numel(), _hip.ptr(sums), 1,
+              F_(R), F_(items), K, F_(reg), softplus, None)
+    _hip.call("cpc_nce_fused_finalize", None, 0, None, 0, None, 0, _hip.ptr(sums), 2, F_(R), F_(items), K, F_(reg), softplus, _hip.ptr(out2))
+    assert torch.equal(out[:6], out2[:6])
+
+
+@pytest.mark.parametrize("softplus", [0, 1])
+def test_fused_score_strips_equal_the_whole_matrix(softplus):
+    """The strips a rank of a global-negatives run forms — (all predictions) x (own targets) and (own predictions) x (all targets),
+    engine.GlobalNegatives._all_timesteps_strips — give the same log-sum-exps, loss sums and gradient blocks as the whole score matrix."""
+    items, K, E, W, reg = 64, 8, 128, 2, 0.7
+    R = items * K
+    Rl, il = R // W, items // W
+    g = torch.Generator().manual_seed(99)
+    bf = torch.bfloat16
+    Pm = (torch.randn(R, E, generator=g) * (2.0 / math.sqrt(E))).to(bf).float()
+    Tm = (torch.randn(R, E, generator=g) * 2.0).to(bf).float()
+    whole = _fused_scores(Pm, Tm, softplus, reg, K, 0, R, items)
+    tot = torch.zeros(4, device=DEV)
+    for rank in range(W):
+        lo = rank * Rl
+        col = _fused_scores(Pm, Tm[lo:lo + Rl], softplus, reg, K, -lo, R, items)
+        assert torch.equal(col.lse, whole.lse[lo:lo + Rl])
+        assert torch.equal(col.dS, whole.dS[:, lo:lo + Rl]) and torch.equal(col.dST, whole.dST[lo:lo + Rl])
+        assert torch.equal(col.valid[lo:lo + Rl], whole.valid[lo:lo + Rl])
+        row = _fused_scores(Pm[lo:lo + Rl], Tm, softplus, reg, K, lo, R, items, lse_in=whole.lse, want_T=False)
+        assert torch.equal(row.dS, whole.dS[lo:lo + Rl])
+        sums = torch.zeros(4, device=DEV)
+        F_ = C.c_float
+        _hip.call("cpc_nce_fused_finalize", _hip.ptr(col.colp), col.colp.shape[0], _hip.ptr(col.valid, lo), Rl, _hip.ptr(col.gradp),
+                  col.gradp.numel(), _hip.ptr(sums), 1, F_(R), F_(items), K, F_(reg), softplus, None)
+        tot[:3] += sums[:3]
+        tot[3] = torch.maximum(tot[3], sums[3]) if rank else sums[3]
+    ref = torch.zeros(4, device=DEV)
+    _hip.call("cpc_nce_fused_finalize", _hip.ptr(whole.colp), whole.colp.shape[0], _hip.ptr(whole.valid), R, _hip.ptr(whole.gradp),
+              whole.gradp.numel(), _hip.ptr(ref), 1, C.c_float(R), C.c_float(items), K, C.c_float(reg), softplus, None)
+    assert torch.allclose(tot, ref, rtol=2e-6, atol=0.0), (tot, ref)
+
+
+def test_fused_score_path_refuses_what_it_cannot_tile():
+    a = torch.zeros(512, 128, device=DEV, dtype=torch.bfloat16)
+    pm = torch.zeros(2, 512, device=DEV)
+    with pytest.raises(_hip.HipCallError):          # 300 rows: not a whole number of 256-row tiles
+        _hip.call("cpc_score_lse", _hip.ptr(a), _hip.ptr(a), None, _hip.ptr(pm), _hip.ptr(pm), None, 300, 512, 128, C.c_longlong(128),
+                  C.c_longlong(128), C.c_longlong(512), 0)
+    with pytest.raises(_hip.HipCallError):          # odd K
+        _hip.call("cpc_nce_fused_grad", _hip.ptr(pm), _hip.ptr(pm), _hip.ptr(a), None, None, 64, 7, 128, C.c_longlong(128), C.c_longlong(0), 0, 0,
+                  C.c_float(1.0), C.c_float(448.0), C.c_float(64.0))
 
 
 # --------------------------------------------------------------------------------------- Adam

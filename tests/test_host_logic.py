@@ -86,7 +86,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_hip.EXPORTED_SYMBOLS)
-    assert handle.cpc_abi_version() == 7
+    assert handle.cpc_abi_version() == 8
     nm = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cpc_\w+)", nm))
     assert exported == declared
@@ -110,6 +110,11 @@ def test_over_read_contract_is_checked_before_any_launch():
     args = _hip.GemmNTArgs(P, P, P, None, None, M, N, K, lda, K, N, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, _hip.BF16, M * lda, 0)
     assert lib.cpc_gemm_nt(C.byref(args), s) == -22            # an [M][lda] array is (K - lda) elements short
     args = _hip.GemmNTArgs(P, P, P, None, None, M, N, K, lda, K, N, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, _hip.BF16, 0, N * K - 1)
+    assert lib.cpc_gemm_nt(C.byref(args), s) == -22
+    # CPC_GEMM_KRANGE_EXACT: K ranges that cut out NON-zero pieces need every tile inside one range index; 96 rows per index against
+    # 128-row tiles is refused (without the flag the same launch is admitted: a tile then runs the union of its rows' ranges)
+    args = _hip.GemmNTArgs(P, P, P, None, None, 96 * 8, 128, 256, 256, 256, 128, 96, 96 * 256, 0, 0, 0, 0, 0, 0, 0, 0, 1, _hip.GEMM_KRANGE_EXACT,
+                           _hip.BF16, 0, 0, 0, 0, 0, 0, P, 0, 0, 0)
     assert lib.cpc_gemm_nt(C.byref(args), s) == -22
 
 

@@ -1132,6 +1132,46 @@ def test_odd_shapes_against_oracle(B, V, K, extra, all_t):
         assert ((got - ref).norm() / denom).item() < 2e-3, (n, ((got - ref).norm() / denom).item())
 
 
+@pytest.mark.parametrize("softplus", [True, False])
+def test_all_timesteps_fused_score_path_against_oracle(softplus, monkeypatch):
+    """score_over_all_timesteps=True at a tile-sized problem (32 clips x 8 steps = 256 predictions, 128 channels, bf16): the engine takes
+    the fused route (score GEMM with the column log-sum-exp in its epilogue, engine._nce_all_fused).  Loss against the oracle at 1e-3, the
+    whole gradient parallel to the oracle's; and the unfused kernels (CPC_FUSED_SCORE=0) agree with the fused ones to bf16 rounding."""
+    C_, H, V, K, B = 128, 64, 8, 8, 32
+    L = 465 + (V + K) * 160
+    torch.manual_seed(11)
+    enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C_] * 5, 'bias': True})
+    model = AudioPredictiveCodingModel(enc, AudioGRUModel(C_, H), enc_size=C_, ar_size=H, visible_steps=V, prediction_steps=K,
+                                       compute_dtype="bf16")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("weight") and n.startswith("encoder"):
+                p.mul_(2.0)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    x = torch.randn(B, L, generator=torch.Generator().manual_seed(3)) * 0.5
+    eng = model.engine(B, L)
+    assert eng.fused_scores_ok()
+    out = eng.loss_and_grads(x.to(DEV).contiguous(), softplus=softplus, regularization=0.5, all_timesteps=True)
+    got_loss = float(out[0])
+    names = [n for n, _ in model.named_parameters()]
+    got = torch.cat([model._grad[n].detach().reshape(-1) for n in names]).double().cpu()
+    ot = O.OracleTrainer(state, V, K, score="softplus" if softplus else "linear", all_timesteps=True, regularization=0.5)
+    loss, smax, grads = ot.loss_and_grads(x)
+    assert abs(got_loss - float(loss)) <= 1e-3 * max(1.0, abs(float(loss))), (got_loss, float(loss))
+    assert abs(float(out[1]) - float(smax)) <= 1e-2 * max(1.0, abs(float(smax)))
+    ref = torch.cat([grads[n].reshape(-1) for n in names]).double()
+    cos = float((ref * got).sum() / (ref.norm() * got.norm()))
+    assert cos > 0.995 and abs(float(got.norm() / ref.norm()) - 1.0) < 2e-2, (cos, float(got.norm() / ref.norm()))
+    # the unfused kernels on the same step
+    monkeypatch.setenv("CPC_FUSED_SCORE", "0")
+    assert not eng.fused_scores_ok()
+    out2 = eng.loss_and_grads(x.to(DEV).contiguous(), softplus=softplus, regularization=0.5, all_timesteps=True)
+    got2 = torch.cat([model._grad[n].detach().reshape(-1) for n in names]).double().cpu()
+    assert abs(float(out2[0]) - got_loss) <= 2e-4 * max(1.0, abs(got_loss)), (float(out2[0]), got_loss)
+    assert float((got2 - got).norm() / got.norm()) < 2e-2
+
+
 _DP_WORKER = r'''
 import os, sys, random, json
 import torch, torch.distributed as dist
@@ -1220,17 +1260,21 @@ dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.
 rank, world = dist.get_rank(), dist.get_world_size()
 dev = torch.device("cuda:0")
 C, H, K, V, Bloc, steps = 32, 32, 3, 8, 4, 2
+BIG = os.environ.get("GN_BIG") == "1"          # tile-sized bf16 problem: the fused score kernels and the per-rank strips of the global score matrix
+if BIG:
+    C, H, K, V, Bloc, steps = 128, 64, 8, 8, 32, 1
 L = 465 + (V + K) * 160
 torch.manual_seed(7)
 enc = AudioEncoder({'strides': [5, 4, 2, 2, 2], 'kernel_sizes': [10, 8, 4, 4, 4], 'channel_count': [C] * 5, 'bias': True})
-model = AudioPredictiveCodingModel(enc, AudioGRUModel(C, H), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K, compute_dtype="fp32")
+model = AudioPredictiveCodingModel(enc, AudioGRUModel(C, H), enc_size=C, ar_size=H, visible_steps=V, prediction_steps=K,
+                                   compute_dtype="bf16" if BIG else "fp32")
 with torch.no_grad():
     for n, p in model.named_parameters():
         if n.startswith("encoder") and n.endswith("weight"):
             p.mul_(3.0)
 state0 = {k: v.clone() for k, v in model.state_dict().items()}
 model = model.to(dev)
-data = torch.randn(24, L, generator=torch.Generator().manual_seed(5)) * 0.5
+data = torch.randn(128 if BIG else 24, L, generator=torch.Generator().manual_seed(5)) * 0.5
 ds = TensorAudioDataset(data, device=dev)
 class Log:
     def __init__(self):
@@ -1254,6 +1298,21 @@ if rank == 0:
     random.seed(100)
     lists = O.file_batch_sampler([len(data)], Bloc * world)
     ot = O.OracleTrainer(state0, V, K, score="softplus", all_timesteps=ALL_T, regularization=1.0, lr=1e-3)
+    if BIG:
+        # bf16 storage: the loss within 1e-3 of the reference, the summed gradient of the two ranks parallel to the reference's
+        # (Adam's sign-like first update makes parameters after a step a poor yardstick at this precision)
+        assert model.engine(Bloc, L).fused_scores_ok(), "this configuration is meant to take the fused score path"
+        print("lists", len(lists), "data", tuple(data.shape), "Bloc", Bloc, "world", world, "logged", len(log.losses), flush=True)
+        batch0 = data[torch.tensor(lists[0])]
+        loss, _, grads = ot.loss_and_grads(batch0)
+        assert abs(log.losses[0] - float(loss)) <= 1e-3 * abs(float(loss)), (log.losses[0], float(loss))
+        ref = torch.cat([grads[n].reshape(-1) for n, _ in model.named_parameters()]).double()
+        got = torch.cat([model._grad[n].detach().reshape(-1) for n, _ in model.named_parameters()]).double().cpu()
+        cos = float((ref * got).sum() / (ref.norm() * got.norm()))
+        assert cos > 0.995 and abs(float(got.norm() / ref.norm()) - 1.0) < 2e-2, (cos, float(got.norm() / ref.norm()))
+        print("GN-GPU-OK", cos, log.losses[0], float(loss))
+        dist.destroy_process_group()
+        sys.exit(0)
     ref_losses = [ot.step(data[lists[s]])[0] for s in range(steps)]
     got_losses = log.losses[0::2]
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(got_losses, ref_losses)), (got_losses, ref_losses)
@@ -1267,22 +1326,25 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("all_timesteps", [False, True])
-def test_global_negatives_two_ranks_equal_single_process_reference(tmp_path, all_timesteps):
+@pytest.mark.parametrize("all_timesteps,big", [(False, False), (True, False), (True, True)])
+def test_global_negatives_two_ranks_equal_single_process_reference(tmp_path, all_timesteps, big):
     """trainer.global_negatives: two ranks with 4 clips each reproduce the reference's single-process step on the 8-clip batch
     (losses and parameters after two steps, both loss branches) — the semantics of its nn.DataParallel wrap
-    (setup_functions.py:112-115)."""
+    (setup_functions.py:112-115).  big: 2 x 32 clips, 128 channels, 8 steps in bf16 — a tile-sized problem, so each rank forms its two
+    STRIPS of the global all-timesteps score matrix with the fused kernels (engine.GlobalNegatives._all_timesteps_strips)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "gn_worker.py"
     script.write_text(_GN_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29652" if all_timesteps else "29651", WORLD_SIZE="2",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", GN_ALL_TIMESTEPS="1" if all_timesteps else "0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29651 + int(all_timesteps) + 2 * int(big)), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", GN_ALL_TIMESTEPS="1" if all_timesteps else "0", GN_BIG="1" if big else "0")
     procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    for r, o in enumerate(outs):          # (shown by pytest when the test fails: the assertion's own repr cuts the ranks' output short)
+        print(f"--- rank {r} ---\n{o[-4000:]}")
+    assert all(p.returncode == 0 for p in procs), [o[-600:] for o in outs]
     assert "GN-GPU-OK" in outs[0]
 
 
