@@ -25,6 +25,10 @@ def newest(pattern):
 
 stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats_bench_b256_bf16.csv" if workload == "cfg1" else f"{tag}_kernel_stats.csv"))
+try:          # one step of the timed region, kernel by kernel
+    shutil.copy(os.path.join(src, "timeline_one_step.txt"), os.path.join(dst, f"{tag}_timeline_one_step.txt"))
+except FileNotFoundError:
+    pass
 try:          # the JSON line bench.py printed under the profiler (HIP-event figures of the same run)
     line = [ln for ln in open(os.path.join(src, "stats.log")) if ln.startswith("{")][-1]
     open(os.path.join(dst, f"{tag}_bench_line_under_rocprof.json"), "w").write(line)
