@@ -25,7 +25,7 @@ child process, decided before anything touches the GPU) and relays rank 0's JSON
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline      dominant kernel (the bf16 MFMA gemm_nt that carries the conv forward + data-gradient GEMMs): algorithmic
                 FLOPs of its launches / their HIP-event durations measured inside the timed region, on a sample of its steps
-                (every tenth: an event pair around a launch leaves ~12 us of idle queue).  In the step the
+                (every tenth: an event pair around a launch leaves ~12 us of idle queue, see docs/DESIGN_HISTORY_r1-r3.md section 6).  In the step the
                 weight-gradient GEMMs run beside these launches on a second stream; `alone` = the same kernel with everything on
                 one stream, from 6 extra untimed steps after the timed region.
   hbm_kernel    the HBM-bound piece of the conv stack (encoder layer 1, C_in = 1): algorithmic bytes / HIP-event duration vs 8 TB/s.
@@ -627,7 +627,7 @@ def main():
                     help="cfg1 = BASELINE configs[1] (headline); scalogram = configs[2]; conv_ar / attention = configs[3]")
     ap.add_argument("--prewarm", type=int, default=0,
                     help="untimed steps BEFORE the W warm-up steps: the first dozen steps of a process run 6-8 %% slower (every kernel; the "
-                         "clocks ramp under sustained load, DESIGN.md section 9.3), which a 5-step warm-up does not cover; reported as "
+                         "clocks ramp under sustained load, docs/DESIGN_HISTORY_r1-r3.md section 9.3), which a 5-step warm-up does not cover; reported as "
                          "prewarm_steps.  0 = off")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 256; 128 for --workload scalogram)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])

@@ -1260,7 +1260,7 @@ def test_e29_architectures_at_real_shapes():
 
 
 def test_nan_return_restores_batchnorm_statistics_and_step_count(golden_dir):
-    """The host learns of a NaN loss one step late and has launched another step by then: that step's
+    """The host learns of a NaN loss one step late and has launched another step by then (docs/DESIGN_HISTORY_r1-r3.md section 11): that step's
     update is skipped on the device, and train() puts back what its forward pass moved — the BatchNorm running statistics
     (num_batches_tracked counts the NaN step's own forward, as in the reference, which returns after it, :124-133, and not the
     step launched behind it) and Adam's step count (no update since the start of the NaN step)."""

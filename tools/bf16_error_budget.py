@@ -22,7 +22,7 @@ def rnd(t):
 
 
 def rnd_centred(g):
-    """What storing (value - per-channel mean) in bf16 would do: the candidate fix for the residual stream."""
+    """What storing (value - per-channel mean) in bf16 would do: the candidate fix for the residual stream (docs/DESIGN_HISTORY_r1-r3.md section 13)."""
     v = g.t.view(-1, g.C)
     nz = v != 0
     c = (v.sum(0) / nz.sum(0).clamp(min=1)).unsqueeze(0)

@@ -137,7 +137,16 @@ int main(int argc, char** argv) {
     {
         dim3 g256((rows + 255) / 256, items), g128((rows + 127) / 128, items);
 #define CAPPED(RPB, CAP, SLEEP, IL, LDS, G, NAME) report(NAME, time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_capped<RPB, CAP, SLEEP, IL>), G, dim3(256), LDS, s, buf, rows); }))
-        for (int pass = 0; pass < 3; ++pass) {
+        printf("-- layer-1 mapping (wave = RPB / 4 contiguous rows), rows per block\n");
+        for (int pass = 0; pass < 2; ++pass) {
+            report("  16 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<16, 0>), dim3((rows + 15) / 16, items), dim3(256), 0, s, buf, rows); }));
+            report("  32 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<32, 0>), dim3((rows + 31) / 32, items), dim3(256), 0, s, buf, rows); }));
+            report("  64 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<64, 0>), dim3((rows + 63) / 64, items), dim3(256), 0, s, buf, rows); }));
+            report(" 128 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<128, 0>), dim3((rows + 127) / 128, items), dim3(256), 0, s, buf, rows); }));
+            report(" 256 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<256, 0>), dim3((rows + 255) / 256, items), dim3(256), 0, s, buf, rows); }));
+            report(" 512 rows per block", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_rot<512, 0>), dim3((rows + 511) / 512, items), dim3(256), 0, s, buf, rows); }));
+        }
+        for (int pass = 0; pass < 1; ++pass) {
             printf("-- pass %d: identical mappings from three kernels, then rotations\n", pass);
             report("conv1_like<nt,256>", time_ms(s, 9, [&] { hipLaunchKernelGGL((conv1_like<true, 256, false>), g256, dim3(256), 0, s, buf, rows, 0); }));
             CAPPED(256, -1, 0, false, 0, g256, "conv1_capped<256, no cap>");
