@@ -14,6 +14,8 @@ import math
 import os
 
 import numpy as np
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -201,7 +203,9 @@ class CQT(nn.Module):
                     _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(self._split_buf), M, npad, K // 2, 3 * hop, K, npad,
                                  _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], a_batch=K // 2, b_batch=K // 2, c_batch=M * npad, batch=2,
                                  flags=_hip.GEMM_OUT_F32)
-                    torch.add(self._split_buf[0], self._split_buf[1], out=cq.view(M, ldq)[:, 2 * start:2 * start + npad])
+                    # cq[m][2 start + j] = half 0 + half 1 (a strided torch.add here was the last torch arithmetic of the scalogram step)
+                    _hip.call("cpc_reduce_slabs", _hip.ptr(self._split_buf), _hip.ptr(cq, 2 * start), M, npad, 2, C.c_longlong(M * npad), 1,
+                              C.c_longlong(1), C.c_longlong(ldq), C.c_longlong(0))
                     continue
                 _hip.gemm_nt(_hip.ptr(x3, 3 * offset), _hip.ptr(filt), _hip.ptr(cq, 2 * start), M, npad, K, 3 * hop,
                              K, ldq, _hip.BF16, a_rpi=Tn, a_item=3 * x.shape[1], flags=_hip.GEMM_OUT_F32)

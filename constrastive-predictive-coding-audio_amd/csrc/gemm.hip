@@ -1047,6 +1047,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
 // scores the tile leaves, for each of its 256 columns, the online log-sum-exp pair (max, sum exp(s - max)) over its 256 rows, taken from the
 // f32 accumulators, and the diagonal scores s[r][r + lse_diag_off]; cpc_nce_lse_merge combines the pairs of a column over the M tiles.  The
 // scores themselves are stored as f32 (optional): ONE matrix instead of the unfused path's two (scores and transposed scores).
+// one DPP move of a float within its row of 16 lanes (all lanes enabled, bound_ctrl: out-of-row sources read 0 — none here)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int DBG, bool LSE = false>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
     typedef bf16_t T;
@@ -1187,18 +1193,26 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNT p) {
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) cm[q] = fmaxf(cm[q], acc[i][q >> 2][q & 3]);
+            // (reductions over the 16 lanes of a row group as DPP moves — quad permutes, then half-row and row mirrors — on the vector
+            // pipe; __shfl_xor goes through the LDS crossbar: 128 ds_bpermute per lane and tile)
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) cm[q] = fmaxf(cm[q], __shfl_xor(cm[q], o, 64));
+            for (int q = 0; q < 16; ++q) {
+                cm[q] = fmaxf(cm[q], dpp_f32<0xB1>(cm[q]));          // quad_perm [1,0,3,2]
+                cm[q] = fmaxf(cm[q], dpp_f32<0x4E>(cm[q]));          // quad_perm [2,3,0,1]
+                cm[q] = fmaxf(cm[q], dpp_f32<0x141>(cm[q]));         // row_half_mirror
+                cm[q] = fmaxf(cm[q], dpp_f32<0x140>(cm[q]));         // row_mirror
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) cs[q] += __expf(acc[i][q >> 2][q & 3] - cm[q]);
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+            for (int q = 0; q < 16; ++q) {
+                cs[q] += dpp_f32<0xB1>(cs[q]);
+                cs[q] += dpp_f32<0x4E>(cs[q]);
+                cs[q] += dpp_f32<0x141>(cs[q]);
+                cs[q] += dpp_f32<0x140>(cs[q]);
+            }
             float* red = (float*)(lds + 2 * STAGE);
             if (frow == 0) {
 #pragma unroll
@@ -1692,8 +1706,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         for (int z = 0; z < nslab; ++z) s += *(const f32x4*)(slabs + (long long)z * slab_stride + e);
         const int i = (int)(e / J), j = (int)(e % J);
         const long long base = (long long)(i / cdiv) * s_hi + (long long)(i % cdiv) * s_lo;
+        float* dst = out + base + (long long)j * s_j;
+        if (s_j == 1 && ((unsigned long long)dst & 15ull) == 0) {          // rows of a matrix: one 16-byte store
+            *(f32x4*)dst = s;
+            continue;
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[base + (long long)(j + q) * s_j] = s[q];
+        for (int q = 0; q < 4; ++q) dst[(long long)q * s_j] = s[q];
     }
 }
 
