@@ -82,6 +82,7 @@ _SIGNATURES = {
     "cpc_sign_bits": ([_P, _P, _L, _I, _P], _I),
     "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),
+    "cpc_reduce_conv_w2d": ([_P, _P, _I, _L, _I, _I, _I, _I, _L, _L, _L, _I, _L, _P], _I),
     "cpc_conv_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
     "cpc_conv_dgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P, _P], _I),
     "cpc_conv_dgrad_colsum_floats": ([_I, _I, _I, _I], _L),

@@ -108,6 +108,11 @@ int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw,
     return launch_reduce_conv_w(slabs, out, cin, cout, kw, nslab, slab_stride, (hipStream_t)stream);
 }
 
+int cpc_reduce_conv_w2d(const float* slabs, float* out, int nslab, long long slab_stride, int cout, int cin, int kh, int kw, long long s_dw,
+                        long long s_dh, long long s_c, int G, long long s_g, void* stream) {
+    return launch_reduce_conv_w2d(slabs, out, nslab, slab_stride, cout, cin, kh, kw, s_dw, s_dh, s_c, G, s_g, (hipStream_t)stream);
+}
+
 int cpc_conv_fwd(const void* x, const void* w_fwd, const float* bias, void* y, int B, int Cin, int Cout, int kw, int stride,
                  int Lout_alloc, int Lout_valid, int relu, long long x_tail, int dtype, void* stream) {
     if (!x || !w_fwd || !y || B <= 0 || Lout_alloc <= 0 || Lout_valid > Lout_alloc || kw <= 0 || stride <= 0) return CPC_EINVAL;

@@ -128,6 +128,8 @@ int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
 int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,
                               hipStream_t stream);
+int launch_reduce_conv_w2d(const float* slabs, float* out, int nslab, long long slab_stride, int cout, int cin, int kh, int kw,
+                           long long s_dw, long long s_dh, long long s_c, int G, long long s_g, hipStream_t stream);
 int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
                          hipStream_t stream);
 long long gru_tape_elems(int B, int V, int H, int dtype);

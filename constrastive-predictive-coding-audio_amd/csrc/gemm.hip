@@ -1779,6 +1779,38 @@ __global__ __launch_bounds__(256) void reduce_conv_w_kernel(const float* __restr
     }
 }
 
+// Weight gradient of an nn.Conv2d from split-K slabs in the layouts the grid convolutions produce (scalogram_engine._Conv._wgrad):
+//   out[((co cin + c) kh + dh) kw + dw] = sum_z sum_{g < G} slab[z][dw s_dw + (dh + g) s_dh + c s_c + g s_g + co]
+// G = 1: slabs [kw][kh][cin][cout] of the gathered-window GEMM (one batch entry per kernel column).  G > 1: the row-grouped tall (k,1)
+// kernels, slab [(r, c)][(g, co)] = sum_R X[G R + r][c] dY[G R + g][co]: dW[co][c][j] collects the G diagonals r = j + g.
+// One thread per output element, co fastest (contiguous slab reads); fixed summation order (z outer, g inner), four accumulators.
+__global__ __launch_bounds__(256) void reduce_conv_w2d_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslab,
+                                                              long long slab_stride, int cout, int cin, int kh, int kw, long long s_dw,
+                                                              long long s_dh, long long s_c, int G, long long s_g) {
+    const long long total = (long long)cout * cin * kh * kw;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int co = (int)(t % cout);
+    long long r = t / cout;
+    const int dw = (int)(r % kw); r /= kw;
+    const int dh = (int)(r % kh);
+    const int c = (int)(r / kh);
+    const float* base = slabs + dw * s_dw + dh * s_dh + c * s_c + co;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int z = 0; z < nslab; ++z) {
+        const float* p = base + (long long)z * slab_stride;
+        int g = 0;
+        for (; g + 3 < G; g += 4) {
+            a0 += p[(long long)g * (s_dh + s_g)];
+            a1 += p[(long long)(g + 1) * (s_dh + s_g)];
+            a2 += p[(long long)(g + 2) * (s_dh + s_g)];
+            a3 += p[(long long)(g + 3) * (s_dh + s_g)];
+        }
+        for (; g < G; ++g) a0 += p[(long long)g * (s_dh + s_g)];
+    }
+    out[(((long long)co * cin + c) * kh + dh) * kw + dw] = (a0 + a1) + (a2 + a3);
+}
+
 // Column sums of a [M][N] T matrix into per-block partial slabs [gridDim.x][N] (f32); reduced by reduce_slabs.
 // A thread owns a group of CW columns — 16 bytes of a row: 8 bf16 or 4 f32 (VEC16), else 4 columns — and walks the rows of its row
 // lane four at a time, all four loads in flight before the first add (a wave then has 4 KiB in flight instead of the 512 B of
@@ -2207,6 +2239,17 @@ int launch_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab,
     const int blocks = (int)min((long long)2048, (total4 + 255) / 256);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, slabs, out, I, J, nslab, slab_stride,
                        cdiv, s_j, s_hi, s_lo);
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_reduce_conv_w2d(const float* slabs, float* out, int nslab, long long slab_stride, int cout, int cin, int kh, int kw,
+                           long long s_dw, long long s_dh, long long s_c, int G, long long s_g, hipStream_t stream) {
+    if (!slabs || !out || nslab <= 0 || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || G <= 0) return CPC_EINVAL;
+    const long long total = (long long)cout * cin * kh * kw;
+    if ((total + 255) / 256 > 0x7fffffffLL) return CPC_EINVAL;
+    hipLaunchKernelGGL(reduce_conv_w2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, slabs, out, nslab, slab_stride, cout, cin,
+                       kh, kw, s_dw, s_dh, s_c, G, s_g);
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -398,8 +398,24 @@ class CPCEngine:
 
     def forward(self, x):
         self.prepare_weights()
-        self.encoder_forward(x)
-        self.context_forward()
+        self._nbt_batch = []          # BatchNorm `num_batches_tracked` counters of this pass: ONE multi-tensor add instead of a launch each
+        try:
+            self.encoder_forward(x)
+            self.context_forward()
+        finally:
+            batch, self._nbt_batch = self._nbt_batch, None
+            if batch:
+                torch._foreach_add_(batch, 1)
+
+    _nbt_batch = None
+
+    def count_batch(self, counter):
+        """`num_batches_tracked += 1` of a train-mode BatchNorm (twelve of them in a configs[2] step, each a 5 us launch on the main queue):
+        collected while forward() runs and added with one launch at its end; outside forward() (stand-alone calls) added at once."""
+        if self._nbt_batch is None:
+            counter += 1
+        else:
+            self._nbt_batch.append(counter)
 
     # views of the forward results in the reference's shapes (storage dtype, no copies)
     def view_top(self):

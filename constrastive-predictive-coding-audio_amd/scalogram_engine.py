@@ -440,11 +440,10 @@ class _Conv:
 
             def reduce():
                 # slab[(r,c)][(dh,co)] = sum_R X[G R + r][c] dY[G R + dh][co]  ->  dW[co][c][j] = sum_dh slab[(j+dh, c)][(dh, co)]
-                S = wslab[:self.nsplit * Kg * Ng].view(self.nsplit, self.Rw, self.cin, G, self.cout).sum(0)
-                acc = S[0:self.kh, :, 0, :]
-                for dh in range(1, G):
-                    acc = acc + S[dh:dh + self.kh, :, dh, :]
-                gw.view(self.cout, self.cin, self.kh).copy_(acc.permute(2, 1, 0))
+                # (one kernel: split sum, the G diagonals and the transposition into the reference layout; it was a torch sum + G - 1 adds + a copy)
+                L = C.c_longlong
+                _hip.call("cpc_reduce_conv_w2d", _hip.ptr(wslab), _hip.ptr(gw), self.nsplit, L(Kg * Ng), self.cout, self.cin, self.kh, 1, L(0),
+                          L(self.cin * G * self.cout), L(G * self.cout), G, L(self.cout))
 
             staged(lambda: _hip.gemm_tn(gin.ptr(), dy0.ptr(), _hip.ptr(wslab), Mg, Kg, Ng, G * self.cin, Ng, Ng, code, nsplit=self.nsplit,
                                         m_chunk=chunk, slab_stride=Kg * Ng, flags=_hip.GEMM_OUT_F32, **rows), reduce)
@@ -470,9 +469,10 @@ class _Conv:
                                  a_item2=gin.W * gin.Ha * self.cin, a_batch=gin.Ha * self.cin, b_rpi=self.Ho, b_item=dy0.Ha * self.cout,
                                  c_batch=kc, batch=self.kw, nsplit=self.nsplit, m_chunk=chunk, slab_stride=self.kw * kc, flags=_hip.GEMM_OUT_F32)
 
-                def reduce_g():
-                    S = wslab[:self.nsplit * self.kw * kc].view(self.nsplit, self.kw, self.kh, self.cin, self.cout).sum(0)      # [dw][dh][c][co]
-                    gw.view(self.cout, self.cin, self.kh, self.kw).copy_(S.permute(3, 2, 1, 0))
+                def reduce_g():          # slabs [z][dw][dh][c][co] -> dW[co][c][dh][dw]
+                    L = C.c_longlong
+                    _hip.call("cpc_reduce_conv_w2d", _hip.ptr(wslab), _hip.ptr(gw), self.nsplit, L(self.kw * kc), self.cout, self.cin, self.kh, self.kw,
+                              L(kc), L(self.cin * self.cout), L(self.cout), 1, L(0))
                 staged(gemm_g, reduce_g)
                 return
 
@@ -714,7 +714,7 @@ class _BatchNorm:
             _hip.call("cpc_bn_finalize", _hip.ptr(e.slabs), self.nb, self.C, float(self.y0.count), float(mod.eps), momentum,
                       _hip.ptr(self.stats), _hip.ptr(rm), _hip.ptr(rv))
             if mod.track_running_stats and mod.num_batches_tracked is not None:
-                mod.num_batches_tracked += 1
+                e.count_batch(mod.num_batches_tracked)
         else:
             self.stats[0].copy_(mod.running_mean)
             self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))
@@ -895,7 +895,7 @@ class _Stem:
             _hip.call("cpc_bn_finalize", _hip.ptr(e.slabs), self.nb, self.C, self.count, float(mod.eps), momentum, _hip.ptr(self.stats),
                       _hip.ptr(rm), _hip.ptr(rv))
             if mod.track_running_stats and mod.num_batches_tracked is not None:
-                mod.num_batches_tracked += 1
+                e.count_batch(mod.num_batches_tracked)
         else:
             self.stats[0].copy_(mod.running_mean)
             self.stats[1].copy_(torch.rsqrt(mod.running_var + mod.eps))

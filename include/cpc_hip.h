@@ -39,7 +39,7 @@ extern "C" {
                                     * launcher picks.  Without the flag a tile runs the union of its rows' ranges (correct for known-zero cuts only). */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
-/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize).
+/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d.
  * 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
  * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
  * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
@@ -122,6 +122,13 @@ int cpc_reduce_slabs(const float* slabs, float* out, int I, int J, int nslab, lo
 /* Conv weight gradient slabs (cpc_conv_wgrad) -> reference layout: out[co][c][j] = sum_z slabs[z][j*cin + c][co]. */
 int cpc_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
                       void* stream);
+
+/* Weight gradient of an nn.Conv2d in the reference's [cout][cin][kh][kw] layout from split-K slabs of the grid GEMMs (ABI 8):
+ *   out[((co cin + c) kh + dh) kw + dw] = sum_z sum_{g < G} slabs[z slab_stride + dw s_dw + (dh + g) s_dh + c s_c + g s_g + co]
+ * G = 1: slabs [kw][kh][cin][cout] (windows gathered from the grid, one GEMM batch entry per kernel column); G > 1: the row-grouped tall (k,1)
+ * kernels, slab [(r, c)][(g, co)], whose G diagonals r = dh + g make up dW (scalogram_model.py:392-417's nn.Conv2d autograd). */
+int cpc_reduce_conv_w2d(const float* slabs, float* out, int nslab, long long slab_stride, int cout, int cin, int kh, int kw, long long s_dw,
+                        long long s_dh, long long s_c, int G, long long s_g, void* stream);
 
 /* slabs[blk][n] = partial column sums of X[M][N] (T) — bias gradients; reduce with cpc_reduce_slabs(I=1). */
 int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nblocks, int dtype, void* stream);
