@@ -79,6 +79,7 @@ _SIGNATURES = {
     "cpc_reduce_slabs": ([_P, _P, _I, _I, _I, _L, _I, _L, _L, _L, _P], _I),
     "cpc_colsum": ([_P, _P, _I, _I, _L, _I, _I, _P], _I),
     "cpc_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P], _I),
+    "cpc_conv1_fwd_rows": ([_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _I, _I, _P], _I),
     "cpc_sign_bits": ([_P, _P, _L, _I, _P], _I),
     "cpc_conv1_bwd": ([_P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P], _I),
     "cpc_reduce_conv_w": ([_P, _P, _I, _I, _I, _I, _L, _P], _I),

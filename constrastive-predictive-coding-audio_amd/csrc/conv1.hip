@@ -56,13 +56,13 @@ template <typename T, int KW, bool WROW, bool BITS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int C,
                                                         int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu,
-                                                        unsigned char* __restrict__ y_bits) {
+                                                        unsigned char* __restrict__ y_bits, int row_lo, int row_hi) {
     static_assert(!BITS || WROW, "sign bits: one wave per row");
     const int kw = KW > 0 ? KW : kw_rt;
     __shared__ float xs[C1_FPOS * 8 + C1_MAXK + 8];     // stride <= 8 supported
     __shared__ __attribute__((aligned(16))) unsigned char bimg[BITS ? C1_FPOS * 64 : 16];
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * C1_FPOS;
+    const int t0 = row_lo + blockIdx.x * C1_FPOS;          // (rows [row_lo, row_hi) of every item: cpc_conv1_fwd_rows)
     const int tid = threadIdx.x;
     const int lpr = WROW ? 64 : C / 8;
     const int cg = tid % lpr, nrl = 256 / lpr;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     __syncthreads();
 
     T* yb = y + ((long long)b * L_alloc + t0) * C + cg * 8;
-    const int nrows = min(C1_FPOS, L_alloc - t0);
+    const int nrows = min(C1_FPOS, row_hi - t0);
     const int niter = BITS ? RPW : (nrows - rl + nrl - 1) / nrl;
     // Pad rows are stored from their own branch (no per-row zero fill of v).  Tried against this loop and not faster: one v_max_f32 per
     // value instead of relu_f's compare / select pair (with a NaN put-back); persistent kernels that stream the rows in memory order
@@ -213,16 +213,19 @@ static bool c1_ok(int C, int stride, int kw) {
 }
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream) {
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream,
+                     int row_lo, int row_hi) {
     if (!c1_ok(C, stride, kw) || B <= 0 || L_valid <= 0 || L_alloc < L_valid) return CPC_EINVAL;
+    if (row_hi < 0) row_hi = L_alloc;
+    if (row_lo < 0 || row_lo >= row_hi || row_hi > L_alloc) return CPC_EINVAL;
     if (y_bits && (C != 512 || (uintptr_t)y_bits % 16)) return CPC_EINVAL;        // sign bits: one wave per row (see the kernel)
     // 256 output positions per workgroup: the 88 weight / bias registers of a thread are loaded once per workgroup
-    dim3 grid((L_alloc + C1_FPOS - 1) / C1_FPOS, B);
+    dim3 grid((row_hi - row_lo + C1_FPOS - 1) / C1_FPOS, B);
 #define LAUNCH(T, KWT) \
     do { \
-        if (y_bits) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, true>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
-        else if (C == 512) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
-        else hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, false, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits); \
+        if (y_bits) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, true>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits, row_lo, row_hi); \
+        else if (C == 512) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits, row_lo, row_hi); \
+        else hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, false, false>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits, row_lo, row_hi); \
     } while (0)
     if (dtype == CPC_DTYPE_BF16) {
         if (kw == 10) LAUNCH(bf16_t, 10); else LAUNCH(bf16_t, 0);

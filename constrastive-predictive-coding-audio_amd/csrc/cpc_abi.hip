@@ -91,6 +91,14 @@ int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, in
     return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, relu, dtype, (unsigned char*)y_bits, (hipStream_t)stream);
 }
 
+int cpc_conv1_fwd_rows(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw, long long ldx,
+                       int L_valid, int L_alloc, int relu, int dtype, void* y_bits, int row_lo, int row_hi, void* stream) {
+    if (!x || !w || !y) return CPC_EINVAL;
+    if ((long long)(L_valid - 1) * stride + kw > ldx) return CPC_EINVAL;
+    return launch_conv1_fwd(x, w, bias, y, B, C, stride, kw, ldx, L_valid, L_alloc, relu, dtype, (unsigned char*)y_bits, (hipStream_t)stream,
+                            row_lo, row_hi);
+}
+
 int cpc_sign_bits(const void* x, void* bits, long long n, int dtype, void* stream) {
     if (!x || !bits || n <= 0 || n % 32) return CPC_EINVAL;
     return launch_sign_bits(x, (unsigned char*)bits, n, dtype, (hipStream_t)stream);

@@ -123,7 +123,8 @@ int launch_cast2d_batch(const void* jobs, int njobs, int dtype, hipStream_t stre
 int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int dtype, int nblocks, hipStream_t stream);
 
 int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
-                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream);
+                     long long ldx, int L_valid, int L_alloc, int relu, int dtype, unsigned char* y_bits, hipStream_t stream,
+                     int row_lo = 0, int row_hi = -1);
 int launch_conv1_bwd(const float* x, const void* dy, float* slabs, int B, int C, int stride, int kw, long long ldx,
                      int L_valid, int L_alloc, int nblk_t, int nblk_b, int dtype, hipStream_t stream);
 int launch_conv1_fused_reduce(const float* slabs, float* tmp, float* dw, float* db, int numM, int cin, int sub, int kw,

@@ -373,10 +373,65 @@ class CPCEngine:
         if x.dtype != torch.float32 or tuple(x.shape) != (self.B, self.L) or not x.is_contiguous():
             raise ValueError(f"expected a contiguous float32 batch of shape ({self.B}, {self.L}), got {tuple(x.shape)} {x.dtype}")
 
+    # ---- the rows only the TARGETS need, beside the GRU recurrence -------------------------------------------------------------
+    # The context network reads the first V of the V + K top-layer frames; frames V .. V+K-1 are the targets (audio_model.py:197-198).
+    # With unpadded causal convolutions top rows [0, V) need rows [0, n_l) of layer l, n_{l-1} = s_l (n_l - 1) + k_l — a prefix of every
+    # layer.  The GRU occupies 16 of the 256 CUs for 0.27 ms (100 dependent steps): the remaining rows of every layer (11 % of the encoder's
+    # forward work at V = 100, K = 12) are computed on the side stream while it runs, and the main stream's forward launches are
+    # that much shorter.  Same kernels on row ranges, identical results (CPC_TARGET_LANE=0: one launch per layer).
+    def _target_lane_rows(self):
+        """n_l per layer (rows of layer l that the context network's frames depend on), or None when the split does not apply."""
+        if getattr(self, "_tl_rows", 0) != 0:
+            return self._tl_rows
+        self._tl_rows = None
+        if (os.environ.get("CPC_TARGET_LANE", "1") == "0" or not self.use_aux or not isinstance(self.ctx, GRUContext) or self.K <= 0
+                or self.V <= 0 or self.n < 2 or self.T != self.V + self.K):
+            return None
+        La = self.geo.alloc
+        n = [0] * self.n
+        n[-1] = self.V
+        for l in range(self.n - 1, 0, -1):
+            n[l - 1] = self.strides[l] * (n[l] - 1) + self.kernels[l]
+        if any(n[l] >= La[l] or n[l] <= 0 for l in range(self.n)):
+            return None
+        # (worth it only where the side lane is small and the main lane still fills the chip)
+        if n[-1] * 4 < La[-1] * 3 or self.B * n[-1] < 4096:
+            return None
+        self._tl_rows = n
+        self._tl_ev = (torch.cuda.Event(), torch.cuda.Event())
+        return n
+
+    def _encoder_rows(self, x, lo, hi):
+        """Layers 1 .. n on rows [lo[l], hi[l]) of every item (hi[l] = L_alloc[l]: to the end, pad rows included)."""
+        p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
+        _hip.call("cpc_conv1_fwd_rows", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
+                  _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
+                  1 if self.n > 1 else 0, code, _hip.ptr(self.act_bits[0]), lo[0], hi[0], key="cpc_conv1_fwd")
+        for l in range(1, self.n):
+            cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
+            r0, rows = lo[l], hi[l] - lo[l]
+            M = B * rows
+            _hip.gemm_nt(_hip.ptr(self.act[l - 1], r0 * s * cin), _hip.ptr(self.w_fwd[l]), _hip.ptr(self.act[l], r0 * cout), M, cout, kw * cin,
+                         s * cin, kw * cin, cout, code, bias=_hip.ptr(p.get(f"encoder.layers.{l}.bias")),
+                         a_rpi=rows, a_item=La[l - 1] * cin, c_rpi=rows, c_item=La[l] * cout, c_valid=max(0, min(Lv[l], hi[l]) - r0),
+                         flags=_hip.GEMM_RELU if l < self.n - 1 else 0)
+
     def encoder_forward(self, x):
         """AudioEncoder.forward (audio_model.py:36-44): relu(conv) x (n-1), then a bare conv."""
         self._check_input(x)
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
+        # (only inside forward(), which joins the lanes again; not under a hipGraph capture, which runs on one stream)
+        nrows = self._target_lane_rows() if (self._tl_in_forward and self.use_aux) else None
+        if nrows is not None:
+            self._encoder_rows(x, [0] * self.n, nrows)                       # what the context network needs: main stream
+            ev0, ev1 = self._tl_ev
+            ev0.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.aux):
+                self.aux.wait_event(ev0)
+                self._encoder_rows(x, nrows, list(La))                      # what only the targets need: side stream, beside the GRU
+                ev1.record(self.aux)
+            self._tl_pending = ev1
+            return
         _hip.call("cpc_conv1_fwd", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
                   1 if self.n > 1 else 0, code, _hip.ptr(self.act_bits[0]))
@@ -395,19 +450,26 @@ class CPCEngine:
         ct, coff, cstride = self.ctx.c_operand()
         _hip.gemm_nt(_hip.ptr(ct, coff), _hip.ptr(self.w_p), _hip.ptr(self.pred), B, K * E, H, H, H, K * E, code,
                      a_rpi=1, a_item=cstride)
+        ev = getattr(self, "_tl_pending", None)
+        if ev is not None:          # the target rows of the encoder (side stream, see encoder_forward) are complete from here on
+            torch.cuda.current_stream().wait_event(ev)
+            self._tl_pending = None
 
     def forward(self, x):
         self.prepare_weights()
         self._nbt_batch = []          # BatchNorm `num_batches_tracked` counters of this pass: ONE multi-tensor add instead of a launch each
+        self._tl_in_forward = True
         try:
             self.encoder_forward(x)
             self.context_forward()
         finally:
+            self._tl_in_forward = False
             batch, self._nbt_batch = self._nbt_batch, None
             if batch:
                 torch._foreach_add_(batch, 1)
 
     _nbt_batch = None
+    _tl_in_forward = False
 
     def count_batch(self, counter):
         """`num_batches_tracked += 1` of a train-mode BatchNorm (twelve of them in a configs[2] step, each a 5 us launch on the main queue):

@@ -39,7 +39,7 @@ extern "C" {
                                     * launcher picks.  Without the flag a tile runs the union of its rows' ranges (correct for known-zero cuts only). */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
-/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d.
+/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d; cpc_conv1_fwd_rows.
  * 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
  * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
  * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
@@ -140,6 +140,10 @@ int cpc_colsum(const void* X, float* slabs, int M, int N, long long ldx, int nbl
  * before they are rounded to the storage type (what the reference's ReLU mask is taken from). */
 int cpc_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw,
                   long long ldx, int L_valid, int L_alloc, int relu, int dtype, void* y_bits, void* stream);
+/* The same for positions [row_lo, row_hi) of every item only (0 <= row_lo < row_hi <= L_alloc; ABI 8): the train step computes the rows
+ * the context network needs first and the rows only the targets need beside the GRU recurrence (engine.CPCEngine.encoder_forward). */
+int cpc_conv1_fwd_rows(const float* x, const float* w, const float* bias, void* y, int B, int C, int stride, int kw, long long ldx,
+                       int L_valid, int L_alloc, int relu, int dtype, void* y_bits, int row_lo, int row_hi, void* stream);
 /* SIGN-BIT MASKS: bits[i] bit e = x[8 i + e] > 0 (for bf16: of the stored value), n elements (a multiple of 32; x 16-byte, bits
  * 4-byte aligned).  The ReLU-backward mask of a data gradient at 1/16 of the bytes of the activation it is taken from:
  * cpc_conv_dgrad / cpc_conv_dgrad_conv1 take it as x_act_bits in place of x_act — the same decision per element, identical
