@@ -91,6 +91,9 @@ _SIGNATURES = {
     "cpc_conv_dgrad_conv1": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P, _P], _I),
     "cpc_conv1_fused_reduce": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_wgrad": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P], _I),
+    "cpc_conv_dgrad_rows": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P, _I, _I, _P], _I),
+    "cpc_conv_dgrad_conv1_rows": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _I, _L, _I, _P, _I, _I, _P], _I),
+    "cpc_conv1_fused_reduce_tiles": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep_group": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "cpc_conv_w_prep_plan": ([_P, _I, _P, _P], _I),

@@ -205,6 +205,63 @@ int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, 
     return launch_gemm_tn(p, dtype, nsplit, 1, (hipStream_t)stream);
 }
 
+// ---- the data-gradient launches on rows [row_lo, row_hi) of every item (engine.CPCEngine: the rows only the targets need are
+// differentiated beside the GRU's backward recurrence).  A data-gradient GEMM row q produces input positions q s .. q s + s - 1 from output-
+// gradient rows q - D + 1 .. q.
+static bool rows_ok(int row_lo, int row_hi, int Lout_alloc) { return row_lo >= 0 && row_lo < row_hi && row_hi <= Lout_alloc; }
+
+int cpc_conv_dgrad_rows(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw, int stride,
+                        int Lout_alloc, long long dy_head, int dtype, const void* x_act_bits, float* dx_colsum_slabs, int row_lo, int row_hi,
+                        void* stream) {
+    if (!dy || !w_dgrad || !dx || B <= 0 || Lout_alloc <= 0 || kw <= 0 || stride <= 0 || !rows_ok(row_lo, row_hi, Lout_alloc)) return CPC_EINVAL;
+    const int D = (kw + stride - 1) / stride;
+    if (dy_head < (long long)(D - 1) * Cout) return CPC_EINVAL;
+    const int rows = row_hi - row_lo;
+    const long long es = esize(dtype), c0 = (long long)row_lo * stride * Cin;          // element offset of the first output row in dx / x_act
+    GemmNT p = {};
+    p.A = (const char*)dy + ((long long)row_lo - (D - 1)) * Cout * es;
+    p.Bt = w_dgrad; p.C = (char*)dx + c0 * es; p.bias = nullptr;
+    p.mask = x_act ? (const char*)x_act + c0 * es : nullptr;
+    p.mask_bits = x_act_bits ? (const unsigned char*)x_act_bits + c0 / 8 : nullptr;
+    p.colsum_slabs = dx_colsum_slabs;
+    p.M = B * rows; p.N = stride * Cin; p.K = D * Cout;
+    p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
+    p.a_rpi = rows; p.a_item = (long long)Lout_alloc * Cout;
+    p.c_rpi = rows; p.c_item = (long long)Lout_alloc * stride * Cin; p.c_valid = rows;
+    p.flags = (dtype == CPC_DTYPE_F32 ? GEMM_OUT_F32 : 0) | (dx_colsum_slabs ? GEMM_BIG_TILE : 0);
+    return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+int cpc_conv_dgrad_conv1_rows(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
+                              int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
+                              long long dy_head, int dtype, const void* x_act_bits, int row_lo, int row_hi, void* stream) {
+    if (!dy || !w_dgrad || !(x_act || x_act_bits) || !x || !slabs || B <= 0 || Lout_alloc <= 0 || dtype != CPC_DTYPE_BF16) return CPC_EINVAL;
+    if (Cin % 256 || kw1 < 1 || kw1 > 15 || stride1 < 1 || L1_valid < 1 || kw <= 0 || stride <= 0 || !rows_ok(row_lo, row_hi, Lout_alloc)) return CPC_EINVAL;
+    const int D = (kw + stride - 1) / stride;
+    if (dy_head < (long long)(D - 1) * Cout) return CPC_EINVAL;
+    const int rows = row_hi - row_lo;
+    const long long es = esize(dtype), c0 = (long long)row_lo * stride * Cin;
+    GemmNT p = {};
+    p.A = (const char*)dy + ((long long)row_lo - (D - 1)) * Cout * es;
+    p.Bt = w_dgrad; p.C = slabs /* not written */; p.bias = nullptr;
+    p.mask = x_act ? (const char*)x_act + c0 * es : nullptr;
+    p.mask_bits = x_act_bits ? (const unsigned char*)x_act_bits + c0 / 8 : nullptr;
+    p.M = B * rows; p.N = stride * Cin; p.K = D * Cout;
+    p.lda = Cout; p.ldb = p.K; p.ldc = (long long)stride * Cin;
+    p.a_rpi = rows; p.a_item = (long long)Lout_alloc * Cout;
+    p.c_rpi = rows; p.c_item = (long long)Lout_alloc * stride * Cin; p.c_valid = rows;
+    p.flags = GEMM_EPI_CONV1 | GEMM_BIG_TILE;
+    p.c1_x = x; p.c1_ldx = ldx; p.c1_slabs = slabs;
+    p.c1_rpi = rows; p.c1_row0 = row_lo; p.c1_sub = stride; p.c1_stride = stride1; p.c1_kw = kw1; p.c1_valid = L1_valid;
+    return launch_gemm_nt(p, dtype, 1, (hipStream_t)stream);
+}
+
+int cpc_conv1_fused_reduce_tiles(const float* slabs, float* tmp, float* dw, float* db, int num_row_tiles, int Cin, int stride, int kw1,
+                                 void* stream) {
+    if (num_row_tiles <= 0) return CPC_EINVAL;
+    return launch_conv1_fused_reduce(slabs, tmp, dw, db, num_row_tiles, Cin, stride, kw1, (hipStream_t)stream);
+}
+
 static_assert(sizeof(cpc_conv_prep_job) == 56, "cpc_conv_prep_job layout (three pointers + eight ints)");
 int cpc_conv_w_prep_plan(cpc_conv_prep_job* jobs, int njobs, int* total_blocks, int* lds_bytes) {
     return conv_w_prep_plan(jobs, njobs, total_blocks, lds_bytes);

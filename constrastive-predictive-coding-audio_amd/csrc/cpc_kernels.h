@@ -17,6 +17,7 @@
 #define GEMM_KRANGE_EXACT 2048  // NT fast path with k_ranges: the ranges cut out pieces that are NOT zero (a neighbouring item's data), so a tile must lie in ONE
                                 // range index: the launch is refused unless a_rpi * max(a_rpi2, 1) is a multiple of the tile height the launcher picks
 #define GEMM_LINEAR_K 256       // NT fast path: visit K in storage order even for overlapped-row operands (A-B check, see GemmNT::k_taps)
+#define GEMM_BIG_TILE 0x100000  // internal: the 256x256 tile also where fewer than 200 of them exist (a row-range launch that needs the per-tile column sums)
 #define GEMM_WT_AGENT 0x40000   // internal (cpc_debug_set key 6): output stores of the NT fast kernels write through at agent scope (sc1)
 #define GEMM_WT_SYSTEM 0x80000  // ... at system scope (sc0 sc1): the default
 #define GEMM_FORCE_GENERIC 8   // use the register-staged generic kernel even when the LDS-DMA fast path applies (A-B check)
@@ -79,6 +80,7 @@ struct GemmNT {
     // with t = q*c1_sub + r (rows with t >= c1_valid contribute nothing); tile = mt * numN + nt, 256 columns per tile.
     const float* c1_x = nullptr; long long c1_ldx = 0; float* c1_slabs = nullptr;
     int c1_rpi = 0, c1_sub = 0, c1_stride = 0, c1_kw = 0, c1_valid = 0;
+    int c1_row0 = 0;      // row m of the launch is row c1_row0 + m % c1_rpi of item m / c1_rpi (a launch over a row range of every item)
     // internal, launch_score_lse (persistent 256x256 bf16 kernel, LSE epilogue): per M tile and column the pair (max, sum exp(s - max)) over
     // the tile's rows -> lse_pm / lse_ps [M / 256][N]; lse_valid[r] = s[r][r + lse_diag_off] where that column exists (or null)
     float* lse_pm = nullptr; float* lse_ps = nullptr; float* lse_valid = nullptr; int lse_diag_off = 0;

@@ -702,7 +702,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(GemmNT p) {
             bool ok = m < p.M;
             long long xo = 0;
             if (ok) {
-                const int b = m / p.c1_rpi, t = (m % p.c1_rpi) * p.c1_sub + rsel;
+                const int b = m / p.c1_rpi, t = (p.c1_row0 + m % p.c1_rpi) * p.c1_sub + rsel;
                 ok = t < p.c1_valid;
                 xo = (long long)b * p.c1_ldx + (long long)t * p.c1_stride;
             }
@@ -2020,8 +2020,8 @@ int launch_gemm_nt(const GemmNT& p, int dtype, int batch, hipStream_t stream) {
     // 256x256 tiles only where they fill the chip: below ~200 of them (e.g. the 3072 x 3072 all-timesteps score matrix: 144)
     // four times as many 128x128 tiles keep more CUs busy
     const long long big_tiles = (long long)((p.M - p.m_off + 255) / 256) * ((p.N + 255) / 256);
-    const bool big = fast && dtype == CPC_DTYPE_BF16 && p.M >= 1024 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE) &&
-                     (big_tiles >= 200 || big_tiles * batch >= 200);
+    const bool big = fast && dtype == CPC_DTYPE_BF16 && p.N >= 256 && !(p.flags & GEMM_SMALL_TILE) &&
+                     ((p.M >= 1024 && (big_tiles >= 200 || big_tiles * batch >= 200)) || ((p.flags & GEMM_BIG_TILE) && p.M >= 256));
     GemmNT q = p;
     if (g_nt_wt == 1) q.flags |= GEMM_WT_AGENT; else if (g_nt_wt == 2) q.flags |= GEMM_WT_SYSTEM;
     // overlapped-row A operand (strided-conv view): visit K tap-innermost, see GemmNT::k_taps

@@ -702,6 +702,10 @@ class CPCEngine:
                          flags=_hip.GEMM_OUT_F32)
         if add_dc is not None:
             self.dc.add_(add_dc)
+        lanes_ok = self.use_aux and self.fuse_c1 and os.environ.get("CPC_WGRAD_STREAM", "1") != "0" and getattr(self, "_gp_phase", 0) == 0
+        self._bl_active = self._bwd_lane() if lanes_ok else None
+        if self._bl_active is not None:
+            self._backward_target_rows(x, self._bl_active)
         self.ctx.backward(self.dc)      # parameter gradients of the context network + dz into rows [t0, t0+V) of dtop
         if add_dz is not None:
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(add_dz.transpose(1, 2), alpha=getattr(self.ctx, "z_scale", 1.0))
@@ -712,11 +716,77 @@ class CPCEngine:
         if self.use_aux:
             torch.cuda.current_stream().wait_stream(self.aux)
 
+    def _bwd_lane(self):
+        """The row split of the encoder's backward pass that mirrors encoder_forward's target lane, or None.  With kernel = 2 stride in
+        every layer above the first, the data gradient at positions >= n_(l-1) of layer l-1 depends on output-gradient rows >= n_l only
+        (n_l as in _target_lane_rows): GEMM rows [n_l + 1, L_alloc) of every data gradient — the part of the backward pass behind the TARGET
+        frames, whose top-layer gradient is final once the loss kernels are — run on the side stream beside the GRU's backward recurrence
+        (_backward_target_rows); the main stream's launches after the recurrence cover rows [0, n_l + 1).  The weight gradients stay
+        one launch per layer: split at row n_l the same way (two slab sets, one reduction) they cost the step 0.37 ms — the chip is full
+        once the recurrence has ended, and the second slab set is pure extra traffic (round 4, CPC_TARGET_LANE_BWD A/B: 4.52 off, 4.49 on,
+        4.89 with the weight gradients split).  Tried on top of this and removed again: the recurrence itself in two step
+        ranges with the encoder rows of the later frames beside the first (forward) / the earlier steps beside the encoder's backward pass
+        over the late rows (backward) — bit-identical, and 0.0 - 0.1 ms SLOWER: what the hidden recurrence saves, the split launches lose."""
+        bl = getattr(self, "_bl", 0)
+        if bl != 0:
+            return bl
+        self._bl = None
+        nr = self._target_lane_rows()
+        n, B, La = self.n, self.B, self.geo.alloc
+        if (nr is None or os.environ.get("CPC_TARGET_LANE_BWD", "1") == "0" or self.dt != torch.bfloat16 or not self.fuse_c1
+                or type(self)._backward_encoder is not CPCEngine._backward_encoder
+                or any(self.kernels[l] != 2 * self.strides[l] for l in range(1, n))
+                or any(B * (La[l] - nr[l] - 1) < 256 for l in range(1, n))):
+            return None
+        dev, f32 = self.device, torch.float32
+        bl = SimpleNamespace(n=nr, ev0=torch.cuda.Event(), ev=[torch.cuda.Event() for _ in range(n)], cs=[None] * n, tiles=[None] * n)
+        for l in range(1, n):
+            cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
+            bl.tiles[l] = (_ceil_div(B * (nr[l] + 1), 256), _ceil_div(B * (La[l] - nr[l] - 1), 256))
+            if l >= 2 and self.cs_slabs[l - 1] is not None:        # (per-tile column sums: where the one-launch path has them)
+                bl.cs[l - 1] = torch.zeros(sum(bl.tiles[l]) * s * cin, device=dev, dtype=f32)
+        bl.c1_tile = (self.strides[1] * self.channels[0] // 256) * (self.kernels[0] + 1) * 256          # slab floats of one 256-row tile
+        bl.c1 = torch.empty(sum(bl.tiles[1]) * bl.c1_tile, device=dev, dtype=f32)
+        self._bl = bl
+        return bl
+
+    def _lane_dgrad(self, bl, l, part, x):
+        """Data gradient of layer l: GEMM rows [0, n_l + 1) (part 0) or [n_l + 1, L_alloc) (part 1); layer 2's is fused with layer 1's
+        weight gradient (cpc_conv_dgrad_conv1_rows)."""
+        B, code, La, Lv = self.B, self.code, self.geo.alloc, self.geo.valid
+        cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
+        lo, hi = (0, bl.n[l] + 1) if part == 0 else (bl.n[l] + 1, La[l])
+        M = B * (hi - lo)
+        tile = 256 if (l == 1 or bl.cs[l - 1] is not None) else _hip.nt_tile(code, M, s * cin, self.geo.taps[l] * cout)
+        tkey = dict(key="gemm_nt" + _hip._variant(code, 0, tile), work=2.0 * M * s * cin * self.geo.taps[l] * cout,
+                    shape=("dgrad", M, s * cin, self.geo.taps[l] * cout))
+        if l == 1:
+            _hip.call("cpc_conv_dgrad_conv1_rows", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
+                      _hip.ptr(x, self.x_off), _hip.ptr(bl.c1, part * bl.tiles[1][0] * bl.c1_tile), B, cin, cout, kw, s, La[1], self.L,
+                      self.kernels[0], self.strides[0], Lv[0], C.c_longlong(self.guard[1]), code, _hip.ptr(self.act_bits[0]), lo, hi,
+                      **dict(tkey, key=tkey["key"].replace("gemm_nt", "gemm_nt_conv1")))
+        else:
+            _hip.call("cpc_conv_dgrad_rows", _hip.ptr(self.dact[l]), _hip.ptr(self.w_dgrad[l]), _hip.ptr(self.act[l - 1]),
+                      _hip.ptr(self.dact[l - 1]), B, cin, cout, kw, s, La[l], C.c_longlong(self.guard[l]), code,
+                      _hip.ptr(self.act_bits[l - 1]), _hip.ptr(bl.cs[l - 1], part * bl.tiles[l][0] * s * cin), lo, hi, **tkey)
+
+    def _backward_target_rows(self, x, bl):
+        """Side stream, issued before the context network's backward pass: everything of the encoder's backward pass that hangs on the
+        target frames alone (see _bwd_lane): the data-gradient chain; the main stream's launches wait for its events layer by layer."""
+        bl.ev0.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(bl.ev0)
+            for l in range(self.n - 1, 0, -1):
+                self._lane_dgrad(bl, l, 1, x)
+                bl.ev[l].record(self.aux)
+
     def _backward_encoder(self, x, grad_ready_hook=None):
         """Encoder part of the backward pass: consumes the top-layer gradient, fills the encoder's parameter gradients."""
         g, code = self.model._grad, self.code
         B, n = self.B, self.n
         La, Lv = self.geo.alloc, self.geo.valid
+        bl, self._bl_active = getattr(self, "_bl_active", None), None      # target lane (_bwd_lane): this pass covers rows [0, n_l + 1) only
+        cs_slabs = self.cs_slabs if bl is None else bl.cs
         # encoder, top layer down to layer 2.  Main stream: weight-gradient GEMM, data-gradient GEMM.  Side stream, after the
         # weight-gradient GEMM: the bias column sum (needs dact[l]) and the slab reduction, see _alloc_encoder.
         for l in range(n - 1, 0, -1):
@@ -748,8 +818,8 @@ class CPCEngine:
                     wgrad_call()
                 # (ONE event per layer on the main stream: a recorded event between two GEMMs costs ~6 us of idle queue)
                 if bname in g:
-                    if self.cs_slabs[l] is not None:           # per-tile sums left by layer l+1's data gradient
-                        _hip.call("cpc_reduce_slabs", _hip.ptr(self.cs_slabs[l]), _hip.ptr(g[bname]), 1, cout, self.cs_slabs[l].numel() // cout,
+                    if cs_slabs[l] is not None:           # per-tile sums left by layer l+1's data gradient
+                        _hip.call("cpc_reduce_slabs", _hip.ptr(cs_slabs[l]), _hip.ptr(g[bname]), 1, cout, cs_slabs[l].numel() // cout,
                                   cout, 1, 1, 0, 0)
                     else:
                         self._colsum_to_grad(_hip.ptr(self.dact[l]), g[bname], B * La[l], cout, scratch=self.aux_slabs)
@@ -765,7 +835,11 @@ class CPCEngine:
             tkey = dict(key="gemm_nt" + _hip._variant(code, 0, _hip.nt_tile(code, B * La[l], s * cin, self.geo.taps[l] * cout)),
                         work=2.0 * B * La[l] * s * cin * self.geo.taps[l] * cout,
                         shape=("dgrad", B * La[l], s * cin, self.geo.taps[l] * cout))
-            if l == 1 and self.fuse_c1:
+            if bl is not None:
+                if l < n - 1:
+                    torch.cuda.current_stream().wait_event(bl.ev[l + 1])     # rows >= n_l of dact[l]: the side stream's data gradient of layer l+1
+                self._lane_dgrad(bl, l, 0, x)
+            elif l == 1 and self.fuse_c1:
                 _hip.call("cpc_conv_dgrad_conv1", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
                           _hip.ptr(x, self.x_off), _hip.ptr(self.c1_slabs), B, cin, cout, kw, s, La[1], self.L, self.kernels[0],
                           self.strides[0], Lv[0], C.c_longlong(self.guard[1]), code, _hip.ptr(self.act_bits[0]),
@@ -776,6 +850,10 @@ class CPCEngine:
                           _hip.ptr(self.act_bits[l - 1]), _hip.ptr(self.cs_slabs[l - 1]), **tkey)
         # layer 1
         c0, k0, s0 = self.channels[0], self.kernels[0], self.strides[0]
+        if bl is not None:
+            _hip.call("cpc_conv1_fused_reduce_tiles", _hip.ptr(bl.c1), _hip.ptr(self.c1_tmp), _hip.ptr(g["encoder.layers.0.weight"]),
+                      _hip.ptr(g.get("encoder.layers.0.bias")), sum(bl.tiles[1]), c0, self.strides[1], k0)
+            return
         if self.fuse_c1:
             _hip.call("cpc_conv1_fused_reduce", _hip.ptr(self.c1_slabs), _hip.ptr(self.c1_tmp), _hip.ptr(g["encoder.layers.0.weight"]),
                       _hip.ptr(g.get("encoder.layers.0.bias")), B, c0, self.strides[1], La[1], k0)
@@ -900,31 +978,38 @@ class GRUContext:
             self._gp_buffers()
             self.gp_dc1.copy_(dc)
         _hip.call("cpc_gru_bwd", _hip.ptr(dc), _hip.ptr(self.tape), _hip.ptr(self.w_hh_t_frag), _hip.ptr(self.dG), B, V, H, code)
-        # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
-        # [3H,4H) that of the recurrent term
-        g_ih, g_hh = g[self.prefix + "weight_ih"], g[self.prefix + "weight_hh"]
         # the GRU's parameter gradients (ten short launches) are off the critical path dG -> dz -> encoder backward: side stream
-        sl = self.scratch
         with e.side(self._ev):
-            e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
-                          b_rpi=V, b_item=Ltop * E, scratch=sl)
-            e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
-                          b_rpi=V, b_item=(V + 1) * H, scratch=sl)
-            e._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
-                          b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H, scratch=sl)
-            if (self.prefix + "bias_ih") in g:
-                g_bi, g_bh = g[self.prefix + "bias_ih"], g[self.prefix + "bias_hh"]
-                M = B * V
-                nb = min(e.colsum_blocks, max(1, M // 64))
-                _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(sl), M, 4 * H, 4 * H, nb, code)
-                _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
-                _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
-                _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
+            self.backward_params()
         # dz -> rows [t0, t0+V) of the top-layer gradient
         _hip.gemm_nt(_hip.ptr(self.dG), _hip.ptr(self.w_ih_t), _hip.ptr(dtop, t0 * E), B * V, E, 3 * H, 4 * H, 3 * H, E, code,
                      c_rpi=V, c_item=Ltop * E, c_valid=V)
         if phase == 3:               # gradient penalty, pass 3: what z gains through the tangent recurrence's coefficients
             dtop.view(B, Ltop, E)[:, t0:t0 + V, :].add_(self.gp_dz.view(B, V, E))
+
+    def backward_params(self):
+        """Parameter gradients of the recurrence from dG (all steps), on the current stream."""
+        e, H = self.eng, self.H
+        g, code, B, V, E, K = e.model._grad, e.code, e.B, e.V, e.E, e.K
+        Ltop, t0, top = e.geo.alloc[-1], e.T - K - V, e.act[-1]
+        # dG[b][t] = [dr | du | dn | dn*r]: columns [0,3H) are the gradient of the input-projection term, columns [0,2H) and
+        # [3H,4H) that of the recurrent term
+        g_ih, g_hh = g[self.prefix + "weight_ih"], g[self.prefix + "weight_hh"]
+        sl = self.scratch
+        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(top, t0 * E), g_ih, B * V, 3 * H, E, 4 * H, E, self.split_ih,
+                      b_rpi=V, b_item=Ltop * E, scratch=sl)
+        e._tn_to_grad(_hip.ptr(self.dG), _hip.ptr(self.Hall), g_hh, B * V, 2 * H, H, 4 * H, H, self.split_hh,
+                      b_rpi=V, b_item=(V + 1) * H, scratch=sl)
+        e._tn_to_grad(_hip.ptr(self.dG, 3 * H), _hip.ptr(self.Hall), g_hh, B * V, H, H, 4 * H, H, self.split_hh,
+                      b_rpi=V, b_item=(V + 1) * H, grad_offset=2 * H * H, scratch=sl)
+        if (self.prefix + "bias_ih") in g:
+            g_bi, g_bh = g[self.prefix + "bias_ih"], g[self.prefix + "bias_hh"]
+            M = B * V
+            nb = min(e.colsum_blocks, max(1, M // 64))
+            _hip.call("cpc_colsum", _hip.ptr(self.dG), _hip.ptr(sl), M, 4 * H, 4 * H, nb, code)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bi), 1, 3 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl), _hip.ptr(g_bh), 1, 2 * H, nb, 4 * H, 1, 1, 0, 0)
+            _hip.call("cpc_reduce_slabs", _hip.ptr(sl, 3 * H), _hip.ptr(g_bh, 2 * H), 1, H, nb, 4 * H, 1, 1, 0, 0)
 
     # ---- Wasserstein gradient penalty (scalogram_engine._gp_step; exact-f32 mode): tangent of c, penalty parts of the gradients
     def _gp_buffers(self):

@@ -39,7 +39,7 @@ extern "C" {
                                     * launcher picks.  Without the flag a tile runs the union of its rows' ranges (correct for known-zero cuts only). */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
-/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d; cpc_conv1_fwd_rows.
+/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d; the row-range launches cpc_conv1_fwd_rows, cpc_conv_dgrad_rows, cpc_conv_dgrad_conv1_rows, cpc_conv1_fused_reduce_tiles.
  * 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
  * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
  * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
@@ -194,6 +194,21 @@ int cpc_conv_dgrad(const void* dy, const void* w_dgrad, const void* x_act, void*
                    float* dx_colsum_slabs, void* stream);
 int cpc_conv_wgrad(const void* x, const void* dy, float* slabs, int B, int Cin, int Cout, int kw, int stride,
                    int Lout_alloc, int nsplit, long long x_tail, int dtype, void* stream);
+
+/* The data-gradient launches above on rows [row_lo, row_hi) of every item only (ABI 8).  A data-gradient row q produces the input positions
+ * q stride .. q stride + stride - 1 from the output-gradient rows q - D + 1 .. q (D = ceil(kw / stride)).  With kw = 2 stride the rows
+ * [n_l + 1, L_alloc) of a data gradient need output-gradient rows >= n_l only: the part of the backward pass behind the TARGET frames runs
+ * beside the GRU's backward recurrence (engine.CPCEngine._bwd_lane), the rest afterwards.  dx_colsum_slabs / the fused launch's slabs are
+ * indexed by the launch's own 256-row tiles (ceil(B rows / 256) of them: pass an offset pointer to a second launch;
+ * cpc_conv1_fused_reduce_tiles sums num_row_tiles of them). */
+int cpc_conv_dgrad_rows(const void* dy, const void* w_dgrad, const void* x_act, void* dx, int B, int Cin, int Cout, int kw, int stride,
+                        int Lout_alloc, long long dy_head, int dtype, const void* x_act_bits, float* dx_colsum_slabs, int row_lo, int row_hi,
+                        void* stream);
+int cpc_conv_dgrad_conv1_rows(const void* dy, const void* w_dgrad, const void* x_act, const float* x, float* slabs, int B, int Cin,
+                              int Cout, int kw, int stride, int Lout_alloc, long long ldx, int kw1, int stride1, int L1_valid,
+                              long long dy_head, int dtype, const void* x_act_bits, int row_lo, int row_hi, void* stream);
+int cpc_conv1_fused_reduce_tiles(const float* slabs, float* tmp, float* dw, float* db, int num_row_tiles, int Cin, int stride, int kw1,
+                                 void* stream);
 int cpc_conv_w_prep(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int kw, int stride, int dtype,
                     void* stream);
 /* cpc_conv_w_prep for a LIST of convolutions in one launch (a context network's eleven 5 x 512 x 512 kernels: eleven launches of 20 us in

@@ -1474,6 +1474,40 @@ def test_fused_layer1_weight_gradient_equals_unfused_path():
         assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), n
 
 
+def test_target_lanes_equal_the_single_lane_step():
+    """bf16, default encoder, 64 clips: the step with the encoder rows behind the TARGET frames on the side stream — forward beside the
+    GRU recurrence (engine.encoder_forward), backward beside its backward recurrence (engine._bwd_lane: row-range data-gradient launches)
+    — and the step with the forward lane only, against the same engine with one launch per layer.  The same products in the same K order
+    enter all of them; only the per-tile column sums are associated differently."""
+    B, L = 64, 20480
+    x = (torch.randn(B, L, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV)
+    torch.manual_seed(0)
+    model = AudioPredictiveCodingModel(AudioEncoder(), AudioGRUModel(512, 256), enc_size=512, ar_size=256, compute_dtype="bf16")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "encoder" in n and n.endswith("weight"):
+                p.mul_(2.0)
+    model.to(DEV)
+    eng = model.engine(B, L)
+    assert eng._target_lane_rows() is not None and eng._bwd_lane() is not None, "the headline configuration is expected to split"
+    lanes = {"both": (eng._tl_rows, eng._bl), "forward": (eng._tl_rows, None), "none": (None, None)}
+    got = {}
+    for name, (rows, bl) in lanes.items():
+        eng._tl_rows, eng._bl = rows, bl
+        for _ in range(2):
+            out = eng.loss_and_grads(x, softplus=True, regularization=1.0)
+        got[name] = (float(out[0]), model._flat_grad.detach().double().cpu().clone())
+    ref_loss, ref = got["none"]
+    for name in ("both", "forward"):
+        loss, grad = got[name]
+        assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss), (name, loss, ref_loss)
+        assert torch.isfinite(grad).all()
+        for pname, g in model._grad.items():
+            lo = model._offset[pname]
+            a, b = grad[lo:lo + g.numel()], ref[lo:lo + g.numel()]
+            assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-12, (name, pname)
+
+
 def test_fused_layer1_weight_gradient_two_layer_encoder_without_bias():
     """The fused path on a two-layer encoder without biases (no bias-gradient output, layer 2 is also the top layer)."""
     B, L = 16, 20480
