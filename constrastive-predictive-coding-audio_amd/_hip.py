@@ -148,6 +148,7 @@ _SIGNATURES = {
     "cpc_gp_direction": ([_P, _P, _L, _I, _F, _P, _I, _P], _I),
     "cpc_bn_gp_cross": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _P], _I),
     "cpc_relu_mask": ([_P, _P, _L, _I, _P], _I),
+    "cpc_accumulate": ([_P, _P, _L, _I, _P], _I),
     "cpc_split3_bf16": ([_P, _P, _L, _P], _I),
     "cpc_cast2d": ([_P, _P, _I, _I, _L, _L, _I, _P], _I),
     "cpc_cast2d_batch": ([_P, _I, _I, _P], _I),

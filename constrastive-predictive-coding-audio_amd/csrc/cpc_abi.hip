@@ -574,6 +574,11 @@ int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream) 
     return launch_relu_mask(g, y, n, dtype, (hipStream_t)stream);
 }
 
+int cpc_accumulate(void* a, const void* b, long long n, int dtype, void* stream) {
+    if (!a || !b) return CPC_EINVAL;
+    return launch_accumulate(a, b, n, dtype, (hipStream_t)stream);
+}
+
 int cpc_split3_bf16(const float* src, void* dst, long long n, void* stream) {
     if (!src || !dst) return CPC_EINVAL;
     return launch_split3_bf16(src, dst, n, (hipStream_t)stream);

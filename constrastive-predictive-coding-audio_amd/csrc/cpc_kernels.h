@@ -246,6 +246,7 @@ int launch_gp_direction(const float* g, float* v, long long npix, int C, float f
 int launch_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out, const int* gx, const float* stats, const float* coef,
                        int x_f32, int dtype, hipStream_t st);
 int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t stream);
+int launch_accumulate(void* a, const void* b, long long n, int dtype, hipStream_t stream);
 int launch_split3_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float* state,
                     float grad_scale, const float* skip, hipStream_t stream);

@@ -985,6 +985,13 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(T* __restrict__ g, const
     }
 }
 
+// a[i] += b[i] over flat buffers (f32 sum, one rounding to the storage type: what `a += b` gives the reference's autograd when two branches
+// meet): the data gradient of a residual projection joining the main branch's where the GEMM cannot write into the same grid
+template <typename T>
+__global__ __launch_bounds__(256) void accumulate_kernel(T* __restrict__ a, const T* __restrict__ b, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        store4(a + i * 4, load4(a + i * 4) + load4(b + i * 4));
+}
 
 // ---- Wasserstein gradient penalty (contrastive_estimation_training.py:144-155) ----
 // out = the element of `sel` at the position of the FIRST maximum of `in` in each pooling window: a max pooling applied to a
@@ -1417,6 +1424,16 @@ int launch_relu_mask(void* g, const void* y, long long n, int dtype, hipStream_t
     DISPATCH2(dtype,
               hipLaunchKernelGGL((relu_mask_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (bf16_t*)g, (const bf16_t*)y, n / 4),
               hipLaunchKernelGGL((relu_mask_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)g, (const float*)y, n / 4));
+    CPC_CHECK_LAUNCH();
+    return CPC_OK;
+}
+
+int launch_accumulate(void* a, const void* b, long long n, int dtype, hipStream_t st) {
+    if (n <= 0 || n % 4) return CPC_EINVAL;
+    const int nb = blocks_for(n / 4);
+    DISPATCH2(dtype,
+              hipLaunchKernelGGL((accumulate_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (bf16_t*)a, (const bf16_t*)b, n / 4),
+              hipLaunchKernelGGL((accumulate_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)a, (const float*)b, n / 4));
     CPC_CHECK_LAUNCH();
     return CPC_OK;
 }

@@ -702,7 +702,7 @@ class CPCEngine:
                          flags=_hip.GEMM_OUT_F32)
         if add_dc is not None:
             self.dc.add_(add_dc)
-        lanes_ok = self.use_aux and self.fuse_c1 and os.environ.get("CPC_WGRAD_STREAM", "1") != "0" and getattr(self, "_gp_phase", 0) == 0
+        lanes_ok = self.use_aux and getattr(self, "fuse_c1", False) and os.environ.get("CPC_WGRAD_STREAM", "1") != "0" and getattr(self, "_gp_phase", 0) == 0
         self._bl_active = self._bwd_lane() if lanes_ok else None
         if self._bl_active is not None:
             self._backward_target_rows(x, self._bl_active)

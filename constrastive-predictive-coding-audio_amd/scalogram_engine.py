@@ -60,6 +60,14 @@ def _desc(t, desc):
     return C.cast(desc, C.c_void_p)
 
 
+def _accumulate(dst: Grid, src: Grid):
+    """dst += src over two grids of one geometry (two branches' data gradients meeting, scalogram_model.py:462-476 under autograd)."""
+    n = dst.t.numel()
+    if src.t.numel() != n or src.dtype != dst.dtype or n % 4:
+        raise ValueError("accumulate: the two grids must share one geometry and storage type")
+    _hip.call("cpc_accumulate", dst.ptr(), src.ptr(), C.c_longlong(n), dst.code)
+
+
 def _twin(eng, grid: Grid) -> Grid:
     """The grid that holds the TANGENT of ``grid`` during a gradient-penalty step (same geometry, dtype and guards), made on
     first use.  Keyed by identity, so grids that alias in the primal graph alias in the tangent graph too."""
@@ -534,7 +542,7 @@ class _Conv:
                 _hip.gemm_nt(dy0.ptr(-(self.kh - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), Mg, G * self.cin, Kd, G * self.cout,
                              Kd, G * self.cin, code, mask=gin.ptr() if mask_input else None)
             if accumulate:
-                din.t.add_(dst.t)
+                _accumulate(din, dst)
         elif self.mode == 'col':
             D = self.kh
             dst = din
@@ -553,7 +561,7 @@ class _Conv:
                 _hip.gemm_nt(dy0.ptr(-(D - 1) * self.cout), _hip.ptr(self.w_dgrad), dst.ptr(), self.M, self.cin, D * self.cout, self.cout,
                              D * self.cout, self.cin, code, mask=gin.ptr() if mask_input else None)
             if accumulate:
-                din.t.add_(dst.t)
+                _accumulate(din, dst)
         elif self.parity and not accumulate:
             self._dgrad_parity(dy0, din, mask_input)
         else:
@@ -753,7 +761,7 @@ class _BatchNorm:
                 self.s2 = torch.empty_like(gw)
             self.s2.copy_(gw)
         elif gp == 3:        # last pass: the second-order terms of this BatchNorm join the adjoint of its input (gp_terms)
-            self.dy0.t.add_(self.xterm.t)
+            _accumulate(self.dy0, self.xterm)
 
     # ---- Wasserstein gradient penalty: tangent pass and second-order terms
     def tangent(self):
@@ -1293,7 +1301,7 @@ class _Block:
                     _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_res.ptr(),
                               _desc(self.rp, self.rp.desc), self.blk.res_pool, 1, self.rp.code)
                 else:
-                    self.d_in.t.add_(self.d_res.t)
+                    _accumulate(self.d_in, self.d_res)
 
 
 class ScalogramCPCEngine(CPCEngine):
@@ -1742,7 +1750,7 @@ class _ArBlock:
             if self.res_conv is not None:
                 self.res_conv.backward(self.d_xp, accumulate=True)
             else:
-                self.d_xp.t.add_(self.d_res.t)
+                _accumulate(self.d_xp, self.d_res)
         if self.pool > 1:
             _hip.call("cpc_maxpool2d_bwd", self.gin.ptr(), self.d_in.ptr(), _desc(self.gin, self.gin.desc), self.d_xp.ptr(),
                       _desc(self.xp, self.xp.desc), self.pool, 0, code)

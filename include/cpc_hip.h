@@ -39,7 +39,7 @@ extern "C" {
                                     * launcher picks.  Without the flag a tile runs the union of its rows' ranges (correct for known-zero cuts only). */
 #define CPC_GEMM_SMALL_TILE 16   /* keep the 128x128 tile where the 256x256 one would be chosen (A/B check) */
 
-/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d; the row-range launches cpc_conv1_fwd_rows, cpc_conv_dgrad_rows, cpc_conv_dgrad_conv1_rows, cpc_conv1_fused_reduce_tiles.
+/* 8 (round 4): the fused all-timesteps score path (cpc_score_lse, cpc_nce_lse_merge, cpc_nce_fused_grad(_blocks), cpc_nce_fused_finalize); cpc_reduce_conv_w2d; cpc_accumulate; the row-range launches cpc_conv1_fwd_rows, cpc_conv_dgrad_rows, cpc_conv_dgrad_conv1_rows, cpc_conv1_fused_reduce_tiles.
  * 7 (round 3, second half): cpc_gemm_nt_args grew the second row level (a_rpi2 / c_rpi2), k_ranges and the gathered-row taps (k_taps,
  * k_tap_stride, k_tap_stride_a); new entry points cpc_conv_w_prep_group / _plan / _batch, cpc_bn_apply_residual, cpc_bn_bwd_reduce_res / _apply_res, cpc_stem_residual_bn_add,
  * cpc_stem_residual_wgrad_bits; cpc_gemm_tn_args grew a_rpi2 / a_item2.
@@ -477,6 +477,10 @@ int cpc_bn_gp_cross(const void* x, const void* yt, const void* delta, void* out,
 
 /* g[i] = y[i] > 0 ? g[i] : 0 for i < n (n % 4 == 0): ReLU backward on whole buffers where no fused epilogue applies. */
 int cpc_relu_mask(void* g, const void* y, long long n, int dtype, void* stream);
+
+/* a[i] += b[i] for i < n (n % 4 == 0; ABI 8): the sum in f32, rounded once to the storage type.  Where two branches' data gradients meet
+ * and the GEMM that produces the second cannot write into the first's grid (scalogram_model.py:462-476 under autograd). */
+int cpc_accumulate(void* a, const void* b, long long n, int dtype, void* stream);
 
 /* dst[r][c] = (T) src[r*sr + c*sc] — cast / transpose of a master weight into an operand layout. */
 int cpc_cast2d(const float* src, void* dst, int R, int C, long long sr, long long sc, int dtype, void* stream);

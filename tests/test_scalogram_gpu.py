@@ -257,6 +257,20 @@ def test_bn_apply_residual_equals_the_two_passes(r_f32):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_accumulate_equals_the_elementwise_sum(dt):
+    """cpc_accumulate (two branches' data gradients meeting): a += b with one rounding, bit for bit what torch's add gives."""
+    g = torch.Generator().manual_seed(11)
+    n = 4 * 70001
+    a = (torch.randn(n, generator=g) * 3).to(dt).to(DEV)
+    b = torch.randn(n, generator=g).to(dt).to(DEV)
+    want = a + b
+    _hip.call("cpc_accumulate", _hip.ptr(a), _hip.ptr(b), C.c_longlong(n), _hip.dtype_code(dt))
+    assert torch.equal(a, want)
+    with pytest.raises(_hip.HipCallError):
+        _hip.call("cpc_accumulate", _hip.ptr(a), _hip.ptr(b), C.c_longlong(n - 1), _hip.dtype_code(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_maxpool2d_and_residual_add(dt):
     B, Cc, H, W, p = 2, 8, 7, 9, 2
     g = torch.Generator().manual_seed(8)
