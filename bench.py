@@ -699,6 +699,7 @@ def main():
     # HBM-bound layer-1 forward (`hbm_kernel`)
     dom = DOMINANT if args.dtype == "bf16" else "gemm_nt<f32,f32,128>"
     dom_keys = [dom, dom.replace("gemm_nt<", "gemm_nt_conv1<")]
+    dom_keys += [k + "@target_rows" for k in dom_keys]       # the side stream's row-range launches beside the GRU's backward recurrence
     timer = _hip.KernelTimer(only=None if args.breakdown else dom_keys + ["cpc_conv1_fwd"], by_shape=args.breakdown)
     timer.active = False
     _hip.set_timer(timer)
@@ -850,6 +851,15 @@ def main():
                                          "achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 4)}
                                      for k, v in per_key.items() if v[0] and v[1] > 0}},
         }
+        main_only = [v for k, v in per_key.items() if "@target_rows" not in k and v[0] and v[1] > 0]
+        if len(main_only) < len([v for v in per_key.values() if v[0] and v[1] > 0]):
+            mf, mm = sum(v[2] for v in main_only), sum(v[1] for v in main_only)
+            line["roofline"]["main_stream_launches"] = {
+                "achieved": round(mf / (mm * 1e-3) / 1e12, 2), "frac": round(mf / (mm * 1e-3) / 1e12 / peak, 4),
+                "launches": sum(v[0] for v in main_only),
+                "note": "without the @target_rows launches: the data gradients behind the target frames, a fraction of a round of tiles each, "
+                        "issued on the side stream beside the GRU's backward recurrence (engine.CPCEngine._bwd_lane); achieved / frac above "
+                        "include them"}
         if alone is not None:
             alone["frac"] = round(alone["achieved"] / peak, 4)
             line["roofline"]["alone"] = alone
@@ -862,18 +872,23 @@ def main():
                                   "peak": peak, "frac": round(tf / peak, 4),
                                   "note": "executed FLOPs of every GEMM launch of one step (NT and TN forms) over ms_per_step: the matrix pipe's "
                                           "share of the whole step, GRU recurrence / layer 1 / loss / Adam time included in the denominator"}
-        c1 = [v for k, v in summary.items() if k.startswith("cpc_conv1_fwd")]
+        c1 = [v for k, v in summary.items() if k == "cpc_conv1_fwd"]
         if c1 and sum(v[1] for v in c1) > 0:
-            # encoder layer 1 (C_in = 1): writes its [B][L_alloc][512] output once, reads 4 B per input sample
+            # encoder layer 1 (C_in = 1): writes its [B][rows][512] output once (+ one sign bit per element), reads 4 B per input sample
+            # (DESIGN.md section 3).  With the target lane (engine.encoder_forward) this is the main stream's launch over the rows the context
+            # network needs (91 % of them); the side stream's launch over the target rows runs beside the GRU and is not counted here.
             esz = 2 if args.dtype == "bf16" else 4
-            nbytes = float(B) * eng.geo.alloc[0] * eng.channels[0] * esz + float(B) * eng.L_eff * 4
+            lane = eng._target_lane_rows() if hasattr(eng, "_target_lane_rows") else None
+            rows = eng.geo.alloc[0] if lane is None else lane[0]
+            nbytes = float(B) * rows * eng.channels[0] * esz + float(B) * min(eng.L_eff, rows * eng.strides[0] + eng.kernels[0]) * 4
             if eng.act_bits[0] is not None:                       # + the sign-bit mask of the output, one bit per element
-                nbytes += float(B) * eng.geo.alloc[0] * eng.channels[0] / 8
+                nbytes += float(B) * rows * eng.channels[0] / 8
             cn, cms = sum(v[0] for v in c1), sum(v[1] for v in c1)
             gbs = nbytes * cn / (cms * 1e-3) / 1e9
             line["hbm_kernel"] = {"kernel": "conv1_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0,
                                   "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "launches": cn,
-                                  "avg_launch_ms": round(cms / cn, 4), "algorithmic_bytes_per_launch": nbytes}
+                                  "avg_launch_ms": round(cms / cn, 4), "algorithmic_bytes_per_launch": nbytes,
+                                  "rows_per_item": int(rows), "rows_allocated": int(eng.geo.alloc[0])}
         if args.breakdown:
             rows = sorted(summary.items(), key=lambda kv: -kv[1][1])
             tot = sum(v[1] for _, v in rows)

@@ -406,7 +406,8 @@ class CPCEngine:
         p, code, B, La, Lv = self.model._param, self.code, self.B, self.geo.alloc, self.geo.valid
         _hip.call("cpc_conv1_fwd_rows", _hip.ptr(x, self.x_off), _hip.ptr(p["encoder.layers.0.weight"]), _hip.ptr(p.get("encoder.layers.0.bias")),
                   _hip.ptr(self.act[0]), B, self.channels[0], self.strides[0], self.kernels[0], self.L, Lv[0], La[0],
-                  1 if self.n > 1 else 0, code, _hip.ptr(self.act_bits[0]), lo[0], hi[0], key="cpc_conv1_fwd")
+                  1 if self.n > 1 else 0, code, _hip.ptr(self.act_bits[0]), lo[0], hi[0],
+                  key="cpc_conv1_fwd" if lo[0] == 0 else "cpc_conv1_fwd_target_rows")
         for l in range(1, self.n):
             cin, cout, kw, s = self.channels[l - 1], self.channels[l], self.kernels[l], self.strides[l]
             r0, rows = lo[l], hi[l] - lo[l]
@@ -758,7 +759,8 @@ class CPCEngine:
         lo, hi = (0, bl.n[l] + 1) if part == 0 else (bl.n[l] + 1, La[l])
         M = B * (hi - lo)
         tile = 256 if (l == 1 or bl.cs[l - 1] is not None) else _hip.nt_tile(code, M, s * cin, self.geo.taps[l] * cout)
-        tkey = dict(key="gemm_nt" + _hip._variant(code, 0, tile), work=2.0 * M * s * cin * self.geo.taps[l] * cout,
+        # (the side stream's launches, a fraction of a round of tiles each beside the recurrence, are booked under their own key)
+        tkey = dict(key="gemm_nt" + _hip._variant(code, 0, tile) + ("@target_rows" if part else ""), work=2.0 * M * s * cin * self.geo.taps[l] * cout,
                     shape=("dgrad", M, s * cin, self.geo.taps[l] * cout))
         if l == 1:
             _hip.call("cpc_conv_dgrad_conv1_rows", _hip.ptr(self.dact[1]), _hip.ptr(self.w_dgrad[1]), _hip.ptr(self.act[0]),
