@@ -1219,14 +1219,19 @@ def test_e29_architectures_at_real_shapes():
     Exact-f32 mode (the parity gate): plain loss against the CPU oracle (1e-4; measured 4.5e-6), penalty step against the oracle's
     double backward (1e-3; measured 1.1e-4).  bf16 storage is only SANITY-CHECKED on this architecture, not held to the north
     star's 1e-3: measured 1.3e-2 ... 1.6e-2 on the plain loss and 5e-2 ... 1.2e-1 on the penalty step at B = 4 (two builds that differ
-    in the number of BatchNorm partial sums): the penalty is a mean of (|g| - 1)^2 with input-gradient norms |g| ~ 30.  Cause (tools/bf16_error_budget.py):
-    the blocks' residual projections carry the unnormalised power scalogram (values of O(100)) into every block output, and a bf16
-    block output then keeps ~2 significant digits of the normalised main branch riding on it; the reference's float32 does not.  The
-    fix (float32 residual stream with split-bf16 consumers) is listed in DESIGN.md; INTEGRATION.md lists the deviation."""
+    in the number of BatchNorm partial sums): the penalty is a mean of (|g| - 1)^2 with input-gradient norms |g| ~ 30.  Cause
+    (tools/bf16_error_budget.py --arch 9, round 4: the exact-f32 engine with ONE group of tensors rounded to bf16 at a time): at this
+    point the loss (80) is a log-sum-exp over linear scores of several hundred, and it moves by 3.3e-3 when only the residual stream
+    (block outputs + projections) is rounded, by 3.5e-3 when everything EXCEPT the stream is, and by up to 2.4e-2 for a single
+    block output — a float32 residual stream alone would not bring it inside 1e-3 here.  What IS held to the north star's bounds: the
+    same forward pass at a conditioned point (prediction weights x 0.01: the encoder and the context network compute exactly the same
+    activations, the scores are a few units): bf16 loss within 1e-3 of the oracle (measured 7.1e-4), exact-f32 within 1e-4 (measured
+    < 1e-7), whole-model gradient cosine bf16 vs exact-f32 > 0.9 (measured 0.955)."""
     from cpc_audio_amd import configs
     from cpc_audio_amd.audio_model import ConvolutionalArModel
     B, V, K = 4, 43, 16
-    wave_cpu, oracle, losses = None, {}, {}
+    PRED_SCALE = 0.01
+    wave_cpu, oracle, losses, grads_c = None, {}, {}, {}
     for dtype in ("fp32", "bf16"):
         torch.manual_seed(0)
         enc_cfg = configs.fresh(configs.scalogram_resnet_architecture_9)
@@ -1252,6 +1257,12 @@ def test_e29_architectures_at_real_shapes():
             ot = O.OracleTrainer(params, V, K, score="linear", all_timesteps=True, regularization=0.0, lr=1e-5, scalogram=blocks,
                                  conv_ar=dict(ar_cfg), gradient_penalty_factor=1.0)
             oracle["gp"] = float(ot.loss_and_grads(scal)[0])
+            # the same forward pass at a CONDITIONED point: prediction weights x 0.01, scores of a few units instead of several hundred
+            with torch.no_grad():
+                pc = {k: v.clone() for k, v in params.items()}
+                pc["prediction_model.weight"] *= PRED_SCALE
+                pz, tg, _, _ = O.cpc_forward(scal, pc, V, K, scalogram=blocks, conv_ar=dict(ar_cfg), training=True)
+                oracle["plain_c"] = float(O.info_nce_loss(O.linear_scores(pz, tg), True, 0.0)[0])
         pre, model = pre.to(DEV), model.to(DEV)
         model.gradient_penalty_engine = True
         pre.cqt.precision = "fp32" if dtype == "fp32" else "bf16x3"
@@ -1263,7 +1274,12 @@ def test_e29_architectures_at_real_shapes():
         model.load_state_dict(state)              # (the BatchNorm running statistics moved)
         gp = float(eng.loss_and_grads(x, softplus=False, regularization=0.0, all_timesteps=True, gradient_penalty=1.0)[0])
         assert torch.isfinite(model._flat_grad).all() and model._flat_grad.abs().max().item() > 0
-        losses[dtype] = (plain, gp)
+        model.load_state_dict(state)
+        with torch.no_grad():
+            model.prediction_model.weight.mul_(PRED_SCALE)
+        plain_c = float(eng.loss_and_grads(x, softplus=False, regularization=0.0, all_timesteps=True)[0])
+        grads_c[dtype] = model._flat_grad.detach().double().cpu().clone()
+        losses[dtype] = (plain, gp, plain_c)
         del eng, model, pre, x
         torch.cuda.empty_cache()
     print(f"e29 at real shapes: oracle plain {oracle['plain']:.5f} gp {oracle['gp']:.3f}; f32 {losses['fp32']}; bf16 {losses['bf16']}")
@@ -1271,6 +1287,17 @@ def test_e29_architectures_at_real_shapes():
     assert abs(losses["fp32"][1] - oracle["gp"]) <= 1e-3 * abs(oracle["gp"]), (losses, oracle)
     assert abs(losses["bf16"][0] - oracle["plain"]) <= 3e-2 * abs(oracle["plain"]), (losses, oracle)
     assert abs(losses["bf16"][1] - oracle["gp"]) <= 0.25 * abs(oracle["gp"]), (losses, oracle)            # sanity only, see above
+    # conditioned point (same encoder and context activations, scores of a few units): the north star's bounds without a band
+    cos = float(torch.dot(grads_c["fp32"], grads_c["bf16"]) / (grads_c["fp32"].norm() * grads_c["bf16"].norm()))
+    err_c = abs(losses["bf16"][2] - oracle["plain_c"]) / abs(oracle["plain_c"])
+    print(f"e29 conditioned point (prediction weights x {PRED_SCALE}): oracle {oracle['plain_c']:.6f}, f32 {losses['fp32'][2]:.6f}, bf16 {losses['bf16'][2]:.6f} "
+          f"(relative error {err_c:.2e}); whole-model gradient cosine bf16 vs f32 {cos:.5f}")
+    assert abs(losses["fp32"][2] - oracle["plain_c"]) <= 1e-4 * abs(oracle["plain_c"]), (losses, oracle)
+    assert err_c <= 1e-3, (losses, oracle)
+    # (measured: loss error 7.1e-4, cosine 0.955 — at B = 4 every BatchNorm normalises over four clips, and the encoder output of the bf16 run
+    # differs from the exact one by a few per cent in L2 whichever tensor group is rounded, see the budget above: this architecture is the
+    # least bf16-friendly of the reference's nine; INTEGRATION.md lists it)
+    assert cos > 0.9, cos
 
 
 def test_nan_return_restores_batchnorm_statistics_and_step_count(golden_dir):
