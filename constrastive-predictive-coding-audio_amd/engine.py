@@ -1612,8 +1612,93 @@ class AttentionContext:
         _hip.call("cpc_pe_scale_bwd", P(g1), P(g2), P(e.dact[-1], t0 * C), B, S, C, Ltop * C, self.z_scale, code)
 
 
+class _Float32EngineView:
+    """What a context network sees of an engine with bf16 storage when it computes in float32 inside it (Float32Context): ``dt`` /
+    ``code`` are float32's, ``act[-1]`` / ``dact[-1]`` float32 shadows of the top-layer buffer and its gradient in the same
+    [B][L_top][E] indexing; every other attribute is the engine's own, and the engine's methods run with this object as ``self``
+    (so that _tn_to_grad, _colsum_to_grad, _pick_split, _chunk pick the float32 kernels); attribute writes go to the engine."""
+
+    def __init__(self, eng, top32, dtop32):
+        d = self.__dict__
+        d["_e"], d["dt"], d["code"] = eng, torch.float32, _hip.dtype_code(torch.float32)
+        d["act"], d["dact"] = list(eng.act[:-1]) + [top32], list(eng.dact[:-1]) + [dtop32]
+
+    def __getattr__(self, name):
+        v = getattr(self._e, name)
+        if getattr(v, "__self__", None) is self._e and hasattr(v, "__func__"):
+            return v.__func__.__get__(self, type(self))
+        return v
+
+    def __setattr__(self, name, value):
+        setattr(self._e, name, value)
+
+
+class Float32Context:
+    """An AudioGRUModel / AttentionModel context that computes in float32 inside an engine with bf16 storage.  Built for the
+    gradient-penalty engines only (make_context): the penalty's tangent recurrence and reverse sweep of these two networks
+    (GRUContext.tangent / gp_grads, AttentionContext.tangent / _backward_gp) carry second-order terms of saturating gates,
+    LayerNorm and softmax and exist as float32 kernels; the encoder — where the FLOPs are — keeps bf16 storage.  The frames the
+    context reads are converted into a float32 shadow of the top-layer buffer on the way in, dz and c on the way out."""
+
+    def __init__(self, eng, cls, ar):
+        self.eng = eng
+        B, Ltop, E, H = eng.B, eng.geo.alloc[-1], eng.E, eng.H
+        f32 = dict(device=eng.device, dtype=torch.float32)
+        self.top32, self.dtop32 = torch.zeros(B * Ltop * E, **f32), torch.zeros(B * Ltop * E, **f32)
+        self.top_t32 = None
+        self.inner = cls(_Float32EngineView(eng, self.top32, self.dtop32), ar)
+        self.c_st = torch.zeros(B * H, device=eng.device, dtype=eng.dt)
+        self.ct_st = torch.zeros(B * H, device=eng.device, dtype=eng.dt)
+        self.z_scale = getattr(self.inner, "z_scale", 1.0)
+        self.ahead_ok = getattr(self.inner, "ahead_ok", False)
+
+    def _z(self, flat):
+        e = self.eng
+        t0 = e.T - e.K - e.V
+        return flat.view(e.B, e.geo.alloc[-1], e.E)[:, t0:t0 + e.V, :]
+
+    def allocate(self):
+        self.inner.allocate()
+
+    def slab_floats(self):
+        return self.inner.slab_floats()
+
+    def prepare_weights(self):
+        self.inner.prepare_weights()
+
+    def forward(self):
+        self._z(self.top32).copy_(self._z(self.eng.act[-1]))
+        self.inner.forward()
+        self.c_st.view(self.eng.B, self.eng.H).copy_(self.inner.c_float())
+
+    def c_operand(self):
+        return self.c_st, 0, self.eng.H
+
+    def c_float(self):
+        return self.inner.c_float()
+
+    def backward(self, dc):
+        self.inner.backward(dc)
+        self._z(self.eng.dact[-1]).copy_(self._z(self.dtop32))
+
+    def tangent(self, top_t):
+        if self.top_t32 is None:
+            self.top_t32 = torch.zeros_like(self.top32)
+        self._z(self.top_t32).copy_(self._z(top_t))
+        ct, off, stride = self.inner.tangent(self.top_t32)
+        B, H = self.eng.B, self.eng.H
+        self.ct_st.view(B, H).copy_(ct.reshape(-1)[off:].as_strided((B, H), (stride, 1)))
+        return self.ct_st, 0, H
+
+    def gp_grads(self, gp_grad):
+        self.inner.gp_grads(gp_grad)
+
+
 def make_context(eng, ar):
     from .audio_model import AudioGRUModel, ConvolutionalArModel
+    from .attention_model import AttentionModel
+    if getattr(eng, "gp_capable", False) and eng.dt != torch.float32 and isinstance(ar, (AudioGRUModel, AttentionModel)):
+        return Float32Context(eng, GRUContext if isinstance(ar, AudioGRUModel) else AttentionContext, ar)
     if isinstance(ar, AudioGRUModel):
         return GRUContext(eng, ar)
     if isinstance(ar, ConvolutionalArModel):

@@ -17,7 +17,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip
-from .engine import CPCEngine, _ceil_div, make_context, side_stream
+from .engine import CPCEngine, Float32Context, _ceil_div, make_context, side_stream
 
 
 class Grid:
@@ -1456,6 +1456,17 @@ class ScalogramCPCEngine(CPCEngine):
         self._gp_sp = SimpleNamespace(key=key, W1=new(n), W1T=new(n), W2=new(n), W2T=new(n), St1=new(n), St2=new(n),
                                       pred_a=torch.zeros_like(self.pred), pred_b=torch.zeros_like(self.pred),
                                       top_a=torch.zeros_like(self.dact[-1]), top_b=torch.zeros_like(self.dact[-1]))
+        # cpc_gp_score_coeff writes float32 coefficients; the contractions behind them take GEMM operands in the storage dtype
+        sp = self._gp_sp
+        for name in ("W1", "W1T", "W2", "W2T"):
+            setattr(sp, name + "s", getattr(sp, name) if self.dt == torch.float32 else torch.zeros(n, device=self.device, dtype=self.dt))
+
+    def _gp_coeff(self, *names):
+        sp = self._gp_sp
+        for name in names:
+            dst, src = getattr(sp, name + "s"), getattr(sp, name)
+            if dst is not src:
+                dst.copy_(src)
 
     def _gp_step(self, x, softplus, regularization, all_timesteps, factor, global_negatives, after_loss):
         """One train step with the Wasserstein gradient penalty (contrastive_estimation_training.py:141-161):
@@ -1484,13 +1495,12 @@ class ScalogramCPCEngine(CPCEngine):
             return f.to(t.dtype)
         if self.dt != torch.float32:
             # bf16 storage: tangent grids and penalty weight-gradient GEMMs in bf16 like the primal ones, the float32 first stage kept.
-            # Built for the grid-based context networks (ConvolutionalArModel / ScalogramResidualEncoder contexts: the reference's
-            # e22-e26 and its script default e29) and linear scores (every penalty experiment of the reference).
-            if softplus:
-                raise NotImplementedError("gradient penalty with softplus scores runs in the exact-f32 mode (compute_dtype='fp32')")
-            if not isinstance(self.ctx, (ConvArGridContext, ResNetArContext)):
-                raise NotImplementedError(f"gradient penalty with bf16 storage is built for convolutional context networks; "
-                                          f"{type(self.ctx).__name__} runs it in the exact-f32 mode (compute_dtype='fp32')")
+            # Grid-based context networks (ConvolutionalArModel / ScalogramResidualEncoder contexts: the reference's e22-e26 and its
+            # script default e29) run in bf16 too; a GRU or attention context computes in float32 inside the bf16 engine
+            # (engine.Float32Context: their second-order sweeps are float32 kernels).
+            if not isinstance(self.ctx, (ConvArGridContext, ResNetArContext, Float32Context)):
+                raise NotImplementedError(f"gradient penalty with bf16 storage: no route for {type(self.ctx).__name__} "
+                                          f"(compute_dtype='fp32' runs it)")
         if not hasattr(self.ctx, "tangent"):
             raise NotImplementedError(f"no gradient-penalty tangent pass for {type(self.ctx).__name__}")
         model, code = self.model, self.code
@@ -1523,11 +1533,13 @@ class ScalogramCPCEngine(CPCEngine):
                 ldR = (R + 7) // 8 * 8
                 self.score_gemm_all()
                 _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S_all), None, None, _hip.ptr(sp.W1), _hip.ptr(sp.W1T), 1, R, R, ldR, ldR, 0)
-                self._score_grads_all(sp.W1, sp.W1T, self.pred, self.act[-1], self.dpred, self.dact[-1])
+                self._gp_coeff("W1", "W1T")
+                self._score_grads_all(sp.W1s, sp.W1Ts, self.pred, self.act[-1], self.dpred, self.dact[-1])
             else:
                 self.score_gemm()
                 _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S), None, None, _hip.ptr(sp.W1), _hip.ptr(sp.W1T), K, B, B, self.ldS, self.ldS, 0)
-                self._score_grads(sp.W1, sp.W1T, self.pred, self.act[-1], self.dpred, self.dact[-1])
+                self._gp_coeff("W1", "W1T")
+                self._score_grads(sp.W1s, sp.W1Ts, self.pred, self.act[-1], self.dpred, self.dact[-1])
         else:
             self.dpred.view(B, K, E).copy_(seed_p)
             dtop[:, T - K:T, :].copy_(seed_t)
@@ -1572,15 +1584,17 @@ class ScalogramCPCEngine(CPCEngine):
                 self.score_gemm_all(top=top_t, out=sp.St2)
                 _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S_all), _hip.ptr(sp.St1), _hip.ptr(sp.St2), _hip.ptr(sp.W2), _hip.ptr(sp.W2T),
                           1, R, R, ldR, ldR, 1)
-                self._score_grads_all(sp.W1, sp.W1T, self.pred_t, top_t, sp.pred_a, sp.top_a)
-                self._score_grads_all(sp.W2, sp.W2T, self.pred, self.act[-1], sp.pred_b, sp.top_b)
+                self._gp_coeff("W2", "W2T")
+                self._score_grads_all(sp.W1s, sp.W1Ts, self.pred_t, top_t, sp.pred_a, sp.top_a)
+                self._score_grads_all(sp.W2s, sp.W2Ts, self.pred, self.act[-1], sp.pred_b, sp.top_b)
             else:
                 self.score_gemm(pred=self.pred_t, out=sp.St1)
                 self.score_gemm(top=top_t, out=sp.St2)
                 _hip.call("cpc_gp_score_coeff", _hip.ptr(self.S), _hip.ptr(sp.St1), _hip.ptr(sp.St2), _hip.ptr(sp.W2), _hip.ptr(sp.W2T),
                           K, B, B, self.ldS, self.ldS, 1)
-                self._score_grads(sp.W1, sp.W1T, self.pred_t, top_t, sp.pred_a, sp.top_a)
-                self._score_grads(sp.W2, sp.W2T, self.pred, self.act[-1], sp.pred_b, sp.top_b)
+                self._gp_coeff("W2", "W2T")
+                self._score_grads(sp.W1s, sp.W1Ts, self.pred_t, top_t, sp.pred_a, sp.top_a)
+                self._score_grads(sp.W2s, sp.W2Ts, self.pred, self.act[-1], sp.pred_b, sp.top_b)
             add_p = sp.pred_a.view(B, K, E) + sp.pred_b.view(B, K, E)
             add_t = sp.top_a.view(B, Ltop, E)[:, T - K:T, :] + sp.top_b.view(B, Ltop, E)[:, T - K:T, :]
         elif all_timesteps:
