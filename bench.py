@@ -457,9 +457,36 @@ def measure_secondary(name, args, world, rank, device, dist, brief=False):
     opt.skip_flag = eng.nan_flag()
     opt.after_update = eng.prepare_ahead          # next step's operand copies rebuilt off the critical path (as the trainer sets it)
 
+    # the scalogram of batch i + 1 (CQT GEMMs + pointwise kernel) is computed on the side stream while step i runs, as the trainer does
+    # (contrastive_estimation_training.InputAhead; CPC_PREPROCESS_AHEAD=0: on the main stream in front of every step, the reference's
+    # order).  Every timed step still issues exactly one preprocessing pass and one train step.
+    ahead = None
+    if wl.pre is not None and os.environ.get("CPC_PREPROCESS_AHEAD", "1") != "0":
+        from cpc_audio_amd.contrastive_estimation_training import InputAhead
+        ahead = InputAhead(lambda w: wl.pre(w.unsqueeze(1)), device)
+    ahead_at = os.environ.get("CPC_PREPROCESS_AHEAD_AT", "block")
+
     def step(i):
-        out = eng.loss_and_grads(inputs(i), softplus=True, regularization=1.0, all_timesteps=args.all_timesteps,
-                                 after_loss=sync.reduce_flag if sync is not None else None)
+        after = sync.reduce_flag if sync is not None else None
+        if ahead is not None:
+            if not ahead.pending:
+                ahead.submit(pool[i % len(pool)])
+            _, x = ahead.take()
+            nxt = pool[(i + 1) % len(pool)]
+            if ahead_at == "loss":          # A/B: queued behind the loss kernels, i.e. beside the backward pass
+                flag = after
+
+                def after(out_):
+                    ahead.submit(nxt)
+                    if flag is not None:
+                        flag(out_)
+            elif ahead_at == "start":       # A/B: in front of the step
+                ahead.submit(nxt)
+            else:                           # default: where the engine's main queue turns latency-bound (ScalogramCPCEngine.side_job)
+                eng.side_job = lambda: ahead.submit(nxt)
+        else:
+            x = inputs(i)
+        out = eng.loss_and_grads(x, softplus=True, regularization=1.0, all_timesteps=args.all_timesteps, after_loss=after)
         if sync is not None:
             sync.finish()                       # one RCCL all-reduce (sum) of the flat gradient buffer
         opt.step(grad_scale=1.0 / world)

@@ -14,6 +14,7 @@ DeterministicSampler :363-382, grad_mean_var :385-391).  ``train`` has two route
 from __future__ import annotations
 
 import math
+import os
 import random
 
 import torch
@@ -28,6 +29,64 @@ from .audio_dataset import FileBatchSampler
 def _need_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError(f"{what} runs on the GPU only (libcpc_hip.so; there is no CPU fallback): move the tensors to the device")
+
+
+class InputAhead:
+    """The preprocessing module of batch i + 1 (CQT GEMMs + the pointwise scalogram kernel: 1.3 of the 12 ms of a BASELINE configs[2]
+    step) issued on the side stream while step i runs, instead of on the main stream in front of step i + 1's encoder.  The reference
+    preprocesses inside the step (:99-103); the scalogram does not depend on the parameters, so the result is the same tensor, one
+    step early: ``submit(batch)`` queues it behind everything the main stream has been given so far (so that the batch itself is
+    complete) and returns at once, ``take()`` makes the main stream wait for the oldest submitted batch and returns
+    (batch, model input).  Buffers: the module allocates a fresh output per call; record_stream keeps the caching allocator from
+    handing a block to the other stream while it is still being read."""
+
+    def __init__(self, fn, device):
+        from .engine import side_stream
+        self.fn, self.device = fn, torch.device(device)
+        self.aux = side_stream(self.device)
+        if os.environ.get("CPC_PREPROCESS_STREAM", "side") == "own":          # A/B: a stream of its own at the default priority
+            self.aux = _own_stream(self.device)
+        self.pending = []
+
+    def submit(self, batch):
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(ready)
+            x = self.fn(batch)
+            done = torch.cuda.Event()
+            done.record(self.aux)
+        batch.record_stream(self.aux)
+        self.pending.append((batch, x, done))
+
+    def take(self):
+        batch, x, done = self.pending.pop(0)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(done)
+        if isinstance(x, torch.Tensor):
+            x.record_stream(main)
+        return batch, x
+
+
+_OWN_STREAMS = {}
+
+
+def _own_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _OWN_STREAMS:
+        _OWN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _OWN_STREAMS[key]
+
+
+def _with_next(it):
+    """(item, next item or None) pairs of an iterator."""
+    it = iter(it)
+    cur = next(it, None)
+    while cur is not None:
+        nxt = next(it, None)
+        yield cur, nxt
+        cur = nxt
 
 
 class _ScoreContraction(torch.autograd.Function):
@@ -175,6 +234,8 @@ class ContrastiveEstimationTrainer:
         # Not in the reference's signature: under torch.distributed take the InfoNCE loss over the batches of ALL ranks — what
         # the reference's nn.DataParallel wrap computes — instead of per-GPU negatives (engine.GlobalNegatives).
         self.global_negatives = False
+        # Not in the reference: the preprocessing module of the NEXT batch runs on the side stream beside the current step (InputAhead)
+        self.preprocess_ahead = True
         self.verbose = True
         if wasserstein_gradient_penalty:
             # reference :144-158.  Its penalty differentiates the summed scores with respect to the PREPROCESSED batch, which only
@@ -383,7 +444,11 @@ class ContrastiveEstimationTrainer:
                 print("epoch", current_epoch)
             ctx = torch.autograd.profiler.profile(use_device="cuda", enabled=profile)
             with ctx as prof_ctx:
-                for batch in self._batches(self.dataset, sampler, device, num_workers, True, rank, world):
+                ahead = None
+                if (fused and not graphed and self.preprocessing is not None and self.preprocess_ahead and device.type == "cuda"
+                        and os.environ.get("CPC_PREPROCESS_AHEAD", "1") != "0"):
+                    ahead = InputAhead(self._model_input, device)
+                for batch, next_batch in _with_next(self._batches(self.dataset, sampler, device, num_workers, True, rank, world)):
                     snapshot(self.training_step)
                     if fused and graphed:
                         eng = self.model.engine(batch.shape[0], batch.shape[1], device)
@@ -397,8 +462,16 @@ class ContrastiveEstimationTrainer:
                         vals = graph_steps[key](batch)
                     elif fused:
                         if self.preprocessing is not None:
-                            x_eng = self._model_input(batch)
+                            if ahead is not None:
+                                if not ahead.pending:              # first step of the epoch: nothing was submitted beside a previous one
+                                    ahead.submit(batch)
+                                _, x_eng = ahead.take()
+                            else:
+                                x_eng = self._model_input(batch)
                             eng = self.model.engine_for(x_eng)
+                            if ahead is not None and next_batch is not None:
+                                # the engine runs it behind its encoder's forward pass, where its main queue turns latency-bound
+                                eng.side_job = lambda nb=next_batch: ahead.submit(nb)
                         else:
                             x_eng = batch.contiguous()
                             eng = self.model.engine(batch.shape[0], batch.shape[1], device)

@@ -1409,8 +1409,19 @@ class ScalogramCPCEngine(CPCEngine):
                 self._x_own = self.x_grid.allocate()
             self.x_grid.t = self._x_own
             self.x_grid.t.view(cl.shape).copy_(cl)
-        for b in self.blocks:
+        # ``side_job``: a callable the caller left for this step (the trainer's InputAhead: the NEXT batch's CQT + scalogram kernels on the
+        # side stream), run once, behind the encoder's last block: from there to the first large data gradient (context network, loss,
+        # the upper blocks' backward passes) the main queue holds short, latency-bound launches.  Measured on configs[2] (30 steps after
+        # 15, one box): off 12.08 - 12.17 ms, in front of the step 12.25, after block 0 / 1 / 2 / 3: 12.15 / 12.04 / 12.00 / 11.84, behind
+        # the loss kernels 11.86; on a stream of its own at the default priority 11.88 - 12.25.  CPC_SIDE_JOB_BLOCK: after which block.
+        job, self.side_job = getattr(self, "side_job", None), None
+        at = min(int(os.environ.get("CPC_SIDE_JOB_BLOCK", str(len(self.blocks) - 1))), len(self.blocks) - 1)
+        if job is not None and at < 0:
+            job()
+        for i, b in enumerate(self.blocks):
             b.forward()
+            if job is not None and i == at:
+                job()
         if self.top_grid is not None:
             self.top_grid.t.view(self.B, self.T, self.E).copy_(self._row0(self.blocks[-1].out))
 

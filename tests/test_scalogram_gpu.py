@@ -1330,6 +1330,35 @@ def test_e29_architectures_at_real_shapes():
     assert cos > 0.9, cos
 
 
+@pytest.mark.parametrize("resident", [True, False])
+def test_preprocessing_one_step_ahead_changes_nothing(golden_dir, resident):
+    """trainer.preprocess_ahead (contrastive_estimation_training.InputAhead): the CQT + scalogram kernels of batch i + 1 run on the side
+    stream while step i trains, queued behind the encoder's forward pass (ScalogramCPCEngine.side_job).  Losses of every step and every
+    parameter / BatchNorm buffer after six steps are bit-identical to the reference's order (preprocessing inside the step, :99-103) —
+    with a device-resident dataset and with a host dataset behind the double-buffered upload."""
+    g = _load(golden_dir, "scalogram_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "scalogram_model.json")))
+    B, K, H = meta["B"], meta["K"], meta["H"]
+    data = torch.from_numpy(g["data"])
+    results = []
+    for ahead in (False, True):
+        pre, model = _build_scalogram_model(g, meta, "bf16")
+        logger = _Logger()
+        ds = TensorAudioDataset(data, device=DEV if resident else None)
+        tr = ContrastiveEstimationTrainer(model=model, dataset=ds, logger=logger, device=DEV, regularization=1.0,
+                                          score_function=SCORE["softplus"], prediction_steps=K, ar_size=H, preprocessing=pre)
+        tr.verbose = False
+        tr.preprocess_ahead = ahead
+        random.seed(17)
+        tr.train(batch_size=B, epochs=10, lr=1e-3, num_workers=0, max_steps=6)
+        torch.cuda.synchronize()
+        results.append((list(logger.loss_meter.values), {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    assert len(l0) == 6 and l0 == l1, (l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_nan_return_restores_batchnorm_statistics_and_step_count(golden_dir):
     """The host learns of a NaN loss one step late and has launched another step by then (docs/DESIGN_HISTORY_r1-r3.md section 11): that step's
     update is skipped on the device, and train() puts back what its forward pass moved — the BatchNorm running statistics
