@@ -448,7 +448,9 @@ class ContrastiveEstimationTrainer:
                 if (fused and not graphed and self.preprocessing is not None and self.preprocess_ahead and device.type == "cuda"
                         and os.environ.get("CPC_PREPROCESS_AHEAD", "1") != "0"):
                     ahead = InputAhead(self._model_input, device)
-                for batch, next_batch in _with_next(self._batches(self.dataset, sampler, device, num_workers, True, rank, world)):
+                batches = self._batches(self.dataset, sampler, device, num_workers, True, rank, world)
+                # (the sampler is read one batch ahead only where that batch is preprocessed ahead)
+                for batch, next_batch in (_with_next(batches) if ahead is not None else ((b_, None) for b_ in batches)):
                     snapshot(self.training_step)
                     if fused and graphed:
                         eng = self.model.engine(batch.shape[0], batch.shape[1], device)

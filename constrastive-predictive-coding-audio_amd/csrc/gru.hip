@@ -340,21 +340,28 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* 
             hprev[q][e] = (h0 && b_ok && (FULL || jt < NT)) ? h0[(long long)b * H + jt * 16 + fg * 4 + e] : 0.f;
         }
     const long long tape_bt = (long long)blockIdx.x * V;
+    // Nothing may be in flight when the loop starts: with the (conditional) loads of h0 still counted as pending at the loop header, the
+    // compiler's wait-count pass — which has one counter for loads and stores and cannot count through conditional requests — put
+    // s_waitcnt vmcnt(0) in front of every step's first LDS read, i.e. right behind the requests for the next step's input-projection
+    // rows: a full HBM round trip (and the acknowledgement of the previous step's tape stores) on the critical path of each of the V steps.
+    // (The builtin, not inline asm: the pass reads S_WAITCNT instructions, not asm strings.  0x0F70 = vmcnt(0), the other counters open.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    if (V > 1) {          // the rows of step 1 (those of step 0 are in the LDS tile already)
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) {
+            const int i = tid + u * NTHR;
+            if (i < GCHUNKS) {
+                const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
+                if (b0 + rb < B) gpre[u] = *(const uint4*)(Gi + ((long long)(b0 + rb) * V + 1) * 3 * H + cc * 8);
+            }
+        }
+    }
 
     for (int t = 0; t < V; ++t) {
         const unsigned char* hcur = (t & 1) ? hbuf1 : hbuf0;
         unsigned char* hnext = (t & 1) ? hbuf0 : hbuf1;
-        // next step's input-projection rows: issued now, parked in LDS after this step's gate math
-        if (t + 1 < V) {
-#pragma unroll
-            for (int u = 0; u < GPT; ++u) {
-                const int i = tid + u * NTHR;
-                if (i < GCHUNKS) {
-                    const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
-                    if (b0 + rb < B) gpre[u] = *(const uint4*)(Gi + ((long long)(b0 + rb) * V + t + 1) * 3 * H + cc * 8);
-                }
-            }
-        }
+        // (gpre holds the input-projection rows of step t + 1, requested at the end of step t - 1; they are parked in LDS after this step's gate math)
         f32x4 acc[NJT][3];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
@@ -378,6 +385,11 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* 
                 mfma_chunk<bf16_t>(acc[q][2], w2, hf);
             }
         }
+        // The next step's rows (requested at the top of this step, a matrix phase ago) and the previous step's stores are waited for HERE,
+        // before this step's first store is issued: loads and stores share the counter, so a wait placed behind the tape stores below
+        // (where the compiler would put it: in front of the LDS writes of gpre at the end of the step) waits for their acknowledgement too.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
         f32x4 hp_keep[NJT];
 #pragma unroll
         for (int q = 0; q < NJT; ++q) {
@@ -424,6 +436,17 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_fwd_res_kernel(const bf16_t* 
                     if (i < GCHUNKS) {
                         const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
                         *(uint4*)(gtile + rb * GROW + cc * 16) = gpre[u];
+                    }
+                }
+            }
+            // the rows of step t + 2: requested here, a whole step (barrier, matrix phase) before the wait in front of step t + 1's stores
+            if (t + 2 < V) {
+#pragma unroll
+                for (int u = 0; u < GPT; ++u) {
+                    const int i = tid + u * NTHR;
+                    if (i < GCHUNKS) {
+                        const int rb = i / (3 * H / 8), cc = i % (3 * H / 8);
+                        if (b0 + rb < B) gpre[u] = *(const uint4*)(Gi + ((long long)(b0 + rb) * V + t + 2) * 3 * H + cc * 8);
                     }
                 }
             }
@@ -522,13 +545,14 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_bwd_res_kernel(const float* _
             }
         }
         __syncthreads();
-        // the gradient tile goes to HBM as whole rows (16 rows x 4H bf16) while the MFMAs below read it
-        if (!(dbg & 1)) {
-            for (int i = tid; i < 16 * 4 * H / 8; i += NTHR) {
-                const int rb = i / (4 * H / 8), cc = i % (4 * H / 8);
-                if (b0 + rb < B)
-                    *(uint4*)(dG + ((long long)(b0 + rb) * V + t) * 4 * H + cc * 8) = *(const uint4*)(gcur + rb * ROWB + cc * 16);
-            }
+        // the gradient tile goes to HBM as whole rows (16 rows x 4H bf16): read from LDS here, stored behind the matrix phase (below)
+        constexpr int GCH = 16 * 4 * H / 8, GST = (GCH + NTHR - 1) / NTHR;
+        uint4 gst[GST];
+#pragma unroll
+        for (int u = 0; u < GST; ++u) {
+            const int i = tid + u * NTHR;
+            gst[u] = make_uint4(0, 0, 0, 0);
+            if (GCH % NTHR == 0 || i < GCH) gst[u] = *(const uint4*)(gcur + (i / (4 * H / 8)) * ROWB + (i % (4 * H / 8)) * 16);
         }
         f32x4 acc[NJT];
 #pragma unroll
@@ -552,6 +576,19 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_bwd_res_kernel(const float* _
         for (int q = 0; q < NJT; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dh[q][e] = keep[q][e] + acc[q][e];
+        // The tape of step t - 1 (requested at the top of this step, a gate pass and a matrix phase ago) is waited for BEFORE this step's
+        // stores are issued: loads and stores share one counter, and the wait the compiler would place in front of `sv = svn` below would
+        // also wait for the acknowledgement of the stores issued just before it (gru_fwd_res_kernel has the same arrangement).
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), the other counters open
+        asm volatile("" ::: "memory");
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int u = 0; u < GST; ++u) {
+                const int i = tid + u * NTHR;
+                const int rb = i / (4 * H / 8), cc = i % (4 * H / 8);
+                if ((GCH % NTHR == 0 || i < GCH) && b0 + rb < B) *(uint4*)(dG + ((long long)(b0 + rb) * V + t) * 4 * H + cc * 8) = gst[u];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < Cfg::SLOTS; ++k) sv[k] = svn[k];
         __syncthreads();
