@@ -12,6 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_OUT_F32, GEMM_TN_NO_TR, GEMM_FORCE_GENERIC, GEMM_SMALL_TILE, GEMM_NARROW_EPI, GEMM_NO_DMA, GEMM_SKIP_PAD_ROWS = 1, 2, 4, 8, 16, 32, 64, 128
+GEMM_BIG_TILE = 0x100000          # CPC_GEMM_BIG_TILE: the 256 x 256 tile also where fewer than 200 of them exist
 GEMM_LINEAR_K, GEMM_NO_PERS, GEMM_DIRECT_MASK, GEMM_KRANGE_EXACT = 256, 512, 1024, 2048
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -287,7 +288,8 @@ def nt_tile(dtype, M, N, K, flags=0, batch=1):
     ch = 8 if dtype == BF16 else 4
     fast = K % (8 * ch) == 0 and not (flags & GEMM_FORCE_GENERIC)
     big_tiles = ((M + 255) // 256) * ((N + 255) // 256) * batch
-    return 256 if (fast and dtype == BF16 and M >= 1024 and N >= 256 and not (flags & GEMM_SMALL_TILE) and big_tiles >= 200) else 128
+    return 256 if (fast and dtype == BF16 and N >= 256 and not (flags & GEMM_SMALL_TILE) and
+                   ((M >= 1024 and big_tiles >= 200) or ((flags & GEMM_BIG_TILE) and M >= 256))) else 128
 
 
 def tn_tile(dtype, M, I, J, nsplit, m_chunk, flags=0):
