@@ -13,7 +13,7 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 25 --no-cpu-baseline $EXTRA > $OUT/stats.log 2>&1
 # one step of the timed region, kernel by kernel (start, queue, duration, idle gap): tools/timeline.py on the trace before it is trimmed
 TR=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
-if [ "$WL" = "cfg1" ]; then FIRST=conv1_fwd; elif [ "$WL" = "scalogram" ]; then FIRST=scalogram_pointwise; else FIRST=conv1_fwd; fi
+if [ "$WL" = "cfg1" ]; then FIRST=conv1_fwd; elif [ "$WL" = "scalogram" ]; then FIRST=stem_stats; else FIRST=conv1_fwd; fi      # (the scalogram of the NEXT batch now runs mid-step on the side stream)
 python3 tools/timeline.py $TR --first $FIRST --back 12 > $OUT/timeline_one_step.txt 2>&1 || true
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1
