@@ -52,25 +52,25 @@ __device__ __forceinline__ void load8<float>(const float* src, float* v) {
 // 16-byte chunks at the end, no block barrier, no byte store per row.
 constexpr int C1_FPOS = 256;
 
-template <typename T, int KW, bool WROW, bool BITS, int FPOS = C1_FPOS>
+template <typename T, int KW, bool WROW, bool BITS>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int C,
                                                         int stride, int kw_rt, long long ldx, int L_valid, int L_alloc, int relu,
                                                         unsigned char* __restrict__ y_bits, int row_lo, int row_hi) {
     static_assert(!BITS || WROW, "sign bits: one wave per row");
     const int kw = KW > 0 ? KW : kw_rt;
-    __shared__ float xs[FPOS * 8 + C1_MAXK + 8];     // stride <= 8 supported
-    __shared__ __attribute__((aligned(16))) unsigned char bimg[BITS ? FPOS * 64 : 16];
+    __shared__ float xs[C1_FPOS * 8 + C1_MAXK + 8];     // stride <= 8 supported
+    __shared__ __attribute__((aligned(16))) unsigned char bimg[BITS ? C1_FPOS * 64 : 16];
     const int b = blockIdx.y;
-    const int t0 = row_lo + blockIdx.x * FPOS;          // (rows [row_lo, row_hi) of every item: cpc_conv1_fwd_rows)
+    const int t0 = row_lo + blockIdx.x * C1_FPOS;          // (rows [row_lo, row_hi) of every item: cpc_conv1_fwd_rows)
     const int tid = threadIdx.x;
     const int lpr = WROW ? 64 : C / 8;
     const int cg = tid % lpr, nrl = 256 / lpr;
     const int rl = WROW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / lpr;
-    constexpr int RPW = FPOS / 4;
+    constexpr int RPW = C1_FPOS / 4;
 
-    // stage the input window of positions [t0, t0 + FPOS): samples [t0*stride, (t0+FPOS-1)*stride + kw)
-    const int npos = min(FPOS, L_valid - t0);          // valid positions in this block (may be <= 0)
+    // stage the input window of positions [t0, t0 + C1_FPOS): samples [t0*stride, (t0+C1_FPOS-1)*stride + kw)
+    const int npos = min(C1_FPOS, L_valid - t0);          // valid positions in this block (may be <= 0)
     const int nsamp = npos > 0 ? (npos - 1) * stride + kw : 0;
     const float* xb = x + (long long)b * ldx + (long long)t0 * stride;
     for (int i = tid; i < nsamp; i += 256) xs[i] = xb[i];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     __syncthreads();
 
     T* yb = y + ((long long)b * L_alloc + t0) * C + cg * 8;
-    const int nrows = min(FPOS, row_hi - t0);
+    const int nrows = min(C1_FPOS, row_hi - t0);
     const int niter = BITS ? RPW : (nrows - rl + nrl - 1) / nrl;
     // Pad rows are stored from their own branch (no per-row zero fill of v).  Tried against this loop and not faster: one v_max_f32 per
     // value instead of relu_f's compare / select pair (with a NaN put-back); persistent kernels that stream the rows in memory order
@@ -204,8 +204,6 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 
 }  // namespace
 
-static const int g_conv1_small_rows = []() { const char* e = getenv("CPC_CONV1_SMALL_ROWS"); return e ? atoi(e) : 1; }();      // A/B switch
-
 static bool c1_ok(int C, int stride, int kw) {
     if (C < 8 || C % 8) return false;
     const int lpr = C / 8;
@@ -223,17 +221,6 @@ int launch_conv1_fwd(const float* x, const float* w, const float* bias, void* y,
     if (y_bits && (C != 512 || (uintptr_t)y_bits % 16)) return CPC_EINVAL;        // sign bits: one wave per row (see the kernel)
     // 256 output positions per workgroup: the 88 weight / bias registers of a thread are loaded once per workgroup
     dim3 grid((row_hi - row_lo + C1_FPOS - 1) / C1_FPOS, B);
-    // A short row range (the forward target lane: 388 of 3 648 rows per clip, two workgroups per clip) leaves every wave a chain of 64
-    // dependent rows with two workgroups per CU to hide it behind: 69 us for a ninth of the rows the full launch writes in 176 us.
-    // 64 positions per workgroup there: a wave walks 16 rows, four times the workgroups share the CUs.
-    if (y_bits && dtype == CPC_DTYPE_BF16 && kw == 10 && (long long)grid.x * B < 1024 && g_conv1_small_rows) {
-        constexpr int FP = 64;
-        dim3 g2((row_hi - row_lo + FP - 1) / FP, B);
-        hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, 10, true, true, FP>), g2, dim3(256), 0, stream, x, w, bias, (bf16_t*)y, C, stride, kw, ldx,
-                           L_valid, L_alloc, relu, y_bits, row_lo, row_hi);
-        CPC_CHECK_LAUNCH();
-        return CPC_OK;
-    }
 #define LAUNCH(T, KWT) \
     do { \
         if (y_bits) hipLaunchKernelGGL((conv1_fwd_kernel<T, KWT, true, true>), grid, dim3(256), 0, stream, x, w, bias, (T*)y, C, stride, kw, ldx, L_valid, L_alloc, relu, y_bits, row_lo, row_hi); \
