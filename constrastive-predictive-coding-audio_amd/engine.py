@@ -1920,6 +1920,113 @@ class GlobalNegatives:
         s.targT.copy_(targ_all.t())
         _hip.gemm_nt(P(s.dSr), P(s.targT), P(self.dpred_all, lo * E), Rl, E, Rg, Rg, Rg, E, code)
 
+    # ---- Wasserstein gradient penalty with softplus scores under global negatives (scalogram_engine._gp_step): the summed scores run over
+    # the GLOBAL score matrix, so the seeds of the penalty's passes are contractions with W1 = sigmoid(s) and W2 = softplus''(s) * (tangent
+    # of s) over all ranks' predictions and targets.  Every rank forms the whole matrix (a parity path: the penalty costs three passes
+    # through the network anyway) and keeps the rows / columns of its own clips.
+    def _gp_sizes(self, all_timesteps):
+        K, GB = self.eng.K, self.GB
+        if all_timesteps:
+            R = GB * K
+            return 1, R, _ceil_div(R, 8) * 8
+        return K, GB, self.ld
+
+    def _gp_state(self, all_timesteps):
+        g = getattr(self, "_gp", None)
+        if g is not None and g.key == bool(all_timesteps):
+            return g
+        e = self.eng
+        nb, R, ld = self._gp_sizes(all_timesteps)
+        n = nb * R * ld
+        f32 = dict(device=e.device, dtype=torch.float32)
+        st = dict(device=e.device, dtype=e.dt)
+        g = self._gp = SimpleNamespace(key=bool(all_timesteps), S=torch.zeros(n, **f32), St1=torch.zeros(n, **f32), St2=torch.zeros(n, **f32),
+                                       W1=torch.zeros(n, **f32), W1T=torch.zeros(n, **f32), W2=torch.zeros(n, **f32), W2T=torch.zeros(n, **f32),
+                                       pred_t_all=torch.zeros_like(self.pred_all), targ_t_all=torch.zeros_like(self.targ_all),
+                                       local=torch.zeros_like(self.local_targ), out_p=torch.zeros_like(self.pred_all),
+                                       out_t=torch.zeros_like(self.targ_all), out_p2=torch.zeros_like(self.pred_all),
+                                       out_t2=torch.zeros_like(self.targ_all))
+        for name in ("W1", "W1T", "W2", "W2T"):          # GEMM operands in the storage dtype
+            setattr(g, name + "s", getattr(g, name) if e.dt == torch.float32 else torch.zeros(n, **st))
+        if all_timesteps:
+            g.aT, g.bT = torch.zeros(e.E, ld, **st), torch.zeros(e.E, ld, **st)
+        return g
+
+    def _gp_gather(self, pred, top, pred_all, targ_all, local):
+        e = self.eng
+        B, K, E, T, Ltop = e.B, e.K, e.E, e.T, e.geo.alloc[-1]
+        n = B * K * E
+        local.view(B, K, E).copy_(top.view(B, Ltop, E)[:, T - K:T, :])
+        self.dist.all_gather([pred_all[r * n:(r + 1) * n] for r in range(self.world)], pred.contiguous())
+        self.dist.all_gather([targ_all[r * n:(r + 1) * n] for r in range(self.world)], local)
+
+    def _gp_scores(self, pa, ta, out, all_timesteps):
+        e = self.eng
+        P, code, E, K, GB = _hip.ptr, e.code, e.E, e.K, self.GB
+        nb, R, ld = self._gp_sizes(all_timesteps)
+        if all_timesteps:
+            _hip.gemm_nt(P(pa), P(ta), P(out), R, R, E, E, E, ld, code, flags=_hip.GEMM_OUT_F32)
+        else:
+            _hip.gemm_nt(P(pa), P(ta), P(out), GB, GB, E, K * E, K * E, ld, code, a_batch=E, b_batch=E, c_batch=GB * ld, batch=K,
+                         flags=_hip.GEMM_OUT_F32)
+
+    def _gp_contract(self, W, WT, pa, ta, out_p, out_t, all_timesteps):
+        """out_p[r] = sum_c W[r][c] ta[c],  out_t[c] = sum_r W[r][c] pa[r]  (W, WT in the storage dtype; all global rows / columns)."""
+        e, g = self.eng, self._gp
+        P, code, E, K, GB = _hip.ptr, e.code, e.E, e.K, self.GB
+        nb, R, ld = self._gp_sizes(all_timesteps)
+        if all_timesteps:
+            g.aT[:, :R].copy_(ta.view(R, E).t())
+            g.bT[:, :R].copy_(pa.view(R, E).t())
+            _hip.gemm_nt(P(W), P(g.aT), P(out_p), R, E, ld, ld, ld, E, code)
+            _hip.gemm_nt(P(WT), P(g.bT), P(out_t), R, E, ld, ld, ld, E, code)
+        else:
+            _hip.gemm_tn(P(WT), P(ta), P(out_p), GB, GB, E, ld, K * E, K * E, code, a_batch=GB * ld, b_batch=E, c_batch=E, batch=K)
+            _hip.gemm_tn(P(W), P(pa), P(out_t), GB, GB, E, ld, K * E, K * E, code, a_batch=GB * ld, b_batch=E, c_batch=E, batch=K)
+
+    def _gp_coeff(self, g, second, all_timesteps):
+        nb, R, ld = self._gp_sizes(all_timesteps)
+        P = _hip.ptr
+        if second:
+            _hip.call("cpc_gp_score_coeff", P(g.S), P(g.St1), P(g.St2), P(g.W2), P(g.W2T), nb, R, R, ld, ld, 1)
+            names = ("W2", "W2T")
+        else:
+            _hip.call("cpc_gp_score_coeff", P(g.S), None, None, P(g.W1), P(g.W1T), nb, R, R, ld, ld, 0)
+            names = ("W1", "W1T")
+        for name in names:
+            dst, src = getattr(g, name + "s"), getattr(g, name)
+            if dst is not src:
+                dst.copy_(src)
+
+    def gp_softplus_seed(self, all_timesteps):
+        """Pass 1: (adjoint of the local predictions [B K E], adjoint of the local targets [B, K, E]) of the summed global scores."""
+        e = self.eng
+        g = self._gp_state(all_timesteps)
+        n = e.B * e.K * e.E
+        self._gp_gather(e.pred, e.act[-1], self.pred_all, self.targ_all, self.local_targ)
+        self._gp_scores(self.pred_all, self.targ_all, g.S, all_timesteps)
+        self._gp_coeff(g, False, all_timesteps)
+        self._gp_contract(g.W1s, g.W1Ts, self.pred_all, self.targ_all, g.out_p, g.out_t, all_timesteps)
+        lo = self.rank * n
+        return g.out_p[lo:lo + n], g.out_t[lo:lo + n].view(e.B, e.K, e.E)
+
+    def gp_softplus_second(self, pred_t, top_t, all_timesteps):
+        """Last pass: what the local predictions / targets gain from the tangent pass, nu_p = W1 (tangent targets) + W2 targets and
+        nu_t = W1^T (tangent predictions) + W2^T predictions over the global batch (pred_all / targ_all / S are pass 1's)."""
+        e = self.eng
+        g = self._gp_state(all_timesteps)
+        n = e.B * e.K * e.E
+        self._gp_gather(pred_t, top_t, g.pred_t_all, g.targ_t_all, g.local)
+        self._gp_scores(g.pred_t_all, self.targ_all, g.St1, all_timesteps)
+        self._gp_scores(self.pred_all, g.targ_t_all, g.St2, all_timesteps)
+        self._gp_coeff(g, True, all_timesteps)
+        self._gp_contract(g.W1s, g.W1Ts, g.pred_t_all, g.targ_t_all, g.out_p, g.out_t, all_timesteps)
+        self._gp_contract(g.W2s, g.W2Ts, self.pred_all, self.targ_all, g.out_p2, g.out_t2, all_timesteps)
+        lo = self.rank * n
+        add_p = g.out_p[lo:lo + n].view(e.B, e.K, e.E) + g.out_p2[lo:lo + n].view(e.B, e.K, e.E)
+        add_t = g.out_t[lo:lo + n].view(e.B, e.K, e.E) + g.out_t2[lo:lo + n].view(e.B, e.K, e.E)
+        return add_p, add_t
+
     def forward_backward(self, softplus: bool, regularization: float, all_timesteps: bool = False):
         e, dist = self.eng, self.dist
         code, B, E, K, GB, ld = e.code, e.B, e.E, e.K, self.GB, self.ld

@@ -1492,8 +1492,6 @@ class ScalogramCPCEngine(CPCEngine):
         if not self.gp_capable:
             raise RuntimeError("this engine was built without gradient-penalty support (model.gradient_penalty_engine = True first)")
         gn = global_negatives
-        if gn is not None and softplus:
-            raise NotImplementedError("gradient penalty + global negatives is built for linear scores (the reference's penalty experiments)")
         world = gn.world if gn is not None else 1
 
         def over_ranks(t):
@@ -1535,7 +1533,12 @@ class ScalogramCPCEngine(CPCEngine):
             seed_p = over_ranks(tg.sum(0, keepdim=True)).expand(B, K, E)
             seed_t = over_ranks(pred3.sum(0, keepdim=True)).expand(B, K, E)
         self.dact[-1].zero_()
-        if softplus:
+        if softplus and gn is not None:
+            # softplus scores over the GLOBAL score matrix (engine.GlobalNegatives.gp_softplus_*)
+            sd_p, sd_t = gn.gp_softplus_seed(all_timesteps)
+            self.dpred.copy_(sd_p)
+            dtop[:, T - K:T, :].copy_(sd_t)
+        elif softplus:
             # softplus scores: the summed scores are sum softplus(s), the seeds carry W1 = sigmoid(s) (cpc_gp_score_coeff)
             self._gp_softplus_buffers(all_timesteps)
             sp = self._gp_sp
@@ -1583,7 +1586,9 @@ class ScalogramCPCEngine(CPCEngine):
         # ---- pass 3: the real loss, plus the penalty's seeds on the primal stream
         top_t3 = top_t.view(B, Ltop, E)
         tg_t, pred_t3 = top_t3[:, T - K:T, :], self.pred_t.view(B, K, E)
-        if softplus:
+        if softplus and gn is not None:
+            add_p, add_t = gn.gp_softplus_second(self.pred_t, top_t, all_timesteps)
+        elif softplus:
             # nu_p = W1 (tangent targets) + W2 targets,  nu_t = W1^T (tangent predictions) + W2^T predictions,
             # W2 = softplus''(s) * (tangent of s),  tangent of s = (tangent predictions) targets^T + predictions (tangent targets)^T
             sp = self._gp_sp

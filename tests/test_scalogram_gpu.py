@@ -1215,9 +1215,51 @@ for run in meta["runs"]:
         worst = max(worst, float((got - ref).norm() / (ref.norm() + 1e-30)))
     assert worst < 1e-3, (run["tag"], worst)
     ok.append((run["tag"], loss, worst))
+# softplus scores (no reference experiment combines them with the penalty): the oracle's double backward on the four-clip batch
+import copy
+from oracle import cpc_oracle as O
+from cpc_audio_amd.audio_dataset import FileBatchSampler
+V = meta["V"]
+oblocks = copy.deepcopy(meta["blocks"])
+for b in oblocks:
+    b["kernel_size_1"], b["kernel_size_2"] = tuple(b["kernel_size_1"]), tuple(b["kernel_size_2"])
+oblocks[0]["in_channels"] = 2
+pre, model = T._build_scalogram_model(g, meta, "fp32")
+model.train()
+params = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+sp_ok = []
+for all_t, reg, factor in ((False, 1.0, 2.0), (True, 0.01, 10.0)):
+    log = T._Logger()
+    tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(data, device=T.DEV), logger=log, device=T.DEV,
+                                      regularization=reg, score_over_all_timesteps=all_t, score_function=T.SCORE["softplus"],
+                                      prediction_steps=K, ar_size=H, preprocessing=pre, wasserstein_gradient_penalty=True,
+                                      gradient_penalty_factor=factor)
+    tr.verbose, tr.global_negatives = False, True
+    model.load_state_dict(params)
+    random.seed(91)
+    idx = [list(b) for b in FileBatchSampler([data.shape[0]], B, 1, True, verbose=False)][0]
+    random.seed(91)
+    tr.train(batch_size=B // world, epochs=1, lr=0.0, num_workers=0, max_steps=1)
+    with torch.no_grad():
+        scal = pre(data[idx].to(T.DEV).unsqueeze(1)).cpu()
+    ot = O.OracleTrainer(params, V, K, score="softplus", all_timesteps=all_t, regularization=reg, lr=0.0, scalogram=oblocks,
+                         gradient_penalty_factor=factor)
+    loss, smax, grads = ot.loss_and_grads(scal)
+    got_loss = log.loss_meter.values[0]
+    assert abs(got_loss - float(loss)) < 1e-4 * abs(float(loss)), ("softplus", all_t, got_loss, float(loss))
+    largest = max(float(v.abs().max()) for v in grads.values() if v is not None)
+    worst = 0.0
+    for name, ref in grads.items():
+        got = model._grad[name].detach().double().cpu()          # after the all-reduce: the sum of the two ranks' gradients
+        if ref.abs().max().item() < 1e-6 * largest:
+            assert got.abs().max().item() < 1e-5 * largest, (all_t, name)
+            continue
+        worst = max(worst, float((got - ref.double()).norm() / (ref.double().norm() + 1e-30)))
+    assert worst < 1e-3, ("softplus", all_t, worst)
+    sp_ok.append((all_t, got_loss, worst))
 if rank == 0:
-    assert len(ok) >= 2
-    print("GP-GN-OK", ok)
+    assert len(ok) >= 2 and len(sp_ok) == 2
+    print("GP-GN-OK", ok, sp_ok)
 dist.destroy_process_group()
 '''
 
@@ -1227,7 +1269,9 @@ def test_gradient_penalty_with_global_negatives_two_ranks_equal_the_reference(tm
     experiments, setup_functions.py:112-115 with contrastive_estimation_training.py:144-158): two ranks with two clips each
     reproduce the REFERENCE's single-process penalty runs on the four-clip batch -- loss (1e-4) and every parameter gradient
     (the ranks' gradients summed) -- on the fixture without BatchNorm (``scalogram_model_c``; BatchNorm statistics are per
-    replica in the reference too), both loss branches, exact-f32 mode."""
+    replica in the reference too), both loss branches, exact-f32 mode.  And with softplus scores (round 4; no reference run exists): the
+    seeds of the penalty's passes over the GLOBAL score matrix (engine.GlobalNegatives.gp_softplus_*) against the oracle's double
+    backward on the four-clip batch."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
