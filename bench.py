@@ -88,7 +88,10 @@ class StepClock:
         return {"ms_per_step_median": round(med, 3), "ms_per_step_max": round(dev[worst], 3), "slowest_timed_step": worst,
                 "first_timed_step_ms": round(dev[0], 3), "ms_per_step_min": round(srt[0], 3),
                 "host_enqueue_ms_max": round(max(host), 3), "host_enqueue_slowest_step": max(range(n), key=lambda i: host[i]),
-                "host_enqueue_ms_median": round(sorted(host)[n // 2], 3), "host_enqueue_ms_first": round(host[0], 3)}
+                "host_enqueue_ms_median": round(sorted(host)[n // 2], 3), "host_enqueue_ms_first": round(host[0], 3),
+                # every timed step, in order (HIP events at the step boundaries): a slow head of the region (the first steps after the
+                # warm-up's fence) or a single stall shows here; steps with the kernel timer active carry ~0.1 ms of event brackets
+                "step_ms": [round(v, 3) for v in dev]}
 
 
 def timed_run(step, steps, warmup, timer, every, fence):
