@@ -24,10 +24,10 @@ class Meter:
 
 class Logger:
     def __init__(self):
-        self.loss_meter, self.score_meter = Meter(), Meter()
+        self.loss_meter, self.score_meter, self.marks = Meter(), Meter(), []
 
     def log(self, step):
-        pass
+        self.marks.append(time.perf_counter())
 
 
 def main():
@@ -62,6 +62,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     v = logger.loss_meter.values
+    m = logger.marks
+    if len(m) > 120:          # steady state: spacing of the log calls over the last steps (the logger sees step i one step late)
+        tail = m[100:]
+        print(f"steady state (steps 100 .. {len(m)}): {(tail[-1] - tail[0]) / (len(tail) - 1) * 1e3:.3f} ms/step")
     print(f"{len(v)} steps in {dt:.2f} s ({dt / len(v) * 1e3:.2f} ms/step incl. host); loss first/last 10 mean "
           f"{sum(v[:10]) / 10:.4f} -> {sum(v[-10:]) / 10:.4f}; finite {all(x == x and abs(x) < 1e30 for x in v)}; "
           f"max memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
