@@ -153,7 +153,19 @@ def test_nan_guard_keeps_the_last_good_parameters(golden_dir, dtype, bad_step):
         _nan_guard_case(g, meta, data, run, dtype, bad_step)
 
 
-def _nan_guard_case(g, meta, data, run, dtype, bad_step):
+@pytest.mark.parametrize("bad_step", [0, 2])
+def test_nan_guard_on_the_graphed_path(golden_dir, bad_step):
+    """The same with trainer.use_graph (the step replayed from a captured hipGraph; Adam's step count lives on the device,
+    cpc_adam_dev): the tick kernel honours the NaN flag before it counts, so after the return the DEVICE step count equals the
+    number of good steps and the parameters are bit for bit those of a clean graphed run of that many steps."""
+    g = _load(golden_dir, "small_model.npz")
+    meta = json.load(open(os.path.join(golden_dir, "small_model.json")))
+    data = torch.from_numpy(g["data"]).clone()
+    for run in [r for r in meta["runs"] if r["steps"] > 1]:
+        _nan_guard_case(g, meta, data, run, "fp32", bad_step, use_graph=True)
+
+
+def _nan_guard_case(g, meta, data, run, dtype, bad_step, use_graph=False):
     from cpc_audio_amd.audio_dataset import FileBatchSampler
     random.seed(run["python_seed"])
     batches = [list(b) for b in FileBatchSampler([data.shape[0]], meta["B"], 1, True, verbose=False)]
@@ -167,7 +179,7 @@ def _nan_guard_case(g, meta, data, run, dtype, bad_step):
         tr = ContrastiveEstimationTrainer(model=model, dataset=TensorAudioDataset(clips, device=DEV), logger=logger, device=DEV,
                                           regularization=run["reg"], score_over_all_timesteps=run["all_timesteps"],
                                           score_function=SCORE[run["score"]], prediction_steps=meta["K"], ar_size=meta["H"])
-        tr.verbose = False
+        tr.verbose, tr.use_graph = False, use_graph
         random.seed(run["python_seed"])
         ret = tr.train(batch_size=meta["B"], epochs=10, lr=run["lr"], num_workers=0, max_steps=steps)
         torch.cuda.synchronize()
@@ -186,6 +198,9 @@ def _nan_guard_case(g, meta, data, run, dtype, bad_step):
     assert len(logger.loss_meter.values) == bad_step and logger.steps == list(range(bad_step))
     for k, v in good.items():
         assert torch.equal(after[k], v), k
+    if use_graph:          # Adam's device-side step count: the updates of the NaN step and of the step launched behind it were not counted
+        count = int(tr.last_optimizer.state[0:1].view(torch.int32).item())
+        assert count == bad_step, (count, bad_step)
 
 
 def test_calc_test_task_data_matches_oracle_context_vectors(golden_dir):
