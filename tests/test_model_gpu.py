@@ -820,10 +820,11 @@ def test_conv_ar_batchnorm_residual_matches_reference(golden_dir, dtype, variant
                 assert l2 < bound, (run["tag"], name, l2)
 
 
-def test_standalone_transformer_layers_forward():
+def test_standalone_transformer_layers_forward_and_backward():
     """TransformerEncoderLayer.forward / TransformerEncoder.forward called on their own (reference transformer.py:150-170, :254-272, a
     vendored copy of torch's nn.Transformer): the HIP kernels against torch's own post-norm layers on the CPU in float64 with the same
-    state_dict; causal mask, eval mode.  Other masks and differentiable calls are refused, never approximated."""
+    state_dict; causal mask, eval mode, forward AND backward (input and parameter gradients against torch's autograd).  Other masks are
+    refused, never approximated."""
     from cpc_audio_amd.attention_model import TransformerEncoder, TransformerEncoderLayer
     torch.manual_seed(11)
     S, B, C, heads, FF, N = 24, 6, 128, 2, 256, 2
@@ -849,13 +850,39 @@ def test_standalone_transformer_layers_forward():
     assert (got_layer.cpu().double() - want_layer).abs().max().item() < 2e-5
     with pytest.raises(NotImplementedError):
         enc(src.to(DEV), None)
-    with pytest.raises(NotImplementedError):
-        enc.layers[0](src.to(DEV).requires_grad_(True), mask.to(DEV))
-    # train mode: dropout masks are drawn (counter-based), the result differs from the eval result and stays finite
+    # differentiable like the reference's modules (round 4): gradients with respect to the input and to every parameter of the stack
+    # against torch's autograd through its own layers (float64), for a seeded upstream gradient
+    up = torch.randn(S, B, C, generator=torch.Generator().manual_seed(12))
+    ref_in = src.double().requires_grad_(True)
+    ref_enc.zero_grad()
+    (ref_enc(ref_in, mask=mask.double()) * up.double()).sum().backward()
+    x_dev = src.to(DEV).requires_grad_(True)
+    enc.zero_grad()
+    (enc(x_dev, mask.to(DEV)) * up.to(DEV)).sum().backward()
+    scale = ref_in.grad.abs().max().item()
+    assert (x_dev.grad.cpu().double() - ref_in.grad).abs().max().item() < 2e-4 * scale
+    ref_grads = dict(ref_enc.named_parameters())
+    for name, p_ in enc.named_parameters():
+        want = ref_grads[name].grad
+        assert p_.grad is not None, name
+        err = (p_.grad.cpu().double() - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        assert err < 5e-4, (name, err)
+    # one layer on its own
+    ref_in2 = src.double().requires_grad_(True)
+    (ref_enc.layers[1](ref_in2, src_mask=mask.double()) * up.double()).sum().backward()
+    x2 = src.to(DEV).requires_grad_(True)
+    (enc.layers[1](x2, mask.to(DEV)) * up.to(DEV)).sum().backward()
+    assert (x2.grad.cpu().double() - ref_in2.grad).abs().max().item() < 2e-4 * ref_in2.grad.abs().max().item()
+    # train mode: dropout masks are drawn (counter-based), the result differs from the eval result and stays finite; the backward pass
+    # regenerates the same masks (finite gradients for every parameter)
     enc.train()
     with torch.no_grad():
         dropped = enc(src.to(DEV), mask.to(DEV))
     assert torch.isfinite(dropped).all() and (dropped - got_enc).abs().max().item() > 1e-3
+    enc.zero_grad()
+    x3 = src.to(DEV).requires_grad_(True)
+    (enc(x3, mask.to(DEV)) * up.to(DEV)).sum().backward()
+    assert torch.isfinite(x3.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in enc.parameters())
 
 
 def test_attention_dropout_against_oracle_with_same_masks(golden_dir):
