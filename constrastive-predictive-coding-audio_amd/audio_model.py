@@ -83,8 +83,8 @@ class AudioEncoder(nn.Module):
                                            self.kernel_sizes[l], self.strides[l], bias=args_dict['bias']))
 
     def forward(self, x):
-        """x (B, 1, L) on the GPU -> (B, C, T) float32, differentiable with respect to the encoder's parameters (stand-alone calls
-        go through the autograd bridge _EncoderForward; the input gets no gradient)."""
+        """x (B, 1, L) on the GPU -> (B, C, T) float32, differentiable with respect to the encoder's parameters and its input (stand-alone
+        calls go through the autograd bridge _EncoderForward)."""
         owner = _standalone_owner(self)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             owner.engine_for(x)                           # (flattens the owner's parameters on first use)
@@ -344,22 +344,24 @@ class _CPCForward(torch.autograd.Function):
 
 class _EncoderForward(torch.autograd.Function):
     """Autograd bridge of a stand-alone encoder call (reference modules are ordinary differentiable nn.Modules, audio_model.py:36-44):
-    forward = the engine's encoder pass, backward = its encoder backward pass fed with the incoming gradient.  The input gets no
-    gradient (layer 1's data gradient is never formed on this path)."""
+    forward = the engine's encoder pass, backward = its encoder backward pass fed with the incoming gradient.  An AudioEncoder also
+    gives the gradient with respect to its input (CPCEngine.input_gradient: one more overlapped-row GEMM over layer 1's output
+    gradient); a ScalogramResidualEncoder does not."""
 
     @staticmethod
     def forward(ctx, owner, names, x, *params):
-        if x.requires_grad:
-            raise NotImplementedError("a stand-alone encoder call gives no gradient with respect to its input (layer 1's data gradient "
-                                      "is never formed on the HIP path): detach the input, or train through AudioPredictiveCodingModel")
         eng = owner.engine_for(x)
+        ctx.need_dx = bool(x.requires_grad)
+        if ctx.need_dx and getattr(owner, "_scalogram", False):
+            raise NotImplementedError("a stand-alone scalogram encoder call gives no gradient with respect to its input: detach the input, "
+                                      "or train through AudioPredictiveCodingModel (the gradient penalty's engine forms it there)")
         xin = x.detach().float() if x.dim() == 4 else x.detach()[:, 0, :].contiguous().float()
         eng.prepare_weights()
         eng.encoder_forward(xin)
         # the backward pass reads the engine's activation buffers: stamp this forward pass, so that a later one (which overwrites
         # them) is noticed instead of silently differentiating the wrong activations
         eng._standalone_stamp = getattr(eng, "_standalone_stamp", 0) + 1
-        ctx.eng, ctx.xin, ctx.names, ctx.stamp = eng, xin, names, eng._standalone_stamp
+        ctx.eng, ctx.xin, ctx.names, ctx.stamp, ctx.x_shape = eng, xin, names, eng._standalone_stamp, tuple(x.shape)
         return eng.view_top()[:, :eng.T, :].float().transpose(1, 2)
 
     @staticmethod
@@ -373,13 +375,21 @@ class _EncoderForward(torch.autograd.Function):
         dtop.zero_()
         dtop[:, :T, :].copy_(d_out.transpose(1, 2))
         eng._ahead = None
-        eng._backward_encoder(ctx.xin)
+        fused = getattr(eng, "fuse_c1", False)
+        if ctx.need_dx and fused:
+            eng.fuse_c1 = False          # the input gradient needs layer 1's output gradient in memory: the unfused layer-2 / layer-1 route
+        try:
+            eng._backward_encoder(ctx.xin)
+        finally:
+            if ctx.need_dx and fused:
+                eng.fuse_c1 = True
         for fn in getattr(eng, "_deferred_side", ()):
             fn()
         eng._deferred_side = ()
         if eng.use_aux:
             torch.cuda.current_stream().wait_stream(eng.aux)
-        return (None, None, None, *[eng.model._grad[n].clone() for n in ctx.names])
+        dx = eng.input_gradient().view(ctx.x_shape) if ctx.need_dx else None
+        return (None, None, dx, *[eng.model._grad[n].clone() for n in ctx.names])
 
 
 class _ContextForward(torch.autograd.Function):

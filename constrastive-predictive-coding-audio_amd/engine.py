@@ -877,6 +877,33 @@ class CPCEngine:
             _hip.call("cpc_reduce_slabs", _hip.ptr(self.slabs, k0 * c0), _hip.ptr(g["encoder.layers.0.bias"]), 1, c0, nbb * nblk, stride,
                       1, 1, 0, 0)
 
+    def input_gradient(self):
+        """d / d x (B, L) float32 of whatever _backward_encoder() has just differentiated — the transposed convolution of layer 1
+        (audio_model.py:38: nn.Conv1d(1, C, k, s), its autograd with respect to the input), for stand-alone encoder calls whose input
+        requires grad.  Needs layer 1's output gradient in memory (the unfused route: dact[0]).  With D = ceil(k / s) taps,
+          dx[b][t s + r] = sum_{d < D} sum_c dY[b][t - (D - 1 - d)][c] * w[c][r + (D - 1 - d) s]          (r < s; taps beyond k are zero)
+        is ONE overlapped-row GEMM over dact[0]: row (b, t) = the D rows ending at t, K = D C, N = s (padded to 8).  Samples in front of
+        x_off (frames the model never consumes, not computed at all) and behind the last window get zero."""
+        B, C0, k0, s0, D = self.B, self.channels[0], self.kernels[0], self.strides[0], self.geo.taps[0]
+        La0, dev = self.geo.alloc[0], self.device
+        w = self.model._param["encoder.layers.0.weight"].detach().float().view(C0, k0)
+        Bt = torch.zeros(8, D, C0, device=dev, dtype=torch.float32)
+        for d in range(D):
+            j0 = (D - 1 - d) * s0
+            n = max(0, min(s0, k0 - j0))
+            if n > 0:
+                Bt[:n, d, :] = w[:, j0:j0 + n].t()
+        Bt = Bt.view(8, D * C0).to(self.dt).contiguous()
+        out = torch.empty(B * La0, 8, device=dev, dtype=torch.float32)
+        if s0 > 8 or self.guard[0] < (D - 1) * C0:
+            raise NotImplementedError("input gradient: layer-1 stride <= 8")
+        _hip.gemm_nt(_hip.ptr(self.dact[0], -(D - 1) * C0), _hip.ptr(Bt), _hip.ptr(out), B * La0, 8, D * C0, C0, D * C0, 8, self.code,
+                     flags=_hip.GEMM_OUT_F32)
+        dx = torch.zeros(B, self.L, device=dev, dtype=torch.float32)
+        n = min(self.L_eff, La0 * s0)
+        dx[:, self.x_off:self.x_off + n] = out.view(B, La0, 8)[:, :, :s0].reshape(B, La0 * s0)[:, :n]
+        return dx
+
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, softplus: bool, regularization: float, all_timesteps: bool = False, grad_ready_hook=None,
                        global_negatives=None, after_loss=None):

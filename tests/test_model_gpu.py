@@ -1060,11 +1060,13 @@ def test_standalone_modules_are_differentiable(golden_dir):
     enc = enc.to(DEV)
     x = torch.from_numpy(ge["x"])
     w_out = torch.randn(7, 32, 28, generator=torch.Generator().manual_seed(4))
-    y = enc(x.to(DEV))
+    x_dev = x.to(DEV).requires_grad_(True)             # (round 4: the input gradient too — layer 1's transposed convolution)
+    y = enc(x_dev)
     assert _rel(y, ge["y"]) < 1e-4
     (y * w_out.to(DEV)).sum().backward()
     ws = [torch.from_numpy(ge[f"param/encoder.layers.{l}.weight"]).double().requires_grad_(True) for l in range(5)]
-    t = x.double()
+    xr = x.double().requires_grad_(True)
+    t = xr
     for l, (wt, st) in enumerate(zip(ws, [5, 4, 2, 2, 2])):
         t = F.conv1d(t, wt, stride=st)
         if l < 4:
@@ -1072,6 +1074,31 @@ def test_standalone_modules_are_differentiable(golden_dir):
     (t * w_out.double()).sum().backward()
     for l in range(5):
         assert _rel(enc.layers[l].weight.grad, ws[l].grad) < 1e-3, l
+    assert x_dev.grad is not None and tuple(x_dev.grad.shape) == tuple(x.shape)
+    assert _rel(x_dev.grad, xr.grad) < 1e-3
+    # the same in bf16 storage with the default 512-channel encoder (the layer-2 data gradient / layer-1 weight gradient are fused
+    # there: a call whose input requires grad takes the unfused route), longer clips so that frames in front of x_off exist
+    torch.manual_seed(7)
+    enc_b = AudioEncoder()
+    enc_b.compute_dtype = torch.bfloat16
+    enc_b = enc_b.to(DEV)
+    xb = (torch.randn(4, 1, 20480, generator=torch.Generator().manual_seed(8)) * 0.5)
+    xb_dev = xb.to(DEV).requires_grad_(True)
+    yb = enc_b(xb_dev)
+    wb = torch.randn(*yb.shape, generator=torch.Generator().manual_seed(9))
+    (yb * wb.to(DEV)).sum().backward()
+    wsb = [enc_b.layers[l].weight.detach().cpu().double() for l in range(5)]
+    bsb = [enc_b.layers[l].bias.detach().cpu().double() for l in range(5)]
+    xrb = xb.double().requires_grad_(True)
+    t = xrb
+    for l, st in enumerate([5, 4, 2, 2, 2]):
+        t = F.conv1d(t, wsb[l], bsb[l], stride=st)
+        if l < 4:
+            t = torch.relu(t)
+    (t * wb.double()).sum().backward()
+    gb, rb = xb_dev.grad.detach().cpu().double().flatten(), xrb.grad.flatten()
+    cosb = float(torch.dot(gb, rb) / (gb.norm() * rb.norm()))
+    assert cosb > 0.995, cosb
     # ---- ConvolutionalArModel (BatchNorm + residual, train mode) and AttentionModel (dropout 0)
     gb = _load(golden_dir, "conv_ar_bn.npz")
     mb = json.load(open(os.path.join(golden_dir, "conv_ar_bn.json")))
