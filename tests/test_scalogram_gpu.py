@@ -513,7 +513,9 @@ def test_gradient_penalty_bf16_matches_reference(golden_dir, fixture):
                 worst = min(worst, (cos, name))
         print(f"bf16 gradient penalty {fixture} {run['tag']}: loss rel {rel:.2e}, worst gradient cosine: weights {worst[0]:.4f} ({worst[1]}), "
               f"per-channel vectors {worst_vec[0]:.4f} ({worst_vec[1]})")
-        assert rel <= 5e-2, (run["tag"], logger.loss_meter.values, run["loss"])
+        # (conv context: the penalty's passes themselves run in bf16, measured 2.35e-2 / 1.16e-2; GRU / attention contexts compute in
+        # float32 inside the bf16 engine: measured 1.7e-3 / 5e-5 and 2.3e-3 / 1.2e-3)
+        assert rel <= (5e-2 if fixture == "scalogram_model_gp" else 6e-3), (run["tag"], logger.loss_meter.values, run["loss"])
         # measured: conv context 0.984 / 0.958 (block 1's residual projection), GRU 0.986 / 0.967, attention 0.893 / 0.985 (run0: the first
         # residual projection: a 1 x 1 convolution of the two scalogram channels, 2 x 8 weights summed over every pixel)
         assert worst[0] >= (0.85 if fixture.endswith("_att") else 0.95), (run["tag"], worst)
@@ -583,8 +585,8 @@ def test_gradient_penalty_softplus_scores_against_oracle(golden_dir, fixture, dt
     there is no reference run: the oracle's double backward is the judge): the seeds of the penalty's passes carry sigmoid(s) and
     softplus''(s) * (tangent of s) (cpc_gp_score_coeff) — convolutional, GRU and attention context networks, both loss branches.
     bf16 storage (round 4; coefficient matrices converted to the storage dtype for the contractions, GRU / attention contexts in
-    float32 inside the bf16 engine): the bounds of test_gradient_penalty_bf16_matches_reference — loss within 5e-2, weight-gradient
-    cosines >= 0.95, per-channel vectors >= 0.85."""
+    float32 inside the bf16 engine): loss within 1e-2 (measured 2.9e-4 ... 3.1e-3), weight-gradient cosines >= 0.95, per-channel
+    vectors >= 0.85."""
     import copy
     from cpc_audio_amd.audio_dataset import FileBatchSampler
     g = _load(golden_dir, fixture + ".npz")
@@ -638,7 +640,7 @@ def test_gradient_penalty_softplus_scores_against_oracle(golden_dir, fixture, dt
                     worst = min(worst, (cos, name))
             print(f"bf16 softplus gradient penalty {fixture} all_timesteps={all_t}: loss rel {rel:.2e}, worst gradient cosine: weights "
                   f"{worst[0]:.4f} ({worst[1]}), per-channel vectors {worst_vec[0]:.4f} ({worst_vec[1]})")
-            assert rel <= 5e-2, (fixture, all_t, logger.loss_meter.values, float(loss))
+            assert rel <= 1e-2, (fixture, all_t, logger.loss_meter.values, float(loss))          # measured 2.9e-4 ... 3.1e-3
             assert worst[0] >= 0.95, (fixture, all_t, worst)
             assert worst_vec[0] >= 0.85, (fixture, all_t, worst_vec)
             continue
