@@ -601,18 +601,21 @@ __global__ __launch_bounds__(64 * GRU_NW) void gru_bwd_res_kernel(const float* _
 template <typename T>
 __global__ __launch_bounds__(256) void prep_frag_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int Kd,
                                                         long long ld, int transpose) {
+    // one thread per lane-fragment: its CH elements (consecutive k) are read together and stored as ONE 16-byte piece (it was one element
+    // per thread and iteration behind three 64-bit div / mod pairs: 27 - 42 us for the 0.2 M elements of W_hh)
     constexpr int CH = Elem<T>::CH;
     const int KC = Kd / (4 * CH);
-    const long long total = (long long)R * Kd;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int e = (int)(idx % CH);
-        const int lane = (int)((idx / CH) % 64);
-        const long long blk = idx / (CH * 64);
-        const int kc = (int)(blk % KC), nt = (int)(blk / KC);
+    const int total = R * (Kd / CH);
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < total; f += gridDim.x * 256) {
+        const int lane = f & 63, blk = f >> 6;
+        const int kc = blk % KC, nt = blk / KC;
         const int n = nt * 16 + (lane & 15);
-        const int k = kc * 4 * CH + (lane >> 4) * CH + e;
-        const float v = transpose ? src[(long long)k * ld + n] : src[(long long)n * ld + k];
-        dst[idx] = from_f32<T>(v);
+        const int k = kc * 4 * CH + (lane >> 4) * CH;
+        __attribute__((aligned(16))) T out[CH];          // CH * sizeof(T) = 16 bytes for both storage types
+#pragma unroll
+        for (int e = 0; e < CH; ++e)
+            out[e] = from_f32<T>(transpose ? src[(long long)(k + e) * ld + n] : src[(long long)n * ld + k + e]);
+        *(uint4*)(dst + (long long)f * CH) = *(const uint4*)out;
     }
 }
 
@@ -690,7 +693,8 @@ int launch_gru_bwd(const float* dc, const void* tape, const void* WTfrag, void* 
 int launch_prep_frag(const float* src, void* dst, int R, int Kd, long long ld, int transpose, int dtype, hipStream_t stream) {
     const int ch = dtype == CPC_DTYPE_BF16 ? 8 : 4;
     if (R <= 0 || Kd <= 0 || R % 16 || Kd % (4 * ch)) return CPC_EINVAL;
-    const long long total = (long long)R * Kd;
+    const long long total = (long long)R * (Kd / ch);          // one thread per 16-byte fragment piece
+    if (total > 0x7fffffffLL) return CPC_EINVAL;
     const int blocks = (int)min((long long)1024, (total + 255) / 256);
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((prep_frag_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, R, Kd, ld, transpose);

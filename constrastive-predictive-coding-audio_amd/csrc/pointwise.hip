@@ -3,6 +3,7 @@
 #include "cpc_common.h"
 #include "cpc_kernels.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -108,6 +109,36 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const float* __restrict__ s
         const int c = (int)(idx % C);
         const long long r = idx / C;
         dst[idx] = from_f32<T>(src[r * sr + (long long)c * sc]);
+    }
+}
+
+// The same through a 32 x 32 LDS tile: the source is read along whichever of its axes has unit stride (sc == 1: rows; otherwise along r,
+// e.g. the transposed copy sr == 1), the destination is written along c.  One element per thread and iteration in cast2d_kernel with
+// 64-bit div / mod and — for a transposed copy — a 4-byte read per 2 KiB of stride: 21 - 30 us for the 0.4 M elements of a GRU input
+// projection; the tile form is bound by the launch.
+template <typename T>
+__global__ __launch_bounds__(256) void cast2d_tile_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, long long sr,
+                                                          long long sc) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (sc == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            t[ty + 8 * k][tx] = (r < R && c < C) ? src[(long long)r * sr + c] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            t[tx][ty + 8 * k] = (r < R && c < C) ? src[(long long)r * sr + (long long)c * sc] : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < R && c < C) dst[(long long)r * C + c] = from_f32<T>(t[ty + 8 * k][tx]);
     }
 }
 
@@ -337,6 +368,10 @@ int launch_conv_w_prep(const float* W, void* fwd, void* dgrd, int Cout, int Cin,
     if (kw > 511) return CPC_EINVAL;
     int tco = 32;                                                            // LDS tile of at most 64 KiB: fewer co for very wide kernels
     while (tco > 1 && (long long)tco * (32 * kw + 1) > 16384) tco >>= 1;
+    // (a 512 x 512 x 8 weight is 256 tiles of 32 x 32 channels: one workgroup per CU, each walking 96 elements per thread through index
+    // arithmetic with nothing to hide its latency behind — 65 us for 2 M elements; 4 output channels per tile, eight times the workgroups: 25 us; 45 / 31 / 27 / 25 / 25 us at 32 / 16 / 8 / 4 / 2)
+    static const int tco_max = [] { const char* v = getenv("CPC_W_PREP_TCO"); return v ? atoi(v) : 4; }();
+    while (tco > tco_max && (long long)((Cin + 31) / 32) * ((Cout + tco - 1) / tco) < 2048) tco >>= 1;
     const dim3 grid((Cin + 31) / 32, (Cout + tco - 1) / tco);
     const size_t lds = (size_t)tco * (32 * kw + 1) * sizeof(float);
     if (dtype == CPC_DTYPE_BF16)
@@ -355,6 +390,18 @@ int launch_cast2d(const float* src, void* dst, int R, int C, long long sr, long 
     if (R <= 0 || C <= 0) return CPC_EINVAL;
     const long long n = (long long)R * C;
     const int blocks = (int)min((long long)2048, (n + 255) / 256);
+    static const int tiled = [] { const char* v = getenv("CPC_CAST2D_TILE"); return v ? atoi(v) : 1; }();
+    if (tiled && n >= 4096 && (C + 31) / 32 <= 65535 && (R + 31) / 32 <= 65535) {
+        const dim3 grid((C + 31) / 32, (R + 31) / 32);
+        if (dtype == CPC_DTYPE_BF16)
+            hipLaunchKernelGGL((cast2d_tile_kernel<bf16_t>), grid, dim3(256), 0, stream, src, (bf16_t*)dst, R, C, sr, sc);
+        else if (dtype == CPC_DTYPE_F32)
+            hipLaunchKernelGGL((cast2d_tile_kernel<float>), grid, dim3(256), 0, stream, src, (float*)dst, R, C, sr, sc);
+        else
+            return CPC_EINVAL;
+        CPC_CHECK_LAUNCH();
+        return CPC_OK;
+    }
     if (dtype == CPC_DTYPE_BF16)
         hipLaunchKernelGGL((cast2d_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, R, C, sr, sc);
     else if (dtype == CPC_DTYPE_F32)
