@@ -464,6 +464,48 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
         }
         return v;
     };
+    // C <= 1024: a lane's (at most four) column groups of the row stay in registers over the three passes — the row is read ONCE (it was
+    // read in every pass: three dependent memory round trips per row and wave; 23 us per launch at 15 360 x 512).  Same values, same
+    // order of summation: identical results.
+    constexpr int LNF_IT = 4;
+    if (c4n <= 64 * LNF_IT) {
+        for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+            f32x4 v[LNF_IT];
+            float s1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < LNF_IT; ++u) {
+                const int c4 = lane + 64 * u;
+                if (c4 < c4n) {
+                    v[u] = rsum(m, c4);
+                    if (r_out) store4(r_out + (long long)m * C + c4 * 4, v[u]);
+                    s1 += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+                }
+            }
+            const float mean = wave_sum(s1) / (float)C;
+            float s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < LNF_IT; ++u) {
+                if (lane + 64 * u < c4n) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s2 += (v[u][e] - mean) * (v[u][e] - mean);
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+            if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+#pragma unroll
+            for (int u = 0; u < LNF_IT; ++u) {
+                const int c4 = lane + 64 * u;
+                if (c4 < c4n) {
+                    const f32x4 wv = *(const f32x4*)(w + c4 * 4), bv = *(const f32x4*)(bias + c4 * 4);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (v[u][e] - mean) * rstd * wv[e] + bv[e];
+                    store4(y + (long long)m * C + c4 * 4, o);
+                }
+            }
+        }
+        return;
+    }
     for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
         float s1 = 0.f;
         for (int c4 = lane; c4 < c4n; c4 += 64) {
@@ -513,18 +555,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, c
         const int c4 = lane + 64 * u;
         wv[u] = c4 < c4n ? *(const f32x4*)(w + c4 * 4) : gw[u];
     }
-    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
-        const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+    // The operands of the wave's NEXT row are requested before this row is reduced (a row was: loads -> two wave reductions -> stores, one
+    // memory round trip after the other, 7 - 8 rows per wave), and they are waited for in front of this row's stores: loads and stores
+    // share the wait counter, a wait behind the stores would also wait for their acknowledgement.
+    const int mstep = gridDim.x * 4;
+    f32x4 na[LN_IT], nb[LN_IT], nr[LN_IT];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](int m) {
+        nmean = stats[2 * m];
+        nrstd = stats[2 * m + 1];
         const long long grow = bcast > 0 ? (long long)(m / bcast) * C : (long long)m * C;
+#pragma unroll
+        for (int u = 0; u < LN_IT; ++u) {
+            const int c4 = lane + 64 * u;
+            if (c4 < c4n) {
+                na[u] = load4(g1 + grow + c4 * 4);
+                if (g2) nb[u] = load4(g2 + (long long)m * C + c4 * 4);
+                nr[u] = load4(r + (long long)m * C + c4 * 4);
+            }
+        }
+    };
+    int m0 = blockIdx.x * 4 + wave;
+    if (m0 < M) fetch(m0);
+    for (int m = m0; m < M; m += mstep) {
+        const float mean = nmean, rstd = nrstd;
+        f32x4 ca[LN_IT], cb[LN_IT], cr[LN_IT];
+#pragma unroll
+        for (int u = 0; u < LN_IT; ++u) { ca[u] = na[u]; cb[u] = nb[u]; cr[u] = nr[u]; }
+        if (m + mstep < M) fetch(m + mstep);
         f32x4 dy[LN_IT], xh[LN_IT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < LN_IT; ++u) {
             const int c4 = lane + 64 * u;
             if (c4 < c4n) {
-                dy[u] = load4(g1 + grow + c4 * 4) * gscale;
-                if (g2) dy[u] += load4(g2 + (long long)m * C + c4 * 4);
-                const f32x4 rv = load4(r + (long long)m * C + c4 * 4);
+                dy[u] = ca[u] * gscale;
+                if (g2) dy[u] += cb[u];
+                const f32x4 rv = cr[u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[u][e] = (rv[e] - mean) * rstd;
@@ -537,6 +604,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g1, c
             }
         }
         const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the next row's operands (and the previous row's stores) before this row's stores
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < LN_IT; ++u) {
             const int c4 = lane + 64 * u;
