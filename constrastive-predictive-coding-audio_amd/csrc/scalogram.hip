@@ -416,15 +416,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     // are formed once (dx = k1 * g - k2 - k3 * (x - mean)) instead of sixteen scalar loads per element.
     const bool fixed = ((gridDim.x * 256u) % (unsigned)c4n) == 0u;
     f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k3 = k1, mu = k1;
-    auto coeffs = [&](int c4) {
+    auto coeffs = [&](int c4) {          // (16-byte loads, as in bn_bwd_apply8_kernel)
+        const int c = c4 * 4;
+        const f32x4 rs4 = *(const f32x4*)(stats + C + c), ga4 = *(const f32x4*)(gamma + c);
+        f32x4 db4 = {0.f, 0.f, 0.f, 0.f}, dg4 = db4;
+        if (train) { db4 = *(const f32x4*)(dbeta + c); dg4 = *(const f32x4*)(dgamma + c); }
+        mu = *(const f32x4*)(stats + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = c4 * 4 + e;
-            const float rs = stats[C + c], ga = gamma[c];
-            mu[e] = stats[c];
+            const float rs = rs4[e], ga = ga4[e];
             k1[e] = ga * rs;
-            k2[e] = train ? ga * rs * dbeta[c] * inv_count : 0.f;
-            k3[e] = train ? ga * rs * rs * dgamma[c] * inv_count : 0.f;
+            k2[e] = train ? ga * rs * db4[e] * inv_count : 0.f;
+            k3[e] = train ? ga * rs * rs * dg4[e] * inv_count : 0.f;
         }
     };
     if (fixed) coeffs((int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)c4n));
