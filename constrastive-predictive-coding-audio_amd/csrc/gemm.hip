@@ -1752,24 +1752,29 @@ __global__ __launch_bounds__(256) void reduce_slabs_small_kernel(const float* __
 __global__ __launch_bounds__(256) void reduce_conv_w_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cin,
                                                             int cout, int kw, int nslab, long long slab_stride) {
     __shared__ float t[8][32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    for (int jj = 0; jj < kw; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cl = ty + 8 * r;
-            const long long off = (long long)(jj * cin + c0 + cl) * cout + co0 + tx;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    {
+        // a thread owns FOUR consecutive output channels of one input channel (16-byte loads, four slabs in flight: it was one float per
+        // load, 256 dependent-ish loads per thread, 58 us for the 64 MB of layer 2's slabs); per element the same four accumulators over
+        // the slabs z = k mod 4 and the same final sum: identical results
+        const int q = threadIdx.x & 7, cl = threadIdx.x >> 3;
+        for (int jj = 0; jj < kw; ++jj) {
+            const long long off = (long long)(jj * cin + c0 + cl) * cout + co0 + 4 * q;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
             int z = 0;
             for (; z + 3 < nslab; z += 4) {
-                s0 += slabs[(long long)z * slab_stride + off];
-                s1 += slabs[(long long)(z + 1) * slab_stride + off];
-                s2 += slabs[(long long)(z + 2) * slab_stride + off];
-                s3 += slabs[(long long)(z + 3) * slab_stride + off];
+                const f32x4 a0 = *(const f32x4*)(slabs + (long long)z * slab_stride + off);
+                const f32x4 a1 = *(const f32x4*)(slabs + (long long)(z + 1) * slab_stride + off);
+                const f32x4 a2 = *(const f32x4*)(slabs + (long long)(z + 2) * slab_stride + off);
+                const f32x4 a3 = *(const f32x4*)(slabs + (long long)(z + 3) * slab_stride + off);
+                s0 += a0; s1 += a1; s2 += a2; s3 += a3;
             }
-            for (; z < nslab; ++z) s0 += slabs[(long long)z * slab_stride + off];
-            t[jj][cl][tx] = (s0 + s1) + (s2 + s3);
+            for (; z < nslab; ++z) s0 += *(const f32x4*)(slabs + (long long)z * slab_stride + off);
+            const f32x4 r4 = (s0 + s1) + (s2 + s3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[jj][cl][4 * q + e] = r4[e];
         }
+    }
     __syncthreads();
     const int per_co = 32 * kw;
     for (int idx = threadIdx.x; idx < 32 * per_co; idx += 256) {
@@ -2278,7 +2283,7 @@ int launch_colsum(const void* X, float* slabs, int M, int N, long long ldx, int 
 int launch_reduce_conv_w(const float* slabs, float* out, int cin, int cout, int kw, int nslab, long long slab_stride,
                          hipStream_t stream) {
     if (cin <= 0 || cout <= 0 || kw <= 0 || nslab <= 0) return CPC_EINVAL;
-    if (cin % 32 || cout % 32 || kw > 8)      // generic permuting reduce
+    if (cin % 32 || cout % 32 || kw > 8 || (uintptr_t)slabs % 16 || slab_stride % 4)      // generic permuting reduce
         return launch_reduce_slabs(slabs, out, kw * cin, cout, nslab, slab_stride, cin, (long long)cin * kw, 1, kw, stream);
     hipLaunchKernelGGL(reduce_conv_w_kernel, dim3(cin / 32, cout / 32), dim3(256), 0, stream, slabs, out, cin, cout, kw, nslab,
                        slab_stride);
